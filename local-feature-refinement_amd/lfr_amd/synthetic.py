@@ -1,0 +1,226 @@
+"""Synthetic match-graph generator G(seed, n_images, n_tracks, ...) of SURVEY.md §8(d).
+
+The reference ships no data and no generator; real match graphs come from its
+two-view network (``two-view-refinement/compute_match_graph.py:163-187``), whose
+output layout this generator reproduces: per match two 3x3 grids of (di, dj)
+flow vectors, ``disp2`` = flow image1->image2 and ``disp1`` = flow image2->image1
+(``compute_match_graph.py:179-187``), one ImagePair per ordered image pair.
+
+Everything stored is float32 (wire precision, ``types.proto:13,16-17``); the
+random stream is ``numpy.random.Generator(PCG64(seed))`` so the same arguments
+give the same graph on every machine.
+"""
+from dataclasses import dataclass
+
+import numpy as np
+
+GRID = np.array([(-0.5 + 0.5 * i, -0.5 + 0.5 * j) for i in range(3) for j in range(3)],
+                dtype=np.float64)  # grid index = i*3+j  (solve.cc:461-465)
+
+
+@dataclass
+class MatchArrays:
+    """Flat (SoA) form of a MatchingFile: what ``lfr_graph_from_arrays`` takes."""
+    image_names: list          # n_images strings
+    facts: np.ndarray          # float32[n_images]
+    pair_img1: np.ndarray      # int32[P]   image index of image_name1
+    pair_img2: np.ndarray      # int32[P]
+    pair_off: np.ndarray       # int64[P+1] matches of pair p are [pair_off[p], pair_off[p+1])
+    feat1: np.ndarray          # uint32[M]
+    feat2: np.ndarray          # uint32[M]
+    sim: np.ndarray            # float32[M]
+    disp1: np.ndarray          # float32[M,9,2]  flow 2->1 (rides edge node2->node1, solve.cc:478)
+    disp2: np.ndarray          # float32[M,9,2]  flow 1->2 (rides edge node1->node2, solve.cc:477)
+
+    @property
+    def n_matches(self):
+        return int(self.feat1.shape[0])
+
+    def to_pairs(self):
+        """Expand into the dict form of :mod:`lfr_amd.wire` (small inputs only)."""
+        pairs = []
+        for p in range(len(self.pair_img1)):
+            lo, hi = int(self.pair_off[p]), int(self.pair_off[p + 1])
+            ms = []
+            for m in range(lo, hi):
+                ms.append({
+                    "feature_idx1": int(self.feat1[m]), "feature_idx2": int(self.feat2[m]),
+                    "similarity": float(self.sim[m]),
+                    "disp1": [(float(a), float(b)) for a, b in self.disp1[m]],
+                    "disp2": [(float(a), float(b)) for a, b in self.disp2[m]],
+                })
+            i1, i2 = int(self.pair_img1[p]), int(self.pair_img2[p])
+            pairs.append({"image_name1": self.image_names[i1], "fact1": float(self.facts[i1]),
+                          "image_name2": self.image_names[i2], "fact2": float(self.facts[i2]),
+                          "matches": ms})
+        return pairs
+
+
+def pairs_to_arrays(pairs):
+    """Inverse of :meth:`MatchArrays.to_pairs` for well-formed inputs (9 grid points)."""
+    names, idx, facts = [], {}, []
+
+    def _img(n, f):
+        if n not in idx:
+            idx[n] = len(names)
+            names.append(n)
+            facts.append(f)
+        return idx[n]
+
+    p1, p2, off, f1, f2, sim, d1, d2 = [], [], [0], [], [], [], [], []
+    for p in pairs:
+        p1.append(_img(p["image_name1"], p["fact1"]))
+        p2.append(_img(p["image_name2"], p["fact2"]))
+        for m in p["matches"]:
+            f1.append(m["feature_idx1"])
+            f2.append(m["feature_idx2"])
+            sim.append(m["similarity"])
+            a = np.zeros((9, 2), np.float32)
+            b = np.zeros((9, 2), np.float32)
+            for k, d in enumerate(m["disp1"]):
+                a[k] = d
+            for k, d in enumerate(m["disp2"]):
+                b[k] = d
+            d1.append(a)
+            d2.append(b)
+        off.append(len(f1))
+    M = len(f1)
+    return MatchArrays(names, np.asarray(facts, np.float32), np.asarray(p1, np.int32),
+                       np.asarray(p2, np.int32), np.asarray(off, np.int64),
+                       np.asarray(f1, np.uint32), np.asarray(f2, np.uint32),
+                       np.asarray(sim, np.float32),
+                       np.asarray(d1, np.float32).reshape(M, 9, 2),
+                       np.asarray(d2, np.float32).reshape(M, 9, 2))
+
+
+def _distinct_images(rng, n_rows, L, n_images):
+    """n_rows x L matrix of distinct image ids per row, uniform."""
+    if n_rows == 0:
+        return np.zeros((0, L), np.int64)
+    if n_rows * n_images <= 30_000_000 or L * 2 > n_images:
+        keys = rng.random((n_rows, n_images))
+        return np.argsort(keys, axis=1, kind="stable")[:, :L].astype(np.int64)
+    out = rng.integers(0, n_images, size=(n_rows, L))
+    while True:
+        s = np.sort(out, axis=1)
+        bad = np.nonzero((s[:, 1:] == s[:, :-1]).any(axis=1))[0]
+        if bad.size == 0:
+            return out.astype(np.int64)
+        out[bad] = rng.integers(0, n_images, size=(bad.size, L))
+
+
+def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=None,
+             eps_out=0.0, sigma_p=0.15, sigma_noise=0.02, sigma_A=0.05, sim_lo=0.8, sim_hi=1.0,
+             fact=1.0):
+    """Generate a synthetic match graph.
+
+    len_dist = "poisson": L = min(n_images, 2 + Poisson(4)) (mean 6);
+    len_dist = "uniform": L ~ U{len_lo..len_hi}.
+    All L(L-1)/2 pairs inside a track are matched; ``eps_out`` adds that fraction
+    of extra wrong matches between nodes of different tracks (different images).
+    """
+    rng = np.random.Generator(np.random.PCG64(seed))
+    if len_dist == "poisson":
+        L = np.minimum(n_images, 2 + rng.poisson(4.0, size=n_tracks)).astype(np.int64)
+    elif len_dist == "uniform":
+        L = rng.integers(len_lo, len_hi + 1, size=n_tracks).astype(np.int64)
+        L = np.minimum(L, n_images)
+    else:
+        raise ValueError(len_dist)
+
+    # nodes, in track order
+    node_off = np.zeros(n_tracks + 1, np.int64)
+    np.cumsum(L, out=node_off[1:])
+    N = int(node_off[-1])
+    node_img = np.empty(N, np.int64)
+    for ell in np.unique(L):
+        rows = np.nonzero(L == ell)[0]
+        imgs = _distinct_images(rng, rows.size, int(ell), n_images)
+        dst = node_off[rows][:, None] + np.arange(ell)[None, :]
+        node_img[dst.ravel()] = imgs.ravel()
+    # feature_idx = running counter per image, in node order
+    order = np.argsort(node_img, kind="stable")
+    sorted_img = node_img[order]
+    first = np.r_[True, sorted_img[1:] != sorted_img[:-1]]
+    start = np.maximum.accumulate(np.where(first, np.arange(N), 0))
+    node_feat = np.empty(N, np.int64)
+    node_feat[order] = np.arange(N) - start
+    node_p = np.clip(rng.normal(0.0, sigma_p, size=(N, 2)), -0.45, 0.45)
+    node_track = np.repeat(np.arange(n_tracks), L)
+
+    # true matches: all pairs inside a track
+    a_list, b_list = [], []
+    for ell in np.unique(L):
+        rows = np.nonzero(L == ell)[0]
+        iu, ju = np.triu_indices(int(ell), k=1)
+        base = node_off[rows][:, None]
+        a_list.append((base + iu[None, :]).ravel())
+        b_list.append((base + ju[None, :]).ravel())
+    a = np.concatenate(a_list) if a_list else np.zeros(0, np.int64)
+    b = np.concatenate(b_list) if b_list else np.zeros(0, np.int64)
+    o = np.lexsort((b, a))
+    a, b = a[o], b[o]
+    n_true = a.size
+    wrong = np.zeros(n_true, bool)
+
+    # wrong matches between different tracks
+    n_out = int(round(eps_out * n_true))
+    if n_out > 0:
+        wa = rng.integers(0, N, size=n_out)
+        wb = rng.integers(0, N, size=n_out)
+        while True:
+            bad = np.nonzero((node_track[wa] == node_track[wb]) | (node_img[wa] == node_img[wb]))[0]
+            if bad.size == 0:
+                break
+            wa[bad] = rng.integers(0, N, size=bad.size)
+            wb[bad] = rng.integers(0, N, size=bad.size)
+        a = np.concatenate([a, wa])
+        b = np.concatenate([b, wb])
+        wrong = np.concatenate([wrong, np.ones(n_out, bool)])
+
+    # orient so image1 < image2 (names are "%06d.png": index order == name order)
+    swap = node_img[a] > node_img[b]
+    a, b = np.where(swap, b, a), np.where(swap, a, b)
+    M = a.size
+
+    def _flow(src, dst):
+        base = node_p[dst] - node_p[src]                       # (M,2)
+        base = np.where(wrong[:, None], rng.normal(0.0, 0.3, size=(M, 2)), base)
+        A = rng.normal(0.0, sigma_A, size=(M, 2, 2))
+        lin = np.einsum("mij,kj->mki", A, GRID)                # (M,9,2)
+        return (base[:, None, :] + lin + rng.normal(0.0, sigma_noise, size=(M, 9, 2))).astype(np.float32)
+
+    disp2 = _flow(a, b)   # flow 1 -> 2
+    disp1 = _flow(b, a)   # flow 2 -> 1
+    sim = rng.uniform(sim_lo, sim_hi, size=M).astype(np.float32)
+
+    # group by image pair, lexicographic, stable
+    i1, i2 = node_img[a], node_img[b]
+    o = np.lexsort((np.arange(M), i2, i1))
+    a, b, i1, i2, sim, disp1, disp2 = a[o], b[o], i1[o], i2[o], sim[o], disp1[o], disp2[o]
+    key = i1 * n_images + i2
+    first = np.r_[True, key[1:] != key[:-1]] if M else np.zeros(0, bool)
+    starts = np.nonzero(first)[0]
+    pair_off = np.r_[starts, M].astype(np.int64)
+    names = ["%06d.png" % i for i in range(n_images)]
+    return MatchArrays(names, np.full(n_images, fact, np.float32),
+                       i1[starts].astype(np.int32), i2[starts].astype(np.int32), pair_off,
+                       node_feat[a].astype(np.uint32), node_feat[b].astype(np.uint32),
+                       sim, disp1, disp2)
+
+
+# named configurations of BASELINE.json / SURVEY.md §8(d)
+def config2():
+    """100k tracks, 64 images, mean length 6 (~3.4M directed edges)."""
+    return generate(seed=1, n_images=64, n_tracks=100_000)
+
+
+def config4(n_tracks=147_000, seed=2):
+    """Headline: 1344 images, ~5.0M directed edges."""
+    return generate(seed=seed, n_images=1344, n_tracks=n_tracks)
+
+
+def config5():
+    """Long-track stress: 96 images, L~U{48..96}, 2000 tracks, 2% wrong matches."""
+    return generate(seed=3, n_images=96, n_tracks=2000, len_dist="uniform", len_lo=48, len_hi=96,
+                    eps_out=0.02)
