@@ -1,0 +1,168 @@
+/* lfr.h — C ABI of liblfr_hip.so: MI355X-native multi-view keypoint-refinement solver.
+ *
+ * Drop-in scope: the reference's `solve` executable, multi-view-refinement/solve.cc:375-682
+ * (+ cost.cc, graph.{h,cc}).  The reference has no library API for this path — its only
+ * interface is the CLI + the two protobuf files (types.proto) — so the entry points below are
+ * the stages of that main(), cut where a host program (the `solve` launcher, bench.py, a
+ * cgo/ctypes binding) needs to hold data between them.  Each declaration cites the reference
+ * lines it replaces.  Plain C types only, caller-owned output buffers, int return codes
+ * (0 = ok, <0 = error, text via lfr_last_error()), no exceptions across the boundary.
+ *
+ * Units/axes: positions[2n] = di (row / y), positions[2n+1] = dj (col / x) of node n, in the
+ * solver's unit (16 px * fact at extraction resolution; colmap_utils.py:133-136).
+ */
+#ifndef LFR_H
+#define LFR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFR_VERSION 1
+
+/* error codes */
+#define LFR_OK 0
+#define LFR_ERR_ARG (-1)
+#define LFR_ERR_IO (-2)
+#define LFR_ERR_PARSE (-3)       /* "Failed to parse proto object."  solve.cc:433-436 */
+#define LFR_ERR_HIP (-4)
+#define LFR_ERR_UNSUPPORTED (-5)
+#define LFR_ERR_NOMEM (-6)
+
+/* Tukey loss flavour: Ceres changed TukeyLoss by a factor 2 between 1.14 and 2.0 and the
+ * reference pins no Ceres version (CMakeLists.txt:9). */
+#define LFR_TUKEY_CERES1 1
+#define LFR_TUKEY_CERES2 2
+
+/* termination types (ceres::TerminationType subset that ceres::Solve can return here) */
+#define LFR_TERM_CONVERGENCE 0
+#define LFR_TERM_NO_CONVERGENCE 1
+#define LFR_TERM_FAILURE 2
+
+typedef struct lfr_graph lfr_graph;       /* parsed match graph: nodes + directed edges (host) */
+typedef struct lfr_problem lfr_problem;   /* tracks, roots, components + device batch layout (host) */
+typedef struct lfr_batch lfr_batch;       /* a problem (or one shard of it) resident in HBM */
+
+int lfr_version(void);
+const char *lfr_last_error(void);          /* thread-local, valid until the next failing call */
+
+/* ---------------------------------------------------------------------------------------------
+ * A0/A3  MatchingFile ingest + graph construction.                    solve.cc:426-481, graph.cc
+ * ------------------------------------------------------------------------------------------- */
+
+/* Parse serialized MatchingFile(s) (types.proto:3-28) in the given order, skipping image pairs
+ * that touch a banned image (solve.cc:444-446).  Nodes are numbered in order of first
+ * appearance, node1 before node2 (solve.cc:474-475). */
+int lfr_graph_from_files(const char *const *paths, int n_paths, const char *const *banned, int n_banned,
+                         lfr_graph **out);
+
+/* Resolve `path`, or `path.part.0`, `path.part.1`, ... up to the first gap (solve.cc:416-424),
+ * then behave as lfr_graph_from_files. */
+int lfr_graph_from_matches_file(const char *path, const char *const *banned, int n_banned, lfr_graph **out);
+
+/* Same graph from flat arrays — the producer contract of compute_match_graph.py:163-187 without
+ * the protobuf hop.  pair_img1/2[p]: image index of ImagePair p; matches of pair p are
+ * [pair_off[p], pair_off[p+1]); disp1/disp2: n_matches x 18 float32 (grid_idx*2 + {di,dj}),
+ * disp2 = flow image1->image2, disp1 = flow image2->image1 (solve.cc:477-478). */
+int lfr_graph_from_arrays(int32_t n_images, const char *const *image_names, const float *image_facts,
+                          int64_t n_pairs, const int32_t *pair_img1, const int32_t *pair_img2,
+                          const int64_t *pair_off, const uint32_t *feat1, const uint32_t *feat2,
+                          const float *sim, const float *disp1, const float *disp2,
+                          const char *const *banned, int n_banned, lfr_graph **out);
+
+void lfr_graph_free(lfr_graph *g);
+int64_t lfr_graph_num_nodes(const lfr_graph *g);      /* "# graph nodes"  solve.cc:484 */
+int64_t lfr_graph_num_edges(const lfr_graph *g);      /* "# graph edges" = 2 x matches  solve.cc:485 */
+int32_t lfr_graph_num_images(const lfr_graph *g);     /* images_set.size()  solve.cc:448,450,586 */
+/* node_image[n] = index into the seen-image list; node_feature[n] = feature_idx */
+int lfr_graph_get_nodes(const lfr_graph *g, int32_t *node_image, uint32_t *node_feature);
+const char *lfr_graph_image_name(const lfr_graph *g, int32_t image);
+float lfr_graph_image_fact(const lfr_graph *g, int32_t image);
+
+/* Serialize a MatchingFile from flat arrays (native counterpart of compute_match_graph.py:163-205;
+ * used by the generators and by callers that want to keep the file hand-off). */
+int lfr_write_matching_file(const char *path, int32_t n_images, const char *const *image_names,
+                            const float *image_facts, int64_t n_pairs, const int32_t *pair_img1,
+                            const int32_t *pair_img2, const int64_t *pair_off, const uint32_t *feat1,
+                            const uint32_t *feat2, const float *sim, const float *disp1, const float *disp2);
+
+/* ---------------------------------------------------------------------------------------------
+ * A4-A7, A9, A11  tracks, roots, components, problem assembly.          solve.cc:487-606, 79-143
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lfr_problem_stats {
+    int64_t n_tracks;              /* "# tracks"            solve.cc:534 */
+    int64_t max_track_size;        /* "max track size"      solve.cc:549 */
+    int64_t n_components;          /* "# components"        solve.cc:591 */
+    int64_t max_component_size;    /* "max component size"  solve.cc:606 */
+    int64_t n_cut_components;      /* components above the cap that went through the graph cut */
+    int64_t n_solved_components;   /* components handed to the solver (>1 node, >=1 variable) */
+    int64_t n_solved_tracks;       /* tracks with >=2 nodes inside solved components */
+    int64_t n_solved_edges;        /* directed edges = residual blocks of the reduced programs */
+    int64_t n_solved_nodes;        /* nodes (variable + constant) inside solved components */
+    double tracks_ms, roots_ms, graph_cut_ms, assemble_ms;
+} lfr_problem_stats;
+
+/* max_nodes_in_component <= 0: use the number of seen images (solve.cc:586).
+ * component_override: NULL, or n_nodes component ids that replace separate_meta_graph()
+ * (solve.cc:586) — the side-car for exact parity with a reference run on inputs whose components
+ * exceeded the cap (Graclus' cut is not reproducible). */
+int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                      lfr_problem **out);
+void lfr_problem_free(lfr_problem *p);
+int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
+/* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */
+int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component);
+
+/* ---------------------------------------------------------------------------------------------
+ * A1, A2, A8, A10  batched Levenberg-Marquardt on the GPU.    solve.cc:79-160,614-635 + cost.cc
+ * ------------------------------------------------------------------------------------------- */
+typedef struct lfr_solve_stats {
+    int64_t n_components, n_edges, n_nodes, n_tracks;    /* of this batch/shard */
+    int64_t n_converged, n_no_convergence, n_failed;
+    int64_t sum_iterations;
+    int64_t ref_jacobian_passes_edges;   /* sum_c E_c * (jacobian evaluations Ceres performs)  */
+    int64_t ref_cost_passes_edges;       /* sum_c E_c * (cost-only evaluations Ceres performs) */
+    int64_t exec_passes_edges;           /* sum_c E_c * (edge sweeps the kernels executed)     */
+    int64_t ref_passes_nodes;            /* sum_c N_c * (all evaluations Ceres performs)       */
+    double sum_final_cost;
+    double kernel_ms;                    /* HIP-event time of the solve kernels, last solve */
+    double h2d_ms, d2h_ms;
+    double dominant_kernel_ms;           /* HIP-event time of the largest kernel launch */
+    int64_t dominant_kernel_edges;       /* edges processed by that launch */
+    int64_t dominant_kernel_nodes;
+    int64_t dominant_ref_passes_edges;   /* (jacobian + cost passes) * edges for that launch */
+    int64_t dominant_ref_passes_nodes;
+} lfr_solve_stats;
+
+/* Upload shard `shard_rank` of `shard_world` (components dealt largest-first to the least
+ * loaded shard, mirroring solve.cc:599-604) to HIP device `device`. */
+int lfr_batch_create(const lfr_problem *p, int device, int shard_rank, int shard_world, int tukey_variant,
+                     lfr_batch **out);
+void lfr_batch_free(lfr_batch *b);
+/* Run every solve kernel of the batch on `hip_stream` (a hipStream_t, NULL = default stream).
+ * Positions are reset to zero first (solve.cc:609-612).  Asynchronous unless stats != NULL, in
+ * which case the call synchronizes the stream and fills stats. */
+int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
+/* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written. */
+int lfr_batch_download(lfr_batch *b, double *positions);
+/* per solved component of the shard, in batch order: original component id, iterations,
+ * termination, final cost (any pointer may be NULL). Returns the count. */
+int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
+                                 double *final_cost, int32_t *n_var_nodes, int32_t *n_edges);
+
+/* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
+int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
+                  lfr_solve_stats *stats);
+
+/* ---------------------------------------------------------------------------------------------
+ * A12  SolutionFile emit.                                                     solve.cc:644-679
+ * ------------------------------------------------------------------------------------------- */
+/* Writes types.proto:30-46; returns through n_outside the count printed at solve.cc:666-670. */
+int lfr_write_solution(const lfr_graph *g, const double *positions, const char *path, int64_t *n_outside);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFR_H */

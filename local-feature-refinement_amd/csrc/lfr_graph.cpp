@@ -1,0 +1,433 @@
+// Graph stage of the solver path, host side (exact greedy semantics of the reference):
+//   tracks      solve.cc:489-549  constrained maximum spanning forest
+//   roots       solve.cc:552-582
+//   components  solve.cc:252-373  meta graph, connected components, size cap + (substitute) cut
+//   assembly    solve.cc:79-143   reduced programs -> 80-byte edge records in residual-block order
+// Image names are interned to integers at ingest: every use in the reference is an equality
+// test (std::set<std::string> intersection/union, solve.cc:493-519).
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <numeric>
+#include <queue>
+
+#include "lfr_internal.hpp"
+
+namespace lfr {
+
+static double ms_since(std::chrono::steady_clock::time_point t0) {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+
+static inline uint32_t sim_key(float s) {   // order-preserving float -> uint32 (as the double compare of solve.cc:489)
+    if (s == 0.f) s = 0.f;                   // -0.0 == +0.0
+    uint32_t b; memcpy(&b, &s, 4);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+struct SortKey { uint64_t hi; uint32_t lo; uint32_t m; };   // (sim, n1) | n2 | match id
+
+static inline int32_t uf_root(std::vector<int32_t> &parent, int32_t i) {
+    int32_t r = i;
+    while (parent[r] >= 0) r = parent[r];
+    while (parent[i] >= 0) { const int32_t nx = parent[i]; parent[i] = r; i = nx; }
+    return r;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Deterministic bisection used where the reference calls Graclus through COLMAP
+// (colmap::ComputeNormalizedMinGraphCut, solve.cc:192).  Graclus' multilevel kernel k-means is
+// third-party, heuristic and not reproducible, so results on inputs that need a cut are NOT
+// claimed to match the reference.  Method: maximum-adjacency region growing from
+// the smallest node id until half of the total edge-weight volume is absorbed, then one pass of
+// boundary refinement on the normalized-cut objective.
+// ----------------------------------------------------------------------------------------------
+void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
+                  std::unordered_map<int, int> &part) {
+    part.clear();
+    std::vector<int> ids;
+    for (auto &e : edges) { ids.push_back(e.first); ids.push_back(e.second); }
+    std::sort(ids.begin(), ids.end());
+    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const int n = (int)ids.size();
+    if (n == 0) return;
+    auto local = [&](int id) { return (int)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
+    std::vector<std::vector<std::pair<int, double>>> adj(n);
+    std::vector<double> deg(n, 0.0);
+    double volume = 0.0;
+    for (size_t k = 0; k < edges.size(); ++k) {
+        const int a = local(edges[k].first), b = local(edges[k].second);
+        const double w = (double)std::max(weights[k], 1);
+        adj[a].push_back({b, w}); adj[b].push_back({a, w});
+        deg[a] += w; deg[b] += w; volume += 2 * w;
+    }
+    std::vector<int> side(n, 1);
+    std::vector<double> attach(n, 0.0);
+    std::vector<char> in(n, 0);
+    double vol0 = 0.0;
+    int n0 = 0;
+    // region growing (ties -> smallest id); restart from the smallest unvisited id if the
+    // frontier empties (disconnected input)
+    while (vol0 * 2 < volume && n0 < n - 1) {
+        int best = -1;
+        for (int i = 0; i < n; ++i)
+            if (!in[i] && (best < 0 || attach[i] > attach[best])) best = i;
+        if (best < 0) break;
+        in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
+        for (auto &nb : adj[best]) attach[nb.first] += nb.second;
+    }
+    // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
+    double cut = 0.0;
+    for (int i = 0; i < n; ++i) for (auto &nb : adj[i]) if (side[i] == 0 && side[nb.first] == 1) cut += nb.second;
+    auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
+    for (int i = 0; i < n; ++i) {
+        double to_same = 0.0, to_other = 0.0;
+        for (auto &nb : adj[i]) (side[nb.first] == side[i] ? to_same : to_other) += nb.second;
+        const double ncut_now = ncut(cut, vol0);
+        const double c2 = cut + to_same - to_other;
+        const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
+        const int cnt0 = side[i] == 0 ? n0 - 1 : n0 + 1;
+        if (cnt0 <= 0 || cnt0 >= n) continue;
+        if (ncut(c2, v2) < ncut_now) { side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; }
+    }
+    for (int i = 0; i < n; ++i) part[ids[i]] = side[i];
+}
+
+// recursive_graph_cut of solve.cc:185-250 with bisect_graph in place of Graclus
+static std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
+                                                  const std::vector<int> &weights,
+                                                  const std::vector<int64_t> &node_weights, int64_t max_weight) {
+    std::unordered_map<int, int> split;
+    bisect_graph(edges, weights, split);
+    int64_t subset_w[2] = {0, 0};
+    std::vector<int> members[2];
+    {
+        std::vector<int> keys;
+        for (auto &it : split) keys.push_back(it.first);
+        std::sort(keys.begin(), keys.end());
+        for (int k : keys) { subset_w[split[k]] += node_weights[k]; members[split[k]].push_back(k); }
+    }
+    int max_idx = 0;
+    std::unordered_map<int, int> final_map;
+    for (int s = 0; s < 2; ++s) {
+        if (subset_w[s] <= max_weight) {
+            for (int k : members[s]) final_map.emplace(k, max_idx);
+            ++max_idx;
+            continue;
+        }
+        std::vector<std::pair<int, int>> sub_e;
+        std::vector<int> sub_w;
+        for (size_t k = 0; k < edges.size(); ++k)
+            if (split[edges[k].first] == s && split[edges[k].second] == s) { sub_e.push_back(edges[k]); sub_w.push_back(weights[k]); }
+        if (!sub_e.empty()) {
+            auto sub = recursive_cut(sub_e, sub_w, node_weights, max_weight);
+            int new_max = max_idx;
+            for (auto &it : sub) { final_map.emplace(it.first, max_idx + it.second); new_max = std::max(new_max, max_idx + it.second); }
+            max_idx = new_max + 1;
+        }
+        for (int k : members[s]) if (!final_map.count(k)) { final_map.emplace(k, max_idx); ++max_idx; }
+    }
+    return final_map;
+}
+
+static int classify(int rows, int64_t n_edges) {
+    if (rows <= 16 && n_edges <= 64) return KC_W16_1;
+    if (rows <= 16 && n_edges <= 128) return KC_W16_2;
+    if (rows <= 32 && n_edges <= 128) return KC_W32_2;
+    if (rows <= 32 && n_edges <= 256) return KC_W32_4;
+    if (rows <= kBlockMaxRows) return KC_BLOCK;
+    return KC_GLOBAL;
+}
+
+int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p) {
+    using clock = std::chrono::steady_clock;
+    p.g = &g;
+    const int64_t N = g.n_nodes(), M = g.n_matches();
+    p.track.assign(N, -1); p.comp.assign(N, -1); p.is_root.assign(N, 0);
+    p.stats = lfr_problem_stats{};
+    if (N == 0) return LFR_OK;
+    if (N >= (int64_t)1 << 31) { set_error("more than 2^31 nodes"); return LFR_ERR_UNSUPPORTED; }
+    if (max_nodes <= 0) max_nodes = (int64_t)g.image_names.size();          // solve.cc:586
+
+    // ------------------------------------------------------------------ tracks (solve.cc:489-541)
+    auto t0 = clock::now();
+    std::vector<SortKey> keys(M);
+    for (int64_t m = 0; m < M; ++m)
+        keys[m] = SortKey{((uint64_t)sim_key(g.m_sim[m]) << 32) | g.m_node1[m], g.m_node2[m], (uint32_t)m};
+    std::sort(keys.begin(), keys.end(), [](const SortKey &a, const SortKey &b) {   // descending (sort + reverse)
+        if (a.hi != b.hi) return a.hi > b.hi;
+        return a.lo > b.lo;
+    });
+    std::vector<int32_t> parent(N, -1), next(N, -1), tail(N), count(N, 1);
+    std::vector<int64_t> stamp(g.image_names.size(), -1);
+    for (int64_t i = 0; i < N; ++i) tail[i] = (int32_t)i;
+    for (int64_t k = 0; k < M; ++k) {
+        const int32_t r1 = uf_root(parent, (int32_t)(keys[k].hi & 0xffffffffu));
+        const int32_t r2 = uf_root(parent, (int32_t)keys[k].lo);
+        if (r1 == r2) continue;
+        // images_in_track[root] == images of the member nodes (all distinct by construction)
+        bool conflict = false;
+        for (int32_t i = r1; i >= 0; i = next[i]) stamp[g.node_image[i]] = k;
+        for (int32_t i = r2; i >= 0; i = next[i]) if (stamp[g.node_image[i]] == k) { conflict = true; break; }
+        if (conflict) continue;                                              // solve.cc:509-511
+        int32_t big = r1, small = r2;
+        if (count[r1] < count[r2]) { big = r2; small = r1; }                  // solve.cc:513-521
+        parent[small] = big;
+        next[tail[big]] = small; tail[big] = tail[small]; count[big] += count[small];
+    }
+    std::vector<SortKey>().swap(keys);
+    int64_t n_tracks = 0;
+    for (int64_t i = 0; i < N; ++i) if (parent[i] < 0) p.track[i] = n_tracks++;       // solve.cc:528-533
+    for (int64_t i = 0; i < N; ++i) if (p.track[i] < 0) p.track[i] = p.track[uf_root(parent, (int32_t)i)];
+    std::vector<int64_t> tsize(n_tracks, 0);
+    for (int64_t i = 0; i < N; ++i) ++tsize[p.track[i]];
+    p.stats.n_tracks = n_tracks;
+    p.stats.max_track_size = *std::max_element(tsize.begin(), tsize.end());
+    p.stats.tracks_ms = ms_since(t0);
+
+    // ------------------------------------------------------------------ roots (solve.cc:552-582)
+    t0 = clock::now();
+    {
+        std::vector<double> score(N, 0.0);
+        for (int64_t m = 0; m < M; ++m) {            // per node: out-edges in insertion order
+            const uint32_t a = g.m_node1[m], b = g.m_node2[m];
+            if (p.track[a] == p.track[b]) { score[a] += (double)g.m_sim[m]; score[b] += (double)g.m_sim[m]; }
+        }
+        std::vector<int64_t> best(n_tracks, -1);
+        for (int64_t i = 0; i < N; ++i) {            // max (score, node_idx): ties -> larger node idx
+            int64_t &b = best[p.track[i]];
+            if (b < 0 || score[i] >= score[b]) b = i;
+        }
+        for (int64_t t = 0; t < n_tracks; ++t) p.is_root[best[t]] = 1;
+    }
+    p.stats.roots_ms = ms_since(t0);
+
+    // out-edge CSR: directed edge ids ascending per source node == insertion order
+    std::vector<int64_t> out_off(N + 1, 0);
+    for (int64_t m = 0; m < M; ++m) { ++out_off[g.m_node1[m] + 1]; ++out_off[g.m_node2[m] + 1]; }
+    for (int64_t i = 0; i < N; ++i) out_off[i + 1] += out_off[i];
+    std::vector<int64_t> out_eid(2 * M);
+    {
+        std::vector<int64_t> cur(out_off.begin(), out_off.end() - 1);
+        for (int64_t m = 0; m < M; ++m) { out_eid[cur[g.m_node1[m]]++] = 2 * m; out_eid[cur[g.m_node2[m]]++] = 2 * m + 1; }
+    }
+    auto edge_dst = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node1[e >> 1] : g.m_node2[e >> 1]; };
+
+    // ------------------------------------------------------------------ components (solve.cc:252-373)
+    t0 = clock::now();
+    int64_t n_components = 0;
+    if (component_override) {
+        for (int64_t i = 0; i < N; ++i) {
+            if (component_override[i] < 0) { set_error("negative component id in override"); return LFR_ERR_ARG; }
+            p.comp[i] = component_override[i];
+            n_components = std::max(n_components, p.comp[i] + 1);
+        }
+    } else {
+        std::vector<int32_t> mp(n_tracks, -1);
+        for (int64_t m = 0; m < M; ++m) {
+            const int64_t ta = p.track[g.m_node1[m]], tb = p.track[g.m_node2[m]];
+            if (ta == tb) continue;
+            const int32_t ra = uf_root(mp, (int32_t)ta), rb = uf_root(mp, (int32_t)tb);
+            if (ra != rb) mp[std::max(ra, rb)] = std::min(ra, rb);
+        }
+        std::vector<int64_t> label(n_tracks, -1);
+        int64_t nc = 0;
+        for (int64_t t = 0; t < n_tracks; ++t) {      // BFS labelling order of solve.cc:292-300
+            const int32_t r = uf_root(mp, (int32_t)t);
+            if (label[r] < 0) label[r] = nc++;
+            label[t] = label[r];
+        }
+        std::vector<int64_t> csize(nc, 0);
+        for (int64_t t = 0; t < n_tracks; ++t) csize[label[t]] += tsize[t];
+        bool any_over = false;
+        for (int64_t c = 0; c < nc; ++c) if (csize[c] > max_nodes) { any_over = true; ++p.stats.n_cut_components; }
+        std::vector<int64_t> final_label = label;
+        int64_t n_final = nc;
+        if (any_over) {
+            // meta edges of the oversized components (solve.cc:268-289, 322-332)
+            std::vector<std::unordered_map<int64_t, double>> meta(n_tracks);
+            for (int64_t i = 0; i < N; ++i) {
+                const int64_t ts = p.track[i];
+                if (csize[label[ts]] <= max_nodes) continue;
+                for (int64_t k = out_off[i]; k < out_off[i + 1]; ++k) {
+                    const int64_t e = out_eid[k], tt = p.track[edge_dst(e)];
+                    if (tt != ts) meta[ts][tt] += (double)g.m_sim[e >> 1];
+                }
+            }
+            std::vector<std::vector<int64_t>> members(nc);
+            for (int64_t t = 0; t < n_tracks; ++t) if (csize[label[t]] > max_nodes) members[label[t]].push_back(t);
+            std::vector<int64_t> gc(n_tracks, 0);
+            int64_t ngc = 0;
+            for (int64_t c = 0; c < nc; ++c) {
+                if (csize[c] <= max_nodes) { ++ngc; continue; }      // ids only need to differ between components
+                std::vector<std::pair<int, int>> e; std::vector<int> w;
+                for (int64_t t : members[c]) {
+                    std::vector<std::pair<int64_t, double>> nb(meta[t].begin(), meta[t].end());
+                    std::sort(nb.begin(), nb.end());
+                    for (auto &it : nb) if (t < it.first) { e.push_back({(int)t, (int)it.first}); w.push_back(static_cast<int>(100 * it.second)); }
+                }
+                auto split = recursive_cut(e, w, tsize, max_nodes);
+                int64_t top = 0;
+                for (auto &it : split) { gc[it.first] = ngc + it.second; top = std::max(top, gc[it.first]); }
+                ngc = top + 1;
+            }
+            // drop cut meta edges, re-split (solve.cc:345-364): union-find restricted to kept edges
+            std::vector<int32_t> mp2(n_tracks, -1);
+            for (int64_t m = 0; m < M; ++m) {
+                const int64_t ta = p.track[g.m_node1[m]], tb = p.track[g.m_node2[m]];
+                if (ta == tb) continue;
+                const bool over = csize[label[ta]] > max_nodes;
+                if (over && gc[ta] != gc[tb]) continue;
+                const int32_t ra = uf_root(mp2, (int32_t)ta), rb = uf_root(mp2, (int32_t)tb);
+                if (ra != rb) mp2[std::max(ra, rb)] = std::min(ra, rb);
+            }
+            std::fill(final_label.begin(), final_label.end(), -1);
+            n_final = 0;
+            for (int64_t t = 0; t < n_tracks; ++t) {
+                const int32_t r = uf_root(mp2, (int32_t)t);
+                if (final_label[r] < 0) final_label[r] = n_final++;
+                final_label[t] = final_label[r];
+            }
+        }
+        for (int64_t i = 0; i < N; ++i) p.comp[i] = final_label[p.track[i]];
+        n_components = n_final;
+    }
+    p.stats.n_components = n_components;
+    p.stats.graph_cut_ms = ms_since(t0);
+
+    // ------------------------------------------------------------------ assembly (solve.cc:594-606, 94-143)
+    t0 = clock::now();
+    std::vector<int64_t> comp_off(n_components + 1, 0);
+    for (int64_t i = 0; i < N; ++i) ++comp_off[p.comp[i] + 1];
+    for (int64_t c = 0; c < n_components; ++c) {
+        p.stats.max_component_size = std::max(p.stats.max_component_size, comp_off[c + 1]);
+        comp_off[c + 1] += comp_off[c];
+    }
+    std::vector<int64_t> comp_nodes(N);
+    {
+        std::vector<int64_t> cur(comp_off.begin(), comp_off.end() - 1);
+        for (int64_t i = 0; i < N; ++i) comp_nodes[cur[p.comp[i]]++] = i;      // ascending node idx
+    }
+    // pass 1: which nodes are variables, how many edges are kept
+    std::vector<uint8_t> is_var(N, 0);
+    struct Meta { int64_t comp; int64_t n_edges; int32_t n_var, n_nodes, cls, n_tracks; };
+    std::vector<Meta> metas;
+    std::vector<int64_t> seen_track(n_tracks, -1);
+    for (int64_t c = 0; c < n_components; ++c) {
+        const int64_t lo = comp_off[c], hi = comp_off[c + 1];
+        if (hi - lo <= 1) continue;                                           // solve.cc:619-622
+        int32_t n_var = 0;
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t n = comp_nodes[k];
+            bool opt = false;
+            for (int64_t q = out_off[n]; q < out_off[n + 1] && !opt; ++q) {
+                const uint32_t d = edge_dst(out_eid[q]);
+                opt = p.track[n] == p.track[d] || p.comp[n] == p.comp[d];       // solve.cc:105,114,127
+            }
+            if (opt && !p.is_root[n]) { is_var[n] = 1; ++n_var; }               // solve.cc:133-141
+        }
+        if (n_var == 0) continue;                     // "No non-constant parameter blocks": nothing moves
+        int64_t n_edges = 0;
+        int32_t n_tr = 0;
+        for (int64_t k = lo; k < hi; ++k) {
+            const int64_t n = comp_nodes[k];
+            if (tsize[p.track[n]] >= 2 && seen_track[p.track[n]] != c) { seen_track[p.track[n]] = c; ++n_tr; }
+            for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
+                const uint32_t d = edge_dst(out_eid[q]);
+                if (!(p.track[n] == p.track[d] || p.comp[n] == p.comp[d])) continue;
+                if (!is_var[n] && !is_var[d]) continue;       // both constant: not in the reduced program
+                ++n_edges;
+            }
+        }
+        if (hi - lo > 32767) { set_error("component with %lld nodes exceeds the 32767-node batch limit", (long long)(hi - lo)); return LFR_ERR_UNSUPPORTED; }
+        metas.push_back(Meta{c, n_edges, n_var, (int32_t)(hi - lo), classify(2 * n_var, n_edges), n_tr});
+    }
+    std::stable_sort(metas.begin(), metas.end(), [](const Meta &a, const Meta &b) {
+        if (a.cls != b.cls) return a.cls < b.cls;
+        if (a.n_edges != b.n_edges) return a.n_edges > b.n_edges;
+        return a.n_var > b.n_var;
+    });
+    int64_t total_edges = 0, total_nodes = 0;
+    for (auto &m : metas) { total_edges += m.n_edges; total_nodes += m.n_nodes; }
+    if (total_edges >= ((int64_t)1 << 32) || total_nodes >= ((int64_t)1 << 32)) { set_error("batch exceeds 2^32 edges/nodes"); return LFR_ERR_UNSUPPORTED; }
+    p.descs.resize(metas.size()); p.desc_component.resize(metas.size()); p.desc_class.resize(metas.size());
+    p.desc_tracks.resize(metas.size());
+    p.edges.resize(total_edges); p.node_ids.resize(total_nodes);
+    std::vector<int32_t> local_of(N, -1);
+    int64_t eo = 0, no = 0;
+    for (size_t di = 0; di < metas.size(); ++di) {
+        const Meta &mt = metas[di];
+        const int64_t lo = comp_off[mt.comp], hi = comp_off[mt.comp + 1];
+        int32_t nv = 0, nc2 = mt.n_var;
+        for (int64_t k = lo; k < hi; ++k) {           // variable nodes first, then constants
+            const int64_t n = comp_nodes[k];
+            const int32_t l = is_var[n] ? nv++ : nc2++;
+            local_of[n] = l;
+            p.node_ids[no + l] = (uint32_t)n;
+        }
+        CompDesc &d = p.descs[di];
+        d.edge_off = (uint32_t)eo; d.n_edges = (uint32_t)mt.n_edges; d.node_off = (uint32_t)no;
+        d.n_nodes = (uint16_t)mt.n_nodes; d.n_var = (uint16_t)mt.n_var;
+        p.desc_component[di] = mt.comp; p.desc_class[di] = mt.cls; p.desc_tracks[di] = mt.n_tracks;
+        for (int64_t k = lo; k < hi; ++k) {           // residual-block order of solve.cc:98-102
+            const int64_t n = comp_nodes[k];
+            for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
+                const int64_t e = out_eid[q];
+                const uint32_t dn = edge_dst(e);
+                int kind;
+                if (p.track[n] == p.track[dn]) kind = 0;
+                else if (p.comp[n] == p.comp[dn]) kind = 1;
+                else continue;
+                if (!is_var[n] && !is_var[dn]) continue;
+                EdgeRec &r = p.edges[eo++];
+                const float *fl = ((e & 1) ? g.m_disp1.data() : g.m_disp2.data()) + 18 * (e >> 1);
+                memcpy(r.flow, fl, sizeof r.flow);
+                r.sim = g.m_sim[e >> 1];
+                r.src = (uint16_t)local_of[n];
+                r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
+            }
+        }
+        no += mt.n_nodes;
+        p.stats.n_solved_tracks += mt.n_tracks;
+    }
+    p.stats.n_solved_components = (int64_t)metas.size();
+    p.stats.n_solved_edges = total_edges;
+    p.stats.n_solved_nodes = total_nodes;
+    p.stats.assemble_ms = ms_since(t0);
+    return LFR_OK;
+}
+
+}  // namespace lfr
+
+using namespace lfr;
+
+extern "C" {
+
+int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                      lfr_problem **out) {
+    if (!g || !out) { set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr_problem *h = new lfr_problem();
+    const int rc = build_problem(g->g, max_nodes_in_component, component_override, h->p);
+    if (rc != LFR_OK) { delete h; *out = nullptr; return rc; }
+    *out = h;
+    return LFR_OK;
+}
+
+void lfr_problem_free(lfr_problem *p) { delete p; }
+
+int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats) {
+    if (!p || !stats) return LFR_ERR_ARG;
+    *stats = p->p.stats;
+    return LFR_OK;
+}
+
+int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component) {
+    if (!p) return LFR_ERR_ARG;
+    const size_t n = p->p.track.size();
+    if (track && n) memcpy(track, p->p.track.data(), sizeof(int64_t) * n);
+    if (is_root && n) memcpy(is_root, p->p.is_root.data(), n);
+    if (component && n) memcpy(component, p->p.comp.data(), sizeof(int64_t) * n);
+    return LFR_OK;
+}
+
+}  // extern "C"

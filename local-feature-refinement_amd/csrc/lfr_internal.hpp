@@ -1,0 +1,102 @@
+// Internal data model of liblfr_hip.so (not part of the C ABI; see include/lfr.h).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "lfr.h"
+
+namespace lfr {
+
+void set_error(const char *fmt, ...);
+
+// ------------------------------------------------------------------------------------------
+// Match graph (solve.cc:405-481).  Directed edge 2m   = node1(m) -> node2(m), flow disp2(m);
+//                                  directed edge 2m+1 = node2(m) -> node1(m), flow disp1(m)
+// (solve.cc:477-478).  A node's out-edges in the reference's insertion order are exactly its
+// directed edges in ascending id.
+// ------------------------------------------------------------------------------------------
+struct Graph {
+    std::vector<std::string> image_names;      // seen (non-banned) images, order of first appearance
+    std::vector<float> image_fact;             // first-wins (solve.cc:449,451)
+    std::unordered_map<std::string, int32_t> image_index;
+    std::vector<uint32_t> m_node1, m_node2;    // per match
+    std::vector<float> m_sim;
+    std::vector<float> m_disp1, m_disp2;       // 18 floats per match, zero padded (solve.cc:460-472)
+    std::vector<int32_t> node_image;
+    std::vector<uint32_t> node_feat;
+
+    // open-addressing (image, feature) -> node map, used only while building
+    std::vector<uint64_t> hkeys;
+    std::vector<int64_t> hvals;
+    uint64_t hmask = 0;
+    int64_t hcount = 0;
+
+    int64_t n_nodes() const { return (int64_t)node_image.size(); }
+    int64_t n_matches() const { return (int64_t)m_sim.size(); }
+    int32_t intern_image(const std::string &name, float fact);
+    uint32_t find_or_create_node(int32_t image, uint32_t feature);
+    void add_match(int32_t img1, int32_t img2, uint32_t f1, uint32_t f2, float sim, const float *d1, int n1,
+                   const float *d2, int n2);
+    void finish();   // drop the hash map
+};
+
+// ------------------------------------------------------------------------------------------
+// Device batch layout (host copy).  One 80-byte record per kept directed edge, components
+// contiguous, records in the reference's residual-block order (solve.cc:98-102).
+// ------------------------------------------------------------------------------------------
+struct alignas(16) EdgeRec {
+    float flow[18];      // grid_idx*2 + {di,dj}
+    float sim;           // ScaledLoss weight (solve.cc:111,120)
+    uint16_t src;        // local node index inside the component (variable nodes first)
+    uint16_t dst_kind;   // bit 15: 1 = inter-track (Tukey), 0 = intra-track (Cauchy); bits 0-14: local dst
+};
+static_assert(sizeof(EdgeRec) == 80, "EdgeRec must be 80 bytes");
+
+struct CompDesc {
+    uint32_t edge_off;       // first EdgeRec
+    uint32_t n_edges;
+    uint32_t node_off;       // into node_ids
+    uint16_t n_nodes;        // variable + constant
+    uint16_t n_var;          // variable nodes (local indices [0, n_var))
+};
+static_assert(sizeof(CompDesc) == 16, "CompDesc must be 16 bytes");
+
+// kernel classes
+enum KernelClass : int {
+    KC_W16_1 = 0,   // wave per component, <=16 rows, <=64 edges
+    KC_W16_2,       // <=16 rows, <=128 edges
+    KC_W32_2,       // <=32 rows, <=128 edges
+    KC_W32_4,       // <=32 rows, <=256 edges
+    KC_BLOCK,       // workgroup per component, normal matrix in LDS
+    KC_GLOBAL,      // workgroup per component, normal matrix in HBM workspace
+    KC_COUNT
+};
+constexpr int kBlockMaxRows = 176;   // packed lower triangle 176*177/2*8 B = 124.6 KB of LDS
+
+struct Problem {
+    const Graph *g = nullptr;
+    std::vector<int64_t> track, comp;      // per node
+    std::vector<uint8_t> is_root;
+    lfr_problem_stats stats{};
+    // batch (all solvable components, sorted by kernel class then size descending)
+    std::vector<CompDesc> descs;
+    std::vector<int64_t> desc_component;   // original component id per desc
+    std::vector<int32_t> desc_class;
+    std::vector<int32_t> desc_tracks;      // tracks (>=2 nodes) inside
+    std::vector<EdgeRec> edges;
+    std::vector<uint32_t> node_ids;        // global node id per local slot
+};
+
+int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p);
+
+// deterministic substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
+// (solve.cc:192): returns part (0/1) per node id appearing in `edges`.
+void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
+                  std::unordered_map<int, int> &part);
+
+}  // namespace lfr
+
+struct lfr_graph { lfr::Graph g; };
+struct lfr_problem { lfr::Problem p; };

@@ -1,0 +1,906 @@
+// Batched per-component Levenberg-Marquardt on MI355X (gfx950) — replaces the hot loop of the
+// reference, solve.cc:614-635 -> create_and_solve_problem (solve.cc:79-160) -> ceres::Solve,
+// with the cost model of cost.cc:13-48,78-90.  Control flow mirrors Ceres' trust-region loop
+// decision for decision; fp64 throughout; no MFMA (2N-variable blocks are tiny).
+//
+// Kernel classes:
+//   solve_wave_kernel<NV,EPL>  one wave64 per component; edges live in VGPRs for the whole solve
+//                              (HBM is read exactly once), J^T J assembled in LDS by ds_add_f64,
+//                              damped system solved in registers (lane = row) with v_readlane
+//                              broadcasts.  No barriers: a wave is its own synchronisation domain.
+//   solve_block_kernel         one workgroup per component; packed J^T J in LDS (<=176 rows) or in
+//                              an HBM workspace (GLOBAL variant); edges re-streamed from L2/HBM
+//                              per pass.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "lfr_device.hpp"
+#include "lfr_internal.hpp"
+
+using namespace lfrdev;
+using lfr::CompDesc;
+using lfr::EdgeRec;
+
+namespace {
+
+struct CompInfoDev {
+    int32_t iterations, termination, n_successful, n_ls_evals, n_cand_evals, exec_passes;
+    double final_cost;
+};
+static_assert(sizeof(CompInfoDev) == 32, "CompInfoDev layout");
+
+struct KernelArgs {
+    const CompDesc *descs;
+    const EdgeRec *edges;
+    const uint32_t *node_ids;
+    double *positions;          // 2 * n_nodes of the whole graph
+    CompInfoDev *infos;
+    double *workspace;          // GLOBAL class: packed matrices
+    const uint64_t *ws_off;     // per desc (GLOBAL class only)
+    int desc_begin, desc_end;
+    int tukey_variant;
+};
+
+// =============================================================================================
+// wave-per-component kernel
+// =============================================================================================
+template <int NV>
+struct WaveLds {
+    static constexpr int LD = NV + 1;                 // odd leading dimension: conflict-free column walks
+    double A[2][NV * LD];                             // J^T J (lower triangle) at x / at the trial point
+    double g[2][NV];                                  // J^T r
+    double x[2][NV + 2];                              // x / trial point; slot 2*n_var.. = 0 (constants)
+};
+
+template <int NV, int EPL>
+__global__ __launch_bounds__(256) void solve_wave_kernel(const KernelArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int ci = a.desc_begin + (int)blockIdx.x * 4 + wave;
+    __shared__ WaveLds<NV> lds_all[4];
+    if (ci >= a.desc_end) return;                     // wave-uniform; no block-level barriers below
+    WaveLds<NV> &L = lds_all[wave];
+    constexpr int LD = WaveLds<NV>::LD;
+
+    const CompDesc d = a.descs[ci];
+    const int n_var = d.n_var, nv2 = 2 * n_var, E = (int)d.n_edges;
+    const int tv = a.tukey_variant;
+
+    // ---- edges -> registers (the only HBM read of the solve: 80 B per edge) ----
+    float flow[EPL][18];
+    float sim[EPL];
+    int xs_src[EPL], xs_dst[EPL], row_src[EPL], row_dst[EPL], kind[EPL];
+    bool act[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int e = lane + 64 * k;
+        act[k] = e < E;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (act[k] ? e : 0));
+        uint4 q[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = act[k] ? rp[i] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            flow[k][4 * i] = __uint_as_float(q[i].x); flow[k][4 * i + 1] = __uint_as_float(q[i].y);
+            flow[k][4 * i + 2] = __uint_as_float(q[i].z); flow[k][4 * i + 3] = __uint_as_float(q[i].w);
+        }
+        flow[k][16] = __uint_as_float(q[4].x); flow[k][17] = __uint_as_float(q[4].y);
+        sim[k] = __uint_as_float(q[4].z);
+        const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
+        const int dn = dk & 0x7fff;
+        kind[k] = dk >> 15;
+        row_src[k] = s < n_var ? 2 * s : -1;
+        row_dst[k] = dn < n_var ? 2 * dn : -1;
+        xs_src[k] = s < n_var ? 2 * s : nv2;          // constants read the zero slot
+        xs_dst[k] = dn < n_var ? 2 * dn : nv2;
+    }
+    if (lane < NV + 2) { L.x[0][lane] = 0.0; L.x[1][lane] = 0.0; }
+
+    // ---- one sweep over the component's edges at L.x[xb]: cost, J^T J -> L.A[ab], J^T r -> L.g[ab]
+    auto evaluate = [&](int xb, int ab) -> double {
+        for (int i = lane; i < NV * LD; i += 64) L.A[ab][i] = 0.0;
+        if (lane < NV) L.g[ab][lane] = 0.0;
+        wave_lds_sync();
+        double cost = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            if (!act[k]) continue;
+            EdgeOut o;
+            eval_edge<true>(flow[k], sim[k], kind[k], tv, L.x[xb][xs_src[k]], L.x[xb][xs_src[k] + 1],
+                            L.x[xb][xs_dst[k]], L.x[xb][xs_dst[k] + 1], o);
+            cost += o.cost;
+            double *A = L.A[ab], *g = L.g[ab];
+            const int ra = row_src[k], rb = row_dst[k];
+            if (ra >= 0) {
+                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10);
+                atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
+                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11);
+                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1);
+                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
+            }
+            if (rb >= 0) {
+                atomicAdd(&A[rb * LD + rb], o.sq * o.sq);
+                atomicAdd(&A[(rb + 1) * LD + rb + 1], o.sq * o.sq);
+                atomicAdd(&g[rb], o.sq * o.r0);
+                atomicAdd(&g[rb + 1], o.sq * o.r1);
+            }
+            if (ra >= 0 && rb >= 0) {
+                if (rb > ra) {
+                    atomicAdd(&A[rb * LD + ra], o.sq * o.j00);
+                    atomicAdd(&A[rb * LD + ra + 1], o.sq * o.j01);
+                    atomicAdd(&A[(rb + 1) * LD + ra], o.sq * o.j10);
+                    atomicAdd(&A[(rb + 1) * LD + ra + 1], o.sq * o.j11);
+                } else {
+                    atomicAdd(&A[ra * LD + rb], o.j00 * o.sq);
+                    atomicAdd(&A[ra * LD + rb + 1], o.j10 * o.sq);
+                    atomicAdd(&A[(ra + 1) * LD + rb], o.j01 * o.sq);
+                    atomicAdd(&A[(ra + 1) * LD + rb + 1], o.j11 * o.sq);
+                }
+            }
+        }
+        wave_lds_sync();
+        return wave_sum(cost);
+    };
+
+    // ---- iteration 0 (TrustRegionMinimizer::IterationZero) ----
+    int cur = 0;                                      // L.A[cur], L.g[cur], L.x[cur] belong to x
+    int exec_passes = 1;
+    double cost = evaluate(0, 0);
+    const bool is_row = lane < nv2;
+    double xi = 0.0;                                  // lane i: x_i
+    double gi = is_row ? L.g[0][lane] : 0.0;
+    const double scale = is_row ? 1.0 / (1.0 + sqrt(L.A[0][lane * LD + lane])) : 1.0;   // jacobi scaling, once
+    double gmax = wave_max(is_row ? fabs(xi - clampb(xi - gi)) : 0.0);
+    double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0, diag = 1.0;
+    bool reuse_diagonal = false, step_successful = true;
+    int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
+    int n_successful = 0, n_ls_evals = 0, n_cand = 0;
+
+    for (;;) {
+        if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; break; }
+        if (step_successful && gmax <= kGradientTol) break;
+        if (radius <= kMinRadius) break;
+        ++iteration;
+        step_successful = false;
+
+        // ---- LevenbergMarquardtStrategy::ComputeStep: (S A S + D^2) y = S g, step = -y ----
+        const double *A = L.A[cur];
+        const double aii = is_row ? A[lane * LD + lane] : 1.0;
+        if (!reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
+        const double Dl = sqrt(diag / radius);
+        reuse_diagonal = true;
+        double h[NV];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const double sj = readlane_f64(scale, j);
+            double v = 0.0;
+            if (is_row && j < nv2) v = (j <= lane ? A[lane * LD + j] : A[j * LD + lane]) * scale * sj;
+            if (j == lane) v = is_row ? v + Dl * Dl : 1.0;
+            h[j] = v;
+        }
+        double rhs = is_row ? scale * gi : 0.0;
+        const double rhs0 = rhs;
+        double piv_own = 1.0;
+        bool fail = false;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {               // Gauss-Jordan, no pivoting (SPD)
+            if (k < nv2) {
+                const double piv = readlane_f64(h[k], k);
+                if (!(piv > 0.0)) fail = true;
+                const double inv = 1.0 / piv;
+                const double f = (lane == k) ? 0.0 : h[k] * inv;
+                if (lane == k) piv_own = piv;
+#pragma unroll
+                for (int j = k + 1; j < NV; ++j) h[j] -= f * readlane_f64(h[j], k);
+                rhs -= f * readlane_f64(rhs, k);
+            }
+        }
+        const double step = is_row ? -(rhs / piv_own) : 0.0;
+        bool valid = !fail && !__any(is_row && !isfinite(step));
+        double model_cost_change = 0.0;
+        if (valid) {
+            // -(J s)^T (r + J s / 2) == 1/2 * sum_i (-(S g)_i s_i + D_i^2 s_i^2)  since (S A S + D^2) s = -S g
+            model_cost_change = 0.5 * wave_sum(is_row ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
+            valid = model_cost_change > 0.0;
+        }
+        if (!valid) {
+            if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
+            radius = radius / decrease_factor;       // StepIsInvalid -> StepRejected(0)
+            decrease_factor *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double delta = step * scale;
+
+        // ---- projected Armijo line search along delta (bounds-constrained problem) ----
+        const double g_dot_delta = wave_sum(gi * delta);
+        const double dir_max = wave_max(fabs(delta));
+        const int nxt = cur ^ 1;
+        double alpha = 1.0, cost_c = 0.0, xt = 0.0;
+        bool ls_ok = false;
+        {
+            LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
+            int n_iter = 0;
+            for (;;) {
+                // trial point: product and sum rounded separately, exactly like the candidate below
+                xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
+                if (is_row) L.x[nxt][lane] = xt;
+                cost_c = evaluate(nxt, nxt);
+                ++exec_passes; ++n_ls_evals;
+                current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
+                current.gradient = 0.0; current.gradient_valid = false;
+                if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
+                if (current.value_valid) {
+                    current.gradient = wave_sum(is_row ? delta * L.g[nxt][lane] : 0.0);
+                    current.gradient_valid = isfinite(current.gradient);
+                }
+                const double nstep = ls_next_step(initial, previous, current, dir_max, n_iter);
+                if (nstep < 0.0) break;
+                previous = current;
+                alpha = nstep;
+            }
+        }
+        // ---- candidate: same point as the accepted line-search sample, so its cost is known ----
+        const double xc = ls_ok ? xt : clampb(__dadd_rn(xi, delta));
+        if (!ls_ok) {                                 // search failed: candidate is the full step
+            if (is_row) L.x[nxt][lane] = xc;
+            cost_c = evaluate(nxt, nxt);
+            ++exec_passes;
+        }
+        ++n_cand;
+        double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
+
+        const double step_norm = sqrt(wave_sum((xi - xc) * (xi - xc)));
+        if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;            // candidate discarded
+        const double cost_change = cost - cost_cand;
+        if (fabs(cost_change) <= kFunctionTol * cost) break;                          // candidate discarded
+        const double rel = cost_change / model_cost_change;
+        if (rel > kMinRelDecrease) {
+            xi = xc;
+            x_norm = sqrt(wave_sum(xi * xi));
+            cur = nxt;                                // J^T J / J^T r at the new x are already assembled
+            cost = cost_cand;
+            gi = is_row ? L.g[cur][lane] : 0.0;
+            gmax = wave_max(is_row ? fabs(xi - clampb(xi - gi)) : 0.0);
+            step_successful = true;
+            ++n_successful;
+            const double t = 2.0 * rel - 1.0;
+            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+        } else {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+
+    // ---- write back (Ceres copies an unusable (FAILURE) solution nowhere: positions stay 0) ----
+    if (is_row && term != LFR_TERM_FAILURE)
+        a.positions[2 * (size_t)a.node_ids[d.node_off + (lane >> 1)] + (lane & 1)] = xi;
+    if (lane == 0) {
+        CompInfoDev inf;
+        inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
+        inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
+        inf.final_cost = cost;
+        a.infos[ci] = inf;
+    }
+}
+
+// =============================================================================================
+// workgroup-per-component kernel (packed lower-triangular normal matrix in LDS or HBM)
+// =============================================================================================
+constexpr int kBlockThreads = 256;
+
+__device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // j <= i
+
+struct BlockShared {
+    double red[kBlockThreads / 64];
+    double bcast[4];
+    int flag;
+};
+
+__device__ __forceinline__ double block_sum(double v, BlockShared &sh) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlockThreads / 64; ++w) s += sh.red[w];
+    return s;
+}
+__device__ __forceinline__ double block_max(double v, BlockShared &sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh.red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = sh.red[0];
+#pragma unroll
+    for (int w = 1; w < kBlockThreads / 64; ++w) s = fmax(s, sh.red[w]);
+    return s;
+}
+
+// vectors live in LDS for both variants: 8 vectors of n doubles
+template <bool GLOBAL_MATRIX>
+__global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const KernelArgs a, int max_rows) {
+    extern __shared__ double dyn[];
+    __shared__ BlockShared sh;
+    const int tid = threadIdx.x;
+    const int ci = a.desc_begin + (int)blockIdx.x;
+    const CompDesc d = a.descs[ci];
+    const int n_var = d.n_var, n = 2 * n_var, E = (int)d.n_edges;
+    const int tv = a.tukey_variant;
+    const EdgeRec *edges = a.edges + d.edge_off;
+
+    // LDS carve-up
+    double *vx = dyn;                 // x (n + 2, zero slot at n)
+    double *vxc = vx + max_rows + 2;  // trial point
+    double *vg = vxc + max_rows + 2;  // gradient at x
+    double *vgn = vg + max_rows;      // gradient at trial point
+    double *vscale = vgn + max_rows;
+    double *vdiag = vscale + max_rows;
+    double *vstep = vdiag + max_rows; // rhs -> step
+    double *vD = vstep + max_rows;
+    double *vadiag = vD + max_rows;   // diagonal of unscaled J^T J at x
+    double *vdelta = vadiag + max_rows;
+    double *Mlds = vdelta + max_rows;
+    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : Mlds;
+
+    for (int i = tid; i < n + 2; i += kBlockThreads) { vx[i] = 0.0; vxc[i] = 0.0; }
+    __syncthreads();
+
+    // one sweep over the edges at xv: returns cost; want_matrix also assembles Mat (unscaled J^T J)
+    auto sweep = [&](const double *xv, double *gout, bool want_matrix) -> double {
+        if (want_matrix) for (size_t i = tid; i < tri(n, 0); i += kBlockThreads) Mat[i] = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) gout[i] = 0.0;
+        if (GLOBAL_MATRIX && want_matrix) __threadfence();
+        __syncthreads();
+        double cost = 0.0;
+        for (int e = tid; e < E; e += kBlockThreads) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
+            uint4 q[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = rp[i];
+            float flow[18];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                flow[4 * i] = __uint_as_float(q[i].x); flow[4 * i + 1] = __uint_as_float(q[i].y);
+                flow[4 * i + 2] = __uint_as_float(q[i].z); flow[4 * i + 3] = __uint_as_float(q[i].w);
+            }
+            flow[16] = __uint_as_float(q[4].x); flow[17] = __uint_as_float(q[4].y);
+            const float sim = __uint_as_float(q[4].z);
+            const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
+            const int dn = dk & 0x7fff, kind = dk >> 15;
+            const int ra = s < n_var ? 2 * s : -1, rb = dn < n_var ? 2 * dn : -1;
+            const int xa = s < n_var ? 2 * s : n, xb = dn < n_var ? 2 * dn : n;
+            EdgeOut o;
+            eval_edge<true>(flow, sim, kind, tv, xv[xa], xv[xa + 1], xv[xb], xv[xb + 1], o);
+            cost += o.cost;
+            if (ra >= 0) {
+                atomicAdd(&gout[ra], o.j00 * o.r0 + o.j10 * o.r1);
+                atomicAdd(&gout[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
+            }
+            if (rb >= 0) {
+                atomicAdd(&gout[rb], o.sq * o.r0);
+                atomicAdd(&gout[rb + 1], o.sq * o.r1);
+            }
+            if (want_matrix) {
+                if (ra >= 0) {
+                    atomicAdd(&Mat[tri(ra, ra)], o.j00 * o.j00 + o.j10 * o.j10);
+                    atomicAdd(&Mat[tri(ra + 1, ra)], o.j01 * o.j00 + o.j11 * o.j10);
+                    atomicAdd(&Mat[tri(ra + 1, ra + 1)], o.j01 * o.j01 + o.j11 * o.j11);
+                }
+                if (rb >= 0) {
+                    atomicAdd(&Mat[tri(rb, rb)], o.sq * o.sq);
+                    atomicAdd(&Mat[tri(rb + 1, rb + 1)], o.sq * o.sq);
+                }
+                if (ra >= 0 && rb >= 0) {
+                    if (rb > ra) {
+                        atomicAdd(&Mat[tri(rb, ra)], o.sq * o.j00);
+                        atomicAdd(&Mat[tri(rb, ra + 1)], o.sq * o.j01);
+                        atomicAdd(&Mat[tri(rb + 1, ra)], o.sq * o.j10);
+                        atomicAdd(&Mat[tri(rb + 1, ra + 1)], o.sq * o.j11);
+                    } else {
+                        atomicAdd(&Mat[tri(ra, rb)], o.j00 * o.sq);
+                        atomicAdd(&Mat[tri(ra, rb + 1)], o.j10 * o.sq);
+                        atomicAdd(&Mat[tri(ra + 1, rb)], o.j01 * o.sq);
+                        atomicAdd(&Mat[tri(ra + 1, rb + 1)], o.j11 * o.sq);
+                    }
+                }
+            }
+        }
+        if (GLOBAL_MATRIX && want_matrix) __threadfence();     // L2 atomics -> visible to this CU's loads
+        const double total = block_sum(cost, sh);
+        if (want_matrix) {
+            for (int i = tid; i < n; i += kBlockThreads) vadiag[i] = Mat[tri(i, i)];
+            __syncthreads();
+        }
+        return total;
+    };
+
+    int exec_passes = 1;
+    double cost = sweep(vx, vg, true);
+    for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
+    __syncthreads();
+    auto grad_max = [&](const double *xv, const double *gv) {
+        double m = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) m = fmax(m, fabs(xv[i] - clampb(xv[i] - gv[i])));
+        return block_max(m, sh);
+    };
+    double gmax = grad_max(vx, vg);
+    double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
+    bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
+    int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
+    int n_successful = 0, n_ls_evals = 0, n_cand = 0;
+
+    for (;;) {
+        if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; break; }
+        if (step_successful && gmax <= kGradientTol) break;
+        if (radius <= kMinRadius) break;
+        ++iteration;
+        step_successful = false;
+
+        if (!matrix_valid) {           // the factorization of a rejected step overwrote J^T J: re-assemble
+            sweep(vx, vg, true);
+            ++exec_passes;
+            matrix_valid = true;
+        }
+        // ---- H = S A S + D^2 in place, rhs = S g ----
+        for (int i = tid; i < n; i += kBlockThreads) {
+            if (!reuse_diagonal) vdiag[i] = fmin(fmax(vscale[i] * vscale[i] * vadiag[i], kMinLmDiag), kMaxLmDiag);
+            vD[i] = sqrt(vdiag[i] / radius);
+            vstep[i] = vscale[i] * vg[i];
+        }
+        reuse_diagonal = true;
+        __syncthreads();
+        for (size_t idx = tid; idx < tri(n, 0); idx += kBlockThreads) {
+            // invert idx -> (i, j)
+            int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
+            while (tri(i + 1, 0) <= idx) ++i;
+            while (tri(i, 0) > idx) --i;
+            const int j = (int)(idx - tri(i, 0));
+            double v = Mat[idx] * vscale[i] * vscale[j];
+            if (i == j) v += vD[i] * vD[i];
+            Mat[idx] = v;
+        }
+        matrix_valid = false;
+        __syncthreads();
+        // ---- LDL^T in place (right-looking), d on the diagonal, unit L below ----
+        if (tid == 0) sh.flag = 0;
+        __syncthreads();
+        for (int k = 0; k < n; ++k) {
+            const double dk = Mat[tri(k, k)];
+            if (!(dk > 0.0)) { if (tid == 0) sh.flag = 1; break; }       // uniform: every thread reads the same dk
+            const double inv = 1.0 / dk;
+            const int m = n - k - 1;                                       // trailing size
+            // trailing update with the UNSCALED column k: A[i][j] -= a_ik * a_jk / d_k, k < j <= i
+            for (int t = tid; t < m * (m + 1) / 2; t += kBlockThreads) {
+                int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
+                while (ii * (ii + 1) / 2 > t) --ii;
+                const int jj = t - ii * (ii + 1) / 2;
+                const int i = k + 1 + ii, j = k + 1 + jj;
+                Mat[tri(i, j)] -= Mat[tri(i, k)] * Mat[tri(j, k)] * inv;
+            }
+            __syncthreads();
+            for (int i = k + 1 + tid; i < n; i += kBlockThreads) Mat[tri(i, k)] *= inv;
+            __syncthreads();
+        }
+        __syncthreads();
+        bool valid = sh.flag == 0;
+        if (valid) {
+            // forward: L z = rhs (column oriented)
+            for (int k = 0; k < n; ++k) {
+                const double zk = vstep[k];
+                for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * zk;
+                __syncthreads();
+            }
+            for (int i = tid; i < n; i += kBlockThreads) vstep[i] /= Mat[tri(i, i)];
+            __syncthreads();
+            // backward: L^T y = z (column oriented over rows of L)
+            for (int k = n - 1; k >= 0; --k) {
+                const double yk = vstep[k];
+                for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * yk;
+                __syncthreads();
+            }
+        }
+        double model_cost_change = 0.0;
+        if (valid) {
+            double part = 0.0, bad = 0.0;
+            for (int i = tid; i < n; i += kBlockThreads) {
+                const double rhs0 = vscale[i] * vg[i];
+                const double st = -vstep[i];
+                if (!isfinite(st)) bad = 1.0;
+                part += -rhs0 * st + vD[i] * vD[i] * st * st;
+            }
+            model_cost_change = 0.5 * block_sum(part, sh);
+            bad = block_max(bad, sh);
+            valid = bad == 0.0 && model_cost_change > 0.0;
+        }
+        if (!valid) {
+            if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double gd_part = 0.0, dm_part = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) {
+            const double dl = -vstep[i] * vscale[i];
+            vdelta[i] = dl;
+            gd_part += vg[i] * dl;
+            dm_part = fmax(dm_part, fabs(dl));
+        }
+        const double g_dot_delta = block_sum(gd_part, sh);
+        const double dir_max = block_max(dm_part, sh);
+
+        // ---- projected Armijo line search ----
+        double alpha = 1.0, cost_c = 0.0;
+        bool ls_ok = false;
+        {
+            LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
+            int n_iter = 0;
+            for (;;) {
+                for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
+                __syncthreads();
+                cost_c = sweep(vxc, vgn, false);
+                ++exec_passes; ++n_ls_evals;
+                current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
+                current.gradient = 0.0; current.gradient_valid = false;
+                if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
+                if (current.value_valid) {
+                    double p = 0.0;
+                    for (int i = tid; i < n; i += kBlockThreads) p += vdelta[i] * vgn[i];
+                    current.gradient = block_sum(p, sh);
+                    current.gradient_valid = isfinite(current.gradient);
+                }
+                const double nstep = ls_next_step(initial, previous, current, dir_max, n_iter);
+                if (nstep < 0.0) break;
+                previous = current;
+                alpha = nstep;
+            }
+        }
+        if (!ls_ok) {
+            for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
+            __syncthreads();
+            cost_c = sweep(vxc, vgn, false);
+            ++exec_passes;
+        }
+        ++n_cand;
+        const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
+        double sn = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) sn += (vx[i] - vxc[i]) * (vx[i] - vxc[i]);
+        const double step_norm = sqrt(block_sum(sn, sh));
+        if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
+        const double cost_change = cost - cost_cand;
+        if (fabs(cost_change) <= kFunctionTol * cost) break;
+        const double rel = cost_change / model_cost_change;
+        if (rel > kMinRelDecrease) {
+            double xn = 0.0;
+            __syncthreads();
+            for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; }
+            x_norm = sqrt(block_sum(xn, sh));
+            cost = sweep(vx, vg, true);               // J^T J at the new point
+            ++exec_passes;
+            matrix_valid = true;
+            gmax = grad_max(vx, vg);
+            step_successful = true;
+            ++n_successful;
+            const double t = 2.0 * rel - 1.0;
+            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+        } else {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+    __syncthreads();
+    if (term != LFR_TERM_FAILURE)
+        for (int i = tid; i < n; i += kBlockThreads)
+            a.positions[2 * (size_t)a.node_ids[d.node_off + (i >> 1)] + (i & 1)] = vx[i];
+    if (tid == 0) {
+        CompInfoDev inf;
+        inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
+        inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
+        inf.final_cost = cost;
+        a.infos[ci] = inf;
+    }
+}
+
+size_t block_lds_bytes(int max_rows, bool global_matrix) {
+    size_t doubles = 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows;
+    if (!global_matrix) doubles += (size_t)max_rows * (max_rows + 1) / 2;
+    return doubles * sizeof(double);
+}
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            lfr::set_error("%s failed: %s", #expr, hipGetErrorString(_e));                    \
+            return LFR_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+}  // namespace
+
+// =============================================================================================
+// batch management + C ABI
+// =============================================================================================
+struct lfr_batch {
+    int device = 0;
+    int tukey_variant = LFR_TUKEY_CERES1;
+    int64_t n_graph_nodes = 0;
+    // shard content (host copies kept for stats / downloads)
+    std::vector<CompDesc> descs;
+    std::vector<int64_t> desc_component;
+    std::vector<int32_t> desc_class, desc_tracks;
+    std::vector<uint32_t> node_ids;
+    std::vector<uint64_t> ws_off;
+    int class_begin[lfr::KC_COUNT + 1] = {0};
+    int block_max_rows = 0, global_max_rows = 0;
+    int64_t n_edges = 0, n_nodes = 0, n_tracks = 0;
+    // device
+    CompDesc *d_descs = nullptr;
+    EdgeRec *d_edges = nullptr;
+    uint32_t *d_node_ids = nullptr;
+    double *d_positions = nullptr;
+    CompInfoDev *d_infos = nullptr;
+    double *d_workspace = nullptr;
+    uint64_t *d_ws_off = nullptr;
+    hipEvent_t ev[2 * (lfr::KC_COUNT + 1)];
+    bool events = false;
+    double h2d_ms = 0.0;
+    std::vector<CompInfoDev> infos;      // last downloaded
+    bool infos_valid = false;
+};
+
+extern "C" {
+
+void lfr_batch_free(lfr_batch *b) {
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->d_descs) (void)hipFree(b->d_descs);
+    if (b->d_edges) (void)hipFree(b->d_edges);
+    if (b->d_node_ids) (void)hipFree(b->d_node_ids);
+    if (b->d_positions) (void)hipFree(b->d_positions);
+    if (b->d_infos) (void)hipFree(b->d_infos);
+    if (b->d_workspace) (void)hipFree(b->d_workspace);
+    if (b->d_ws_off) (void)hipFree(b->d_ws_off);
+    if (b->events) for (auto &e : b->ev) (void)hipEventDestroy(e);
+    delete b;
+}
+
+int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shard_world, int tukey_variant,
+                     lfr_batch **out) {
+    if (!ph || !out || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world ||
+        (tukey_variant != LFR_TUKEY_CERES1 && tukey_variant != LFR_TUKEY_CERES2)) {
+        lfr::set_error("bad argument"); return LFR_ERR_ARG;
+    }
+    const lfr::Problem &p = ph->p;
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
+    HIP_TRY(hipSetDevice(device));
+    lfr_batch *b = new lfr_batch();
+    b->device = device; b->tukey_variant = tukey_variant;
+    b->n_graph_nodes = (int64_t)p.track.size();
+
+    // LPT sharding: components by edge count descending to the least-loaded shard (solve.cc:599-604)
+    std::vector<size_t> mine;
+    if (shard_world == 1) { mine.resize(p.descs.size()); for (size_t i = 0; i < mine.size(); ++i) mine[i] = i; }
+    else {
+        std::vector<size_t> order(p.descs.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return p.descs[x].n_edges > p.descs[y].n_edges; });
+        std::vector<int64_t> load(shard_world, 0);
+        std::vector<uint8_t> take(p.descs.size(), 0);
+        for (size_t i : order) {
+            int best = 0;
+            for (int s = 1; s < shard_world; ++s) if (load[s] < load[best]) best = s;
+            load[best] += (int64_t)p.descs[i].n_edges + 8;      // +8: per-component fixed cost
+            if (best == shard_rank) take[i] = 1;
+        }
+        for (size_t i = 0; i < p.descs.size(); ++i) if (take[i]) mine.push_back(i);   // keeps class/size order
+    }
+    std::vector<EdgeRec> edges;
+    uint64_t ws = 0;
+    for (size_t i : mine) {
+        CompDesc d = p.descs[i];
+        const uint32_t eo = (uint32_t)edges.size(), no = (uint32_t)b->node_ids.size();
+        edges.insert(edges.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
+        b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
+        d.edge_off = eo; d.node_off = no;
+        const int cls = p.desc_class[i], rows = 2 * d.n_var;
+        b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
+        b->desc_class.push_back(cls); b->desc_tracks.push_back(p.desc_tracks[i]);
+        b->ws_off.push_back(ws);
+        if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
+        if (cls == lfr::KC_GLOBAL) { b->global_max_rows = std::max(b->global_max_rows, rows); ws += (uint64_t)rows * (rows + 1) / 2; }
+        b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
+    }
+    {   // class ranges (descs are sorted by class)
+        int c = 0;
+        b->class_begin[0] = 0;
+        for (int i = 0; i <= (int)b->descs.size(); ++i) {
+            const int cls = i < (int)b->descs.size() ? b->desc_class[i] : lfr::KC_COUNT;
+            while (c < cls) b->class_begin[++c] = i;
+        }
+    }
+    if (block_lds_bytes(b->global_max_rows, true) > 160 * 1024) {
+        lfr::set_error("component with %d rows exceeds the LDS vector budget of the global-matrix kernel", b->global_max_rows);
+        delete b; return LFR_ERR_UNSUPPORTED;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    const size_t nd = std::max<size_t>(b->descs.size(), 1), ne = std::max<size_t>(edges.size(), 1), nn = std::max<size_t>(b->node_ids.size(), 1);
+    HIP_TRY(hipMalloc(&b->d_descs, nd * sizeof(CompDesc)));
+    HIP_TRY(hipMalloc(&b->d_edges, ne * sizeof(EdgeRec)));
+    HIP_TRY(hipMalloc(&b->d_node_ids, nn * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(&b->d_positions, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
+    HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
+    HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
+    if (ws) HIP_TRY(hipMalloc(&b->d_workspace, ws * sizeof(double)));
+    if (!b->descs.empty()) {
+        HIP_TRY(hipMemcpy(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_ws_off, b->ws_off.data(), b->ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    b->h2d_ms = ms;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    b->events = true;
+    *out = b;
+    return LFR_OK;
+}
+
+int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
+    if (!b) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    KernelArgs a;
+    a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
+    a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.tukey_variant = b->tukey_variant;
+    HIP_TRY(hipEventRecord(b->ev[0], st));
+    HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
+    for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
+        a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1];
+        const int n = a.desc_end - a.desc_begin;
+        HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
+        if (n > 0) {
+            const dim3 grid_w((n + 3) / 4), blk(256);
+            switch (cls) {
+                case lfr::KC_W16_1: hipLaunchKernelGGL((solve_wave_kernel<16, 1>), grid_w, blk, 0, st, a); break;
+                case lfr::KC_W16_2: hipLaunchKernelGGL((solve_wave_kernel<16, 2>), grid_w, blk, 0, st, a); break;
+                case lfr::KC_W32_2: hipLaunchKernelGGL((solve_wave_kernel<32, 2>), grid_w, blk, 0, st, a); break;
+                case lfr::KC_W32_4: hipLaunchKernelGGL((solve_wave_kernel<32, 4>), grid_w, blk, 0, st, a); break;
+                case lfr::KC_BLOCK: {
+                    const size_t lds = block_lds_bytes(b->block_max_rows, false);
+                    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), lds, st, a, b->block_max_rows);
+                    break;
+                }
+                case lfr::KC_GLOBAL: {
+                    const size_t lds = block_lds_bytes(b->global_max_rows, true);
+                    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                    hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), lds, st, a, b->global_max_rows);
+                    break;
+                }
+            }
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
+    }
+    HIP_TRY(hipEventRecord(b->ev[1], st));
+    b->infos_valid = false;
+    if (!stats) return LFR_OK;
+
+    HIP_TRY(hipStreamSynchronize(st));
+    memset(stats, 0, sizeof *stats);
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
+    stats->kernel_ms = ms;
+    stats->h2d_ms = b->h2d_ms;
+    b->infos.resize(b->descs.size());
+    if (!b->descs.empty())
+        HIP_TRY(hipMemcpy(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost));
+    b->infos_valid = true;
+    stats->n_components = (int64_t)b->descs.size();
+    stats->n_edges = b->n_edges; stats->n_nodes = b->n_nodes; stats->n_tracks = b->n_tracks;
+    double best_ms = -1.0;
+    for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
+        int64_t edges = 0, nodes = 0, refp_e = 0, refp_n = 0;
+        for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) {
+            const CompInfoDev &f = b->infos[i];
+            const int64_t E = b->descs[i].n_edges, N = b->descs[i].n_nodes;
+            const int64_t jac = 1 + f.n_ls_evals + f.n_successful, cst = f.n_cand_evals;
+            stats->ref_jacobian_passes_edges += E * jac;
+            stats->ref_cost_passes_edges += E * cst;
+            stats->ref_passes_nodes += N * (jac + cst);
+            stats->exec_passes_edges += E * f.exec_passes;
+            stats->sum_iterations += f.iterations;
+            stats->sum_final_cost += f.final_cost;
+            if (f.termination == LFR_TERM_CONVERGENCE) ++stats->n_converged;
+            else if (f.termination == LFR_TERM_NO_CONVERGENCE) ++stats->n_no_convergence;
+            else ++stats->n_failed;
+            edges += E; nodes += N; refp_e += E * (jac + cst); refp_n += N * (jac + cst);
+        }
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 + 2 * cls], b->ev[3 + 2 * cls]));
+        if (edges > 0 && ms > best_ms) {
+            best_ms = ms;
+            stats->dominant_kernel_ms = ms; stats->dominant_kernel_edges = edges; stats->dominant_kernel_nodes = nodes;
+            stats->dominant_ref_passes_edges = refp_e; stats->dominant_ref_passes_nodes = refp_n;
+        }
+    }
+    return LFR_OK;
+}
+
+int lfr_batch_download(lfr_batch *b, double *positions) {
+    if (!b || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<double> tmp(std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2));
+    HIP_TRY(hipMemcpy(tmp.data(), b->d_positions, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < b->node_ids.size(); ++i) {
+        const size_t n = b->node_ids[i];
+        positions[2 * n] = tmp[2 * n]; positions[2 * n + 1] = tmp[2 * n + 1];
+    }
+    return LFR_OK;
+}
+
+int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
+                                 double *final_cost, int32_t *n_var_nodes, int32_t *n_edges) {
+    if (!b) return LFR_ERR_ARG;
+    if (!b->infos_valid) {
+        if (hipSetDevice(b->device) != hipSuccess) return LFR_ERR_HIP;
+        b->infos.resize(b->descs.size());
+        if (!b->descs.empty() &&
+            hipMemcpy(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost) != hipSuccess)
+            return LFR_ERR_HIP;
+        b->infos_valid = true;
+    }
+    for (size_t i = 0; i < b->descs.size(); ++i) {
+        if (component) component[i] = b->desc_component[i];
+        if (iterations) iterations[i] = b->infos[i].iterations;
+        if (termination) termination[i] = b->infos[i].termination;
+        if (final_cost) final_cost[i] = b->infos[i].final_cost;
+        if (n_var_nodes) n_var_nodes[i] = b->descs[i].n_var;
+        if (n_edges) n_edges[i] = (int32_t)b->descs[i].n_edges;
+    }
+    return (int64_t)b->descs.size();
+}
+
+int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions, lfr_solve_stats *stats) {
+    if (!p || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr_batch *b = nullptr;
+    int rc = lfr_batch_create(p, device, 0, 1, tukey_variant, &b);
+    if (rc != LFR_OK) return rc;
+    lfr_solve_stats local;
+    rc = lfr_batch_solve(b, nullptr, stats ? stats : &local);
+    if (rc == LFR_OK) {
+        const size_t n = p->p.track.size();
+        memset(positions, 0, sizeof(double) * 2 * n);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+        (void)hipEventRecord(e0, nullptr);
+        rc = lfr_batch_download(b, positions);
+        (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
+        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (stats) stats->d2h_ms = ms;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    }
+    lfr_batch_free(b);
+    return rc;
+}
+
+}  // extern "C"

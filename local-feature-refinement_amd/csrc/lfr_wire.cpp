@@ -1,0 +1,409 @@
+// Native proto3 scanner/emitter for the solver boundary + match-graph construction.
+//   MatchingFile  types.proto:3-28   -> lfr::Graph           (replaces solve.cc:426-481)
+//   SolutionFile  types.proto:30-46  <- positions            (replaces solve.cc:644-679)
+// No libprotobuf: only varint / fixed32 / length-delimited fields occur in these messages.
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <set>
+
+#include "lfr_internal.hpp"
+
+namespace lfr {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------- graph building
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+
+int32_t Graph::intern_image(const std::string &name, float fact) {
+    auto it = image_index.find(name);
+    if (it != image_index.end()) return it->second;      // first fact wins (solve.cc:449,451)
+    const int32_t idx = (int32_t)image_names.size();
+    image_index.emplace(name, idx);
+    image_names.push_back(name);
+    image_fact.push_back(fact);
+    return idx;
+}
+
+uint32_t Graph::find_or_create_node(int32_t image, uint32_t feature) {
+    if ((uint64_t)(hcount + 1) * 2 > hkeys.size()) {      // grow / first use
+        const uint64_t ncap = hkeys.empty() ? (1u << 16) : hkeys.size() * 2;
+        std::vector<uint64_t> nk(ncap);
+        std::vector<int64_t> nv(ncap, -1);
+        const uint64_t nmask = ncap - 1;
+        for (uint64_t i = 0; i < hkeys.size(); ++i)
+            if (hvals[i] >= 0) {
+                uint64_t h = mix64(hkeys[i]) & nmask;
+                while (nv[h] >= 0) h = (h + 1) & nmask;
+                nk[h] = hkeys[i]; nv[h] = hvals[i];
+            }
+        hkeys.swap(nk); hvals.swap(nv); hmask = nmask;
+    }
+    const uint64_t key = ((uint64_t)(uint32_t)image << 32) | feature;
+    uint64_t h = mix64(key) & hmask;
+    for (;;) {
+        if (hvals[h] < 0) {
+            hkeys[h] = key; hvals[h] = (int64_t)node_image.size(); ++hcount;
+            node_image.push_back(image); node_feat.push_back(feature);
+            return (uint32_t)hvals[h];
+        }
+        if (hkeys[h] == key) return (uint32_t)hvals[h];
+        h = (h + 1) & hmask;
+    }
+}
+
+void Graph::add_match(int32_t img1, int32_t img2, uint32_t f1, uint32_t f2, float sim, const float *d1, int n1,
+                      const float *d2, int n2) {
+    const uint32_t a = find_or_create_node(img1, f1);     // node1 before node2 (solve.cc:474-475)
+    const uint32_t b = find_or_create_node(img2, f2);
+    m_node1.push_back(a); m_node2.push_back(b); m_sim.push_back(sim);
+    const size_t o = m_disp1.size();
+    m_disp1.resize(o + 18, 0.f); m_disp2.resize(o + 18, 0.f);
+    if (n1 > 0) memcpy(&m_disp1[o], d1, sizeof(float) * 2 * (size_t)n1);
+    if (n2 > 0) memcpy(&m_disp2[o], d2, sizeof(float) * 2 * (size_t)n2);
+}
+
+void Graph::finish() {
+    std::vector<uint64_t>().swap(hkeys);
+    std::vector<int64_t>().swap(hvals);
+}
+
+// ---------------------------------------------------------------------------- wire primitives
+struct Cursor {
+    const uint8_t *p, *end;
+    bool ok = true;
+    bool done() const { return p >= end; }
+    uint64_t varint() {
+        uint64_t r = 0;
+        for (int shift = 0; shift < 64; shift += 7) {
+            if (p >= end) { ok = false; return 0; }
+            const uint8_t b = *p++;
+            r |= (uint64_t)(b & 0x7F) << shift;
+            if (!(b & 0x80)) return r;
+        }
+        ok = false;
+        return 0;
+    }
+    float f32() {
+        if (end - p < 4) { ok = false; return 0.f; }
+        float v; memcpy(&v, p, 4); p += 4; return v;
+    }
+    Cursor sub() {
+        const uint64_t n = varint();
+        if (!ok || (uint64_t)(end - p) < n) { ok = false; return Cursor{p, p}; }
+        Cursor c{p, p + n}; p += n; return c;
+    }
+    void skip(int wt) {
+        switch (wt) {
+            case 0: varint(); break;
+            case 1: if (end - p < 8) ok = false; else p += 8; break;
+            case 2: sub(); break;
+            case 5: if (end - p < 4) ok = false; else p += 4; break;
+            default: ok = false;      // groups / invalid wire types
+        }
+    }
+};
+
+static bool parse_displacements(Cursor c, float *out, int &n) {   // one Displacement message
+    float di = 0.f, dj = 0.f;
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int field = (int)(key >> 3), wt = (int)(key & 7);
+        if (field == 0) return false;
+        if (field == 1 && wt == 5) di = c.f32();
+        else if (field == 2 && wt == 5) dj = c.f32();
+        else c.skip(wt);
+    }
+    if (!c.ok) return false;
+    if (n >= 9) { n = 10; return true; }        // > 9 grid points: the reference overruns its buffer
+    out[2 * n] = di; out[2 * n + 1] = dj; ++n;
+    return true;
+}
+
+static int parse_match(Cursor c, Graph &g, int32_t img1, int32_t img2) {
+    uint32_t f1 = 0, f2 = 0; float sim = 0.f;
+    float d1[18], d2[18]; int n1 = 0, n2 = 0;
+    memset(d1, 0, sizeof d1); memset(d2, 0, sizeof d2);
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int field = (int)(key >> 3), wt = (int)(key & 7);
+        if (field == 0) return LFR_ERR_PARSE;
+        if (field == 1 && wt == 0) f1 = (uint32_t)c.varint();
+        else if (field == 2 && wt == 0) f2 = (uint32_t)c.varint();
+        else if (field == 3 && wt == 5) sim = c.f32();
+        else if (field == 4 && wt == 2) { if (!parse_displacements(c.sub(), d1, n1)) return LFR_ERR_PARSE; }
+        else if (field == 5 && wt == 2) { if (!parse_displacements(c.sub(), d2, n2)) return LFR_ERR_PARSE; }
+        else c.skip(wt);
+    }
+    if (!c.ok) return LFR_ERR_PARSE;
+    if (n1 > 9 || n2 > 9) {
+        set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
+        return LFR_ERR_UNSUPPORTED;
+    }
+    g.add_match(img1, img2, f1, f2, sim, d1, n1, d2, n2);
+    return LFR_OK;
+}
+
+static int parse_pair(Cursor c, Graph &g, const std::set<std::string> &banned) {
+    std::string name1, name2; float fact1 = 0.f, fact2 = 0.f;
+    std::vector<Cursor> matches;
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int field = (int)(key >> 3), wt = (int)(key & 7);
+        if (field == 0) return LFR_ERR_PARSE;
+        if (field == 1 && wt == 2) { Cursor s = c.sub(); name1.assign((const char *)s.p, s.end - s.p); }
+        else if (field == 2 && wt == 5) fact1 = c.f32();
+        else if (field == 3 && wt == 2) { Cursor s = c.sub(); name2.assign((const char *)s.p, s.end - s.p); }
+        else if (field == 4 && wt == 5) fact2 = c.f32();
+        else if (field == 5 && wt == 2) matches.push_back(c.sub());
+        else c.skip(wt);
+    }
+    if (!c.ok) return LFR_ERR_PARSE;
+    if (banned.count(name1) || banned.count(name2)) return LFR_OK;       // solve.cc:444-446
+    const int32_t i1 = g.intern_image(name1, fact1);                     // solve.cc:448-451
+    const int32_t i2 = g.intern_image(name2, fact2);
+    for (Cursor &m : matches) {
+        if (!m.ok) return LFR_ERR_PARSE;
+        const int rc = parse_match(m, g, i1, i2);
+        if (rc != LFR_OK) return rc;
+    }
+    return LFR_OK;
+}
+
+static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, const std::set<std::string> &banned) {
+    Cursor c{data, data + size};
+    while (!c.done() && c.ok) {
+        const uint64_t key = c.varint();
+        const int field = (int)(key >> 3), wt = (int)(key & 7);
+        if (!c.ok || field == 0) return LFR_ERR_PARSE;
+        if (field == 1 && wt == 2) {
+            Cursor pc = c.sub();
+            if (!c.ok) return LFR_ERR_PARSE;
+            const int rc = parse_pair(pc, g, banned);
+            if (rc != LFR_OK) return rc;
+        } else c.skip(wt);
+    }
+    return c.ok ? LFR_OK : LFR_ERR_PARSE;
+}
+
+static int parse_matching_path(const char *path, Graph &g, const std::set<std::string> &banned) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) { set_error("cannot open %s", path); return LFR_ERR_IO; }
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); set_error("cannot stat %s", path); return LFR_ERR_IO; }
+    int rc = LFR_OK;
+    if (st.st_size > 0) {
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { close(fd); set_error("cannot mmap %s", path); return LFR_ERR_IO; }
+        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        rc = parse_matching_buffer((const uint8_t *)m, (size_t)st.st_size, g, banned);
+        munmap(m, (size_t)st.st_size);
+    }
+    close(fd);
+    if (rc == LFR_ERR_PARSE) set_error("Failed to parse proto object.");
+    return rc;
+}
+
+// ---------------------------------------------------------------------------- emit
+struct Out {
+    std::vector<uint8_t> buf;
+    void varint(uint64_t v) { while (v >= 0x80) { buf.push_back((uint8_t)(v | 0x80)); v >>= 7; } buf.push_back((uint8_t)v); }
+    void tag(int field, int wt) { varint(((uint64_t)field << 3) | wt); }
+    void f32(int field, float v) {           // proto3: zero-valued scalars are omitted (bitwise zero)
+        uint32_t bits; memcpy(&bits, &v, 4);
+        if (!bits) return;
+        tag(field, 5);
+        const size_t o = buf.size(); buf.resize(o + 4); memcpy(&buf[o], &bits, 4);
+    }
+    void u32(int field, uint32_t v) { if (v) { tag(field, 0); varint(v); } }
+    void bytes(int field, const void *p, size_t n) { tag(field, 2); varint(n); const size_t o = buf.size(); buf.resize(o + n); if (n) memcpy(&buf[o], p, n); }
+    void str(int field, const std::string &s) { if (!s.empty()) bytes(field, s.data(), s.size()); }
+};
+static inline size_t varint_size(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
+
+static bool write_file(const char *path, const std::vector<const std::vector<uint8_t> *> &chunks) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return false;
+    bool ok = true;
+    for (auto *c : chunks) if (!c->empty() && fwrite(c->data(), 1, c->size(), f) != c->size()) ok = false;
+    if (fclose(f) != 0) ok = false;
+    return ok;
+}
+
+}  // namespace lfr
+
+using namespace lfr;
+
+extern "C" {
+
+int lfr_version(void) { return LFR_VERSION; }
+const char *lfr_last_error(void) { return g_error; }
+
+int lfr_graph_from_files(const char *const *paths, int n_paths, const char *const *banned, int n_banned,
+                         lfr_graph **out) {
+    if (!out || (n_paths > 0 && !paths)) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::set<std::string> ban;
+    for (int i = 0; i < n_banned; ++i) ban.insert(banned[i]);
+    lfr_graph *h = new lfr_graph();
+    for (int i = 0; i < n_paths; ++i) {
+        const int rc = parse_matching_path(paths[i], h->g, ban);
+        if (rc != LFR_OK) { delete h; *out = nullptr; return rc; }
+    }
+    h->g.finish();
+    *out = h;
+    return LFR_OK;
+}
+
+int lfr_graph_from_matches_file(const char *path, const char *const *banned, int n_banned, lfr_graph **out) {
+    if (!path || !out) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::vector<std::string> files;
+    if (access(path, R_OK) == 0) files.push_back(path);      // solve.cc:416-424
+    else
+        for (size_t part = 0;; ++part) {
+            const std::string f = std::string(path) + ".part." + std::to_string(part);
+            if (access(f.c_str(), R_OK) != 0) break;
+            files.push_back(f);
+        }
+    std::vector<const char *> ptrs;
+    for (auto &f : files) ptrs.push_back(f.c_str());
+    return lfr_graph_from_files(ptrs.data(), (int)ptrs.size(), banned, n_banned, out);
+}
+
+int lfr_graph_from_arrays(int32_t n_images, const char *const *image_names, const float *image_facts,
+                          int64_t n_pairs, const int32_t *pair_img1, const int32_t *pair_img2,
+                          const int64_t *pair_off, const uint32_t *feat1, const uint32_t *feat2,
+                          const float *sim, const float *disp1, const float *disp2,
+                          const char *const *banned, int n_banned, lfr_graph **out) {
+    if (!out || n_images < 0 || n_pairs < 0) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::set<std::string> ban;
+    for (int i = 0; i < n_banned; ++i) ban.insert(banned[i]);
+    lfr_graph *h = new lfr_graph();
+    Graph &g = h->g;
+    const int64_t M = n_pairs ? pair_off[n_pairs] : 0;
+    g.m_node1.reserve(M); g.m_node2.reserve(M); g.m_sim.reserve(M);
+    g.m_disp1.reserve(18 * M); g.m_disp2.reserve(18 * M);
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int32_t a = pair_img1[p], b = pair_img2[p];
+        if (a < 0 || a >= n_images || b < 0 || b >= n_images) { delete h; set_error("image index out of range"); return LFR_ERR_ARG; }
+        const std::string na = image_names[a], nb = image_names[b];
+        if (ban.count(na) || ban.count(nb)) continue;
+        const int32_t i1 = g.intern_image(na, image_facts[a]);
+        const int32_t i2 = g.intern_image(nb, image_facts[b]);
+        for (int64_t m = pair_off[p]; m < pair_off[p + 1]; ++m)
+            g.add_match(i1, i2, feat1[m], feat2[m], sim[m], disp1 + 18 * m, 9, disp2 + 18 * m, 9);
+    }
+    g.finish();
+    *out = h;
+    return LFR_OK;
+}
+
+void lfr_graph_free(lfr_graph *g) { delete g; }
+int64_t lfr_graph_num_nodes(const lfr_graph *g) { return g ? g->g.n_nodes() : 0; }
+int64_t lfr_graph_num_edges(const lfr_graph *g) { return g ? 2 * g->g.n_matches() : 0; }
+int32_t lfr_graph_num_images(const lfr_graph *g) { return g ? (int32_t)g->g.image_names.size() : 0; }
+int lfr_graph_get_nodes(const lfr_graph *g, int32_t *node_image, uint32_t *node_feature) {
+    if (!g) return LFR_ERR_ARG;
+    const int64_t n = g->g.n_nodes();
+    if (node_image && n) memcpy(node_image, g->g.node_image.data(), sizeof(int32_t) * n);
+    if (node_feature && n) memcpy(node_feature, g->g.node_feat.data(), sizeof(uint32_t) * n);
+    return LFR_OK;
+}
+const char *lfr_graph_image_name(const lfr_graph *g, int32_t image) {
+    if (!g || image < 0 || image >= (int32_t)g->g.image_names.size()) return nullptr;
+    return g->g.image_names[image].c_str();
+}
+float lfr_graph_image_fact(const lfr_graph *g, int32_t image) {
+    if (!g || image < 0 || image >= (int32_t)g->g.image_fact.size()) return 0.f;
+    return g->g.image_fact[image];
+}
+
+int lfr_write_matching_file(const char *path, int32_t n_images, const char *const *image_names,
+                            const float *image_facts, int64_t n_pairs, const int32_t *pair_img1,
+                            const int32_t *pair_img2, const int64_t *pair_off, const uint32_t *feat1,
+                            const uint32_t *feat2, const float *sim, const float *disp1, const float *disp2) {
+    if (!path) { set_error("bad argument"); return LFR_ERR_ARG; }
+    FILE *f = fopen(path, "wb");
+    if (!f) { set_error("cannot open %s for writing", path); return LFR_ERR_IO; }
+    Out pair, match, disp, head;
+    bool ok = true;
+    for (int64_t p = 0; p < n_pairs && ok; ++p) {
+        const int32_t a = pair_img1[p], b = pair_img2[p];
+        if (a < 0 || a >= n_images || b < 0 || b >= n_images) { fclose(f); set_error("image index out of range"); return LFR_ERR_ARG; }
+        pair.buf.clear();
+        pair.str(1, image_names[a]); pair.f32(2, image_facts[a]);
+        pair.str(3, image_names[b]); pair.f32(4, image_facts[b]);
+        for (int64_t m = pair_off[p]; m < pair_off[p + 1]; ++m) {
+            match.buf.clear();
+            match.u32(1, feat1[m]); match.u32(2, feat2[m]); match.f32(3, sim[m]);
+            for (int which = 0; which < 2; ++which) {
+                const float *d = (which == 0 ? disp1 : disp2) + 18 * m;
+                for (int k = 0; k < 9; ++k) {
+                    disp.buf.clear();
+                    disp.f32(1, d[2 * k]); disp.f32(2, d[2 * k + 1]);
+                    match.bytes(which == 0 ? 4 : 5, disp.buf.data(), disp.buf.size());
+                }
+            }
+            pair.bytes(5, match.buf.data(), match.buf.size());
+        }
+        head.buf.clear();
+        head.tag(1, 2); head.varint(pair.buf.size());
+        ok = fwrite(head.buf.data(), 1, head.buf.size(), f) == head.buf.size() &&
+             (pair.buf.empty() || fwrite(pair.buf.data(), 1, pair.buf.size(), f) == pair.buf.size());
+    }
+    if (fclose(f) != 0) ok = false;
+    if (!ok) { set_error("Failed to write proto object."); return LFR_ERR_IO; }
+    return LFR_OK;
+}
+
+int lfr_write_solution(const lfr_graph *gh, const double *positions, const char *path, int64_t *n_outside) {
+    if (!gh || !path || (!positions && gh->g.n_nodes() > 0)) { set_error("bad argument"); return LFR_ERR_ARG; }
+    const Graph &g = gh->g;
+    const int64_t n = g.n_nodes();
+    // images in order of first node (solve.cc:647-659); every node is emitted (solve.cc:661-664)
+    std::vector<int32_t> slot(g.image_names.size(), -1);
+    std::vector<int32_t> order;
+    for (int64_t i = 0; i < n; ++i)
+        if (slot[g.node_image[i]] < 0) { slot[g.node_image[i]] = (int32_t)order.size(); order.push_back(g.node_image[i]); }
+    std::vector<Out> bodies(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        bodies[k].str(1, g.image_names[order[k]]);
+        bodies[k].f32(2, g.image_fact[order[k]]);
+    }
+    int64_t outside = 0;
+    Out d;
+    for (int64_t i = 0; i < n; ++i) {
+        const double di = positions[2 * i], dj = positions[2 * i + 1];
+        d.buf.clear();
+        d.u32(1, g.node_feat[i]); d.f32(2, (float)di); d.f32(3, (float)dj);
+        bodies[slot[g.node_image[i]]].bytes(3, d.buf.data(), d.buf.size());
+        if (std::fabs(dj) > 0.5 || std::fabs(di) > 0.5) ++outside;     // solve.cc:666-668
+    }
+    if (n_outside) *n_outside = outside;
+    std::vector<Out> heads(order.size());
+    std::vector<const std::vector<uint8_t> *> chunks;
+    for (size_t k = 0; k < order.size(); ++k) {
+        heads[k].tag(1, 2); heads[k].varint(bodies[k].buf.size());
+        chunks.push_back(&heads[k].buf); chunks.push_back(&bodies[k].buf);
+    }
+    if (!write_file(path, chunks)) { set_error("Failed to write proto object."); return LFR_ERR_IO; }
+    return LFR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+"""ctypes binding of liblfr_hip.so (C ABI: include/lfr.h).
+
+This is the host-side mirror of the reference's solver stages (``solve.cc`` main():
+ingest -> tracks/roots/components -> batched LM -> SolutionFile).  There is no CPU
+fallback: if the HIP library is missing, importing the binding raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfr_hip.so")
+
+TUKEY = {"ceres1": 1, "ceres2": 2}
+TERM_CONVERGENCE, TERM_NO_CONVERGENCE, TERM_FAILURE = 0, 1, 2
+
+
+class LfrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("lfr error %d: %s" % (code, msg))
+        self.code = code
+
+
+class ProblemStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_tracks", "max_track_size", "n_components", "max_component_size", "n_cut_components",
+        "n_solved_components", "n_solved_tracks", "n_solved_edges", "n_solved_nodes")] + \
+        [(n, C.c_double) for n in ("tracks_ms", "roots_ms", "graph_cut_ms", "assemble_ms")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class SolveStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in (
+        "n_components", "n_edges", "n_nodes", "n_tracks", "n_converged", "n_no_convergence", "n_failed",
+        "sum_iterations", "ref_jacobian_passes_edges", "ref_cost_passes_edges", "exec_passes_edges",
+        "ref_passes_nodes")] + \
+        [("sum_final_cost", C.c_double), ("kernel_ms", C.c_double), ("h2d_ms", C.c_double),
+         ("d2h_ms", C.c_double), ("dominant_kernel_ms", C.c_double),
+         ("dominant_kernel_edges", C.c_int64), ("dominant_kernel_nodes", C.c_int64),
+         ("dominant_ref_passes_edges", C.c_int64), ("dominant_ref_passes_nodes", C.c_int64)]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load liblfr_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("%s not found: build it with `python __graft_entry__.py` "
+                          "(there is no CPU fallback for the solver path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    pp = C.POINTER(C.c_void_p)
+    cpp = C.POINTER(C.c_char_p)
+    sig = {
+        "lfr_version": (C.c_int, []),
+        "lfr_last_error": (C.c_char_p, []),
+        "lfr_graph_from_files": (C.c_int, [cpp, C.c_int, cpp, C.c_int, pp]),
+        "lfr_graph_from_matches_file": (C.c_int, [C.c_char_p, cpp, C.c_int, pp]),
+        "lfr_graph_from_arrays": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cpp, C.c_int, pp]),
+        "lfr_graph_free": (None, [vp]),
+        "lfr_graph_num_nodes": (i64, [vp]),
+        "lfr_graph_num_edges": (i64, [vp]),
+        "lfr_graph_num_images": (i32, [vp]),
+        "lfr_graph_get_nodes": (C.c_int, [vp, vp, vp]),
+        "lfr_graph_image_name": (C.c_char_p, [vp, i32]),
+        "lfr_graph_image_fact": (C.c_float, [vp, i32]),
+        "lfr_write_matching_file": (C.c_int, [C.c_char_p, i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "lfr_problem_build": (C.c_int, [vp, i64, vp, pp]),
+        "lfr_problem_free": (None, [vp]),
+        "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
+        "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
+        "lfr_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, pp]),
+        "lfr_batch_free": (None, [vp]),
+        "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
+        "lfr_batch_download": (C.c_int, [vp, vp]),
+        "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
+        "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
+        "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)       # AttributeError here = the .so does not export the ABI
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
+           "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
+           "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_free", "lfr_problem_get_stats",
+           "lfr_problem_get_labels", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
+           "lfr_batch_download", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution"]
+
+
+def _check(rc):
+    if rc != 0:
+        raise LfrError(rc, lib().lfr_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _cstrs(strings):
+    arr = (C.c_char_p * max(len(strings), 1))()
+    for i, s in enumerate(strings):
+        arr[i] = s.encode("utf-8") if isinstance(s, str) else s
+    return arr
+
+
+class Graph:
+    """Parsed match graph (solve.cc:405-481)."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def from_matches_file(cls, path, banned=()):
+        h = C.c_void_p()
+        _check(lib().lfr_graph_from_matches_file(os.fsencode(path), _cstrs(list(banned)), len(banned), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_files(cls, paths, banned=()):
+        h = C.c_void_p()
+        _check(lib().lfr_graph_from_files(_cstrs([os.fsencode(p) for p in paths]), len(paths),
+                                          _cstrs(list(banned)), len(banned), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def from_arrays(cls, ma, banned=()):
+        """ma: :class:`lfr_amd.synthetic.MatchArrays`."""
+        h = C.c_void_p()
+        a = _contig(ma)
+        _check(lib().lfr_graph_from_arrays(len(ma.image_names), _cstrs(ma.image_names), _ptr(a["facts"]),
+                                           len(a["p1"]), _ptr(a["p1"]), _ptr(a["p2"]), _ptr(a["off"]),
+                                           _ptr(a["f1"]), _ptr(a["f2"]), _ptr(a["sim"]), _ptr(a["d1"]),
+                                           _ptr(a["d2"]), _cstrs(list(banned)), len(banned), C.byref(h)))
+        return cls(h)
+
+    def close(self):
+        if self._h:
+            lib().lfr_graph_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    @property
+    def n_nodes(self):
+        return lib().lfr_graph_num_nodes(self._h)
+
+    @property
+    def n_edges(self):
+        return lib().lfr_graph_num_edges(self._h)
+
+    @property
+    def n_images(self):
+        return lib().lfr_graph_num_images(self._h)
+
+    def nodes(self):
+        n = self.n_nodes
+        img = np.zeros(n, np.int32)
+        feat = np.zeros(n, np.uint32)
+        _check(lib().lfr_graph_get_nodes(self._h, _ptr(img), _ptr(feat)))
+        return img, feat
+
+    def image_names(self):
+        return [lib().lfr_graph_image_name(self._h, i).decode("utf-8") for i in range(self.n_images)]
+
+    def image_facts(self):
+        return [lib().lfr_graph_image_fact(self._h, i) for i in range(self.n_images)]
+
+    def write_solution(self, positions, path):
+        """SolutionFile emit (solve.cc:644-679); returns the '> 0.5' count of solve.cc:666-670."""
+        pos = np.ascontiguousarray(positions, np.float64)
+        n_out = C.c_int64(0)
+        _check(lib().lfr_write_solution(self._h, _ptr(pos), os.fsencode(path), C.byref(n_out)))
+        return n_out.value
+
+
+def _contig(ma):
+    M = ma.n_matches
+    return {"facts": np.ascontiguousarray(ma.facts, np.float32),
+            "p1": np.ascontiguousarray(ma.pair_img1, np.int32), "p2": np.ascontiguousarray(ma.pair_img2, np.int32),
+            "off": np.ascontiguousarray(ma.pair_off, np.int64),
+            "f1": np.ascontiguousarray(ma.feat1, np.uint32), "f2": np.ascontiguousarray(ma.feat2, np.uint32),
+            "sim": np.ascontiguousarray(ma.sim, np.float32),
+            "d1": np.ascontiguousarray(ma.disp1, np.float32).reshape(M, 18),
+            "d2": np.ascontiguousarray(ma.disp2, np.float32).reshape(M, 18)}
+
+
+def write_matching_file(path, ma):
+    """Native MatchingFile writer (compute_match_graph.py:163-205 equivalent)."""
+    a = _contig(ma)
+    _check(lib().lfr_write_matching_file(os.fsencode(path), len(ma.image_names), _cstrs(ma.image_names),
+                                         _ptr(a["facts"]), len(a["p1"]), _ptr(a["p1"]), _ptr(a["p2"]),
+                                         _ptr(a["off"]), _ptr(a["f1"]), _ptr(a["f2"]), _ptr(a["sim"]),
+                                         _ptr(a["d1"]), _ptr(a["d2"])))
+
+
+class Problem:
+    """Tracks, roots, components and the device batch layout (solve.cc:487-606, 79-143)."""
+
+    def __init__(self, graph, max_nodes_in_component=0, component_override=None):
+        self.graph = graph
+        h = C.c_void_p()
+        co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
+        _check(lib().lfr_problem_build(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lfr_problem_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def stats(self):
+        s = ProblemStats()
+        _check(lib().lfr_problem_get_stats(self._h, C.byref(s)))
+        return s.as_dict()
+
+    def labels(self):
+        n = self.graph.n_nodes
+        track = np.zeros(n, np.int64)
+        root = np.zeros(n, np.uint8)
+        comp = np.zeros(n, np.int64)
+        _check(lib().lfr_problem_get_labels(self._h, _ptr(track), _ptr(root), _ptr(comp)))
+        return track, root.astype(bool), comp
+
+    def solve_hip(self, device=0, tukey_variant="ceres1"):
+        """Upload + solve + download on one GPU.  Returns (positions[n,2], stats dict)."""
+        n = self.graph.n_nodes
+        pos = np.zeros((n, 2), np.float64)
+        st = SolveStats()
+        _check(lib().lfr_solve_hip(self._h, device, TUKEY[tukey_variant], _ptr(pos), C.byref(st)))
+        return pos, st.as_dict()
+
+
+class Batch:
+    """A problem (or one LPT shard of it) resident in HBM."""
+
+    def __init__(self, problem, device=0, shard_rank=0, shard_world=1, tukey_variant="ceres1"):
+        self.problem = problem
+        h = C.c_void_p()
+        _check(lib().lfr_batch_create(problem._h, device, shard_rank, shard_world, TUKEY[tukey_variant], C.byref(h)))
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().lfr_batch_free(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def solve(self, stream=None, want_stats=True):
+        """stream: a hipStream_t as int (e.g. torch.cuda.current_stream().cuda_stream) or None."""
+        st = SolveStats()
+        _check(lib().lfr_batch_solve(self._h, C.c_void_p(stream) if stream else None,
+                                     C.byref(st) if want_stats else None))
+        return st.as_dict() if want_stats else None
+
+    def download(self, positions=None):
+        n = self.problem.graph.n_nodes
+        if positions is None:
+            positions = np.zeros((n, 2), np.float64)
+        _check(lib().lfr_batch_download(self._h, _ptr(positions)))
+        return positions
+
+    def component_info(self):
+        n = lib().lfr_batch_component_info(self._h, None, None, None, None, None, None)
+        if n < 0:
+            _check(int(n))
+        comp = np.zeros(n, np.int64)
+        it = np.zeros(n, np.int32)
+        term = np.zeros(n, np.int32)
+        cost = np.zeros(n, np.float64)
+        nvar = np.zeros(n, np.int32)
+        ne = np.zeros(n, np.int32)
+        lib().lfr_batch_component_info(self._h, _ptr(comp), _ptr(it), _ptr(term), _ptr(cost), _ptr(nvar), _ptr(ne))
+        return {"component": comp, "iterations": it, "termination": term, "final_cost": cost,
+                "n_var_nodes": nvar, "n_edges": ne}

@@ -188,6 +188,12 @@ static double problem_eval(Problem *p, const double *x, int want_jac, double *g 
 }
 
 /* ---- Ceres polynomial.cc ------------------------------------------------------------------ */
+static double ipow(double x, int n) {   /* x^n, n >= 0 (Ceres uses pow()) */
+    double v = 1.0;
+    for (int i = 0; i < n; ++i) v *= x;
+    return v;
+}
+
 static double polyval(const double *p, int n, double x) {
     double v = 0.0;
     for (int i = 0; i < n; ++i) v = v * x + p[i];
@@ -216,10 +222,9 @@ static int poly_root_real_parts(const double *pin, int n, double *out) {
     for (int i = 0; i <= deg; ++i) a[i] = pin[i] / pin[0];
     for (int i = 1; i <= deg; ++i) R = fmax(R, fabs(a[i]));
     R = 1.0 + R;
-    for (int k = 0; k < deg; ++k) {
-        const double th = 2.0 * M_PI * k / deg + 0.4;
-        zr[k] = R * cos(th); zi[k] = R * sin(th);
-    }
+    /* Durand-Kerner style start points R * (0.4 + 0.9i)^k */
+    const double sr0[4] = {1.0, 0.4, -0.65, -0.908}, si0[4] = {0.0, 0.9, 0.72, -0.297};
+    for (int k = 0; k < deg; ++k) { zr[k] = R * sr0[k]; zi[k] = R * si0[k]; }
     for (int it = 0; it < 200; ++it) {
         double maxw = 0.0;
         for (int k = 0; k < deg; ++k) {
@@ -287,11 +292,11 @@ static double minimize_interpolating_polynomial(const Sample *s, int ns, double 
     int row = 0;
     for (int i = 0; i < ns; ++i) {
         if (s[i].value_valid) {
-            for (int j = 0; j <= deg; ++j) lhs[row * ncons + j] = pow(s[i].x, deg - j);
+            for (int j = 0; j <= deg; ++j) lhs[row * ncons + j] = ipow(s[i].x, deg - j);
             poly[row++] = s[i].value;
         }
         if (s[i].gradient_valid) {
-            for (int j = 0; j < deg; ++j) lhs[row * ncons + j] = (deg - j) * pow(s[i].x, deg - j - 1);
+            for (int j = 0; j < deg; ++j) lhs[row * ncons + j] = (deg - j) * ipow(s[i].x, deg - j - 1);
             poly[row++] = s[i].gradient;
         }
     }
