@@ -115,6 +115,12 @@ int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component);
 
+/* Solvable components dealt to shard `shard_rank` of `shard_world` (largest edge count first to
+ * the least-loaded shard; the multi-GPU analogue of the largest-first task order, solve.cc:599-634).
+ * Fills original component ids / edge counts (either may be NULL); returns the count. */
+int64_t lfr_problem_shard_components(const lfr_problem *p, int shard_rank, int shard_world, int64_t *components,
+                                     int64_t *n_edges);
+
 /* ---------------------------------------------------------------------------------------------
  * A1, A2, A8, A10  batched Levenberg-Marquardt on the GPU.    solve.cc:79-160,614-635 + cost.cc
  * ------------------------------------------------------------------------------------------- */
@@ -145,6 +151,11 @@ void lfr_batch_free(lfr_batch *b);
  * Positions are reset to zero first (solve.cc:609-612).  Asynchronous unless stats != NULL, in
  * which case the call synchronizes the stream and fills stats. */
 int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
+/* HIP-event timings of one of the last 64 lfr_batch_solve calls (solves_back = 0: the latest);
+ * waits for that solve to finish.  class_ms / class_edges: LFR_NUM_KERNEL_CLASSES entries, one
+ * per kernel launch (wave<16,1>, wave<16,2>, wave<32,2>, wave<32,4>, block, global-matrix). */
+#define LFR_NUM_KERNEL_CLASSES 6
+int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written. */
 int lfr_batch_download(lfr_batch *b, double *positions);
 /* per solved component of the shard, in batch order: original component id, iterations,

@@ -397,6 +397,22 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     return LFR_OK;
 }
 
+std::vector<int32_t> assign_shards(const Problem &p, int world) {
+    std::vector<int32_t> shard(p.descs.size(), 0);
+    if (world <= 1) return shard;
+    std::vector<size_t> order(p.descs.size());
+    std::iota(order.begin(), order.end(), (size_t)0);
+    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return p.descs[x].n_edges > p.descs[y].n_edges; });
+    std::vector<int64_t> load(world, 0);
+    for (size_t i : order) {
+        int best = 0;
+        for (int s = 1; s < world; ++s) if (load[s] < load[best]) best = s;
+        load[best] += (int64_t)p.descs[i].n_edges + 8;      // +8: fixed per-component cost
+        shard[i] = best;
+    }
+    return shard;
+}
+
 }  // namespace lfr
 
 using namespace lfr;
@@ -419,6 +435,20 @@ int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats) {
     if (!p || !stats) return LFR_ERR_ARG;
     *stats = p->p.stats;
     return LFR_OK;
+}
+
+int64_t lfr_problem_shard_components(const lfr_problem *p, int shard_rank, int shard_world, int64_t *components,
+                                     int64_t *n_edges) {
+    if (!p || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return LFR_ERR_ARG;
+    const std::vector<int32_t> shard = assign_shards(p->p, shard_world);
+    int64_t n = 0;
+    for (size_t i = 0; i < shard.size(); ++i)
+        if (shard[i] == shard_rank) {
+            if (components) components[n] = p->p.desc_component[i];
+            if (n_edges) n_edges[n] = p->p.descs[i].n_edges;
+            ++n;
+        }
+    return n;
 }
 
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component) {

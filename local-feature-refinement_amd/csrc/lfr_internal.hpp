@@ -89,6 +89,10 @@ struct Problem {
     std::vector<uint32_t> node_ids;        // global node id per local slot
 };
 
+// LPT deal of the solvable components to `world` shards (largest edge count first to the least
+// loaded shard; mirrors the largest-first task order of solve.cc:599-634).  Returns shard per desc.
+std::vector<int32_t> assign_shards(const Problem &p, int world);
+
 int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p);
 
 // deterministic substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)

@@ -653,7 +653,11 @@ struct lfr_batch {
     CompInfoDev *d_infos = nullptr;
     double *d_workspace = nullptr;
     uint64_t *d_ws_off = nullptr;
-    hipEvent_t ev[2 * (lfr::KC_COUNT + 1)];
+    static constexpr int kSlots = 64;                    // event ring: timings of the last 64 solves
+    static constexpr int kEvPerSlot = 2 * (lfr::KC_COUNT + 1);
+    hipEvent_t ev_ring[kSlots * kEvPerSlot];
+    hipEvent_t *ev = ev_ring;                            // slot of the current solve
+    int64_t n_solves = 0;
     bool events = false;
     double h2d_ms = 0.0;
     std::vector<CompInfoDev> infos;      // last downloaded
@@ -672,7 +676,7 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_infos) (void)hipFree(b->d_infos);
     if (b->d_workspace) (void)hipFree(b->d_workspace);
     if (b->d_ws_off) (void)hipFree(b->d_ws_off);
-    if (b->events) for (auto &e : b->ev) (void)hipEventDestroy(e);
+    if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
     delete b;
 }
 
@@ -691,22 +695,11 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     b->device = device; b->tukey_variant = tukey_variant;
     b->n_graph_nodes = (int64_t)p.track.size();
 
-    // LPT sharding: components by edge count descending to the least-loaded shard (solve.cc:599-604)
+    // LPT sharding (lfr::assign_shards); the shard keeps the class/size order of the batch
     std::vector<size_t> mine;
-    if (shard_world == 1) { mine.resize(p.descs.size()); for (size_t i = 0; i < mine.size(); ++i) mine[i] = i; }
-    else {
-        std::vector<size_t> order(p.descs.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return p.descs[x].n_edges > p.descs[y].n_edges; });
-        std::vector<int64_t> load(shard_world, 0);
-        std::vector<uint8_t> take(p.descs.size(), 0);
-        for (size_t i : order) {
-            int best = 0;
-            for (int s = 1; s < shard_world; ++s) if (load[s] < load[best]) best = s;
-            load[best] += (int64_t)p.descs[i].n_edges + 8;      // +8: per-component fixed cost
-            if (best == shard_rank) take[i] = 1;
-        }
-        for (size_t i = 0; i < p.descs.size(); ++i) if (take[i]) mine.push_back(i);   // keeps class/size order
+    {
+        const std::vector<int32_t> shard = lfr::assign_shards(p, shard_world);
+        for (size_t i = 0; i < p.descs.size(); ++i) if (shard[i] == shard_rank) mine.push_back(i);
     }
     std::vector<EdgeRec> edges;
     uint64_t ws = 0;
@@ -759,7 +752,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     b->h2d_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (auto &e : b->ev) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : b->ev_ring) HIP_TRY(hipEventCreate(&e));
     b->events = true;
     *out = b;
     return LFR_OK;
@@ -772,6 +765,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     KernelArgs a;
     a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
     a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.tukey_variant = b->tukey_variant;
+    b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
+    ++b->n_solves;
     HIP_TRY(hipEventRecord(b->ev[0], st));
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
     for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
@@ -841,6 +836,25 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             best_ms = ms;
             stats->dominant_kernel_ms = ms; stats->dominant_kernel_edges = edges; stats->dominant_kernel_nodes = nodes;
             stats->dominant_ref_passes_edges = refp_e; stats->dominant_ref_passes_nodes = refp_n;
+        }
+    }
+    return LFR_OK;
+}
+
+int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges) {
+    if (!b || solves_back < 0 || solves_back >= lfr_batch::kSlots || solves_back >= b->n_solves) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    HIP_TRY(hipSetDevice(b->device));
+    hipEvent_t *ev = b->ev_ring + ((b->n_solves - 1 - solves_back) % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
+    HIP_TRY(hipEventSynchronize(ev[1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
+    if (total_ms) *total_ms = ms;
+    for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
+        if (class_ms) { HIP_TRY(hipEventElapsedTime(&ms, ev[2 + 2 * cls], ev[3 + 2 * cls])); class_ms[cls] = ms; }
+        if (class_edges) {
+            int64_t e = 0;
+            for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) e += b->descs[i].n_edges;
+            class_edges[cls] = e;
         }
     }
     return LFR_OK;

@@ -79,10 +79,12 @@ def lib():
         "lfr_problem_free": (None, [vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
+        "lfr_problem_shard_components": (i64, [vp, C.c_int, C.c_int, vp, vp]),
         "lfr_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, pp]),
         "lfr_batch_free": (None, [vp]),
         "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
         "lfr_batch_download": (C.c_int, [vp, vp]),
+        "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
@@ -99,8 +101,8 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_free", "lfr_problem_get_stats",
-           "lfr_problem_get_labels", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution"]
+           "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution"]
 
 
 def _check(rc):
@@ -239,6 +241,16 @@ class Problem:
         _check(lib().lfr_problem_get_labels(self._h, _ptr(track), _ptr(root), _ptr(comp)))
         return track, root.astype(bool), comp
 
+    def shard_components(self, rank, world):
+        """(component ids, edge counts) of the solvable components dealt to shard rank/world."""
+        n = lib().lfr_problem_shard_components(self._h, rank, world, None, None)
+        if n < 0:
+            _check(int(n))
+        comps = np.zeros(n, np.int64)
+        edges = np.zeros(n, np.int64)
+        lib().lfr_problem_shard_components(self._h, rank, world, _ptr(comps), _ptr(edges))
+        return comps, edges
+
     def solve_hip(self, device=0, tukey_variant="ceres1"):
         """Upload + solve + download on one GPU.  Returns (positions[n,2], stats dict)."""
         n = self.graph.n_nodes
@@ -270,6 +282,14 @@ class Batch:
         _check(lib().lfr_batch_solve(self._h, C.c_void_p(stream) if stream else None,
                                      C.byref(st) if want_stats else None))
         return st.as_dict() if want_stats else None
+
+    def timing(self, solves_back=0):
+        """HIP-event times of one of the last 64 solves: (total_ms, per-kernel-class ms, per-class edges)."""
+        tot = C.c_double(0.0)
+        cls = np.zeros(6, np.float64)
+        edges = np.zeros(6, np.int64)
+        _check(lib().lfr_batch_timing(self._h, solves_back, C.byref(tot), _ptr(cls), _ptr(edges)))
+        return tot.value, cls, edges
 
     def download(self, positions=None):
         n = self.problem.graph.n_nodes

@@ -1,0 +1,186 @@
+"""Drop-in for the reference's `solve` executable (multi-view-refinement/solve.cc:375-682).
+
+Same flags (Boost.program_options semantics: ``--flag value``, ``--flag=value``, unambiguous
+prefixes; solve.cc:379-385), same stdout lines in the same order (solve.cc:484-485,534,549,589,
+591,606,638,641,670), same exit codes (0; 1 for flag errors, solve.cc:397-401; 255 for
+parse/write failures, solve.cc:433-436,674-677).  The work is done by liblfr_hip.so on a
+MI355X; there is no CPU fallback — a missing library or GPU is a loud error (exit 2).
+
+Environment (additions that default so the reference's scripts run unchanged):
+  LFR_DEVICE            HIP device ordinal (default 0)
+  LFR_TUKEY_VARIANT     ceres1 (default; Ceres <= 1.14) | ceres2 (Ceres >= 2.0)
+  LFR_COMPONENTS_FILE   raw little-endian int64[n_nodes] component ids replacing the size-cap
+                        graph cut (side-car for exact parity with a reference run)
+"""
+import os
+import sys
+import time
+
+OPTIONS = [  # name, takes value, default text, help
+    ("help", False, None, "print the help"),
+    ("matches_file", True, None, "path to the matches file"),
+    ("output_file", True, None, "path to the output file"),
+    ("n_threads", True, "8", "# threads"),
+    ("banned_images", True, "{}", "banned images"),
+]
+
+
+def usage():
+    lines = ["Options:"]
+    for name, takes, default, text in OPTIONS:
+        left = "  --" + name
+        if takes:
+            left += " arg"
+            if default is not None:
+                left += " (=%s)" % default
+        lines.append("%-26s %s" % (left, text) if len(left) < 26 else "%s %s" % (left, text))
+    return "\n".join(lines) + "\n"
+
+
+class FlagError(Exception):
+    pass
+
+
+def parse_args(argv):
+    """Boost.program_options-compatible parsing of solve.cc:379-396."""
+    names = [o[0] for o in OPTIONS]
+    takes = {o[0]: o[1] for o in OPTIONS}
+    out = {"help": False, "matches_file": None, "output_file": None, "n_threads": 8, "banned_images": []}
+    seen = set()
+    i = 0
+    while i < len(argv):
+        tok = argv[i]
+        i += 1
+        if not tok.startswith("--") or tok == "--":
+            raise FlagError("too many positional options have been specified on the command line")
+        body = tok[2:]
+        value = None
+        if "=" in body:
+            body, value = body.split("=", 1)
+        if body in names:
+            name = body
+        else:
+            cands = [n for n in names if n.startswith(body)] if body else []
+            if len(cands) == 1:
+                name = cands[0]
+            elif len(cands) > 1:
+                raise FlagError("option '--%s' is ambiguous and matches %s" % (body, ", ".join("'--%s'" % c for c in cands)))
+            else:
+                raise FlagError("unrecognised option '--%s'" % body)
+        if not takes[name]:
+            if value is not None:
+                raise FlagError("option '--%s' does not take any arguments" % name)
+            out[name] = True
+            continue
+        if value is None:
+            if i >= len(argv) or (argv[i].startswith("--") and len(argv[i]) > 2):
+                raise FlagError("the required argument for option '--%s' is missing" % name)
+            value = argv[i]
+            i += 1
+        if name == "banned_images":
+            out[name].append(value)
+            continue
+        if name in seen:
+            raise FlagError("option '--%s' cannot be specified more than once" % name)
+        seen.add(name)
+        if name == "n_threads":
+            try:
+                out[name] = int(value)
+                if out[name] < 0:
+                    raise ValueError
+            except ValueError:
+                raise FlagError("the argument ('%s') for option '--n_threads' is invalid" % value)
+        else:
+            out[name] = value
+    if out["help"]:
+        return out
+    for req in ("matches_file", "output_file"):
+        if out[req] is None:
+            raise FlagError("the option '--%s' is required but missing" % req)
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    try:
+        args = parse_args(argv)
+    except FlagError as e:                                    # solve.cc:397-401
+        sys.stderr.write("ERROR: %s\n\n" % e)
+        sys.stderr.write(usage())
+        return 1
+    if args["help"]:                                          # solve.cc:391-394
+        sys.stdout.write("Patch Match graph problem solver\n\n" + usage())
+        return 0
+
+    import numpy as np
+    try:
+        from . import capi
+        capi.lib()
+    except (ImportError, OSError) as e:
+        sys.stderr.write("FATAL: %s\n" % e)
+        return 2
+
+    try:
+        graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"])
+    except capi.LfrError as e:
+        if e.code == -3:
+            sys.stderr.write("Failed to parse proto object.\n")          # solve.cc:433-436
+            return 255
+        sys.stderr.write("%s\n" % e)
+        return 255
+    print("# graph nodes: %d" % graph.n_nodes)                            # solve.cc:484
+    print("# graph edges: %d" % graph.n_edges)                            # solve.cc:485
+    sys.stdout.flush()
+
+    t_start = time.perf_counter()                                         # solve.cc:487
+    override = None
+    comp_file = os.environ.get("LFR_COMPONENTS_FILE")
+    if comp_file:
+        override = np.fromfile(comp_file, dtype="<i8")
+        if override.shape[0] != graph.n_nodes:
+            sys.stderr.write("FATAL: %s holds %d ids, the graph has %d nodes\n" % (comp_file, override.shape[0], graph.n_nodes))
+            return 2
+    n_nodes = graph.n_nodes
+    positions = np.zeros((n_nodes, 2), np.float64)                        # solve.cc:609-612
+    if n_nodes > 0:
+        try:
+            problem = capi.Problem(graph, 0, override)
+        except capi.LfrError as e:
+            sys.stderr.write("FATAL: %s\n" % e)
+            return 2
+        st = problem.stats()
+        print("# tracks: %d" % st["n_tracks"])                            # solve.cc:534
+        print("max track size: %d" % st["max_track_size"])                # solve.cc:549
+        print("Graph-cut time: %dms" % int(st["graph_cut_ms"]))           # solve.cc:589
+        print("# components: %d" % st["n_components"])                    # solve.cc:591
+        print("max component size: %d" % st["max_component_size"])        # solve.cc:606
+        if st["n_cut_components"]:
+            sys.stderr.write("note: %d component(s) above the size cap were split by the built-in bisection, "
+                             "not by Graclus (see DESIGN.md)\n" % st["n_cut_components"])
+        sys.stdout.flush()
+        t1 = time.perf_counter()                                          # solve.cc:615
+        try:
+            positions, sst = problem.solve_hip(int(os.environ.get("LFR_DEVICE", "0")),
+                                               os.environ.get("LFR_TUKEY_VARIANT", "ceres1"))
+        except (capi.LfrError, KeyError) as e:
+            sys.stderr.write("FATAL: HIP solve failed: %s\n" % e)
+            return 2
+        t2 = time.perf_counter()
+        print("Solver time: %dms" % int((t2 - t1) * 1e3))                 # solve.cc:638
+        print("Total time: %dms" % int((t2 - t_start) * 1e3))             # solve.cc:641
+        if os.environ.get("LFR_VERBOSE"):
+            sys.stderr.write("lfr: kernels %.3f ms, h2d %.3f ms, d2h %.3f ms, %d components (%d failed, %d not converged)\n"
+                             % (sst["kernel_ms"], sst["h2d_ms"], sst["d2h_ms"], sst["n_components"], sst["n_failed"],
+                                sst["n_no_convergence"]))
+    try:
+        n_outside = graph.write_solution(positions, args["output_file"])
+    except capi.LfrError:
+        print("# points with at least one coordinate > 0.5: %d" % int((abs(positions) > 0.5).any(axis=1).sum()))
+        sys.stderr.write("Failed to write proto object.\n")               # solve.cc:674-677
+        return 255
+    print("# points with at least one coordinate > 0.5: %d" % n_outside)  # solve.cc:670
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -97,10 +97,10 @@ def _distinct_images(rng, n_rows, L, n_images):
     """n_rows x L matrix of distinct image ids per row, uniform."""
     if n_rows == 0:
         return np.zeros((0, L), np.int64)
-    if n_rows * n_images <= 30_000_000 or L * 2 > n_images:
-        keys = rng.random((n_rows, n_images))
+    if 4 * L * L > n_images:            # collisions likely: random keys + argsort
+        keys = rng.random((n_rows, n_images), dtype=np.float32)
         return np.argsort(keys, axis=1, kind="stable")[:, :L].astype(np.int64)
-    out = rng.integers(0, n_images, size=(n_rows, L))
+    out = rng.integers(0, n_images, size=(n_rows, L))       # rare collisions: redraw those rows
     while True:
         s = np.sort(out, axis=1)
         bad = np.nonzero((s[:, 1:] == s[:, :-1]).any(axis=1))[0]
@@ -183,12 +183,19 @@ def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=N
     a, b = np.where(swap, b, a), np.where(swap, a, b)
     M = a.size
 
+    grid32 = GRID.astype(np.float32)
+
     def _flow(src, dst):
-        base = node_p[dst] - node_p[src]                       # (M,2)
-        base = np.where(wrong[:, None], rng.normal(0.0, 0.3, size=(M, 2)), base)
-        A = rng.normal(0.0, sigma_A, size=(M, 2, 2))
-        lin = np.einsum("mij,kj->mki", A, GRID)                # (M,9,2)
-        return (base[:, None, :] + lin + rng.normal(0.0, sigma_noise, size=(M, 9, 2))).astype(np.float32)
+        base = (node_p[dst] - node_p[src]).astype(np.float32)                    # (M,2)
+        if n_out > 0:
+            base = np.where(wrong[:, None], rng.normal(0.0, 0.3, size=(M, 2)).astype(np.float32), base)
+        A = rng.standard_normal(size=(M, 2, 2), dtype=np.float32) * np.float32(sigma_A)
+        out = rng.standard_normal(size=(M, 9, 2), dtype=np.float32)
+        out *= np.float32(sigma_noise)
+        out += base[:, None, :]
+        out += A[:, None, :, 0] * grid32[None, :, 0, None]                       # A . u, u = grid point
+        out += A[:, None, :, 1] * grid32[None, :, 1, None]
+        return out
 
     disp2 = _flow(a, b)   # flow 1 -> 2
     disp1 = _flow(b, a)   # flow 2 -> 1

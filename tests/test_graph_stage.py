@@ -1,0 +1,121 @@
+"""Graph stage: tracks (solve.cc:489-549), roots (552-582), components (252-373), assembly
+(79-143).  The literal Python restatement (oracle/lfr_ref.py: std::set<std::string> semantics,
+std::sort+reverse tie-breaks) is the spec; the C oracle and the native host code of
+liblfr_hip.so (interned images, linked-list image sets) must agree with it exactly."""
+import numpy as np
+import pytest
+
+import lfr_oracle as O
+import lfr_ref as R
+from lfr_amd import capi, synthetic
+
+
+def fuzz_pairs(seed):
+    rng = np.random.default_rng(seed)
+    n_images = int(rng.integers(3, 7))
+    n_feat = int(rng.integers(2, 6))
+    pairs = []
+    for _ in range(int(rng.integers(3, 12))):
+        a, b = rng.choice(n_images, size=2, replace=False)
+        ms = []
+        for _ in range(int(rng.integers(0, 6))):
+            ms.append({"feature_idx1": int(rng.integers(0, n_feat)), "feature_idx2": int(rng.integers(0, n_feat)),
+                       "similarity": float(np.float32(rng.choice([0.5, 0.75, 0.9]))),     # many exact ties
+                       "disp1": [tuple(float(np.float32(v)) for v in rng.normal(0, 0.1, 2)) for _ in range(9)],
+                       "disp2": [tuple(float(np.float32(v)) for v in rng.normal(0, 0.1, 2)) for _ in range(9)]})
+        pairs.append({"image_name1": "im%d" % a, "fact1": 1.0, "image_name2": "im%d" % b, "fact2": 1.0, "matches": ms})
+    return pairs
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_tracks_and_roots_fuzz(lfr_lib, seed):
+    pairs = fuzz_pairs(seed)
+    g = R.MatchGraph(pairs)
+    if g.n_nodes == 0:
+        pytest.skip("empty graph")
+    track, n_tracks = R.build_tracks(g)
+    roots = R.select_roots(g, track, n_tracks)
+    ma = synthetic.pairs_to_arrays(pairs)
+    native_g = capi.Graph.from_arrays(ma)
+    prob = capi.Problem(native_g)
+    t2, r2, c2 = prob.labels()
+    assert native_g.n_nodes == g.n_nodes
+    assert (t2 == np.asarray(track)).all()
+    assert (r2 == np.asarray(roots)).all()
+    o = O.run(ma, solve=False)
+    assert (o["track"] == np.asarray(track)).all() and (o["is_root"] == np.asarray(roots)).all()
+    # every track holds at most one node per image (the merge rule of solve.cc:506-511)
+    for t in range(n_tracks):
+        imgs = [g.node_key[i][0] for i in range(g.n_nodes) if track[i] == t]
+        assert len(imgs) == len(set(imgs))
+    # components: identical when nothing exceeds the cap; otherwise the product must respect the cap
+    cap = len(g.images_set)
+    st = prob.stats()
+    try:
+        comp, n_comp, _ = R.split_components(g, track, n_tracks, cap)
+        assert (c2 == np.asarray(comp)).all() and st["n_components"] == n_comp and st["n_cut_components"] == 0
+        assert o["rc"] == 0 and (o["comp"] == np.asarray(comp)).all()
+    except NotImplementedError:
+        assert st["n_cut_components"] >= 1 and o["rc"] != 0
+        # a component may exceed the cap only if it is a single track (tracks are never split)
+        for c in np.unique(c2):
+            members = np.nonzero(c2 == c)[0]
+            assert len(members) <= cap or len(set(t2[members])) == 1
+
+
+def test_component_equal_to_cap_is_not_cut(lfr_lib):
+    """solve.cc:314 uses <=: a component with exactly #images nodes stays whole."""
+    def m(f1, f2, s):
+        z = [(0.0, 0.0)] * 9
+        return {"feature_idx1": f1, "feature_idx2": f2, "similarity": s, "disp1": z, "disp2": z}
+    # images a,b,c,d (cap 4).  track {a0,b0}; track {a1,c0}; a1-b0 is rejected (image a twice) -> inter-track edge
+    pairs = [{"image_name1": "a", "fact1": 1.0, "image_name2": "b", "fact2": 1.0, "matches": [m(0, 0, 0.9), m(1, 0, 0.5)]},
+             {"image_name1": "a", "fact1": 1.0, "image_name2": "c", "fact2": 1.0, "matches": [m(1, 0, 0.8)]},
+             {"image_name1": "c", "fact1": 1.0, "image_name2": "d", "fact2": 1.0, "matches": []}]
+    res = R.solve_pairs(pairs)
+    assert res["n_tracks"] == 2 and res["n_components"] == 1 and res["max_component_size"] == 4 == len({"a", "b", "c", "d"})
+    g = capi.Graph.from_arrays(synthetic.pairs_to_arrays(pairs))
+    st = capi.Problem(g).stats()
+    assert st["n_components"] == 1 and st["n_cut_components"] == 0 and st["max_component_size"] == 4
+    # one image fewer (drop the empty c-d pair): cap 3 < 4 nodes -> must be cut
+    st2 = capi.Problem(capi.Graph.from_arrays(synthetic.pairs_to_arrays(pairs[:2]))).stats()
+    assert st2["n_cut_components"] == 1 and st2["n_components"] == 2
+
+
+def test_synthetic_graphs_match_oracle_at_scale(lfr_lib):
+    ma = synthetic.generate(seed=51, n_images=300, n_tracks=4000, eps_out=0.001)
+    g = capi.Graph.from_arrays(ma)
+    p = capi.Problem(g)
+    o = O.run(ma, solve=False)
+    assert o["rc"] == 0
+    t, r, c = p.labels()
+    assert (t == o["track"]).all() and (r == o["is_root"]).all() and (c == o["comp"]).all()
+    st = p.stats()
+    for k in ("n_tracks", "max_track_size", "n_components", "max_component_size"):
+        assert st[k] == o[k]
+    assert st["n_solved_edges"] <= g.n_edges and st["n_solved_components"] <= st["n_components"]
+
+
+def test_component_override_sidecar(lfr_lib):
+    ma = synthetic.generate(seed=52, n_images=10, n_tracks=40, eps_out=0.05)      # forces oversized components
+    g = capi.Graph.from_arrays(ma)
+    p = capi.Problem(g)
+    assert p.stats()["n_cut_components"] >= 1
+    _, _, comp = p.labels()
+    p2 = capi.Problem(g, 0, comp)
+    assert (p2.labels()[2] == comp).all() and p2.stats()["n_cut_components"] == 0
+    o = O.run(ma, solve=False, comp_override=comp)
+    assert o["rc"] == 0 and o["n_components"] == p2.stats()["n_components"]
+
+
+def test_shards_partition_the_solvable_components(lfr_lib):
+    ma = synthetic.generate(seed=53, n_images=100, n_tracks=2000)
+    p = capi.Problem(capi.Graph.from_arrays(ma))
+    all_c, all_e = p.shard_components(0, 1)
+    assert len(all_c) == p.stats()["n_solved_components"] and all_e.sum() == p.stats()["n_solved_edges"]
+    for world in (2, 3, 8):
+        parts = [p.shard_components(r, world) for r in range(world)]
+        merged = np.concatenate([c for c, _ in parts])
+        assert len(merged) == len(all_c) and set(merged) == set(all_c)          # disjoint cover
+        loads = np.array([e.sum() for _, e in parts], float)
+        assert loads.max() / loads.mean() < 1.02                                  # LPT balance by edges
