@@ -353,6 +353,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     p.descs.resize(metas.size()); p.desc_component.resize(metas.size()); p.desc_class.resize(metas.size());
     p.desc_tracks.resize(metas.size());
     p.edges.resize(total_edges); p.node_ids.resize(total_nodes);
+    p.node_inc.assign(total_nodes, NodeInc{0, 0, 0, 0}); p.in_idx.resize(total_edges);
     std::vector<int32_t> local_of(N, -1);
     int64_t eo = 0, no = 0;
     for (size_t di = 0; di < metas.size(); ++di) {
@@ -369,8 +370,10 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
         d.edge_off = (uint32_t)eo; d.n_edges = (uint32_t)mt.n_edges; d.node_off = (uint32_t)no;
         d.n_nodes = (uint16_t)mt.n_nodes; d.n_var = (uint16_t)mt.n_var;
         p.desc_component[di] = mt.comp; p.desc_class[di] = mt.cls; p.desc_tracks[di] = mt.n_tracks;
+        const int64_t eo0 = eo;
         for (int64_t k = lo; k < hi; ++k) {           // residual-block order of solve.cc:98-102
             const int64_t n = comp_nodes[k];
+            p.node_inc[no + local_of[n]].out_begin = (uint32_t)(eo - eo0);
             for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
                 const int64_t e = out_eid[q];
                 const uint32_t dn = edge_dst(e);
@@ -385,6 +388,16 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
                 r.sim = g.m_sim[e >> 1];
                 r.src = (uint16_t)local_of[n];
                 r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
+                ++p.node_inc[no + local_of[n]].out_count;
+                ++p.node_inc[no + local_of[dn]].in_count;
+            }
+        }
+        {   // in-edge lists: counting sort of the component's edges by destination (stable)
+            uint32_t acc = 0;
+            for (int32_t l = 0; l < mt.n_nodes; ++l) { p.node_inc[no + l].in_begin = acc; acc += p.node_inc[no + l].in_count; p.node_inc[no + l].in_count = 0; }
+            for (int64_t e = eo0; e < eo; ++e) {
+                NodeInc &ni = p.node_inc[no + (p.edges[e].dst_kind & 0x7fff)];
+                p.in_idx[eo0 + ni.in_begin + ni.in_count++] = (uint32_t)(e - eo0);
             }
         }
         no += mt.n_nodes;

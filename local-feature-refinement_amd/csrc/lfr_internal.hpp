@@ -63,6 +63,13 @@ struct CompDesc {
 };
 static_assert(sizeof(CompDesc) == 16, "CompDesc must be 16 bytes");
 
+// incidence of one local node: its out-edges are contiguous in the component's edge list
+// (records [out_begin, out_begin+out_count)); its in-edges are in_idx[in_begin .. in_begin+in_count)
+// (component-local edge indices, ascending).  Used by the owner-computes assembly of the
+// workgroup kernels: every row of J^T J is summed by one thread in a fixed order (deterministic).
+struct NodeInc { uint32_t out_begin, out_count, in_begin, in_count; };
+static_assert(sizeof(NodeInc) == 16, "NodeInc must be 16 bytes");
+
 // kernel classes
 enum KernelClass : int {
     KC_W16_1 = 0,   // wave per component, <=16 rows, <=64 edges
@@ -87,6 +94,8 @@ struct Problem {
     std::vector<int32_t> desc_tracks;      // tracks (>=2 nodes) inside
     std::vector<EdgeRec> edges;
     std::vector<uint32_t> node_ids;        // global node id per local slot
+    std::vector<NodeInc> node_inc;         // parallel to node_ids
+    std::vector<uint32_t> in_idx;          // parallel to edges (per component: edge indices sorted by dst)
 };
 
 // LPT deal of the solvable components to `world` shards (largest edge count first to the least

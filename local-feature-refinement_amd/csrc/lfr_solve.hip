@@ -39,8 +39,11 @@ struct KernelArgs {
     const uint32_t *node_ids;
     double *positions;          // 2 * n_nodes of the whole graph
     CompInfoDev *infos;
-    double *workspace;          // GLOBAL class: packed matrices
-    const uint64_t *ws_off;     // per desc (GLOBAL class only)
+    const lfr::NodeInc *node_inc;   // parallel to node_ids
+    const uint32_t *in_idx;     // parallel to edges
+    double *workspace;          // workgroup kernels: per-edge scratch (+ packed matrices for the HBM variant)
+    const uint64_t *ws_off;     // per desc: packed-matrix offset (HBM variant)
+    const uint64_t *es_off;     // per desc: per-edge scratch offset (8 doubles per edge)
     int desc_begin, desc_end;
     int tukey_variant;
 };
@@ -353,12 +356,15 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     for (int i = tid; i < n + 2; i += kBlockThreads) { vx[i] = 0.0; vxc[i] = 0.0; }
     __syncthreads();
 
-    // one sweep over the edges at xv: returns cost; want_matrix also assembles Mat (unscaled J^T J)
+    // One sweep over the edges at xv: returns the cost, fills gout = J^T r and (want_matrix) Mat =
+    // unscaled J^T J.  Deterministic owner-computes assembly: phase 1 evaluates every edge (one
+    // thread per edge, 64 B of corrected jacobian/residual to the scratch); phase 2 gives every row
+    // of the normal matrix to ONE thread, which walks the node's out-edges then in-edges in a
+    // fixed order - no atomics, bitwise reproducible.
+    const lfr::NodeInc *inc = a.node_inc + d.node_off;
+    const uint32_t *in_idx = a.in_idx + d.edge_off;
+    double *es = a.workspace + a.es_off[ci];
     auto sweep = [&](const double *xv, double *gout, bool want_matrix) -> double {
-        if (want_matrix) for (size_t i = tid; i < tri(n, 0); i += kBlockThreads) Mat[i] = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) gout[i] = 0.0;
-        if (GLOBAL_MATRIX && want_matrix) __threadfence();
-        __syncthreads();
         double cost = 0.0;
         for (int e = tid; e < E; e += kBlockThreads) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
@@ -375,50 +381,59 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             const float sim = __uint_as_float(q[4].z);
             const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
             const int dn = dk & 0x7fff, kind = dk >> 15;
-            const int ra = s < n_var ? 2 * s : -1, rb = dn < n_var ? 2 * dn : -1;
             const int xa = s < n_var ? 2 * s : n, xb = dn < n_var ? 2 * dn : n;
             EdgeOut o;
             eval_edge<true>(flow, sim, kind, tv, xv[xa], xv[xa + 1], xv[xb], xv[xb + 1], o);
             cost += o.cost;
-            if (ra >= 0) {
-                atomicAdd(&gout[ra], o.j00 * o.r0 + o.j10 * o.r1);
-                atomicAdd(&gout[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
-            }
-            if (rb >= 0) {
-                atomicAdd(&gout[rb], o.sq * o.r0);
-                atomicAdd(&gout[rb + 1], o.sq * o.r1);
-            }
-            if (want_matrix) {
-                if (ra >= 0) {
-                    atomicAdd(&Mat[tri(ra, ra)], o.j00 * o.j00 + o.j10 * o.j10);
-                    atomicAdd(&Mat[tri(ra + 1, ra)], o.j01 * o.j00 + o.j11 * o.j10);
-                    atomicAdd(&Mat[tri(ra + 1, ra + 1)], o.j01 * o.j01 + o.j11 * o.j11);
-                }
-                if (rb >= 0) {
-                    atomicAdd(&Mat[tri(rb, rb)], o.sq * o.sq);
-                    atomicAdd(&Mat[tri(rb + 1, rb + 1)], o.sq * o.sq);
-                }
-                if (ra >= 0 && rb >= 0) {
-                    if (rb > ra) {
-                        atomicAdd(&Mat[tri(rb, ra)], o.sq * o.j00);
-                        atomicAdd(&Mat[tri(rb, ra + 1)], o.sq * o.j01);
-                        atomicAdd(&Mat[tri(rb + 1, ra)], o.sq * o.j10);
-                        atomicAdd(&Mat[tri(rb + 1, ra + 1)], o.sq * o.j11);
-                    } else {
-                        atomicAdd(&Mat[tri(ra, rb)], o.j00 * o.sq);
-                        atomicAdd(&Mat[tri(ra, rb + 1)], o.j10 * o.sq);
-                        atomicAdd(&Mat[tri(ra + 1, rb)], o.j01 * o.sq);
-                        atomicAdd(&Mat[tri(ra + 1, rb + 1)], o.j11 * o.sq);
+            double2 *w = reinterpret_cast<double2 *>(es + 8 * (size_t)e);
+            w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
+            w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
+        }
+        const double total = block_sum(cost, sh);          // (barriers inside: scratch is complete)
+        for (int row = tid; row < n; row += kBlockThreads) {
+            const int v = row >> 1, c = row & 1;
+            const lfr::NodeInc ni = inc[v];
+            if (want_matrix) for (int j = 0; j <= row; ++j) Mat[tri(row, j)] = 0.0;
+            double gacc = 0.0, dsame = 0.0, dlow = 0.0;     // A[row][row], A[2v+1][2v] (c == 1 only)
+            for (uint32_t k = 0; k < ni.out_count; ++k) {   // edges v -> w : J1 = d r / d x_v
+                const uint32_t e = ni.out_begin + k;
+                const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
+                const double2 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+                const double jc0 = c ? a0.y : a0.x, jc1 = c ? a1.y : a1.x;    // column c of J1
+                gacc += jc0 * a2.y + jc1 * a3.x;
+                if (want_matrix) {
+                    dsame += jc0 * jc0 + jc1 * jc1;
+                    if (c) dlow += a0.y * a0.x + a1.y * a1.x;
+                    const int wn = (int)(edges[e].dst_kind & 0x7fff);
+                    if (wn < v) {                           // block (v, w) += J1^T * sq
+                        Mat[tri(row, 2 * wn)] += jc0 * a2.x;
+                        Mat[tri(row, 2 * wn + 1)] += jc1 * a2.x;
                     }
                 }
             }
+            for (uint32_t k = 0; k < ni.in_count; ++k) {    // edges w -> v : d r / d x_v = sq * I
+                const uint32_t e = in_idx[ni.in_begin + k];
+                const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
+                const double2 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
+                const double sq = a2.x, rc = c ? a3.x : a2.y;
+                gacc += sq * rc;
+                if (want_matrix) {
+                    dsame += sq * sq;
+                    const int wn = (int)edges[e].src;
+                    if (wn < v) {                           // block (v, w) += sq * J1'
+                        Mat[tri(row, 2 * wn)] += sq * (c ? a1.x : a0.x);
+                        Mat[tri(row, 2 * wn + 1)] += sq * (c ? a1.y : a0.y);
+                    }
+                }
+            }
+            gout[row] = gacc;
+            if (want_matrix) {
+                Mat[tri(row, row)] = dsame;
+                if (c) Mat[tri(row, row - 1)] = dlow;
+                vadiag[row] = dsame;
+            }
         }
-        if (GLOBAL_MATRIX && want_matrix) __threadfence();     // L2 atomics -> visible to this CU's loads
-        const double total = block_sum(cost, sh);
-        if (want_matrix) {
-            for (int i = tid; i < n; i += kBlockThreads) vadiag[i] = Mat[tri(i, i)];
-            __syncthreads();
-        }
+        __syncthreads();
         return total;
     };
 
@@ -641,7 +656,8 @@ struct lfr_batch {
     std::vector<int64_t> desc_component;
     std::vector<int32_t> desc_class, desc_tracks;
     std::vector<uint32_t> node_ids;
-    std::vector<uint64_t> ws_off;
+    std::vector<uint64_t> ws_off, es_off;
+    std::vector<lfr::NodeInc> node_inc;
     int class_begin[lfr::KC_COUNT + 1] = {0};
     int block_max_rows = 0, global_max_rows = 0;
     int64_t n_edges = 0, n_nodes = 0, n_tracks = 0;
@@ -652,7 +668,9 @@ struct lfr_batch {
     double *d_positions = nullptr;
     CompInfoDev *d_infos = nullptr;
     double *d_workspace = nullptr;
-    uint64_t *d_ws_off = nullptr;
+    uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
+    lfr::NodeInc *d_node_inc = nullptr;
+    uint32_t *d_in_idx = nullptr;
     static constexpr int kSlots = 64;                    // event ring: timings of the last 64 solves
     static constexpr int kEvPerSlot = 2 * (lfr::KC_COUNT + 1);
     hipEvent_t ev_ring[kSlots * kEvPerSlot];
@@ -676,6 +694,9 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_infos) (void)hipFree(b->d_infos);
     if (b->d_workspace) (void)hipFree(b->d_workspace);
     if (b->d_ws_off) (void)hipFree(b->d_ws_off);
+    if (b->d_es_off) (void)hipFree(b->d_es_off);
+    if (b->d_node_inc) (void)hipFree(b->d_node_inc);
+    if (b->d_in_idx) (void)hipFree(b->d_in_idx);
     if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
     delete b;
 }
@@ -702,19 +723,24 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         for (size_t i = 0; i < p.descs.size(); ++i) if (shard[i] == shard_rank) mine.push_back(i);
     }
     std::vector<EdgeRec> edges;
+    std::vector<uint32_t> in_idx;
     uint64_t ws = 0;
     for (size_t i : mine) {
         CompDesc d = p.descs[i];
         const uint32_t eo = (uint32_t)edges.size(), no = (uint32_t)b->node_ids.size();
         edges.insert(edges.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
+        in_idx.insert(in_idx.end(), p.in_idx.begin() + d.edge_off, p.in_idx.begin() + d.edge_off + d.n_edges);
         b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
+        b->node_inc.insert(b->node_inc.end(), p.node_inc.begin() + d.node_off, p.node_inc.begin() + d.node_off + d.n_nodes);
         d.edge_off = eo; d.node_off = no;
         const int cls = p.desc_class[i], rows = 2 * d.n_var;
         b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
         b->desc_class.push_back(cls); b->desc_tracks.push_back(p.desc_tracks[i]);
+        b->es_off.push_back(ws);
+        if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
         b->ws_off.push_back(ws);
         if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
-        if (cls == lfr::KC_GLOBAL) { b->global_max_rows = std::max(b->global_max_rows, rows); ws += (uint64_t)rows * (rows + 1) / 2; }
+        if (cls == lfr::KC_GLOBAL) { b->global_max_rows = std::max(b->global_max_rows, rows); ws += (uint64_t)rows * (rows + 1) / 2; ws += ws & 1; }
         b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
     }
     {   // class ranges (descs are sorted by class)
@@ -739,12 +765,18 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipMalloc(&b->d_positions, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
     HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&b->d_es_off, nd * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&b->d_node_inc, nn * sizeof(lfr::NodeInc)));
+    HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
     if (ws) HIP_TRY(hipMalloc(&b->d_workspace, ws * sizeof(double)));
     if (!b->descs.empty()) {
         HIP_TRY(hipMemcpy(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_ws_off, b->ws_off.data(), b->ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_es_off, b->es_off.data(), b->es_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_node_inc, b->node_inc.data(), b->node_inc.size() * sizeof(lfr::NodeInc), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(b->d_in_idx, in_idx.data(), in_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
@@ -764,7 +796,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     hipStream_t st = (hipStream_t)hip_stream;
     KernelArgs a;
     a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
-    a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.tukey_variant = b->tukey_variant;
+    a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.es_off = b->d_es_off;
+    a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant;
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
     ++b->n_solves;
     HIP_TRY(hipEventRecord(b->ev[0], st));
