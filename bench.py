@@ -104,7 +104,7 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel launch (SURVEY §8(d) accounting)
-        kernel_names = ["solve_wave_kernel<16,1>", "solve_wave_kernel<16,2>", "solve_wave_kernel<32,2>",
+        kernel_names = ["solve_group_kernel<8,3>", "solve_group_kernel<16,3>", "solve_group_kernel<32,3>",
                         "solve_wave_kernel<32,4>", "solve_block_kernel<lds>", "solve_block_kernel<hbm>"]
         dur_s = cls_ms[dom] * 1e-3
         b_stream = st["dominant_ref_passes_edges"] * EDGE_BYTES + st["dominant_ref_passes_nodes"] * NODE_BYTES
@@ -121,6 +121,8 @@ def main():
                     "/ launch time; the kernel keeps edges in VGPRs so it reads HBM once (read_once_*)",
         }
         res["all_kernels_ms"] = tot_ms
+        res["class_ms"] = dict(zip(kernel_names, [round(float(x), 4) for x in cls_ms]))
+        res["class_edges"] = dict(zip(kernel_names, [int(x) for x in cls_edges]))
         res["host_ms"] = {"generate": t_gen * 1e3, "ingest": t_ingest * 1e3, "graph_stage": t_graph * 1e3,
                           "tracks": pst["tracks_ms"], "roots": pst["roots_ms"], "components": pst["graph_cut_ms"],
                           "assemble": pst["assemble_ms"], "h2d": st["h2d_ms"]}

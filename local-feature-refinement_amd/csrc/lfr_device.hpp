@@ -266,4 +266,98 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// ------------------------------------------------------------------------------------------
+// sub-group helpers: a wave64 hosts 64/S independent groups of S lanes (S = 8, 16, 32).
+// Reductions are butterflies over DPP row operations (VALU, no LDS); every lane of a group ends
+// with the bitwise-identical result (the pairing is symmetric), so group-uniform decisions stay
+// uniform.  Broadcasts use ds_swizzle in bit-mask mode (LDS crossbar, no LDS memory).
+// All of these must run with every lane of the wave active.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int PATTERN>
+__device__ __forceinline__ double swizzle_f64(double v) {
+    const int lo = __builtin_amdgcn_ds_swizzle(__double2loint(v), PATTERN);
+    const int hi = __builtin_amdgcn_ds_swizzle(__double2hiint(v), PATTERN);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppRowRor = 0x120;          // row_ror:n = 0x120 + n (rotate within a 16-lane row)
+constexpr int kDppHalfMirror = 0x141;      // lane i <-> 7 - i within 8 lanes
+constexpr int kDppQuadXor1 = 0xB1;         // quad_perm [1,0,3,2]
+constexpr int kDppQuadXor2 = 0x4E;         // quad_perm [2,3,0,1]
+constexpr int kSwizzleXor16 = (0x10 << 10) | 0x1F;
+
+template <int S, typename Op>
+__device__ __forceinline__ double group_reduce(double v, Op op) {
+    static_assert(S == 8 || S == 16 || S == 32, "group size");
+    if (S == 8) {
+        v = op(v, dpp_f64<kDppHalfMirror>(v));
+        v = op(v, dpp_f64<kDppQuadXor1>(v));
+        v = op(v, dpp_f64<kDppQuadXor2>(v));
+    } else {
+        v = op(v, dpp_f64<kDppRowRor + 8>(v));
+        v = op(v, dpp_f64<kDppRowRor + 4>(v));
+        v = op(v, dpp_f64<kDppRowRor + 2>(v));
+        v = op(v, dpp_f64<kDppRowRor + 1>(v));
+        if (S == 32) v = op(v, swizzle_f64<kSwizzleXor16>(v));
+    }
+    return v;
+}
+template <int S>
+__device__ __forceinline__ double group_sum(double v) { return group_reduce<S>(v, [](double a, double b) { return a + b; }); }
+template <int S>
+__device__ __forceinline__ double group_max(double v) { return group_reduce<S>(v, [](double a, double b) { return fmax(a, b); }); }
+// value of sub-lane K of the own group
+template <int S, int K>
+__device__ __forceinline__ double group_bcast(double v) {
+    constexpr int and_mask = (S == 8) ? 0x18 : (S == 16) ? 0x10 : 0x00;
+    return swizzle_f64<(K << 5) | and_mask>(v);
+}
+// same with the sub-lane as a (compile-time foldable) argument: call it with the induction
+// variable of a fully unrolled loop and the switch disappears
+template <int S>
+__device__ __forceinline__ double group_bcast_k(double v, int k) {
+    switch (k) {
+        case 0: return group_bcast<S, 0>(v);
+        case 1: return group_bcast<S, 1>(v);
+        case 2: return group_bcast<S, 2>(v);
+        case 3: return group_bcast<S, 3>(v);
+        case 4: return group_bcast<S, 4>(v);
+        case 5: return group_bcast<S, 5>(v);
+        case 6: return group_bcast<S, 6>(v);
+        case 7: return group_bcast<S, 7>(v);
+        case 8: return group_bcast<S, 8>(v);
+        case 9: return group_bcast<S, 9>(v);
+        case 10: return group_bcast<S, 10>(v);
+        case 11: return group_bcast<S, 11>(v);
+        case 12: return group_bcast<S, 12>(v);
+        case 13: return group_bcast<S, 13>(v);
+        case 14: return group_bcast<S, 14>(v);
+        case 15: return group_bcast<S, 15>(v);
+        case 16: return group_bcast<S, 16>(v);
+        case 17: return group_bcast<S, 17>(v);
+        case 18: return group_bcast<S, 18>(v);
+        case 19: return group_bcast<S, 19>(v);
+        case 20: return group_bcast<S, 20>(v);
+        case 21: return group_bcast<S, 21>(v);
+        case 22: return group_bcast<S, 22>(v);
+        case 23: return group_bcast<S, 23>(v);
+        case 24: return group_bcast<S, 24>(v);
+        case 25: return group_bcast<S, 25>(v);
+        case 26: return group_bcast<S, 26>(v);
+        case 27: return group_bcast<S, 27>(v);
+        case 28: return group_bcast<S, 28>(v);
+        case 29: return group_bcast<S, 29>(v);
+        case 30: return group_bcast<S, 30>(v);
+        case 31: return group_bcast<S, 31>(v);
+        default: return v;
+    }
+}
+template <int S>
+__device__ __forceinline__ bool group_any(bool p) { return group_max<S>(p ? 1.0 : 0.0) != 0.0; }
+
 }  // namespace lfrdev

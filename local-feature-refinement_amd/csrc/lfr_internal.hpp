@@ -72,10 +72,10 @@ static_assert(sizeof(NodeInc) == 16, "NodeInc must be 16 bytes");
 
 // kernel classes
 enum KernelClass : int {
-    KC_W16_1 = 0,   // wave per component, <=16 rows, <=64 edges
-    KC_W16_2,       // <=16 rows, <=128 edges
-    KC_W32_2,       // <=32 rows, <=128 edges
-    KC_W32_4,       // <=32 rows, <=256 edges
+    KC_G8_3 = 0,    // packed: 8 components per wave (8 lanes each), <=8 rows, <=24 edges
+    KC_G16_3,       // packed: 4 components per wave, <=16 rows, <=48 edges
+    KC_G32_3,       // packed: 2 components per wave, <=32 rows, <=96 edges
+    KC_W32_4,       // one wave per component, <=32 rows, <=256 edges
     KC_BLOCK,       // workgroup per component, normal matrix in LDS
     KC_GLOBAL,      // workgroup per component, normal matrix in HBM workspace
     KC_COUNT

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -290,6 +291,287 @@ __global__ __launch_bounds__(256) void solve_wave_kernel(const KernelArgs a) {
         inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
         inf.final_cost = cost;
         a.infos[ci] = inf;
+    }
+}
+
+// =============================================================================================
+// packed sub-group kernel: a wave64 hosts G = 64/S components, S lanes each (S = 8, 16, 32).
+// lane = edge slot for the evaluation (EPL edges per lane, resident in VGPRs) and lane = row of
+// the damped normal equations for the solve.  Groups advance through the same LM state machine in
+// lockstep rounds (solve -> evaluate -> decide); rare paths (invalid step, line-search contraction,
+// rejected step) just take extra rounds for their group.  Cross-lane traffic stays inside the
+// group: DPP butterflies for reductions, ds_swizzle for the Gauss-Jordan broadcasts.
+// =============================================================================================
+enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
+
+template <int S>
+struct GroupLds {
+    static constexpr int LD = S + 1;
+    double A[S * LD];          // J^T J (lower triangle) of the last evaluation
+    double g[S];               // J^T r of the last evaluation
+    double x[S + 2];           // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
+};
+
+template <int S, int EPL>
+__global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a) {
+    constexpr int G = 64 / S, NV = S, LD = S + 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gid = lane / S, sl = lane % S;
+    const int ci0 = a.desc_begin + ((int)blockIdx.x * 4 + wave) * G;
+    __shared__ GroupLds<S> lds_all[4][G];
+    if (ci0 >= a.desc_end) return;                    // wave-uniform
+    const int ci = ci0 + gid;
+    const bool have = ci < a.desc_end;
+    GroupLds<S> &L = lds_all[wave][gid];
+
+    CompDesc d;
+    d.edge_off = 0; d.n_edges = 0; d.node_off = 0; d.n_nodes = 0; d.n_var = 0;
+    if (have) d = a.descs[ci];
+    const int n_var = d.n_var, nv2 = 2 * n_var, E = (int)d.n_edges;
+    const int tv = a.tukey_variant;
+    const bool is_row = sl < nv2;
+    // largest row count of the wave: bounds the elimination loop (wave-uniform)
+    int nv2_max = nv2;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) nv2_max = max(nv2_max, __shfl_xor(nv2_max, m, 64));
+    nv2_max = __builtin_amdgcn_readfirstlane(nv2_max);
+
+    // ---- edges -> registers (the only HBM read of the solve) ----
+    float flow[EPL][18];
+    float sim[EPL];
+    int xs_src[EPL], xs_dst[EPL], row_src[EPL], row_dst[EPL], kind[EPL];
+    bool act[EPL];
+#pragma unroll
+    for (int k = 0; k < EPL; ++k) {
+        const int e = sl + S * k;
+        act[k] = e < E;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (act[k] ? e : 0));
+        uint4 q[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) q[i] = act[k] ? rp[i] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            flow[k][4 * i] = __uint_as_float(q[i].x); flow[k][4 * i + 1] = __uint_as_float(q[i].y);
+            flow[k][4 * i + 2] = __uint_as_float(q[i].z); flow[k][4 * i + 3] = __uint_as_float(q[i].w);
+        }
+        flow[k][16] = __uint_as_float(q[4].x); flow[k][17] = __uint_as_float(q[4].y);
+        sim[k] = __uint_as_float(q[4].z);
+        const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
+        const int dn = dk & 0x7fff;
+        kind[k] = dk >> 15;
+        row_src[k] = s < n_var ? 2 * s : -1;
+        row_dst[k] = dn < n_var ? 2 * dn : -1;
+        xs_src[k] = s < n_var ? 2 * s : nv2;
+        xs_dst[k] = dn < n_var ? 2 * dn : nv2;
+    }
+    L.x[sl] = 0.0;
+    if (sl < 2) L.x[S + sl] = 0.0;
+
+    // ---- group state (uniform inside a group unless marked 'row') ----
+    int phase = have ? PH_EVAL_INIT : PH_DONE;
+    double xi = 0.0, gi = 0.0, scale = 1.0, diag = 1.0;            // row
+    double xt = 0.0, delta = 0.0;                                    // row
+    double cost = 0.0, radius = kInitialRadius, decrease_factor = 2.0, x_norm = 0.0, gmax = 0.0;
+    double g_dot_delta = 0.0, dir_max = 0.0, model_cost_change = 0.0, alpha = 1.0;
+    LsSample ls_prev{0, 0, 0, false, false};
+    int ls_iter = 0;
+    bool reuse_diagonal = false, step_successful = true, a_dirty = false;
+    int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
+    int n_successful = 0, n_ls_evals = 0, n_cand = 0, exec_passes = 0;
+
+    for (;;) {
+        if (!__any(phase != PH_DONE)) break;
+
+        // ======================= A: iteration entry + LM step =======================
+        if (__any(phase == PH_SOLVE)) {
+            bool ps = phase == PH_SOLVE;
+            if (ps) {   // FinalizeIterationAndCheckIfMinimizerCanContinue
+                if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; phase = PH_DONE; ps = false; }
+                else if ((step_successful && gmax <= kGradientTol) || radius <= kMinRadius) { phase = PH_DONE; ps = false; }
+                else if (a_dirty) { phase = PH_REEVAL; ps = false; if (is_row) L.x[sl] = xi; }   // J^T J at x was overwritten
+            }
+            if (__any(ps)) {
+                if (ps) { ++iteration; step_successful = false; }
+                const double *A = L.A;
+                const double aii = is_row ? A[sl * LD + sl] : 1.0;
+                if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
+                const double Dl = sqrt(diag / radius);
+                double h[NV];
+#pragma unroll
+                for (int j = 0; j < NV; ++j) {
+                    const double sj = group_bcast_k<S>(scale, j);
+                    double v = 0.0;
+                    if (is_row && j < nv2) v = (j <= sl ? A[sl * LD + j] : A[j * LD + sl]) * scale * sj;
+                    if (j == sl) v = is_row ? v + Dl * Dl : 1.0;
+                    h[j] = v;
+                }
+                double rhs = is_row ? scale * gi : 0.0;
+                const double rhs0 = rhs;
+                double piv_own = 1.0;
+                bool fail = false;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {       // Gauss-Jordan, no pivoting (SPD); padded rows are identity
+                    if (k < nv2_max) {
+                        const double piv = group_bcast_k<S>(h[k], k);
+                        if (!(piv > 0.0)) fail = true;
+                        const double inv = 1.0 / piv;
+                        const double f = (sl == k) ? 0.0 : h[k] * inv;
+                        if (sl == k) piv_own = piv;
+#pragma unroll
+                        for (int j = k + 1; j < NV; ++j) h[j] -= f * group_bcast_k<S>(h[j], k);
+                        rhs -= f * group_bcast_k<S>(rhs, k);
+                    }
+                }
+                const double step = is_row ? -(rhs / piv_own) : 0.0;
+                const unsigned long long badmask = __ballot(is_row && !isfinite(step));
+                const bool bad = ((badmask >> (gid * S)) & ((S == 32) ? 0xffffffffull : ((1ull << S) - 1))) != 0;
+                const double mcc = 0.5 * group_sum<S>(is_row ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
+                const double dl = step * scale;
+                const double gdd = group_sum<S>(gi * dl);
+                const double dmx = group_max<S>(fabs(dl));
+                if (ps) {
+                    reuse_diagonal = true;
+                    const bool valid = !fail && !bad && mcc > 0.0;
+                    if (!valid) {
+                        if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; phase = PH_DONE; }
+                        else { radius = radius / decrease_factor; decrease_factor *= 2.0; }      // StepIsInvalid
+                    } else {
+                        n_invalid = 0;
+                        model_cost_change = mcc; delta = dl; g_dot_delta = gdd; dir_max = dmx;
+                        alpha = 1.0; ls_iter = 0; ls_prev.value_valid = false;
+                        xt = clampb(__dadd_rn(xi, delta));
+                        if (is_row) L.x[sl] = xt;
+                        phase = PH_EVAL_LS;
+                    }
+                }
+            }
+        }
+
+        // ======================= B: one sweep over the edges of the evaluating groups =======================
+        const bool pe = phase == PH_EVAL_INIT || phase == PH_EVAL_LS || phase == PH_EVAL_CAND || phase == PH_REEVAL;
+        if (!__any(pe)) continue;
+        if (pe) {
+            for (int i = sl; i < NV * LD; i += S) L.A[i] = 0.0;
+            L.g[sl] = 0.0;
+        }
+        wave_lds_sync();
+        double cost_l = 0.0;
+#pragma unroll
+        for (int k = 0; k < EPL; ++k) {
+            if (!(act[k] && pe)) continue;
+            EdgeOut o;
+            eval_edge<true>(flow[k], sim[k], kind[k], tv, L.x[xs_src[k]], L.x[xs_src[k] + 1],
+                            L.x[xs_dst[k]], L.x[xs_dst[k] + 1], o);
+            cost_l += o.cost;
+            double *A = L.A, *g = L.g;
+            const int ra = row_src[k], rb = row_dst[k];
+            if (ra >= 0) {
+                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10);
+                atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
+                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11);
+                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1);
+                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
+            }
+            if (rb >= 0) {
+                atomicAdd(&A[rb * LD + rb], o.sq * o.sq);
+                atomicAdd(&A[(rb + 1) * LD + rb + 1], o.sq * o.sq);
+                atomicAdd(&g[rb], o.sq * o.r0);
+                atomicAdd(&g[rb + 1], o.sq * o.r1);
+            }
+            if (ra >= 0 && rb >= 0) {
+                if (rb > ra) {
+                    atomicAdd(&A[rb * LD + ra], o.sq * o.j00);
+                    atomicAdd(&A[rb * LD + ra + 1], o.sq * o.j01);
+                    atomicAdd(&A[(rb + 1) * LD + ra], o.sq * o.j10);
+                    atomicAdd(&A[(rb + 1) * LD + ra + 1], o.sq * o.j11);
+                } else {
+                    atomicAdd(&A[ra * LD + rb], o.j00 * o.sq);
+                    atomicAdd(&A[ra * LD + rb + 1], o.j10 * o.sq);
+                    atomicAdd(&A[(ra + 1) * LD + rb], o.j01 * o.sq);
+                    atomicAdd(&A[(ra + 1) * LD + rb + 1], o.j11 * o.sq);
+                }
+            }
+        }
+        wave_lds_sync();
+        // cross-lane quantities of every possible transition (uniform control flow)
+        const double cost_e = group_sum<S>(cost_l);
+        const double xe = (phase == PH_EVAL_INIT || phase == PH_REEVAL) ? xi : xt;     // row: the evaluated point
+        const double gnew = is_row ? L.g[sl] : 0.0;
+        const double gmax_new = group_max<S>(is_row ? fabs(xe - clampb(xe - gnew)) : 0.0);
+        const double gdc = group_sum<S>(delta * gnew);
+        const double step_norm2 = group_sum<S>((xi - xt) * (xi - xt));
+        const double xnorm2_new = group_sum<S>(xt * xt);
+
+        // ======================= C: transitions (no cross-lane operations below) =======================
+        bool decide = false;
+        double cost_cand = 0.0;
+        if (phase == PH_EVAL_INIT) {
+            ++exec_passes;
+            cost = cost_e; gi = gnew; gmax = gmax_new;
+            scale = is_row ? 1.0 / (1.0 + sqrt(L.A[sl * LD + sl])) : 1.0;          // jacobi scaling, once
+            a_dirty = false; phase = PH_SOLVE;
+        } else if (phase == PH_REEVAL) {
+            ++exec_passes;
+            a_dirty = false; phase = PH_SOLVE;
+        } else if (phase == PH_EVAL_LS) {
+            ++exec_passes; ++n_ls_evals;
+            const bool value_valid = isfinite(cost_e);
+            if (value_valid && !(cost_e > cost + kLsSufficientDecrease * g_dot_delta * alpha)) {
+                decide = true; cost_cand = cost_e;                                   // candidate == this sample
+            } else {
+                LsSample initial{0.0, cost, g_dot_delta, true, true}, current;
+                current.x = alpha; current.value = cost_e; current.value_valid = value_valid;
+                current.gradient = value_valid ? gdc : 0.0;
+                current.gradient_valid = value_valid && isfinite(gdc);
+                const double nstep = ls_next_step(initial, ls_prev, current, dir_max, ls_iter);
+                if (nstep < 0.0) {                                                  // search failed: full step
+                    xt = clampb(__dadd_rn(xi, delta));
+                    if (is_row) L.x[sl] = xt;
+                    phase = PH_EVAL_CAND;
+                } else {
+                    ls_prev = current;
+                    alpha = nstep;
+                    xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
+                    if (is_row) L.x[sl] = xt;
+                }
+            }
+        } else if (phase == PH_EVAL_CAND) {
+            ++exec_passes;
+            decide = true; cost_cand = isfinite(cost_e) ? cost_e : DBL_MAX;
+        }
+        if (decide) {
+            ++n_cand;
+            const double step_norm = sqrt(step_norm2);
+            const double cost_change = cost - cost_cand;
+            if (step_norm <= kParameterTol * (x_norm + kParameterTol)) phase = PH_DONE;          // candidate discarded
+            else if (fabs(cost_change) <= kFunctionTol * cost) phase = PH_DONE;                  // candidate discarded
+            else {
+                const double rel = cost_change / model_cost_change;
+                if (rel > kMinRelDecrease) {
+                    xi = xt; x_norm = sqrt(xnorm2_new); cost = cost_cand; gi = gnew; gmax = gmax_new;
+                    step_successful = true; ++n_successful;
+                    const double t = 2.0 * rel - 1.0;
+                    radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                    decrease_factor = 2.0; reuse_diagonal = false; a_dirty = false;
+                } else {
+                    radius = radius / decrease_factor; decrease_factor *= 2.0;
+                    a_dirty = true;
+                }
+                phase = PH_SOLVE;
+            }
+        }
+    }
+
+    if (have) {
+        if (is_row && term != LFR_TERM_FAILURE)
+            a.positions[2 * (size_t)a.node_ids[d.node_off + (sl >> 1)] + (sl & 1)] = xi;
+        if (sl == 0) {
+            CompInfoDev inf;
+            inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
+            inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
+            inf.final_cost = cost;
+            a.infos[ci] = inf;
+        }
     }
 }
 
@@ -677,6 +959,9 @@ struct lfr_batch {
     hipEvent_t *ev = ev_ring;                            // slot of the current solve
     int64_t n_solves = 0;
     bool events = false;
+    bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
+    hipEvent_t ev_fork = nullptr;
+    hipStream_t cls_stream[lfr::KC_COUNT] = {nullptr};
     double h2d_ms = 0.0;
     std::vector<CompInfoDev> infos;      // last downloaded
     bool infos_valid = false;
@@ -698,6 +983,8 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_node_inc) (void)hipFree(b->d_node_inc);
     if (b->d_in_idx) (void)hipFree(b->d_in_idx);
     if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
+    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
+    for (auto &cs : b->cls_stream) if (cs) (void)hipStreamDestroy(cs);
     delete b;
 }
 
@@ -714,6 +1001,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipSetDevice(device));
     lfr_batch *b = new lfr_batch();
     b->device = device; b->tukey_variant = tukey_variant;
+    { const char *e = getenv("LFR_SERIAL_CLASSES"); b->serial = e && e[0] == '1'; }
     b->n_graph_nodes = (int64_t)p.track.size();
 
     // LPT sharding (lfr::assign_shards); the shard keeps the class/size order of the batch
@@ -786,6 +1074,12 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (auto &e : b->ev_ring) HIP_TRY(hipEventCreate(&e));
     b->events = true;
+    HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    for (auto &cs : b->cls_stream) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)block_lds_bytes(std::max(b->block_max_rows, 2), false)));
+    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)block_lds_bytes(std::max(b->global_max_rows, 2), true)));
     *out = b;
     return LFR_OK;
 }
@@ -802,33 +1096,36 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     ++b->n_solves;
     HIP_TRY(hipEventRecord(b->ev[0], st));
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
-    for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
+    // Kernel classes are independent: fork them onto their own streams (long-tailed workgroup
+    // kernels first) so the tails of one launch overlap the bulk of another, then join.
+    HIP_TRY(hipEventRecord(b->ev_fork, st));
+    static const int order[lfr::KC_COUNT] = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_W32_4, lfr::KC_G32_3, lfr::KC_G16_3, lfr::KC_G8_3};
+    for (int oi = 0; oi < lfr::KC_COUNT; ++oi) {
+        const int cls = order[oi];
+        hipStream_t cs = b->serial ? st : b->cls_stream[cls];
         a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1];
         const int n = a.desc_end - a.desc_begin;
-        HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
+        if (n > 0 && !b->serial) HIP_TRY(hipStreamWaitEvent(cs, b->ev_fork, 0));
+        else cs = st;
+        HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], cs));
         if (n > 0) {
-            const dim3 grid_w((n + 3) / 4), blk(256);
+            const dim3 blk(256);
             switch (cls) {
-                case lfr::KC_W16_1: hipLaunchKernelGGL((solve_wave_kernel<16, 1>), grid_w, blk, 0, st, a); break;
-                case lfr::KC_W16_2: hipLaunchKernelGGL((solve_wave_kernel<16, 2>), grid_w, blk, 0, st, a); break;
-                case lfr::KC_W32_2: hipLaunchKernelGGL((solve_wave_kernel<32, 2>), grid_w, blk, 0, st, a); break;
-                case lfr::KC_W32_4: hipLaunchKernelGGL((solve_wave_kernel<32, 4>), grid_w, blk, 0, st, a); break;
-                case lfr::KC_BLOCK: {
-                    const size_t lds = block_lds_bytes(b->block_max_rows, false);
-                    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), lds, st, a, b->block_max_rows);
+                case lfr::KC_G8_3:  hipLaunchKernelGGL((solve_group_kernel<8, 3>), dim3((n + 31) / 32), blk, 0, cs, a); break;
+                case lfr::KC_G16_3: hipLaunchKernelGGL((solve_group_kernel<16, 3>), dim3((n + 15) / 16), blk, 0, cs, a); break;
+                case lfr::KC_G32_3: hipLaunchKernelGGL((solve_group_kernel<32, 3>), dim3((n + 7) / 8), blk, 0, cs, a); break;
+                case lfr::KC_W32_4: hipLaunchKernelGGL((solve_wave_kernel<32, 4>), dim3((n + 3) / 4), blk, 0, cs, a); break;
+                case lfr::KC_BLOCK:
+                    hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->block_max_rows, false), cs, a, b->block_max_rows);
                     break;
-                }
-                case lfr::KC_GLOBAL: {
-                    const size_t lds = block_lds_bytes(b->global_max_rows, true);
-                    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                    hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), lds, st, a, b->global_max_rows);
+                case lfr::KC_GLOBAL:
+                    hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->global_max_rows, true), cs, a, b->global_max_rows);
                     break;
-                }
             }
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
+        HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], cs));
+        if (n > 0 && !b->serial) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * cls], 0));
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;
