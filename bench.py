@@ -75,7 +75,7 @@ def main():
 
     # ---- per-kernel durations of the timed steps (HIP events recorded on the launch stream) ----
     n_ev = min(args.steps, 64)
-    cls_ms = np.zeros(6)
+    cls_ms = np.zeros(7)
     tot_ms = 0.0
     for back in range(n_ev):
         t, c, cls_edges = batch.timing(back)
@@ -104,8 +104,9 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel launch (SURVEY §8(d) accounting)
-        kernel_names = ["solve_group_kernel<8,3>", "solve_group_kernel<16,3>", "solve_group_kernel<32,3>",
-                        "solve_wave_kernel<32,4>", "solve_block_kernel<lds>", "solve_block_kernel<hbm>"]
+        kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,3>", "solve_group_kernel<16,2,3>",
+                        "solve_group_kernel<32,2,2>", "solve_group_kernel<32,2,4>", "solve_block_kernel<lds>",
+                        "solve_block_kernel<hbm>"]
         dur_s = cls_ms[dom] * 1e-3
         b_stream = st["dominant_ref_passes_edges"] * EDGE_BYTES + st["dominant_ref_passes_nodes"] * NODE_BYTES
         b_once = st["dominant_kernel_edges"] * 80 + st["dominant_kernel_nodes"] * 20      # bytes the launch really needs

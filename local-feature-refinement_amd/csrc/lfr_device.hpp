@@ -291,9 +291,12 @@ constexpr int kDppQuadXor1 = 0xB1;         // quad_perm [1,0,3,2]
 constexpr int kDppQuadXor2 = 0x4E;         // quad_perm [2,3,0,1]
 constexpr int kSwizzleXor16 = (0x10 << 10) | 0x1F;
 
+// xor-32 exchange (the two halves of the wave): ds_bpermute through __shfl_xor
+__device__ __forceinline__ double xor32_f64(double v) { return __shfl_xor(v, 32, 64); }
+
 template <int S, typename Op>
 __device__ __forceinline__ double group_reduce(double v, Op op) {
-    static_assert(S == 8 || S == 16 || S == 32, "group size");
+    static_assert(S == 8 || S == 16 || S == 32 || S == 64, "group size");
     if (S == 8) {
         v = op(v, dpp_f64<kDppHalfMirror>(v));
         v = op(v, dpp_f64<kDppQuadXor1>(v));
@@ -303,7 +306,8 @@ __device__ __forceinline__ double group_reduce(double v, Op op) {
         v = op(v, dpp_f64<kDppRowRor + 4>(v));
         v = op(v, dpp_f64<kDppRowRor + 2>(v));
         v = op(v, dpp_f64<kDppRowRor + 1>(v));
-        if (S == 32) v = op(v, swizzle_f64<kSwizzleXor16>(v));
+        if (S >= 32) v = op(v, swizzle_f64<kSwizzleXor16>(v));
+        if (S == 64) v = op(v, xor32_f64(v));
     }
     return v;
 }
@@ -311,53 +315,54 @@ template <int S>
 __device__ __forceinline__ double group_sum(double v) { return group_reduce<S>(v, [](double a, double b) { return a + b; }); }
 template <int S>
 __device__ __forceinline__ double group_max(double v) { return group_reduce<S>(v, [](double a, double b) { return fmax(a, b); }); }
-// value of sub-lane K of the own group
-template <int S, int K>
-__device__ __forceinline__ double group_bcast(double v) {
-    constexpr int and_mask = (S == 8) ? 0x18 : (S == 16) ? 0x10 : 0x00;
-    return swizzle_f64<(K << 5) | and_mask>(v);
-}
-// same with the sub-lane as a (compile-time foldable) argument: call it with the induction
-// variable of a fully unrolled loop and the switch disappears
-template <int S>
-__device__ __forceinline__ double group_bcast_k(double v, int k) {
+
+// value of lane (K mod 32-lane window) selected by a bit-mask swizzle: new = (lane & AND) | K
+template <int AND, int K>
+__device__ __forceinline__ double swz_bcast(double v) { return swizzle_f64<(K << 5) | AND>(v); }
+template <int AND>
+__device__ __forceinline__ double swz_bcast_k(double v, int k) {     // k folds after full unrolling
     switch (k) {
-        case 0: return group_bcast<S, 0>(v);
-        case 1: return group_bcast<S, 1>(v);
-        case 2: return group_bcast<S, 2>(v);
-        case 3: return group_bcast<S, 3>(v);
-        case 4: return group_bcast<S, 4>(v);
-        case 5: return group_bcast<S, 5>(v);
-        case 6: return group_bcast<S, 6>(v);
-        case 7: return group_bcast<S, 7>(v);
-        case 8: return group_bcast<S, 8>(v);
-        case 9: return group_bcast<S, 9>(v);
-        case 10: return group_bcast<S, 10>(v);
-        case 11: return group_bcast<S, 11>(v);
-        case 12: return group_bcast<S, 12>(v);
-        case 13: return group_bcast<S, 13>(v);
-        case 14: return group_bcast<S, 14>(v);
-        case 15: return group_bcast<S, 15>(v);
-        case 16: return group_bcast<S, 16>(v);
-        case 17: return group_bcast<S, 17>(v);
-        case 18: return group_bcast<S, 18>(v);
-        case 19: return group_bcast<S, 19>(v);
-        case 20: return group_bcast<S, 20>(v);
-        case 21: return group_bcast<S, 21>(v);
-        case 22: return group_bcast<S, 22>(v);
-        case 23: return group_bcast<S, 23>(v);
-        case 24: return group_bcast<S, 24>(v);
-        case 25: return group_bcast<S, 25>(v);
-        case 26: return group_bcast<S, 26>(v);
-        case 27: return group_bcast<S, 27>(v);
-        case 28: return group_bcast<S, 28>(v);
-        case 29: return group_bcast<S, 29>(v);
-        case 30: return group_bcast<S, 30>(v);
-        case 31: return group_bcast<S, 31>(v);
+        case 0: return swz_bcast<AND, 0>(v);
+        case 1: return swz_bcast<AND, 1>(v);
+        case 2: return swz_bcast<AND, 2>(v);
+        case 3: return swz_bcast<AND, 3>(v);
+        case 4: return swz_bcast<AND, 4>(v);
+        case 5: return swz_bcast<AND, 5>(v);
+        case 6: return swz_bcast<AND, 6>(v);
+        case 7: return swz_bcast<AND, 7>(v);
+        case 8: return swz_bcast<AND, 8>(v);
+        case 9: return swz_bcast<AND, 9>(v);
+        case 10: return swz_bcast<AND, 10>(v);
+        case 11: return swz_bcast<AND, 11>(v);
+        case 12: return swz_bcast<AND, 12>(v);
+        case 13: return swz_bcast<AND, 13>(v);
+        case 14: return swz_bcast<AND, 14>(v);
+        case 15: return swz_bcast<AND, 15>(v);
+        case 16: return swz_bcast<AND, 16>(v);
+        case 17: return swz_bcast<AND, 17>(v);
+        case 18: return swz_bcast<AND, 18>(v);
+        case 19: return swz_bcast<AND, 19>(v);
+        case 20: return swz_bcast<AND, 20>(v);
+        case 21: return swz_bcast<AND, 21>(v);
+        case 22: return swz_bcast<AND, 22>(v);
+        case 23: return swz_bcast<AND, 23>(v);
+        case 24: return swz_bcast<AND, 24>(v);
+        case 25: return swz_bcast<AND, 25>(v);
+        case 26: return swz_bcast<AND, 26>(v);
+        case 27: return swz_bcast<AND, 27>(v);
+        case 28: return swz_bcast<AND, 28>(v);
+        case 29: return swz_bcast<AND, 29>(v);
+        case 30: return swz_bcast<AND, 30>(v);
+        case 31: return swz_bcast<AND, 31>(v);
         default: return v;
     }
 }
+// value held by sub-lane k of the own S-lane group (k wave-uniform / compile-time after unrolling)
 template <int S>
-__device__ __forceinline__ bool group_any(bool p) { return group_max<S>(p ? 1.0 : 0.0) != 0.0; }
+__device__ __forceinline__ double group_bcast_k(double v, int k) {
+    if (S == 64) return readlane_f64(v, k);
+    constexpr int and_mask = (S == 8) ? 0x18 : (S == 16) ? 0x10 : 0x00;
+    return swz_bcast_k<and_mask>(v, k);
+}
 
 }  // namespace lfrdev

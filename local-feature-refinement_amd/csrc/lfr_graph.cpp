@@ -131,10 +131,11 @@ static std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<in
 }
 
 static int classify(int rows, int64_t n_edges) {
-    if (rows <= 8 && n_edges <= 24) return KC_G8_3;
-    if (rows <= 16 && n_edges <= 48) return KC_G16_3;
-    // KC_G32_3 (2 components per wave) is parked until its register spills are fixed
-    if (rows <= 32 && n_edges <= 256) return KC_W32_4;
+    if (rows <= 8 && n_edges <= 24) return KC_G8;
+    if (rows <= 16 && n_edges <= 48) return KC_G16;
+    if (rows <= 16 && n_edges <= 96) return KC_G32;
+    if (rows <= 32 && n_edges <= 128) return KC_G64_2;
+    if (rows <= 32 && n_edges <= 256) return KC_G64_4;
     if (rows <= kBlockMaxRows) return KC_BLOCK;
     return KC_GLOBAL;
 }

@@ -72,10 +72,11 @@ static_assert(sizeof(NodeInc) == 16, "NodeInc must be 16 bytes");
 
 // kernel classes
 enum KernelClass : int {
-    KC_G8_3 = 0,    // packed: 8 components per wave (8 lanes each), <=8 rows, <=24 edges
-    KC_G16_3,       // packed: 4 components per wave, <=16 rows, <=48 edges
-    KC_G32_3,       // packed: 2 components per wave, <=32 rows, <=96 edges
-    KC_W32_4,       // one wave per component, <=32 rows, <=256 edges
+    KC_G8 = 0,      // packed <NV=8, LPR=1, EPL=3>:  8 comps/wave, <=8 rows,  <=24 edges
+    KC_G16,         // packed <16,1,3>: 4 comps/wave, <=16 rows, <=48 edges
+    KC_G32,         // packed <16,2,3>: 2 comps/wave, <=16 rows, <=96 edges (2 lanes per row)
+    KC_G64_2,       // packed <32,2,2>: 1 comp/wave,  <=32 rows, <=128 edges
+    KC_G64_4,       // packed <32,2,4>: 1 comp/wave,  <=32 rows, <=256 edges
     KC_BLOCK,       // workgroup per component, normal matrix in LDS
     KC_GLOBAL,      // workgroup per component, normal matrix in HBM workspace
     KC_COUNT

@@ -50,288 +50,50 @@ struct KernelArgs {
 };
 
 // =============================================================================================
-// wave-per-component kernel
-// =============================================================================================
-template <int NV>
-struct WaveLds {
-    static constexpr int LD = NV + 1;                 // odd leading dimension: conflict-free column walks
-    double A[2][NV * LD];                             // J^T J (lower triangle) at x / at the trial point
-    double g[2][NV];                                  // J^T r
-    double x[2][NV + 2];                              // x / trial point; slot 2*n_var.. = 0 (constants)
-};
-
-template <int NV, int EPL>
-__global__ __launch_bounds__(256) void solve_wave_kernel(const KernelArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    const int ci = a.desc_begin + (int)blockIdx.x * 4 + wave;
-    __shared__ WaveLds<NV> lds_all[4];
-    if (ci >= a.desc_end) return;                     // wave-uniform; no block-level barriers below
-    WaveLds<NV> &L = lds_all[wave];
-    constexpr int LD = WaveLds<NV>::LD;
-
-    const CompDesc d = a.descs[ci];
-    const int n_var = d.n_var, nv2 = 2 * n_var, E = (int)d.n_edges;
-    const int tv = a.tukey_variant;
-
-    // ---- edges -> registers (the only HBM read of the solve: 80 B per edge) ----
-    float flow[EPL][18];
-    float sim[EPL];
-    int xs_src[EPL], xs_dst[EPL], row_src[EPL], row_dst[EPL], kind[EPL];
-    bool act[EPL];
-#pragma unroll
-    for (int k = 0; k < EPL; ++k) {
-        const int e = lane + 64 * k;
-        act[k] = e < E;
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (act[k] ? e : 0));
-        uint4 q[5];
-#pragma unroll
-        for (int i = 0; i < 5; ++i) q[i] = act[k] ? rp[i] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            flow[k][4 * i] = __uint_as_float(q[i].x); flow[k][4 * i + 1] = __uint_as_float(q[i].y);
-            flow[k][4 * i + 2] = __uint_as_float(q[i].z); flow[k][4 * i + 3] = __uint_as_float(q[i].w);
-        }
-        flow[k][16] = __uint_as_float(q[4].x); flow[k][17] = __uint_as_float(q[4].y);
-        sim[k] = __uint_as_float(q[4].z);
-        const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
-        const int dn = dk & 0x7fff;
-        kind[k] = dk >> 15;
-        row_src[k] = s < n_var ? 2 * s : -1;
-        row_dst[k] = dn < n_var ? 2 * dn : -1;
-        xs_src[k] = s < n_var ? 2 * s : nv2;          // constants read the zero slot
-        xs_dst[k] = dn < n_var ? 2 * dn : nv2;
-    }
-    if (lane < NV + 2) { L.x[0][lane] = 0.0; L.x[1][lane] = 0.0; }
-
-    // ---- one sweep over the component's edges at L.x[xb]: cost, J^T J -> L.A[ab], J^T r -> L.g[ab]
-    auto evaluate = [&](int xb, int ab) -> double {
-        for (int i = lane; i < NV * LD; i += 64) L.A[ab][i] = 0.0;
-        if (lane < NV) L.g[ab][lane] = 0.0;
-        wave_lds_sync();
-        double cost = 0.0;
-#pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            if (!act[k]) continue;
-            EdgeOut o;
-            eval_edge<true>(flow[k], sim[k], kind[k], tv, L.x[xb][xs_src[k]], L.x[xb][xs_src[k] + 1],
-                            L.x[xb][xs_dst[k]], L.x[xb][xs_dst[k] + 1], o);
-            cost += o.cost;
-            double *A = L.A[ab], *g = L.g[ab];
-            const int ra = row_src[k], rb = row_dst[k];
-            if (ra >= 0) {
-                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10);
-                atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
-                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11);
-                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1);
-                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
-            }
-            if (rb >= 0) {
-                atomicAdd(&A[rb * LD + rb], o.sq * o.sq);
-                atomicAdd(&A[(rb + 1) * LD + rb + 1], o.sq * o.sq);
-                atomicAdd(&g[rb], o.sq * o.r0);
-                atomicAdd(&g[rb + 1], o.sq * o.r1);
-            }
-            if (ra >= 0 && rb >= 0) {
-                if (rb > ra) {
-                    atomicAdd(&A[rb * LD + ra], o.sq * o.j00);
-                    atomicAdd(&A[rb * LD + ra + 1], o.sq * o.j01);
-                    atomicAdd(&A[(rb + 1) * LD + ra], o.sq * o.j10);
-                    atomicAdd(&A[(rb + 1) * LD + ra + 1], o.sq * o.j11);
-                } else {
-                    atomicAdd(&A[ra * LD + rb], o.j00 * o.sq);
-                    atomicAdd(&A[ra * LD + rb + 1], o.j10 * o.sq);
-                    atomicAdd(&A[(ra + 1) * LD + rb], o.j01 * o.sq);
-                    atomicAdd(&A[(ra + 1) * LD + rb + 1], o.j11 * o.sq);
-                }
-            }
-        }
-        wave_lds_sync();
-        return wave_sum(cost);
-    };
-
-    // ---- iteration 0 (TrustRegionMinimizer::IterationZero) ----
-    int cur = 0;                                      // L.A[cur], L.g[cur], L.x[cur] belong to x
-    int exec_passes = 1;
-    double cost = evaluate(0, 0);
-    const bool is_row = lane < nv2;
-    double xi = 0.0;                                  // lane i: x_i
-    double gi = is_row ? L.g[0][lane] : 0.0;
-    const double scale = is_row ? 1.0 / (1.0 + sqrt(L.A[0][lane * LD + lane])) : 1.0;   // jacobi scaling, once
-    double gmax = wave_max(is_row ? fabs(xi - clampb(xi - gi)) : 0.0);
-    double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0, diag = 1.0;
-    bool reuse_diagonal = false, step_successful = true;
-    int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
-    int n_successful = 0, n_ls_evals = 0, n_cand = 0;
-
-    for (;;) {
-        if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; break; }
-        if (step_successful && gmax <= kGradientTol) break;
-        if (radius <= kMinRadius) break;
-        ++iteration;
-        step_successful = false;
-
-        // ---- LevenbergMarquardtStrategy::ComputeStep: (S A S + D^2) y = S g, step = -y ----
-        const double *A = L.A[cur];
-        const double aii = is_row ? A[lane * LD + lane] : 1.0;
-        if (!reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
-        const double Dl = sqrt(diag / radius);
-        reuse_diagonal = true;
-        double h[NV];
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-            const double sj = readlane_f64(scale, j);
-            double v = 0.0;
-            if (is_row && j < nv2) v = (j <= lane ? A[lane * LD + j] : A[j * LD + lane]) * scale * sj;
-            if (j == lane) v = is_row ? v + Dl * Dl : 1.0;
-            h[j] = v;
-        }
-        double rhs = is_row ? scale * gi : 0.0;
-        const double rhs0 = rhs;
-        double piv_own = 1.0;
-        bool fail = false;
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {               // Gauss-Jordan, no pivoting (SPD)
-            if (k < nv2) {
-                const double piv = readlane_f64(h[k], k);
-                if (!(piv > 0.0)) fail = true;
-                const double inv = 1.0 / piv;
-                const double f = (lane == k) ? 0.0 : h[k] * inv;
-                if (lane == k) piv_own = piv;
-#pragma unroll
-                for (int j = k + 1; j < NV; ++j) h[j] -= f * readlane_f64(h[j], k);
-                rhs -= f * readlane_f64(rhs, k);
-            }
-        }
-        const double step = is_row ? -(rhs / piv_own) : 0.0;
-        bool valid = !fail && !__any(is_row && !isfinite(step));
-        double model_cost_change = 0.0;
-        if (valid) {
-            // -(J s)^T (r + J s / 2) == 1/2 * sum_i (-(S g)_i s_i + D_i^2 s_i^2)  since (S A S + D^2) s = -S g
-            model_cost_change = 0.5 * wave_sum(is_row ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
-            valid = model_cost_change > 0.0;
-        }
-        if (!valid) {
-            if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
-            radius = radius / decrease_factor;       // StepIsInvalid -> StepRejected(0)
-            decrease_factor *= 2.0;
-            continue;
-        }
-        n_invalid = 0;
-        double delta = step * scale;
-
-        // ---- projected Armijo line search along delta (bounds-constrained problem) ----
-        const double g_dot_delta = wave_sum(gi * delta);
-        const double dir_max = wave_max(fabs(delta));
-        const int nxt = cur ^ 1;
-        double alpha = 1.0, cost_c = 0.0, xt = 0.0;
-        bool ls_ok = false;
-        {
-            LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
-            int n_iter = 0;
-            for (;;) {
-                // trial point: product and sum rounded separately, exactly like the candidate below
-                xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
-                if (is_row) L.x[nxt][lane] = xt;
-                cost_c = evaluate(nxt, nxt);
-                ++exec_passes; ++n_ls_evals;
-                current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
-                current.gradient = 0.0; current.gradient_valid = false;
-                if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
-                if (current.value_valid) {
-                    current.gradient = wave_sum(is_row ? delta * L.g[nxt][lane] : 0.0);
-                    current.gradient_valid = isfinite(current.gradient);
-                }
-                const double nstep = ls_next_step(initial, previous, current, dir_max, n_iter);
-                if (nstep < 0.0) break;
-                previous = current;
-                alpha = nstep;
-            }
-        }
-        // ---- candidate: same point as the accepted line-search sample, so its cost is known ----
-        const double xc = ls_ok ? xt : clampb(__dadd_rn(xi, delta));
-        if (!ls_ok) {                                 // search failed: candidate is the full step
-            if (is_row) L.x[nxt][lane] = xc;
-            cost_c = evaluate(nxt, nxt);
-            ++exec_passes;
-        }
-        ++n_cand;
-        double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
-
-        const double step_norm = sqrt(wave_sum((xi - xc) * (xi - xc)));
-        if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;            // candidate discarded
-        const double cost_change = cost - cost_cand;
-        if (fabs(cost_change) <= kFunctionTol * cost) break;                          // candidate discarded
-        const double rel = cost_change / model_cost_change;
-        if (rel > kMinRelDecrease) {
-            xi = xc;
-            x_norm = sqrt(wave_sum(xi * xi));
-            cur = nxt;                                // J^T J / J^T r at the new x are already assembled
-            cost = cost_cand;
-            gi = is_row ? L.g[cur][lane] : 0.0;
-            gmax = wave_max(is_row ? fabs(xi - clampb(xi - gi)) : 0.0);
-            step_successful = true;
-            ++n_successful;
-            const double t = 2.0 * rel - 1.0;
-            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-            decrease_factor = 2.0;
-            reuse_diagonal = false;
-        } else {
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
-        }
-    }
-
-    // ---- write back (Ceres copies an unusable (FAILURE) solution nowhere: positions stay 0) ----
-    if (is_row && term != LFR_TERM_FAILURE)
-        a.positions[2 * (size_t)a.node_ids[d.node_off + (lane >> 1)] + (lane & 1)] = xi;
-    if (lane == 0) {
-        CompInfoDev inf;
-        inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
-        inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
-        inf.final_cost = cost;
-        a.infos[ci] = inf;
-    }
-}
-
-// =============================================================================================
-// packed sub-group kernel: a wave64 hosts G = 64/S components, S lanes each (S = 8, 16, 32).
-// lane = edge slot for the evaluation (EPL edges per lane, resident in VGPRs) and lane = row of
-// the damped normal equations for the solve.  Groups advance through the same LM state machine in
-// lockstep rounds (solve -> evaluate -> decide); rare paths (invalid step, line-search contraction,
-// rejected step) just take extra rounds for their group.  Cross-lane traffic stays inside the
-// group: DPP butterflies for reductions, ds_swizzle for the Gauss-Jordan broadcasts.
+// packed sub-group kernel: a wave64 hosts G = 64/S components, S = NV*LPR lanes each.
+//   evaluation : lane = edge slot, EPL edges per lane resident in VGPRs (HBM is read once)
+//   solve      : NV rows; a row is held by LPR lanes with CPL = NV/LPR columns each (h[CPL] in
+//                registers), Gauss-Jordan with ds_swizzle / v_readlane broadcasts inside the group
+// Groups advance through the same LM state machine in lockstep rounds (solve -> evaluate ->
+// decide); rare paths (invalid step, line-search contraction, rejected step) just take extra
+// rounds for their group.  Reductions are DPP butterflies; no barriers (a wave is its own
+// synchronisation domain), no cross-group traffic.
 // =============================================================================================
 enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
 
-template <int S>
+template <int NV>
 struct GroupLds {
-    static constexpr int LD = S + 1;
-    double A[S * LD];          // J^T J (lower triangle) of the last evaluation
-    double g[S];               // J^T r of the last evaluation
-    double x[S + 2];           // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
+    static constexpr int LD = NV + 1;
+    double A[NV * LD];         // J^T J (lower triangle) of the last evaluation
+    double g[NV];              // J^T r of the last evaluation
+    double x[NV + 2];          // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
+    double scale[NV];          // jacobi scaling (fixed at iteration 0)
 };
 
-template <int S, int EPL>
+template <int NV, int LPR, int EPL>
 __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a) {
-    constexpr int G = 64 / S, NV = S, LD = S + 1;
+    constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
+    static_assert(S <= 64 && (LPR == 1 || LPR == 2), "group geometry");
+    // swizzle mask that keeps the lane's part (and, for S < 32, its group) and replaces the row
+    constexpr int kPartAnd = (NV == 8) ? 0x18 : (NV == 16) ? 0x10 : 0x00;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = lane / S, sl = lane % S;
+    const int row = sl % NV, part = sl / NV;
     const int ci0 = a.desc_begin + ((int)blockIdx.x * 4 + wave) * G;
-    __shared__ GroupLds<S> lds_all[4][G];
+    __shared__ GroupLds<NV> lds_all[4][G];
     if (ci0 >= a.desc_end) return;                    // wave-uniform
     const int ci = ci0 + gid;
     const bool have = ci < a.desc_end;
-    GroupLds<S> &L = lds_all[wave][gid];
+    GroupLds<NV> &L = lds_all[wave][gid];
 
     CompDesc d;
     d.edge_off = 0; d.n_edges = 0; d.node_off = 0; d.n_nodes = 0; d.n_var = 0;
     if (have) d = a.descs[ci];
     const int n_var = d.n_var, nv2 = 2 * n_var, E = (int)d.n_edges;
     const int tv = a.tukey_variant;
-    const bool is_row = sl < nv2;
-    // largest row count of the wave: bounds the elimination loop (wave-uniform)
-    int nv2_max = nv2;
+    const bool is_row = row < nv2;
+    const bool own = is_row && part == 0;             // one lane per row: reductions, LDS writes
+    int nv2_max = nv2;                                // largest row count of the wave (wave-uniform)
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) nv2_max = max(nv2_max, __shfl_xor(nv2_max, m, 64));
     nv2_max = __builtin_amdgcn_readfirstlane(nv2_max);
@@ -364,10 +126,10 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
         xs_src[k] = s < n_var ? 2 * s : nv2;
         xs_dst[k] = dn < n_var ? 2 * dn : nv2;
     }
-    L.x[sl] = 0.0;
-    if (sl < 2) L.x[S + sl] = 0.0;
+    if (sl < NV) { L.x[sl] = 0.0; L.scale[sl] = 1.0; }
+    if (sl < 2) L.x[NV + sl] = 0.0;
 
-    // ---- group state (uniform inside a group unless marked 'row') ----
+    // ---- group state (uniform inside a group; 'row' values are identical in the LPR lanes of a row) ----
     int phase = have ? PH_EVAL_INIT : PH_DONE;
     double xi = 0.0, gi = 0.0, scale = 1.0, diag = 1.0;            // row
     double xt = 0.0, delta = 0.0;                                    // row
@@ -388,22 +150,23 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
             if (ps) {   // FinalizeIterationAndCheckIfMinimizerCanContinue
                 if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; phase = PH_DONE; ps = false; }
                 else if ((step_successful && gmax <= kGradientTol) || radius <= kMinRadius) { phase = PH_DONE; ps = false; }
-                else if (a_dirty) { phase = PH_REEVAL; ps = false; if (is_row) L.x[sl] = xi; }   // J^T J at x was overwritten
+                else if (a_dirty) { phase = PH_REEVAL; ps = false; if (own) L.x[row] = xi; }     // J^T J at x was overwritten
             }
             if (__any(ps)) {
+                wave_lds_sync();
                 if (ps) { ++iteration; step_successful = false; }
                 const double *A = L.A;
-                const double aii = is_row ? A[sl * LD + sl] : 1.0;
+                const double aii = is_row ? A[row * LD + row] : 1.0;
                 if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
                 const double Dl = sqrt(diag / radius);
-                double h[NV];
+                double h[CPL];                        // columns part*CPL .. part*CPL+CPL-1 of the own row
 #pragma unroll
-                for (int j = 0; j < NV; ++j) {
-                    const double sj = group_bcast_k<S>(scale, j);
+                for (int c = 0; c < CPL; ++c) {
+                    const int j = part * CPL + c;
                     double v = 0.0;
-                    if (is_row && j < nv2) v = (j <= sl ? A[sl * LD + j] : A[j * LD + sl]) * scale * sj;
-                    if (j == sl) v = is_row ? v + Dl * Dl : 1.0;
-                    h[j] = v;
+                    if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]) * scale * L.scale[j];
+                    if (j == row) v = is_row ? v + Dl * Dl : 1.0;
+                    h[c] = v;
                 }
                 double rhs = is_row ? scale * gi : 0.0;
                 const double rhs0 = rhs;
@@ -412,22 +175,31 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
 #pragma unroll
                 for (int k = 0; k < NV; ++k) {       // Gauss-Jordan, no pivoting (SPD); padded rows are identity
                     if (k < nv2_max) {
-                        const double piv = group_bcast_k<S>(h[k], k);
+                        constexpr int kDummy = 0; (void)kDummy;
+                        const int pk = k / CPL, ck = k % CPL;                    // part / register holding column k
+                        const double piv = group_bcast_k<S>(h[ck], k + NV * pk);
                         if (!(piv > 0.0)) fail = true;
                         const double inv = 1.0 / piv;
-                        const double f = (sl == k) ? 0.0 : h[k] * inv;
-                        if (sl == k) piv_own = piv;
+                        double f = h[ck] * inv;                                  // valid in the lanes of part pk
+                        if (LPR == 2) {
+                            const double fx = (NV == 16) ? swizzle_f64<kSwizzleXor16>(f) : xor32_f64(f);
+                            f = (part == pk) ? f : fx;
+                        }
+                        if (row == k) { f = 0.0; piv_own = piv; }
+                        // columns j = part*CPL + c > k somewhere in the group  <=>  c > k - CPL*(LPR-1)
 #pragma unroll
-                        for (int j = k + 1; j < NV; ++j) h[j] -= f * group_bcast_k<S>(h[j], k);
-                        rhs -= f * group_bcast_k<S>(rhs, k);
+                        for (int c = 0; c < CPL; ++c)
+                            if (c > k - CPL * (LPR - 1)) h[c] -= f * swz_bcast_k<kPartAnd>(h[c], k % 32);
+                        rhs -= f * swz_bcast_k<kPartAnd>(rhs, k % 32);
                     }
                 }
                 const double step = is_row ? -(rhs / piv_own) : 0.0;
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
-                const bool bad = ((badmask >> (gid * S)) & ((S == 32) ? 0xffffffffull : ((1ull << S) - 1))) != 0;
-                const double mcc = 0.5 * group_sum<S>(is_row ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
+                const unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << (S & 63)) - 1);
+                const bool bad = ((badmask >> ((gid * S) & 63)) & gmask) != 0;
+                const double mcc = 0.5 * group_sum<S>(own ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
                 const double dl = step * scale;
-                const double gdd = group_sum<S>(gi * dl);
+                const double gdd = group_sum<S>(own ? gi * dl : 0.0);
                 const double dmx = group_max<S>(fabs(dl));
                 if (ps) {
                     reuse_diagonal = true;
@@ -440,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
                         model_cost_change = mcc; delta = dl; g_dot_delta = gdd; dir_max = dmx;
                         alpha = 1.0; ls_iter = 0; ls_prev.value_valid = false;
                         xt = clampb(__dadd_rn(xi, delta));
-                        if (is_row) L.x[sl] = xt;
+                        if (own) L.x[row] = xt;
                         phase = PH_EVAL_LS;
                     }
                 }
@@ -452,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
         if (!__any(pe)) continue;
         if (pe) {
             for (int i = sl; i < NV * LD; i += S) L.A[i] = 0.0;
-            L.g[sl] = 0.0;
+            if (sl < NV) L.g[sl] = 0.0;
         }
         wave_lds_sync();
         double cost_l = 0.0;
@@ -496,11 +268,11 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
         // cross-lane quantities of every possible transition (uniform control flow)
         const double cost_e = group_sum<S>(cost_l);
         const double xe = (phase == PH_EVAL_INIT || phase == PH_REEVAL) ? xi : xt;     // row: the evaluated point
-        const double gnew = is_row ? L.g[sl] : 0.0;
+        const double gnew = is_row ? L.g[row] : 0.0;
         const double gmax_new = group_max<S>(is_row ? fabs(xe - clampb(xe - gnew)) : 0.0);
-        const double gdc = group_sum<S>(delta * gnew);
-        const double step_norm2 = group_sum<S>((xi - xt) * (xi - xt));
-        const double xnorm2_new = group_sum<S>(xt * xt);
+        const double gdc = group_sum<S>(own ? delta * gnew : 0.0);
+        const double step_norm2 = group_sum<S>(own ? (xi - xt) * (xi - xt) : 0.0);
+        const double xnorm2_new = group_sum<S>(own ? xt * xt : 0.0);
 
         // ======================= C: transitions (no cross-lane operations below) =======================
         bool decide = false;
@@ -508,7 +280,8 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
         if (phase == PH_EVAL_INIT) {
             ++exec_passes;
             cost = cost_e; gi = gnew; gmax = gmax_new;
-            scale = is_row ? 1.0 / (1.0 + sqrt(L.A[sl * LD + sl])) : 1.0;          // jacobi scaling, once
+            scale = is_row ? 1.0 / (1.0 + sqrt(L.A[row * LD + row])) : 1.0;        // jacobi scaling, once
+            if (own) L.scale[row] = scale;
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_REEVAL) {
             ++exec_passes;
@@ -526,13 +299,13 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
                 const double nstep = ls_next_step(initial, ls_prev, current, dir_max, ls_iter);
                 if (nstep < 0.0) {                                                  // search failed: full step
                     xt = clampb(__dadd_rn(xi, delta));
-                    if (is_row) L.x[sl] = xt;
+                    if (own) L.x[row] = xt;
                     phase = PH_EVAL_CAND;
                 } else {
                     ls_prev = current;
                     alpha = nstep;
                     xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
-                    if (is_row) L.x[sl] = xt;
+                    if (own) L.x[row] = xt;
                 }
             }
         } else if (phase == PH_EVAL_CAND) {
@@ -563,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a)
     }
 
     if (have) {
-        if (is_row && term != LFR_TERM_FAILURE)
-            a.positions[2 * (size_t)a.node_ids[d.node_off + (sl >> 1)] + (sl & 1)] = xi;
+        if (own && term != LFR_TERM_FAILURE)
+            a.positions[2 * (size_t)a.node_ids[d.node_off + (row >> 1)] + (row & 1)] = xi;
         if (sl == 0) {
             CompInfoDev inf;
             inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
@@ -1099,7 +872,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     // Kernel classes are independent: fork them onto their own streams (long-tailed workgroup
     // kernels first) so the tails of one launch overlap the bulk of another, then join.
     HIP_TRY(hipEventRecord(b->ev_fork, st));
-    static const int order[lfr::KC_COUNT] = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_W32_4, lfr::KC_G32_3, lfr::KC_G16_3, lfr::KC_G8_3};
+    static const int order[lfr::KC_COUNT] = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
     for (int oi = 0; oi < lfr::KC_COUNT; ++oi) {
         const int cls = order[oi];
         hipStream_t cs = b->serial ? st : b->cls_stream[cls];
@@ -1111,10 +884,11 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         if (n > 0) {
             const dim3 blk(256);
             switch (cls) {
-                case lfr::KC_G8_3:  hipLaunchKernelGGL((solve_group_kernel<8, 3>), dim3((n + 31) / 32), blk, 0, cs, a); break;
-                case lfr::KC_G16_3: hipLaunchKernelGGL((solve_group_kernel<16, 3>), dim3((n + 15) / 16), blk, 0, cs, a); break;
-                case lfr::KC_G32_3: hipLaunchKernelGGL((solve_group_kernel<32, 3>), dim3((n + 7) / 8), blk, 0, cs, a); break;
-                case lfr::KC_W32_4: hipLaunchKernelGGL((solve_wave_kernel<32, 4>), dim3((n + 3) / 4), blk, 0, cs, a); break;
+                case lfr::KC_G8:   hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), dim3((n + 31) / 32), blk, 0, cs, a); break;
+                case lfr::KC_G16:  hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), dim3((n + 15) / 16), blk, 0, cs, a); break;
+                case lfr::KC_G32:  hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), dim3((n + 7) / 8), blk, 0, cs, a); break;
+                case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 2, 2>), dim3((n + 3) / 4), blk, 0, cs, a); break;
+                case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 4>), dim3((n + 3) / 4), blk, 0, cs, a); break;
                 case lfr::KC_BLOCK:
                     hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->block_max_rows, false), cs, a, b->block_max_rows);
                     break;

@@ -286,8 +286,8 @@ class Batch:
     def timing(self, solves_back=0):
         """HIP-event times of one of the last 64 solves: (total_ms, per-kernel-class ms, per-class edges)."""
         tot = C.c_double(0.0)
-        cls = np.zeros(6, np.float64)
-        edges = np.zeros(6, np.int64)
+        cls = np.zeros(7, np.float64)
+        edges = np.zeros(7, np.int64)
         _check(lib().lfr_batch_timing(self._h, solves_back, C.byref(tot), _ptr(cls), _ptr(edges)))
         return tot.value, cls, edges
 
