@@ -47,7 +47,12 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double d0 = (double)flow[2 * (i * 3 + j)], d1 = (double)flow[2 * (i * 3 + j) + 1];
+            // The flows never change during a solve, so the compiler would hoist the 18 f32->f64
+            // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
+            // The empty asm makes the value opaque: the conversion stays next to its use.
+            float fa = flow[2 * (i * 3 + j)], fb = flow[2 * (i * 3 + j) + 1];
+            asm volatile("" : "+v"(fa), "+v"(fb));
+            const double d0 = (double)fa, d1 = (double)fb;
             const double w = lr[i] * lc[j];
             f0 += w * d0; f1 += w * d1;
             if (WANT_JAC) {
@@ -62,7 +67,9 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     }
     const double r0 = x2r - x1r - f0, r1 = x2c - x1c - f1;       // cost.cc:87
     const double s = r0 * r0 + r1 * r1;
-    const double w = (double)simf;
+    float simo = simf;
+    asm volatile("" : "+v"(simo));
+    const double w = (double)simo;
     double rho0, rho1;
     if (kind == 0) {                                              // CauchyLoss(0.25)
         const double sum = 1.0 + s * kCauchyC, inv = 1.0 / sum;

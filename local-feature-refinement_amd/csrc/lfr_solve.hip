@@ -70,8 +70,11 @@ struct GroupLds {
     double scale[NV];          // jacobi scaling (fixed at iteration 0)
 };
 
+#ifndef LFR_GROUP_WAVES
+#define LFR_GROUP_WAVES 2          // waves per SIMD the packed kernel is register-budgeted for
+#endif
 template <int NV, int LPR, int EPL>
-__global__ __launch_bounds__(256, 2) void solve_group_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const KernelArgs a) {
     constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
     static_assert(S <= 64 && (LPR == 1 || LPR == 2), "group geometry");
     // swizzle mask that keeps the lane's part (and, for S < 32, its group) and replaces the row

@@ -32,6 +32,7 @@ def build(force=False, verbose=False):
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-munsafe-fp-atomics",          # hardware fp64 atomic add for the HBM-matrix kernel
            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    cmd += os.environ.get("LFR_HIPCC_FLAGS", "").split()
     cmd += [os.path.join(CSRC, f) for f in SOURCES] + ["-o", OUT]
     if verbose:
         print(" ".join(cmd))
