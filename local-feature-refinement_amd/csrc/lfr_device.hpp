@@ -25,6 +25,42 @@ constexpr double kLsMinStep = 1e-9;
 
 __device__ __forceinline__ double clampb(double v) { return fmin(fmax(v, -kBound), kBound); }
 
+// 1/x for finite x > 0: v_rcp_f64 + two Newton steps (error <= 1 ulp; no denormal/inf handling)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+// sqrt(x) for finite x >= 0 in the normal range (here: rho' * sim in [0, ~1]): v_rsq_f64 + Newton/Goldschmidt
+__device__ __forceinline__ double fast_sqrt(double x) {
+    if (!(x > 1e-290)) return sqrt(x);                 // zero / tiny: take the exact path (rare: Tukey outliers give 0)
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    return fma(fma(-g, g, x), h, g);                   // final residual correction
+}
+// log(x) for finite x >= 1 (the Cauchy loss evaluates log(1 + s/b)): x = m * 2^e with m in
+// [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) by its odd series (|z| <= 0.1716, 11 terms),
+// e*ln2 added in two pieces.  ~35 instructions instead of ~90 of the generic libm log; error ~1 ulp.
+__device__ __forceinline__ double log_ge1(double x) {
+    int e = __builtin_amdgcn_frexp_exp(x);             // x = f * 2^e, f in [0.5, 1)
+    double m = __builtin_amdgcn_frexp_mant(x);
+    if (m < 0.70710678118654752440) { m *= 2.0; --e; }
+    const double z = (m - 1.0) * fast_rcp(m + 1.0);
+    const double w = z * z;
+    double p = 1.0 / 23.0;
+    p = fma(p, w, 1.0 / 21.0); p = fma(p, w, 1.0 / 19.0); p = fma(p, w, 1.0 / 17.0); p = fma(p, w, 1.0 / 15.0);
+    p = fma(p, w, 1.0 / 13.0); p = fma(p, w, 1.0 / 11.0); p = fma(p, w, 1.0 / 9.0); p = fma(p, w, 1.0 / 7.0);
+    p = fma(p, w, 1.0 / 5.0); p = fma(p, w, 1.0 / 3.0);
+    const double lm = fma(2.0 * z * w, p, 2.0 * z);    // log(m)
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+}
+
 struct EdgeOut {
     double cost;            // 0.5 * rho(s)
     double r0, r1;          // corrected residual
@@ -33,34 +69,39 @@ struct EdgeOut {
 };
 
 // flow: 18 floats, index 2*(3*i+j)+k.  WANT_JAC=false skips the derivative sums.
+// The biquadratic form f_k = sum_ij Lr_i Lc_j d_ijk (cost.cc:32-35) is evaluated separably,
+// f_k = sum_i Lr_i (sum_j Lc_j d_ijk): same 54 FMAs for value + both partials but no table of 27
+// weight products, so the live set stays ~45 VGPRs (the association differs from the reference's
+// (Lr_i*Lc_j)*d by rounding only, ~1e-16 relative).
 template <bool WANT_JAC>
 __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, int kind, int tukey_variant,
                                           double x1r, double x1c, double x2r, double x2c, EdgeOut &o) {
     const double row = fmax(fmin(x1r, 0.5), -0.5), col = fmax(fmin(x1c, 0.5), -0.5);
     const bool row_in = (row == x1r), col_in = (col == x1c);     // cost.cc:38,41
-    const double lr[3] = {2. * row * (row - .5), (-4.) * (row - .5) * (row + .5), 2. * row * (row + .5)};
     const double lc[3] = {2. * col * (col - .5), (-4.) * (col - .5) * (col + .5), 2. * col * (col + .5)};
-    const double dlr[3] = {2. * row + 2. * (row - .5), (-4.) * (row - .5) + (-4.) * (row + .5), 2. * row + 2. * (row + .5)};
     const double dlc[3] = {2. * col + 2. * (col - .5), (-4.) * (col - .5) + (-4.) * (col + .5), 2. * col + 2. * (col + .5)};
     double f0 = 0., f1 = 0., dr0 = 0., dr1 = 0., dc0 = 0., dc1 = 0.;
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            // The flows never change during a solve, so the compiler would hoist the 18 f32->f64
-            // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
-            // The empty asm makes the value opaque: the conversion stays next to its use.
-            float fa = flow[2 * (i * 3 + j)], fb = flow[2 * (i * 3 + j) + 1];
-            asm volatile("" : "+v"(fa), "+v"(fb));
-            const double d0 = (double)fa, d1 = (double)fb;
-            const double w = lr[i] * lc[j];
-            f0 += w * d0; f1 += w * d1;
-            if (WANT_JAC) {
-                const double wr = dlr[i] * lc[j], wc = lr[i] * dlc[j];
-                dr0 += wr * d0; dr1 += wr * d1;
-                dc0 += wc * d0; dc1 += wc * d1;
-            }
+    for (int i = 0; i < 3; ++i) {
+        // The flows never change during a solve, so the compiler would hoist the f32->f64
+        // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
+        // The empty asm makes the values opaque: the conversions stay next to their use.
+        float a0 = flow[6 * i], a1 = flow[6 * i + 1], b0 = flow[6 * i + 2], b1 = flow[6 * i + 3],
+              c0 = flow[6 * i + 4], c1 = flow[6 * i + 5];
+        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
+        const double t0 = lc[0] * (double)a0 + lc[1] * (double)b0 + lc[2] * (double)c0;
+        const double t1 = lc[0] * (double)a1 + lc[1] * (double)b1 + lc[2] * (double)c1;
+        const double lri = (i == 0) ? 2. * row * (row - .5) : (i == 1) ? (-4.) * (row - .5) * (row + .5) : 2. * row * (row + .5);
+        f0 += lri * t0; f1 += lri * t1;
+        if (WANT_JAC) {
+            const double u0 = dlc[0] * (double)a0 + dlc[1] * (double)b0 + dlc[2] * (double)c0;
+            const double u1 = dlc[0] * (double)a1 + dlc[1] * (double)b1 + dlc[2] * (double)c1;
+            const double dlri = (i == 0) ? 2. * row + 2. * (row - .5) : (i == 1) ? (-4.) * (row - .5) + (-4.) * (row + .5)
+                                                                                 : 2. * row + 2. * (row + .5);
+            dr0 += dlri * t0; dr1 += dlri * t1;
+            dc0 += lri * u0; dc1 += lri * u1;
         }
+    }
     if (WANT_JAC) {
         if (!row_in) { dr0 = 0.; dr1 = 0.; }
         if (!col_in) { dc0 = 0.; dc1 = 0.; }
@@ -72,8 +113,8 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     const double w = (double)simo;
     double rho0, rho1;
     if (kind == 0) {                                              // CauchyLoss(0.25)
-        const double sum = 1.0 + s * kCauchyC, inv = 1.0 / sum;
-        rho0 = kCauchyB * log(sum);
+        const double sum = 1.0 + s * kCauchyC, inv = fast_rcp(sum);
+        rho0 = kCauchyB * log_ge1(sum);
         rho1 = fmax(DBL_MIN, inv);
     } else {                                                      // TukeyLoss(0.0625)
         const double k0 = (tukey_variant == 1) ? kTukeyA2 / 6.0 : kTukeyA2 / 3.0;
@@ -85,7 +126,7 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
         } else { rho0 = k0; rho1 = 0.0; }
     }
     rho0 *= w; rho1 *= w;
-    const double sq = sqrt(rho1);       // Corrector, rho'' <= 0 branch
+    const double sq = fast_sqrt(rho1);  // Corrector, rho'' <= 0 branch
     o.cost = 0.5 * rho0;
     o.r0 = r0 * sq; o.r1 = r1 * sq; o.sq = sq;
     if (WANT_JAC) {
@@ -282,8 +323,9 @@ __device__ __forceinline__ void wave_lds_sync() {
 // ------------------------------------------------------------------------------------------
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    const int l = __double2loint(v), h = __double2hiint(v);       // old = src: no zero-init moves needed
+    const int lo = __builtin_amdgcn_update_dpp(l, l, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(h, h, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 template <int PATTERN>

@@ -45,8 +45,10 @@ struct KernelArgs {
     double *workspace;          // workgroup kernels: per-edge scratch (+ packed matrices for the HBM variant)
     const uint64_t *ws_off;     // per desc: packed-matrix offset (HBM variant)
     const uint64_t *es_off;     // per desc: per-edge scratch offset (8 doubles per edge)
+    unsigned long long *prof;   // -DLFR_PROFILE_PHASES: per-class cycle counters [cls*8 + phase]
     int desc_begin, desc_end;
     int tukey_variant;
+    int cls;
 };
 
 // =============================================================================================
@@ -59,7 +61,54 @@ struct KernelArgs {
 // rounds for their group.  Reductions are DPP butterflies; no barriers (a wave is its own
 // synchronisation domain), no cross-group traffic.
 // =============================================================================================
+#ifdef LFR_PROFILE_PHASES
+#define PROF_DECL unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long pt0_ = __builtin_amdgcn_s_memtime();
+#define PROF_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_[i] += t_ - pt0_; pt0_ = t_; } while (0)
+#define PROF_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&a.prof[a.cls * 8 + i_], pt_[i_]); if (lane == 0) atomicAdd(&a.prof[a.cls * 8 + 7], 1ull); } while (0)
+#else
+#define PROF_DECL
+#define PROF_MARK(i)
+#define PROF_FLUSH()
+#endif
 enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
+
+// Gauss-Jordan elimination of the damped normal equations held one row per lane (h[CPL] = the
+// lane's columns), no pivoting (SPD); padded rows are identity.  Step K: ONE burst of ds_swizzle
+// broadcasts of the pivot row into distinct registers (a single LDS-crossbar round trip), a Newton
+// reciprocal of the pivot, then the rank-1 update.  Written as a compile-time recursion of nested
+// `if (K+1 < n)` so the unrolled steps share one exit and no copies of h[] are made at merges.
+template <int NV, int LPR, int K>
+struct GaussJordan {
+    static constexpr int S = NV * LPR, CPL = NV / LPR;
+    static constexpr int kPartAnd = (NV == 8) ? 0x18 : (NV == 16) ? 0x10 : 0x00;
+    static __device__ __forceinline__ void run(double (&h)[NV / LPR], double &rhs, double &piv_own, double &minpiv,
+                                               int row, int part, int n_steps) {
+        constexpr int pk = K / CPL, ck = K % CPL;                      // part / register holding column K
+        constexpr int c0 = (K - CPL * (LPR - 1) + 1 > 0) ? K - CPL * (LPR - 1) + 1 : 0;   // first column still live
+        double pr[CPL];
+#pragma unroll
+        for (int c = c0; c < CPL; ++c) pr[c] = swz_bcast<kPartAnd, K % 32>(h[c]);
+        const double prhs = swz_bcast<kPartAnd, K % 32>(rhs);
+        const double piv = (S == 64) ? readlane_f64(h[ck], K + NV * pk)
+                                     : swz_bcast<(S == 8) ? 0x18 : (S == 16) ? 0x10 : 0x00, (K + NV * pk) % 32>(h[ck]);
+        double f = h[ck];                                              // valid in the lanes of part pk
+        if (LPR == 2) {
+            const double fx = (NV == 16) ? swizzle_f64<kSwizzleXor16>(f) : xor32_f64(f);
+            f = (part == pk) ? f : fx;
+        }
+        minpiv = fmin(minpiv, piv);
+        f *= fast_rcp(piv);
+        const bool is_k = row == K;
+        f = is_k ? 0.0 : f;
+        piv_own = is_k ? piv : piv_own;
+#pragma unroll
+        for (int c = c0; c < CPL; ++c) h[c] = fma(-f, pr[c], h[c]);
+        rhs = fma(-f, prhs, rhs);
+        if constexpr (K + 1 < NV) {
+            if (K + 1 < n_steps) GaussJordan<NV, LPR, K + 1>::run(h, rhs, piv_own, minpiv, row, part, n_steps);
+        }
+    }
+};
 
 template <int NV>
 struct GroupLds {
@@ -68,6 +117,11 @@ struct GroupLds {
     double g[NV];              // J^T r of the last evaluation
     double x[NV + 2];          // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
     double scale[NV];          // jacobi scaling (fixed at iteration 0)
+    double prow[NV + 2];       // Gauss-Jordan: pivot row (NV columns) + its right-hand side
+    double fcol[NV];           // Gauss-Jordan: pivot column (only when a row is split over 2 lanes)
+    // cold per-group state (line-search bookkeeping, counters): lives here, not in VGPRs
+    double ls_prev_x, ls_prev_value, ls_prev_gradient, dir_max;
+    int ls_prev_flags, ls_iter, n_successful, n_ls_evals, n_cand, exec_passes;
 };
 
 #ifndef LFR_GROUP_WAVES
@@ -104,16 +158,15 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
     // ---- edges -> registers (the only HBM read of the solve) ----
     float flow[EPL][18];
     float sim[EPL];
-    int xs_src[EPL], xs_dst[EPL], row_src[EPL], row_dst[EPL], kind[EPL];
-    bool act[EPL];
+    uint32_t idx[EPL];          // src | (dst|kind<<15) << 16, decoded at every use (keeps 5 VGPRs/slot free)
 #pragma unroll
     for (int k = 0; k < EPL; ++k) {
         const int e = sl + S * k;
-        act[k] = e < E;
-        const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (act[k] ? e : 0));
+        const bool on = e < E;
+        const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (on ? e : 0));
         uint4 q[5];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) q[i] = act[k] ? rp[i] : make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < 5; ++i) q[i] = on ? rp[i] : make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             flow[k][4 * i] = __uint_as_float(q[i].x); flow[k][4 * i + 1] = __uint_as_float(q[i].y);
@@ -121,13 +174,7 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
         }
         flow[k][16] = __uint_as_float(q[4].x); flow[k][17] = __uint_as_float(q[4].y);
         sim[k] = __uint_as_float(q[4].z);
-        const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
-        const int dn = dk & 0x7fff;
-        kind[k] = dk >> 15;
-        row_src[k] = s < n_var ? 2 * s : -1;
-        row_dst[k] = dn < n_var ? 2 * dn : -1;
-        xs_src[k] = s < n_var ? 2 * s : nv2;
-        xs_dst[k] = dn < n_var ? 2 * dn : nv2;
+        idx[k] = q[4].w;
     }
     if (sl < NV) { L.x[sl] = 0.0; L.scale[sl] = 1.0; }
     if (sl < 2) L.x[NV + sl] = 0.0;
@@ -136,14 +183,15 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
     int phase = have ? PH_EVAL_INIT : PH_DONE;
     double xi = 0.0, gi = 0.0, scale = 1.0, diag = 1.0;            // row
     double xt = 0.0, delta = 0.0;                                    // row
-    double cost = 0.0, radius = kInitialRadius, decrease_factor = 2.0, x_norm = 0.0, gmax = 0.0;
-    double g_dot_delta = 0.0, dir_max = 0.0, model_cost_change = 0.0, alpha = 1.0;
-    LsSample ls_prev{0, 0, 0, false, false};
-    int ls_iter = 0;
+    double cost = 0.0, radius = kInitialRadius, x_norm = 0.0, gmax = 0.0;
+    double g_dot_delta = 0.0, model_cost_change = 0.0, alpha = 1.0;
+    int n_reject = 0;                                 // decrease_factor = 2^(1 + n_reject)  (Ceres: 2, 4, 8, ...)
     bool reuse_diagonal = false, step_successful = true, a_dirty = false;
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
-    int n_successful = 0, n_ls_evals = 0, n_cand = 0, exec_passes = 0;
+    if (sl == 0) { L.n_successful = 0; L.n_ls_evals = 0; L.n_cand = 0; L.exec_passes = 0; L.ls_iter = 0; L.ls_prev_flags = 0; }
 
+    PROF_DECL
+    PROF_MARK(0);                                     // 0: prologue (edge load)
     for (;;) {
         if (!__any(phase != PH_DONE)) break;
 
@@ -175,28 +223,11 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
                 const double rhs0 = rhs;
                 double piv_own = 1.0;
                 bool fail = false;
-#pragma unroll
-                for (int k = 0; k < NV; ++k) {       // Gauss-Jordan, no pivoting (SPD); padded rows are identity
-                    if (k < nv2_max) {
-                        constexpr int kDummy = 0; (void)kDummy;
-                        const int pk = k / CPL, ck = k % CPL;                    // part / register holding column k
-                        const double piv = group_bcast_k<S>(h[ck], k + NV * pk);
-                        if (!(piv > 0.0)) fail = true;
-                        const double inv = 1.0 / piv;
-                        double f = h[ck] * inv;                                  // valid in the lanes of part pk
-                        if (LPR == 2) {
-                            const double fx = (NV == 16) ? swizzle_f64<kSwizzleXor16>(f) : xor32_f64(f);
-                            f = (part == pk) ? f : fx;
-                        }
-                        if (row == k) { f = 0.0; piv_own = piv; }
-                        // columns j = part*CPL + c > k somewhere in the group  <=>  c > k - CPL*(LPR-1)
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c)
-                            if (c > k - CPL * (LPR - 1)) h[c] -= f * swz_bcast_k<kPartAnd>(h[c], k % 32);
-                        rhs -= f * swz_bcast_k<kPartAnd>(rhs, k % 32);
-                    }
-                }
-                const double step = is_row ? -(rhs / piv_own) : 0.0;
+                PROF_MARK(5);                         // 5: step setup (diagonal, h build)
+                double minpiv = 1.0;
+                GaussJordan<NV, LPR, 0>::run(h, rhs, piv_own, minpiv, row, part, nv2_max);
+                fail = !(minpiv > 0.0);
+                const double step = is_row ? -(rhs * fast_rcp(piv_own)) : 0.0;
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
                 const unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << (S & 63)) - 1);
                 const bool bad = ((badmask >> ((gid * S) & 63)) & gmask) != 0;
@@ -209,11 +240,12 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
                     const bool valid = !fail && !bad && mcc > 0.0;
                     if (!valid) {
                         if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; phase = PH_DONE; }
-                        else { radius = radius / decrease_factor; decrease_factor *= 2.0; }      // StepIsInvalid
+                        else { radius = radius / ldexp(1.0, 1 + n_reject); ++n_reject; }      // StepIsInvalid -> StepRejected(0)
                     } else {
                         n_invalid = 0;
-                        model_cost_change = mcc; delta = dl; g_dot_delta = gdd; dir_max = dmx;
-                        alpha = 1.0; ls_iter = 0; ls_prev.value_valid = false;
+                        model_cost_change = mcc; delta = dl; g_dot_delta = gdd;
+                        alpha = 1.0;
+                        if (sl == 0) { L.dir_max = dmx; L.ls_iter = 0; L.ls_prev_flags = 0; }
                         xt = clampb(__dadd_rn(xi, delta));
                         if (own) L.x[row] = xt;
                         phase = PH_EVAL_LS;
@@ -222,6 +254,7 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
             }
         }
 
+        PROF_MARK(1);                                 // 1: iteration entry + LM step
         // ======================= B: one sweep over the edges of the evaluating groups =======================
         const bool pe = phase == PH_EVAL_INIT || phase == PH_EVAL_LS || phase == PH_EVAL_CAND || phase == PH_REEVAL;
         if (!__any(pe)) continue;
@@ -230,16 +263,20 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
             if (sl < NV) L.g[sl] = 0.0;
         }
         wave_lds_sync();
+        PROF_MARK(6);                                 // 6: zero J^T J
         double cost_l = 0.0;
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
-            if (!(act[k] && pe)) continue;
+            if (!(pe && sl + S * k < E)) continue;
+            uint32_t pk = idx[k];
+            asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
+            const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
+            const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
+            const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
             EdgeOut o;
-            eval_edge<true>(flow[k], sim[k], kind[k], tv, L.x[xs_src[k]], L.x[xs_src[k] + 1],
-                            L.x[xs_dst[k]], L.x[xs_dst[k] + 1], o);
+            eval_edge<true>(flow[k], sim[k], ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
             cost_l += o.cost;
             double *A = L.A, *g = L.g;
-            const int ra = row_src[k], rb = row_dst[k];
             if (ra >= 0) {
                 atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10);
                 atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
@@ -268,6 +305,7 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
             }
         }
         wave_lds_sync();
+        PROF_MARK(2);                                 // 2: edge sweep (evaluate + assemble)
         // cross-lane quantities of every possible transition (uniform control flow)
         const double cost_e = group_sum<S>(cost_l);
         const double xe = (phase == PH_EVAL_INIT || phase == PH_REEVAL) ? xi : xt;     // row: the evaluated point
@@ -277,46 +315,58 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
         const double step_norm2 = group_sum<S>(own ? (xi - xt) * (xi - xt) : 0.0);
         const double xnorm2_new = group_sum<S>(own ? xt * xt : 0.0);
 
+        PROF_MARK(3);                                 // 3: post-sweep reductions
         // ======================= C: transitions (no cross-lane operations below) =======================
         bool decide = false;
         double cost_cand = 0.0;
         if (phase == PH_EVAL_INIT) {
-            ++exec_passes;
+            if (sl == 0) ++L.exec_passes;
             cost = cost_e; gi = gnew; gmax = gmax_new;
             scale = is_row ? 1.0 / (1.0 + sqrt(L.A[row * LD + row])) : 1.0;        // jacobi scaling, once
             if (own) L.scale[row] = scale;
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_REEVAL) {
-            ++exec_passes;
+            if (sl == 0) ++L.exec_passes;
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_EVAL_LS) {
-            ++exec_passes; ++n_ls_evals;
+            if (sl == 0) { ++L.exec_passes; ++L.n_ls_evals; }
             const bool value_valid = isfinite(cost_e);
             if (value_valid && !(cost_e > cost + kLsSufficientDecrease * g_dot_delta * alpha)) {
                 decide = true; cost_cand = cost_e;                                   // candidate == this sample
             } else {
-                LsSample initial{0.0, cost, g_dot_delta, true, true}, current;
+                // rare: contraction.  Every lane of the group reads the same bookkeeping from LDS,
+                // computes the same next step; lane 0 writes the bookkeeping back.
+                LsSample initial{0.0, cost, g_dot_delta, true, true}, previous, current;
+                const int pf = L.ls_prev_flags;
+                previous.x = L.ls_prev_x; previous.value = L.ls_prev_value; previous.gradient = L.ls_prev_gradient;
+                previous.value_valid = (pf & 1) != 0; previous.gradient_valid = (pf & 2) != 0;
                 current.x = alpha; current.value = cost_e; current.value_valid = value_valid;
                 current.gradient = value_valid ? gdc : 0.0;
                 current.gradient_valid = value_valid && isfinite(gdc);
-                const double nstep = ls_next_step(initial, ls_prev, current, dir_max, ls_iter);
+                int ls_iter = L.ls_iter;
+                const double nstep = ls_next_step(initial, previous, current, L.dir_max, ls_iter);
+                wave_lds_sync();
+                if (sl == 0) {
+                    L.ls_iter = ls_iter;
+                    L.ls_prev_x = current.x; L.ls_prev_value = current.value; L.ls_prev_gradient = current.gradient;
+                    L.ls_prev_flags = (current.value_valid ? 1 : 0) | (current.gradient_valid ? 2 : 0);
+                }
                 if (nstep < 0.0) {                                                  // search failed: full step
                     xt = clampb(__dadd_rn(xi, delta));
                     if (own) L.x[row] = xt;
                     phase = PH_EVAL_CAND;
                 } else {
-                    ls_prev = current;
                     alpha = nstep;
                     xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
                     if (own) L.x[row] = xt;
                 }
             }
         } else if (phase == PH_EVAL_CAND) {
-            ++exec_passes;
+            if (sl == 0) ++L.exec_passes;
             decide = true; cost_cand = isfinite(cost_e) ? cost_e : DBL_MAX;
         }
         if (decide) {
-            ++n_cand;
+            if (sl == 0) ++L.n_cand;
             const double step_norm = sqrt(step_norm2);
             const double cost_change = cost - cost_cand;
             if (step_norm <= kParameterTol * (x_norm + kParameterTol)) phase = PH_DONE;          // candidate discarded
@@ -325,26 +375,29 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
                 const double rel = cost_change / model_cost_change;
                 if (rel > kMinRelDecrease) {
                     xi = xt; x_norm = sqrt(xnorm2_new); cost = cost_cand; gi = gnew; gmax = gmax_new;
-                    step_successful = true; ++n_successful;
+                    step_successful = true;
+                    if (sl == 0) ++L.n_successful;
                     const double t = 2.0 * rel - 1.0;
                     radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
-                    decrease_factor = 2.0; reuse_diagonal = false; a_dirty = false;
+                    n_reject = 0; reuse_diagonal = false; a_dirty = false;
                 } else {
-                    radius = radius / decrease_factor; decrease_factor *= 2.0;
+                    radius = radius / ldexp(1.0, 1 + n_reject); ++n_reject;          // StepRejected
                     a_dirty = true;
                 }
                 phase = PH_SOLVE;
             }
         }
+        PROF_MARK(4);                                 // 4: transitions
     }
+    PROF_FLUSH();
 
     if (have) {
         if (own && term != LFR_TERM_FAILURE)
             a.positions[2 * (size_t)a.node_ids[d.node_off + (row >> 1)] + (row & 1)] = xi;
         if (sl == 0) {
             CompInfoDev inf;
-            inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
-            inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
+            inf.iterations = iteration; inf.termination = term; inf.n_successful = L.n_successful;
+            inf.n_ls_evals = L.n_ls_evals; inf.n_cand_evals = L.n_cand; inf.exec_passes = L.exec_passes;
             inf.final_cost = cost;
             a.infos[ci] = inf;
         }
@@ -727,6 +780,7 @@ struct lfr_batch {
     CompInfoDev *d_infos = nullptr;
     double *d_workspace = nullptr;
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
+    unsigned long long *d_prof = nullptr;
     lfr::NodeInc *d_node_inc = nullptr;
     uint32_t *d_in_idx = nullptr;
     static constexpr int kSlots = 64;                    // event ring: timings of the last 64 solves
@@ -756,6 +810,7 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_workspace) (void)hipFree(b->d_workspace);
     if (b->d_ws_off) (void)hipFree(b->d_ws_off);
     if (b->d_es_off) (void)hipFree(b->d_es_off);
+    if (b->d_prof) (void)hipFree(b->d_prof);
     if (b->d_node_inc) (void)hipFree(b->d_node_inc);
     if (b->d_in_idx) (void)hipFree(b->d_in_idx);
     if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
@@ -830,6 +885,8 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
     HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_es_off, nd * sizeof(uint64_t)));
+    HIP_TRY(hipMalloc(&b->d_prof, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMalloc(&b->d_node_inc, nn * sizeof(lfr::NodeInc)));
     HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
     if (ws) HIP_TRY(hipMalloc(&b->d_workspace, ws * sizeof(double)));
@@ -867,7 +924,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     KernelArgs a;
     a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
     a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.es_off = b->d_es_off;
-    a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant;
+    a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
     ++b->n_solves;
     HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -879,7 +936,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     for (int oi = 0; oi < lfr::KC_COUNT; ++oi) {
         const int cls = order[oi];
         hipStream_t cs = b->serial ? st : b->cls_stream[cls];
-        a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1];
+        a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
         const int n = a.desc_end - a.desc_begin;
         if (n > 0 && !b->serial) HIP_TRY(hipStreamWaitEvent(cs, b->ev_fork, 0));
         else cs = st;
@@ -909,6 +966,17 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     if (!stats) return LFR_OK;
 
     HIP_TRY(hipStreamSynchronize(st));
+#ifdef LFR_PROFILE_PHASES
+    {
+        unsigned long long h[8 * lfr::KC_COUNT];
+        HIP_TRY(hipMemcpy(h, b->d_prof, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(b->d_prof, 0, sizeof h));
+        for (int c = 0; c < lfr::KC_COUNT; ++c) if (h[c * 8 + 7])
+            fprintf(stderr, "lfr-prof class %d: waves %llu  per-wave cycles: prologue %.0f  elim %.0f  sweep %.0f  reduce %.0f  transitions %.0f  setup %.0f  zero %.0f\n", c,
+                    h[c * 8 + 7], (double)h[c * 8] / h[c * 8 + 7], (double)h[c * 8 + 1] / h[c * 8 + 7], (double)h[c * 8 + 2] / h[c * 8 + 7],
+                    (double)h[c * 8 + 3] / h[c * 8 + 7], (double)h[c * 8 + 4] / h[c * 8 + 7], (double)h[c * 8 + 5] / h[c * 8 + 7], (double)h[c * 8 + 6] / h[c * 8 + 7]);
+    }
+#endif
     memset(stats, 0, sizeof *stats);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
