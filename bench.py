@@ -24,6 +24,21 @@ EDGE_BYTES = 84                 # u32 src + u32 dst + f32 sim + 1
 NODE_BYTES = 32                 # 16 B position read + 16 B written per variable node per pass
 
 
+def pmc_traffic(kernel, n_edges):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE collected in separate --pmc runs of this
+    same command, corrected as MI355X_MICROARCH.md prescribes).  None when the profile is for a
+    different kernel/workload."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        d = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if d.get("kernel") != kernel or d.get("edges_per_launch") != n_edges:
+        return None
+    return d.get("hbm_bytes_per_launch")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -104,16 +119,19 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel launch (SURVEY §8(d) accounting)
+        serial = os.environ.get("LFR_SERIAL_CLASSES") == "1"
         kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,3>", "solve_group_kernel<16,2,3>",
                         "solve_group_kernel<32,2,2>", "solve_group_kernel<32,2,4>", "solve_block_kernel<lds>",
                         "solve_block_kernel<hbm>"]
+        if not serial:      # one launch for all packed classes; its events sit in the slot of the largest class
+            kernel_names[dom if dom < 5 else 0] = "solve_packed_kernel"
         dur_s = cls_ms[dom] * 1e-3
         b_stream = st["dominant_ref_passes_edges"] * EDGE_BYTES + st["dominant_ref_passes_nodes"] * NODE_BYTES
         b_once = st["dominant_kernel_edges"] * 80 + st["dominant_kernel_nodes"] * 20      # bytes the launch really needs
         res["roofline"] = {
             "bound": "hbm", "kernel": kernel_names[dom],
             "achieved": b_stream / dur_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": b_stream / dur_s / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+            "frac": b_stream / dur_s / 1e9 / HBM_PEAK_GBPS, "traffic": pmc_traffic(kernel_names[dom], st["n_edges"]),
             "launch_ms": cls_ms[dom], "launch_edges": int(st["dominant_kernel_edges"]),
             "algorithmic_bytes": int(b_stream),
             "passes_per_edge_reference": st["dominant_ref_passes_edges"] / max(1, st["dominant_kernel_edges"]),
@@ -122,8 +140,9 @@ def main():
                     "/ launch time; the kernel keeps edges in VGPRs so it reads HBM once (read_once_*)",
         }
         res["all_kernels_ms"] = tot_ms
-        res["class_ms"] = dict(zip(kernel_names, [round(float(x), 4) for x in cls_ms]))
-        res["class_edges"] = dict(zip(kernel_names, [int(x) for x in cls_edges]))
+        keep = range(7) if serial else [dom if dom < 5 else 0, 5, 6]
+        res["class_ms"] = {kernel_names[i]: round(float(cls_ms[i]), 4) for i in keep if cls_edges[i] > 0}
+        res["class_edges"] = {kernel_names[i]: int(cls_edges[i]) for i in keep if cls_edges[i] > 0}
         res["host_ms"] = {"generate": t_gen * 1e3, "ingest": t_ingest * 1e3, "graph_stage": t_graph * 1e3,
                           "tracks": pst["tracks_ms"], "roots": pst["roots_ms"], "components": pst["graph_cut_ms"],
                           "assemble": pst["assemble_ms"], "h2d": st["h2d_ms"]}

@@ -128,7 +128,7 @@ struct GroupLds {
 #define LFR_GROUP_WAVES 2          // waves per SIMD the packed kernel is register-budgeted for
 #endif
 template <int NV, int LPR, int EPL>
-__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const KernelArgs a) {
+__device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int block_in_class, unsigned char *lds_raw) {
     constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
     static_assert(S <= 64 && (LPR == 1 || LPR == 2), "group geometry");
     // swizzle mask that keeps the lane's part (and, for S < 32, its group) and replaces the row
@@ -136,12 +136,11 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = lane / S, sl = lane % S;
     const int row = sl % NV, part = sl / NV;
-    const int ci0 = a.desc_begin + ((int)blockIdx.x * 4 + wave) * G;
-    __shared__ GroupLds<NV> lds_all[4][G];
+    const int ci0 = a.desc_begin + (block_in_class * 4 + wave) * G;
     if (ci0 >= a.desc_end) return;                    // wave-uniform
     const int ci = ci0 + gid;
     const bool have = ci < a.desc_end;
-    GroupLds<NV> &L = lds_all[wave][gid];
+    GroupLds<NV> &L = reinterpret_cast<GroupLds<NV> *>(lds_raw)[wave * G + gid];
 
     CompDesc d;
     d.edge_off = 0; d.n_edges = 0; d.node_off = 0; d.n_nodes = 0; d.n_var = 0;
@@ -401,6 +400,45 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const
             inf.final_cost = cost;
             a.infos[ci] = inf;
         }
+    }
+}
+
+constexpr size_t kPackedLdsBytes = 4 * sizeof(GroupLds<16>) * 4 > 4 * sizeof(GroupLds<32>) ? 4 * sizeof(GroupLds<16>) * 4 : 4 * sizeof(GroupLds<32>);
+static_assert(kPackedLdsBytes >= 4 * 8 * sizeof(GroupLds<8>) && kPackedLdsBytes >= 4 * 2 * sizeof(GroupLds<16>), "LDS budget");
+
+// one class per launch (diagnostics: LFR_SERIAL_CLASSES=1 gives per-class timings)
+template <int NV, int LPR, int EPL>
+__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const KernelArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[4 * (64 / (NV * LPR)) * sizeof(GroupLds<NV>)];
+    solve_group_body<NV, LPR, EPL>(a, (int)blockIdx.x, lds_raw);
+}
+
+// All packed classes in ONE launch: blocks [blk_begin[i], blk_begin[i+1]) belong to class i, the
+// long-running one-component-per-wave classes first so their tail overlaps the bulk of the small
+// classes (workgroups are dispatched in index order).  The classes are compiled into one kernel;
+// its register/LDS budget is the maximum over the classes (all are built for 2 waves per SIMD).
+struct PackedRanges {
+    int blk_begin[6];          // G64_4, G64_2, G32, G16, G8 in dispatch order
+    int desc_begin[5], desc_end[5];
+};
+__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_packed_kernel(KernelArgs a, const PackedRanges r) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kPackedLdsBytes];
+    const int b = (int)blockIdx.x;
+    if (b < r.blk_begin[1]) {
+        a.desc_begin = r.desc_begin[0]; a.desc_end = r.desc_end[0]; a.cls = lfr::KC_G64_4;
+        solve_group_body<32, 2, 4>(a, b - r.blk_begin[0], lds_raw);
+    } else if (b < r.blk_begin[2]) {
+        a.desc_begin = r.desc_begin[1]; a.desc_end = r.desc_end[1]; a.cls = lfr::KC_G64_2;
+        solve_group_body<32, 2, 2>(a, b - r.blk_begin[1], lds_raw);
+    } else if (b < r.blk_begin[3]) {
+        a.desc_begin = r.desc_begin[2]; a.desc_end = r.desc_end[2]; a.cls = lfr::KC_G32;
+        solve_group_body<16, 2, 3>(a, b - r.blk_begin[2], lds_raw);
+    } else if (b < r.blk_begin[4]) {
+        a.desc_begin = r.desc_begin[3]; a.desc_end = r.desc_end[3]; a.cls = lfr::KC_G16;
+        solve_group_body<16, 1, 3>(a, b - r.blk_begin[3], lds_raw);
+    } else {
+        a.desc_begin = r.desc_begin[4]; a.desc_end = r.desc_end[4]; a.cls = lfr::KC_G8;
+        solve_group_body<8, 1, 3>(a, b - r.blk_begin[4], lds_raw);
     }
 }
 
@@ -791,7 +829,8 @@ struct lfr_batch {
     bool events = false;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
-    hipStream_t cls_stream[lfr::KC_COUNT] = {nullptr};
+    hipStream_t side_stream = nullptr;                 // workgroup-per-component kernels run beside the packed launch
+    int packed_slot = 0;                               // class slot that carries the packed launch's events
     double h2d_ms = 0.0;
     std::vector<CompInfoDev> infos;      // last downloaded
     bool infos_valid = false;
@@ -815,7 +854,7 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_in_idx) (void)hipFree(b->d_in_idx);
     if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-    for (auto &cs : b->cls_stream) if (cs) (void)hipStreamDestroy(cs);
+    if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
     delete b;
 }
 
@@ -908,7 +947,15 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     for (auto &e : b->ev_ring) HIP_TRY(hipEventCreate(&e));
     b->events = true;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-    for (auto &cs : b->cls_stream) HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+    {   // the packed launch is reported in the slot of its largest class (by edges)
+        int64_t best = -1;
+        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) {
+            int64_t e = 0;
+            for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) e += b->descs[i].n_edges;
+            if (e > best) { best = e; b->packed_slot = cls; }
+        }
+    }
     HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)block_lds_bytes(std::max(b->block_max_rows, 2), false)));
     HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -929,37 +976,74 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     ++b->n_solves;
     HIP_TRY(hipEventRecord(b->ev[0], st));
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
-    // Kernel classes are independent: fork them onto their own streams (long-tailed workgroup
-    // kernels first) so the tails of one launch overlap the bulk of another, then join.
-    HIP_TRY(hipEventRecord(b->ev_fork, st));
-    static const int order[lfr::KC_COUNT] = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
-    for (int oi = 0; oi < lfr::KC_COUNT; ++oi) {
-        const int cls = order[oi];
-        hipStream_t cs = b->serial ? st : b->cls_stream[cls];
+    // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
+    // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
+    // launches every class separately on the caller's stream (per-class timings for diagnostics).
+    static const int kPackedOrder[5] = {lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
+    static const int kCompsPerBlock[lfr::KC_COUNT] = {32, 16, 8, 4, 4, 1, 1};
+    const dim3 blk(256);
+    auto launch_block = [&](int cls, hipStream_t cs) -> int {
         a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
         const int n = a.desc_end - a.desc_begin;
-        if (n > 0 && !b->serial) HIP_TRY(hipStreamWaitEvent(cs, b->ev_fork, 0));
-        else cs = st;
-        HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], cs));
-        if (n > 0) {
-            const dim3 blk(256);
-            switch (cls) {
-                case lfr::KC_G8:   hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), dim3((n + 31) / 32), blk, 0, cs, a); break;
-                case lfr::KC_G16:  hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), dim3((n + 15) / 16), blk, 0, cs, a); break;
-                case lfr::KC_G32:  hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), dim3((n + 7) / 8), blk, 0, cs, a); break;
-                case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 2, 2>), dim3((n + 3) / 4), blk, 0, cs, a); break;
-                case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 4>), dim3((n + 3) / 4), blk, 0, cs, a); break;
-                case lfr::KC_BLOCK:
-                    hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->block_max_rows, false), cs, a, b->block_max_rows);
-                    break;
-                case lfr::KC_GLOBAL:
-                    hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->global_max_rows, true), cs, a, b->global_max_rows);
-                    break;
+        if (n <= 0) return LFR_OK;
+        if (cls == lfr::KC_BLOCK)
+            hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->block_max_rows, false), cs, a, b->block_max_rows);
+        else
+            hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->global_max_rows, true), cs, a, b->global_max_rows);
+        HIP_TRY(hipGetLastError());
+        return LFR_OK;
+    };
+    const bool have_side = b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK];
+    if (b->serial) {
+        for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
+            a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
+            const int n = a.desc_end - a.desc_begin;
+            HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
+            if (n > 0) {
+                const dim3 grid((n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls]);
+                switch (cls) {
+                    case lfr::KC_G8:    hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G32:   hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 2, 2>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 4>), grid, blk, 0, st, a); break;
+                    default: { const int rc = launch_block(cls, st); if (rc != LFR_OK) return rc; }
+                }
+                HIP_TRY(hipGetLastError());
             }
+            HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
+        }
+    } else {
+        if (have_side) {
+            HIP_TRY(hipEventRecord(b->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+            for (int cls = lfr::KC_GLOBAL; cls >= lfr::KC_BLOCK; --cls) {
+                HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], b->side_stream));
+                const int rc = launch_block(cls, b->side_stream);
+                if (rc != LFR_OK) return rc;
+                HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], b->side_stream));
+            }
+        }
+        PackedRanges r;
+        int nb = 0;
+        for (int i = 0; i < 5; ++i) {
+            const int cls = kPackedOrder[i];
+            r.blk_begin[i] = nb;
+            r.desc_begin[i] = b->class_begin[cls]; r.desc_end[i] = b->class_begin[cls + 1];
+            const int n = r.desc_end[i] - r.desc_begin[i];
+            nb += (n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls];
+        }
+        r.blk_begin[5] = nb;
+        // the packed launch is timed as one unit: its events sit in the slot of the largest class
+        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
+        if (nb > 0) {
+            hipLaunchKernelGGL(solve_packed_kernel, dim3(nb), blk, 0, st, a, r);
             HIP_TRY(hipGetLastError());
         }
-        HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], cs));
-        if (n > 0 && !b->serial) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * cls], 0));
+        HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], st));
+        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) if (cls != b->packed_slot) HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
+        if (!have_side) for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls) { HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st)); HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st)); }
+        if (have_side) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0));
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;
@@ -989,8 +1073,11 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     stats->n_components = (int64_t)b->descs.size();
     stats->n_edges = b->n_edges; stats->n_nodes = b->n_nodes; stats->n_tracks = b->n_tracks;
     double best_ms = -1.0;
+    int64_t edges = 0, nodes = 0, refp_e = 0, refp_n = 0;
     for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
-        int64_t edges = 0, nodes = 0, refp_e = 0, refp_n = 0;
+        // one accounting unit per kernel LAUNCH: the packed classes are one launch unless serial
+        const bool merged = !b->serial && cls < lfr::KC_BLOCK;
+        if (!merged || cls == 0) { edges = 0; nodes = 0; refp_e = 0; refp_n = 0; }
         for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) {
             const CompInfoDev &f = b->infos[i];
             const int64_t E = b->descs[i].n_edges, N = b->descs[i].n_nodes;
@@ -1006,7 +1093,9 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             else ++stats->n_failed;
             edges += E; nodes += N; refp_e += E * (jac + cst); refp_n += N * (jac + cst);
         }
-        HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 + 2 * cls], b->ev[3 + 2 * cls]));
+        if (merged && cls != lfr::KC_BLOCK - 1) continue;
+        const int slot = merged ? b->packed_slot : cls;
+        HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 + 2 * slot], b->ev[3 + 2 * slot]));
         if (edges > 0 && ms > best_ms) {
             best_ms = ms;
             stats->dominant_kernel_ms = ms; stats->dominant_kernel_edges = edges; stats->dominant_kernel_nodes = nodes;
@@ -1026,9 +1115,12 @@ int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *cl
     if (total_ms) *total_ms = ms;
     for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
         if (class_ms) { HIP_TRY(hipEventElapsedTime(&ms, ev[2 + 2 * cls], ev[3 + 2 * cls])); class_ms[cls] = ms; }
-        if (class_edges) {
+        if (class_edges) {      // edges of the LAUNCH timed in this slot (the packed launch carries all packed classes)
             int64_t e = 0;
-            for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) e += b->descs[i].n_edges;
+            const bool packed = !b->serial && cls < lfr::KC_BLOCK;
+            const int lo = packed ? (cls == b->packed_slot ? 0 : cls + 1) : cls, hi = packed ? (cls == b->packed_slot ? lfr::KC_BLOCK : cls + 1) : cls + 1;
+            for (int c = lo; c < hi; ++c)
+                for (int i = b->class_begin[c]; i < b->class_begin[c + 1]; ++i) e += b->descs[i].n_edges;
             class_edges[cls] = e;
         }
     }
