@@ -488,8 +488,11 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     const int tv = a.tukey_variant;
     const EdgeRec *edges = a.edges + d.edge_off;
 
-    // LDS carve-up
-    double *vx = dyn;                 // x (n + 2, zero slot at n)
+    // LDS variant: vectors + packed matrix in dynamic LDS.  HBM variant: packed matrix, then the
+    // vectors, in this component's workspace (L2-resident); no dynamic LDS at all, so the row count
+    // is only bounded by the 32767-node limit of the batch format.
+    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : (dyn + 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows);
+    double *vx = GLOBAL_MATRIX ? (Mat + tri(n, 0) + (tri(n, 0) & 1)) : dyn;   // x (n + 2, zero slot at n)
     double *vxc = vx + max_rows + 2;  // trial point
     double *vg = vxc + max_rows + 2;  // gradient at x
     double *vgn = vg + max_rows;      // gradient at trial point
@@ -499,8 +502,6 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     double *vD = vstep + max_rows;
     double *vadiag = vD + max_rows;   // diagonal of unscaled J^T J at x
     double *vdelta = vadiag + max_rows;
-    double *Mlds = vdelta + max_rows;
-    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : Mlds;
 
     for (int i = tid; i < n + 2; i += kBlockThreads) { vx[i] = 0.0; vxc[i] = 0.0; }
     __syncthreads();
@@ -586,8 +587,12 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         return total;
     };
 
+    const int lane = tid;     // PROF_FLUSH uses `lane == 0`
+    (void)lane;
+    PROF_DECL
     int exec_passes = 1;
     double cost = sweep(vx, vg, true);
+    PROF_MARK(0);                                     // 0: sweeps (evaluate + owner-computes assembly)
     for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
     __syncthreads();
     auto grad_max = [&](const double *xv, const double *gv) {
@@ -608,10 +613,12 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         ++iteration;
         step_successful = false;
 
+        PROF_MARK(4);                                 // 4: bookkeeping
         if (!matrix_valid) {           // the factorization of a rejected step overwrote J^T J: re-assemble
             sweep(vx, vg, true);
             ++exec_passes;
             matrix_valid = true;
+            PROF_MARK(0);
         }
         // ---- H = S A S + D^2 in place, rhs = S g ----
         for (int i = tid; i < n; i += kBlockThreads) {
@@ -621,18 +628,19 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         }
         reuse_diagonal = true;
         __syncthreads();
-        for (size_t idx = tid; idx < tri(n, 0); idx += kBlockThreads) {
-            // invert idx -> (i, j)
-            int i = (int)((sqrt(8.0 * (double)idx + 1.0) - 1.0) * 0.5);
-            while (tri(i + 1, 0) <= idx) ++i;
-            while (tri(i, 0) > idx) --i;
-            const int j = (int)(idx - tri(i, 0));
-            double v = Mat[idx] * vscale[i] * vscale[j];
-            if (i == j) v += vD[i] * vD[i];
-            Mat[idx] = v;
+        // 16 x 16 thread tiling over (row, column): no index inversion, balanced trailing updates
+        const int ti = tid >> 4, tj = tid & 15;
+        for (int i = ti; i < n; i += 16) {
+            const double si = vscale[i];
+            for (int j = tj; j <= i; j += 16) {
+                double v = Mat[tri(i, j)] * si * vscale[j];
+                if (i == j) v += vD[i] * vD[i];
+                Mat[tri(i, j)] = v;
+            }
         }
         matrix_valid = false;
         __syncthreads();
+        PROF_MARK(5);                                 // 5: scaling
         // ---- LDL^T in place (right-looking), d on the diagonal, unit L below ----
         if (tid == 0) sh.flag = 0;
         __syncthreads();
@@ -640,21 +648,17 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             const double dk = Mat[tri(k, k)];
             if (!(dk > 0.0)) { if (tid == 0) sh.flag = 1; break; }       // uniform: every thread reads the same dk
             const double inv = 1.0 / dk;
-            const int m = n - k - 1;                                       // trailing size
             // trailing update with the UNSCALED column k: A[i][j] -= a_ik * a_jk / d_k, k < j <= i
-            for (int t = tid; t < m * (m + 1) / 2; t += kBlockThreads) {
-                int ii = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-                while ((ii + 1) * (ii + 2) / 2 <= t) ++ii;
-                while (ii * (ii + 1) / 2 > t) --ii;
-                const int jj = t - ii * (ii + 1) / 2;
-                const int i = k + 1 + ii, j = k + 1 + jj;
-                Mat[tri(i, j)] -= Mat[tri(i, k)] * Mat[tri(j, k)] * inv;
+            for (int i = k + 1 + ti; i < n; i += 16) {
+                const double aik = Mat[tri(i, k)] * inv;
+                for (int j = k + 1 + tj; j <= i; j += 16) Mat[tri(i, j)] -= aik * Mat[tri(j, k)];
             }
             __syncthreads();
             for (int i = k + 1 + tid; i < n; i += kBlockThreads) Mat[tri(i, k)] *= inv;
             __syncthreads();
         }
         __syncthreads();
+        PROF_MARK(1);                                 // 1: factorization
         bool valid = sh.flag == 0;
         if (valid) {
             // forward: L z = rhs (column oriented)
@@ -672,6 +676,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 __syncthreads();
             }
         }
+        PROF_MARK(6);                                 // 6: triangular solves
         double model_cost_change = 0.0;
         if (valid) {
             double part = 0.0, bad = 0.0;
@@ -711,7 +716,9 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             for (;;) {
                 for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
                 __syncthreads();
+                PROF_MARK(4);
                 cost_c = sweep(vxc, vgn, false);
+                PROF_MARK(2);                         // 2: line-search sweeps (cost + gradient)
                 ++exec_passes; ++n_ls_evals;
                 current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
                 current.gradient = 0.0; current.gradient_valid = false;
@@ -748,7 +755,9 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             __syncthreads();
             for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; }
             x_norm = sqrt(block_sum(xn, sh));
+            PROF_MARK(4);
             cost = sweep(vx, vg, true);               // J^T J at the new point
+            PROF_MARK(0);
             ++exec_passes;
             matrix_valid = true;
             gmax = grad_max(vx, vg);
@@ -764,6 +773,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         }
     }
     __syncthreads();
+    PROF_MARK(4);
+    PROF_FLUSH();
     if (term != LFR_TERM_FAILURE)
         for (int i = tid; i < n; i += kBlockThreads)
             a.positions[2 * (size_t)a.node_ids[d.node_off + (i >> 1)] + (i & 1)] = vx[i];
@@ -776,10 +787,10 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     }
 }
 
+size_t block_vector_doubles(int max_rows) { return 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows; }
 size_t block_lds_bytes(int max_rows, bool global_matrix) {
-    size_t doubles = 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows;
-    if (!global_matrix) doubles += (size_t)max_rows * (max_rows + 1) / 2;
-    return doubles * sizeof(double);
+    if (global_matrix) return 0;                       // matrix and vectors live in the HBM workspace
+    return (block_vector_doubles(max_rows) + (size_t)max_rows * (max_rows + 1) / 2) * sizeof(double);
 }
 
 #define HIP_TRY(expr)                                                                         \
@@ -829,7 +840,7 @@ struct lfr_batch {
     bool events = false;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
-    hipStream_t side_stream = nullptr;                 // workgroup-per-component kernels run beside the packed launch
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // workgroup-per-component kernels run beside the packed launch
     int packed_slot = 0;                               // class slot that carries the packed launch's events
     double h2d_ms = 0.0;
     std::vector<CompInfoDev> infos;      // last downloaded
@@ -855,6 +866,7 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
+    if (b->side_stream2) (void)hipStreamDestroy(b->side_stream2);
     delete b;
 }
 
@@ -896,11 +908,18 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         b->desc_class.push_back(cls); b->desc_tracks.push_back(p.desc_tracks[i]);
         b->es_off.push_back(ws);
         if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
-        b->ws_off.push_back(ws);
+        b->ws_off.push_back(0);
         if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
-        if (cls == lfr::KC_GLOBAL) { b->global_max_rows = std::max(b->global_max_rows, rows); ws += (uint64_t)rows * (rows + 1) / 2; ws += ws & 1; }
+        if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
         b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
     }
+    for (size_t i = 0; i < b->descs.size(); ++i)      // HBM variant: packed matrix + vectors per component
+        if (b->desc_class[i] == lfr::KC_GLOBAL) {
+            const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;
+            ws += ws & 1;
+            b->ws_off[i] = ws;
+            ws += mat + (mat & 1) + block_vector_doubles(b->global_max_rows);
+        }
     {   // class ranges (descs are sorted by class)
         int c = 0;
         b->class_begin[0] = 0;
@@ -908,10 +927,6 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
             const int cls = i < (int)b->descs.size() ? b->desc_class[i] : lfr::KC_COUNT;
             while (c < cls) b->class_begin[++c] = i;
         }
-    }
-    if (block_lds_bytes(b->global_max_rows, true) > 160 * 1024) {
-        lfr::set_error("component with %d rows exceeds the LDS vector budget of the global-matrix kernel", b->global_max_rows);
-        delete b; return LFR_ERR_UNSUPPORTED;
     }
     hipEvent_t e0, e1;
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
@@ -948,6 +963,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     b->events = true;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&b->side_stream2, hipStreamNonBlocking));
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
         for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) {
@@ -1016,12 +1032,13 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     } else {
         if (have_side) {
             HIP_TRY(hipEventRecord(b->ev_fork, st));
-            HIP_TRY(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
             for (int cls = lfr::KC_GLOBAL; cls >= lfr::KC_BLOCK; --cls) {
-                HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], b->side_stream));
-                const int rc = launch_block(cls, b->side_stream);
+                hipStream_t ss = cls == lfr::KC_GLOBAL ? b->side_stream2 : b->side_stream;
+                HIP_TRY(hipStreamWaitEvent(ss, b->ev_fork, 0));
+                HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], ss));
+                const int rc = launch_block(cls, ss);
                 if (rc != LFR_OK) return rc;
-                HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], b->side_stream));
+                HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], ss));
             }
         }
         PackedRanges r;
@@ -1043,7 +1060,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], st));
         for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) if (cls != b->packed_slot) HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
         if (!have_side) for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls) { HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st)); HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st)); }
-        if (have_side) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0));
+        if (have_side) { HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0)); HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_GLOBAL], 0)); }
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;
@@ -1056,7 +1073,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         HIP_TRY(hipMemcpy(h, b->d_prof, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(b->d_prof, 0, sizeof h));
         for (int c = 0; c < lfr::KC_COUNT; ++c) if (h[c * 8 + 7])
-            fprintf(stderr, "lfr-prof class %d: waves %llu  per-wave cycles: prologue %.0f  elim %.0f  sweep %.0f  reduce %.0f  transitions %.0f  setup %.0f  zero %.0f\n", c,
+            fprintf(stderr, "lfr-prof class %d: waves %llu  per-wave cycles: [0] %.0f  [1] %.0f  [2] %.0f  [3] %.0f  [4] %.0f  [5] %.0f  [6] %.0f   (packed: prologue/elim/sweep/reduce/transitions/setup/zero; block: jac-sweeps/factor/ls-sweeps/-/bookkeeping/scaling/trisolve)\n", c,
                     h[c * 8 + 7], (double)h[c * 8] / h[c * 8 + 7], (double)h[c * 8 + 1] / h[c * 8 + 7], (double)h[c * 8 + 2] / h[c * 8 + 7],
                     (double)h[c * 8 + 3] / h[c * 8 + 7], (double)h[c * 8 + 4] / h[c * 8 + 7], (double)h[c * 8 + 5] / h[c * 8 + 7], (double)h[c * 8 + 6] / h[c * 8 + 7]);
     }

@@ -127,3 +127,15 @@ def test_headline_size_properties(lfr_lib):
     assert st["exec_passes_edges"] <= st["ref_jacobian_passes_edges"] + st["ref_cost_passes_edges"]
     ref = O.run(ma, n_threads=8)
     assert np.abs(x - ref["positions"]).max() <= TOL_UNITS
+
+
+def test_huge_component_hbm_matrix(lfr_lib):
+    """A single 1100-node track (2198 rows, 1.2 M edges): the HBM-matrix workgroup kernel with its
+    vectors in the workspace (no LDS row limit)."""
+    ma = synthetic.generate(seed=91, n_images=1200, n_tracks=1, len_dist="uniform", len_lo=1100, len_hi=1100,
+                            sigma_noise=0.01)
+    g, p, b, st, pos, ref = solve_both(ma)
+    assert st["n_components"] == 1 and p.stats()["max_component_size"] == 1100
+    assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
+    info = b.component_info()
+    assert info["n_var_nodes"][0] == 1099 and info["termination"][0] == ref["infos"]["termination"][info["component"][0]]
