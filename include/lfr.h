@@ -142,6 +142,10 @@ typedef struct lfr_solve_stats {
     int64_t dominant_ref_passes_nodes;
 } lfr_solve_stats;
 
+/* Create the HIP context of `device` (a few hundred ms the first time); safe to call from a side
+ * thread while the caller parses its input. */
+int lfr_hip_warmup(int device);
+
 /* Upload shard `shard_rank` of `shard_world` (components dealt largest-first to the least
  * loaded shard, mirroring solve.cc:599-604) to HIP device `device`. */
 int lfr_batch_create(const lfr_problem *p, int device, int shard_rank, int shard_world, int tukey_variant,

@@ -10,6 +10,9 @@
 #include <cstring>
 #include <numeric>
 #include <queue>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 
 #include "lfr_internal.hpp"
 
@@ -26,6 +29,38 @@ static inline uint32_t sim_key(float s) {   // order-preserving float -> uint32 
 }
 
 struct SortKey { uint64_t hi; uint32_t lo; uint32_t m; };   // (sim, n1) | n2 | match id
+
+// host worker threads for the embarrassingly parallel parts (sort, assembly): LFR_HOST_THREADS or
+// min(hardware threads, 32)
+static int host_threads() {
+    if (const char *e = getenv("LFR_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 256); }
+    const unsigned h = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(h ? h : 1u, 32u));
+}
+// run f(chunk, lo, hi) over [0, n) split at `cuts` (size chunks+1) on one thread per chunk
+static void parallel_chunks(const std::vector<int64_t> &cuts, const std::function<void(int, int64_t, int64_t)> &f) {
+    const int chunks = (int)cuts.size() - 1;
+    if (chunks <= 1) { if (chunks == 1) f(0, cuts[0], cuts[1]); return; }
+    std::vector<std::thread> th;
+    for (int c = 1; c < chunks; ++c) th.emplace_back(f, c, cuts[c], cuts[c + 1]);
+    f(0, cuts[0], cuts[1]);
+    for (auto &t : th) t.join();
+}
+template <class T, class Cmp>
+static void parallel_sort(std::vector<T> &v, Cmp cmp, int threads) {
+    const int64_t n = (int64_t)v.size();
+    int chunks = 1;
+    while (chunks * 2 <= threads && n / (chunks * 2) >= 65536) chunks *= 2;
+    std::vector<int64_t> cuts(chunks + 1);
+    for (int c = 0; c <= chunks; ++c) cuts[c] = n * c / chunks;
+    parallel_chunks(cuts, [&](int, int64_t lo, int64_t hi) { std::sort(v.begin() + lo, v.begin() + hi, cmp); });
+    for (int width = 1; width < chunks; width *= 2) {            // pairwise merges, one thread per pair
+        std::vector<std::thread> th;
+        for (int c = 0; c + width < chunks; c += 2 * width)
+            th.emplace_back([&, c, width] { std::inplace_merge(v.begin() + cuts[c], v.begin() + cuts[c + width], v.begin() + cuts[std::min(c + 2 * width, chunks)], cmp); });
+        for (auto &t : th) t.join();
+    }
+}
 
 static inline int32_t uf_root(std::vector<int32_t> &parent, int32_t i) {
     int32_t r = i;
@@ -155,10 +190,10 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     std::vector<SortKey> keys(M);
     for (int64_t m = 0; m < M; ++m)
         keys[m] = SortKey{((uint64_t)sim_key(g.m_sim[m]) << 32) | g.m_node1[m], g.m_node2[m], (uint32_t)m};
-    std::sort(keys.begin(), keys.end(), [](const SortKey &a, const SortKey &b) {   // descending (sort + reverse)
+    parallel_sort(keys, [](const SortKey &a, const SortKey &b) {   // descending (sort + reverse); keys are unique up to duplicates
         if (a.hi != b.hi) return a.hi > b.hi;
         return a.lo > b.lo;
-    });
+    }, host_threads());
     std::vector<int32_t> parent(N, -1), next(N, -1), tail(N), count(N, 1);
     std::vector<int64_t> stamp(g.image_names.size(), -1);
     for (int64_t i = 0; i < N; ++i) tail[i] = (int32_t)i;
@@ -309,101 +344,133 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
         std::vector<int64_t> cur(comp_off.begin(), comp_off.end() - 1);
         for (int64_t i = 0; i < N; ++i) comp_nodes[cur[p.comp[i]]++] = i;      // ascending node idx
     }
-    // pass 1: which nodes are variables, how many edges are kept
+    // pass 1 (parallel over components): which nodes are variables, how many edges are kept
     std::vector<uint8_t> is_var(N, 0);
     struct Meta { int64_t comp; int64_t n_edges; int32_t n_var, n_nodes, cls, n_tracks; };
-    std::vector<Meta> metas;
     std::vector<int64_t> seen_track(n_tracks, -1);
-    for (int64_t c = 0; c < n_components; ++c) {
-        const int64_t lo = comp_off[c], hi = comp_off[c + 1];
-        if (hi - lo <= 1) continue;                                           // solve.cc:619-622
-        int32_t n_var = 0;
-        for (int64_t k = lo; k < hi; ++k) {
-            const int64_t n = comp_nodes[k];
-            bool opt = false;
-            for (int64_t q = out_off[n]; q < out_off[n + 1] && !opt; ++q) {
-                const uint32_t d = edge_dst(out_eid[q]);
-                opt = p.track[n] == p.track[d] || p.comp[n] == p.comp[d];       // solve.cc:105,114,127
-            }
-            if (opt && !p.is_root[n]) { is_var[n] = 1; ++n_var; }               // solve.cc:133-141
+    const int T = host_threads();
+    std::vector<int64_t> ccuts;                       // component ranges balanced by node count
+    {
+        int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(T, N / 20000));
+        ccuts.push_back(0);
+        for (int c = 1; c < chunks; ++c) {
+            const int64_t target = N * c / chunks;
+            const int64_t pos = std::lower_bound(comp_off.begin(), comp_off.end(), target) - comp_off.begin();
+            ccuts.push_back(std::max(ccuts.back(), std::min<int64_t>(pos, n_components)));
         }
-        if (n_var == 0) continue;                     // "No non-constant parameter blocks": nothing moves
-        int64_t n_edges = 0;
-        int32_t n_tr = 0;
-        for (int64_t k = lo; k < hi; ++k) {
-            const int64_t n = comp_nodes[k];
-            if (tsize[p.track[n]] >= 2 && seen_track[p.track[n]] != c) { seen_track[p.track[n]] = c; ++n_tr; }
-            for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
-                const uint32_t d = edge_dst(out_eid[q]);
-                if (!(p.track[n] == p.track[d] || p.comp[n] == p.comp[d])) continue;
-                if (!is_var[n] && !is_var[d]) continue;       // both constant: not in the reduced program
-                ++n_edges;
-            }
-        }
-        if (hi - lo > 32767) { set_error("component with %lld nodes exceeds the 32767-node batch limit", (long long)(hi - lo)); return LFR_ERR_UNSUPPORTED; }
-        metas.push_back(Meta{c, n_edges, n_var, (int32_t)(hi - lo), classify(2 * n_var, n_edges), n_tr});
+        ccuts.push_back(n_components);
     }
+    std::vector<std::vector<Meta>> metas_t(ccuts.size() - 1);
+    std::vector<int> err_t(ccuts.size() - 1, 0);
+    parallel_chunks(ccuts, [&](int chunk, int64_t clo, int64_t chi) {
+        std::vector<Meta> &out = metas_t[chunk];
+        for (int64_t c = clo; c < chi; ++c) {
+            const int64_t lo = comp_off[c], hi = comp_off[c + 1];
+            if (hi - lo <= 1) continue;                                           // solve.cc:619-622
+            int32_t n_var = 0;
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t n = comp_nodes[k];
+                bool opt = false;
+                for (int64_t q = out_off[n]; q < out_off[n + 1] && !opt; ++q) {
+                    const uint32_t d = edge_dst(out_eid[q]);
+                    opt = p.track[n] == p.track[d] || p.comp[n] == p.comp[d];       // solve.cc:105,114,127
+                }
+                if (opt && !p.is_root[n]) { is_var[n] = 1; ++n_var; }               // solve.cc:133-141
+            }
+            if (n_var == 0) continue;                     // "No non-constant parameter blocks": nothing moves
+            int64_t n_edges = 0;
+            int32_t n_tr = 0;
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t n = comp_nodes[k];
+                if (tsize[p.track[n]] >= 2 && seen_track[p.track[n]] != c) { seen_track[p.track[n]] = c; ++n_tr; }
+                for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
+                    const uint32_t d = edge_dst(out_eid[q]);
+                    if (!(p.track[n] == p.track[d] || p.comp[n] == p.comp[d])) continue;
+                    if (!is_var[n] && !is_var[d]) continue;       // both constant: not in the reduced program
+                    ++n_edges;
+                }
+            }
+            if (hi - lo > 32767) { err_t[chunk] = 1; return; }
+            out.push_back(Meta{c, n_edges, n_var, (int32_t)(hi - lo), classify(2 * n_var, n_edges), n_tr});
+        }
+    });
+    for (int e : err_t) if (e) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
+    std::vector<Meta> metas;
+    for (auto &v : metas_t) metas.insert(metas.end(), v.begin(), v.end());
     std::stable_sort(metas.begin(), metas.end(), [](const Meta &a, const Meta &b) {
         if (a.cls != b.cls) return a.cls < b.cls;
         if (a.n_edges != b.n_edges) return a.n_edges > b.n_edges;
         return a.n_var > b.n_var;
     });
-    int64_t total_edges = 0, total_nodes = 0;
-    for (auto &m : metas) { total_edges += m.n_edges; total_nodes += m.n_nodes; }
+    std::vector<int64_t> eoff(metas.size() + 1, 0), noff(metas.size() + 1, 0);
+    for (size_t i = 0; i < metas.size(); ++i) { eoff[i + 1] = eoff[i] + metas[i].n_edges; noff[i + 1] = noff[i] + metas[i].n_nodes; }
+    const int64_t total_edges = eoff.back(), total_nodes = noff.back();
     if (total_edges >= ((int64_t)1 << 32) || total_nodes >= ((int64_t)1 << 32)) { set_error("batch exceeds 2^32 edges/nodes"); return LFR_ERR_UNSUPPORTED; }
     p.descs.resize(metas.size()); p.desc_component.resize(metas.size()); p.desc_class.resize(metas.size());
     p.desc_tracks.resize(metas.size());
     p.edges.resize(total_edges); p.node_ids.resize(total_nodes);
     p.node_inc.assign(total_nodes, NodeInc{0, 0, 0, 0}); p.in_idx.resize(total_edges);
     std::vector<int32_t> local_of(N, -1);
-    int64_t eo = 0, no = 0;
-    for (size_t di = 0; di < metas.size(); ++di) {
-        const Meta &mt = metas[di];
-        const int64_t lo = comp_off[mt.comp], hi = comp_off[mt.comp + 1];
-        int32_t nv = 0, nc2 = mt.n_var;
-        for (int64_t k = lo; k < hi; ++k) {           // variable nodes first, then constants
-            const int64_t n = comp_nodes[k];
-            const int32_t l = is_var[n] ? nv++ : nc2++;
-            local_of[n] = l;
-            p.node_ids[no + l] = (uint32_t)n;
+    // pass 2 (parallel over the sorted components, balanced by edges): emit the batch
+    std::vector<int64_t> dcuts;
+    {
+        int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(T, total_edges / 50000));
+        dcuts.push_back(0);
+        for (int c = 1; c < chunks; ++c) {
+            const int64_t pos = std::lower_bound(eoff.begin(), eoff.end(), total_edges * c / chunks) - eoff.begin();
+            dcuts.push_back(std::max(dcuts.back(), std::min<int64_t>(pos, (int64_t)metas.size())));
         }
-        CompDesc &d = p.descs[di];
-        d.edge_off = (uint32_t)eo; d.n_edges = (uint32_t)mt.n_edges; d.node_off = (uint32_t)no;
-        d.n_nodes = (uint16_t)mt.n_nodes; d.n_var = (uint16_t)mt.n_var;
-        p.desc_component[di] = mt.comp; p.desc_class[di] = mt.cls; p.desc_tracks[di] = mt.n_tracks;
-        const int64_t eo0 = eo;
-        for (int64_t k = lo; k < hi; ++k) {           // residual-block order of solve.cc:98-102
-            const int64_t n = comp_nodes[k];
-            p.node_inc[no + local_of[n]].out_begin = (uint32_t)(eo - eo0);
-            for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
-                const int64_t e = out_eid[q];
-                const uint32_t dn = edge_dst(e);
-                int kind;
-                if (p.track[n] == p.track[dn]) kind = 0;
-                else if (p.comp[n] == p.comp[dn]) kind = 1;
-                else continue;
-                if (!is_var[n] && !is_var[dn]) continue;
-                EdgeRec &r = p.edges[eo++];
-                const float *fl = ((e & 1) ? g.m_disp1.data() : g.m_disp2.data()) + 18 * (e >> 1);
-                memcpy(r.flow, fl, sizeof r.flow);
-                r.sim = g.m_sim[e >> 1];
-                r.src = (uint16_t)local_of[n];
-                r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
-                ++p.node_inc[no + local_of[n]].out_count;
-                ++p.node_inc[no + local_of[dn]].in_count;
-            }
-        }
-        {   // in-edge lists: counting sort of the component's edges by destination (stable)
-            uint32_t acc = 0;
-            for (int32_t l = 0; l < mt.n_nodes; ++l) { p.node_inc[no + l].in_begin = acc; acc += p.node_inc[no + l].in_count; p.node_inc[no + l].in_count = 0; }
-            for (int64_t e = eo0; e < eo; ++e) {
-                NodeInc &ni = p.node_inc[no + (p.edges[e].dst_kind & 0x7fff)];
-                p.in_idx[eo0 + ni.in_begin + ni.in_count++] = (uint32_t)(e - eo0);
-            }
-        }
-        no += mt.n_nodes;
-        p.stats.n_solved_tracks += mt.n_tracks;
+        dcuts.push_back((int64_t)metas.size());
     }
+    parallel_chunks(dcuts, [&](int, int64_t dlo, int64_t dhi) {
+        for (int64_t di = dlo; di < dhi; ++di) {
+            const Meta &mt = metas[di];
+            const int64_t lo = comp_off[mt.comp], hi = comp_off[mt.comp + 1];
+            const int64_t no = noff[di], eo0 = eoff[di];
+            int64_t eo = eo0;
+            int32_t nv = 0, nc2 = mt.n_var;
+            for (int64_t k = lo; k < hi; ++k) {           // variable nodes first, then constants
+                const int64_t n = comp_nodes[k];
+                const int32_t l = is_var[n] ? nv++ : nc2++;
+                local_of[n] = l;
+                p.node_ids[no + l] = (uint32_t)n;
+            }
+            CompDesc &d = p.descs[di];
+            d.edge_off = (uint32_t)eo0; d.n_edges = (uint32_t)mt.n_edges; d.node_off = (uint32_t)no;
+            d.n_nodes = (uint16_t)mt.n_nodes; d.n_var = (uint16_t)mt.n_var;
+            p.desc_component[di] = mt.comp; p.desc_class[di] = mt.cls; p.desc_tracks[di] = mt.n_tracks;
+            for (int64_t k = lo; k < hi; ++k) {           // residual-block order of solve.cc:98-102
+                const int64_t n = comp_nodes[k];
+                p.node_inc[no + local_of[n]].out_begin = (uint32_t)(eo - eo0);
+                for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
+                    const int64_t e = out_eid[q];
+                    const uint32_t dn = edge_dst(e);
+                    int kind;
+                    if (p.track[n] == p.track[dn]) kind = 0;
+                    else if (p.comp[n] == p.comp[dn]) kind = 1;
+                    else continue;
+                    if (!is_var[n] && !is_var[dn]) continue;
+                    EdgeRec &r = p.edges[eo++];
+                    const float *fl = ((e & 1) ? g.m_disp1.data() : g.m_disp2.data()) + 18 * (e >> 1);
+                    memcpy(r.flow, fl, sizeof r.flow);
+                    r.sim = g.m_sim[e >> 1];
+                    r.src = (uint16_t)local_of[n];
+                    r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
+                    ++p.node_inc[no + local_of[n]].out_count;
+                    ++p.node_inc[no + local_of[dn]].in_count;
+                }
+            }
+            {   // in-edge lists: counting sort of the component's edges by destination (stable)
+                uint32_t acc = 0;
+                for (int32_t l = 0; l < mt.n_nodes; ++l) { p.node_inc[no + l].in_begin = acc; acc += p.node_inc[no + l].in_count; p.node_inc[no + l].in_count = 0; }
+                for (int64_t e = eo0; e < eo; ++e) {
+                    NodeInc &ni = p.node_inc[no + (p.edges[e].dst_kind & 0x7fff)];
+                    p.in_idx[eo0 + ni.in_begin + ni.in_count++] = (uint32_t)(e - eo0);
+                }
+            }
+        }
+    });
+    for (const Meta &mt : metas) p.stats.n_solved_tracks += mt.n_tracks;
     p.stats.n_solved_components = (int64_t)metas.size();
     p.stats.n_solved_edges = total_edges;
     p.stats.n_solved_nodes = total_nodes;

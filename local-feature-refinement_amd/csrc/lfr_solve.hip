@@ -849,6 +849,17 @@ struct lfr_batch {
 
 extern "C" {
 
+int lfr_hip_warmup(int device) {
+    // Creating the HIP context costs a few hundred ms; a host program can call this from a side
+    // thread while it parses its input (the `solve` launcher does).
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipFree(nullptr));
+    return LFR_OK;
+}
+
 void lfr_batch_free(lfr_batch *b) {
     if (!b) return;
     (void)hipSetDevice(b->device);
@@ -892,27 +903,39 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         const std::vector<int32_t> shard = lfr::assign_shards(p, shard_world);
         for (size_t i = 0; i < p.descs.size(); ++i) if (shard[i] == shard_rank) mine.push_back(i);
     }
-    std::vector<EdgeRec> edges;
-    std::vector<uint32_t> in_idx;
+    // Whole problem on one GPU: upload straight from the problem's arrays (no 400 MB host copy).
+    const bool whole = shard_world == 1;
+    std::vector<EdgeRec> edges_copy;
+    std::vector<uint32_t> in_idx_copy;
     uint64_t ws = 0;
-    for (size_t i : mine) {
+    if (whole) {
+        b->node_ids = p.node_ids; b->node_inc = p.node_inc;
+        b->descs = p.descs; b->desc_component = p.desc_component; b->desc_class = p.desc_class; b->desc_tracks = p.desc_tracks;
+        b->es_off.resize(p.descs.size()); b->ws_off.assign(p.descs.size(), 0);
+    }
+    for (size_t k = 0; k < mine.size(); ++k) {
+        const size_t i = mine[k];
         CompDesc d = p.descs[i];
-        const uint32_t eo = (uint32_t)edges.size(), no = (uint32_t)b->node_ids.size();
-        edges.insert(edges.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
-        in_idx.insert(in_idx.end(), p.in_idx.begin() + d.edge_off, p.in_idx.begin() + d.edge_off + d.n_edges);
-        b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
-        b->node_inc.insert(b->node_inc.end(), p.node_inc.begin() + d.node_off, p.node_inc.begin() + d.node_off + d.n_nodes);
-        d.edge_off = eo; d.node_off = no;
+        if (!whole) {
+            const uint32_t eo = (uint32_t)edges_copy.size(), no = (uint32_t)b->node_ids.size();
+            edges_copy.insert(edges_copy.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
+            in_idx_copy.insert(in_idx_copy.end(), p.in_idx.begin() + d.edge_off, p.in_idx.begin() + d.edge_off + d.n_edges);
+            b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
+            b->node_inc.insert(b->node_inc.end(), p.node_inc.begin() + d.node_off, p.node_inc.begin() + d.node_off + d.n_nodes);
+            d.edge_off = eo; d.node_off = no;
+            b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
+            b->desc_class.push_back(p.desc_class[i]); b->desc_tracks.push_back(p.desc_tracks[i]);
+            b->es_off.push_back(0); b->ws_off.push_back(0);
+        }
         const int cls = p.desc_class[i], rows = 2 * d.n_var;
-        b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
-        b->desc_class.push_back(cls); b->desc_tracks.push_back(p.desc_tracks[i]);
-        b->es_off.push_back(ws);
+        b->es_off[k] = ws;
         if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
-        b->ws_off.push_back(0);
         if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
         if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
         b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
     }
+    const std::vector<EdgeRec> &edges = whole ? p.edges : edges_copy;
+    const std::vector<uint32_t> &in_idx = whole ? p.in_idx : in_idx_copy;
     for (size_t i = 0; i < b->descs.size(); ++i)      // HBM variant: packed matrix + vectors per component
         if (b->desc_class[i] == lfr::KC_GLOBAL) {
             const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;

@@ -80,6 +80,7 @@ def lib():
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
         "lfr_problem_shard_components": (i64, [vp, C.c_int, C.c_int, vp, vp]),
+        "lfr_hip_warmup": (C.c_int, [C.c_int]),
         "lfr_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, pp]),
         "lfr_batch_free": (None, [vp]),
         "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
@@ -101,7 +102,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_free", "lfr_problem_get_stats",
-           "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
+           "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
            "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution"]
 
 
@@ -119,6 +120,15 @@ def _cstrs(strings):
     for i, s in enumerate(strings):
         arr[i] = s.encode("utf-8") if isinstance(s, str) else s
     return arr
+
+
+def hip_warmup_async(device=0):
+    """Start creating the HIP context on a side thread (ctypes releases the GIL); returns the thread."""
+    import threading
+    L = lib()
+    t = threading.Thread(target=lambda: L.lfr_hip_warmup(device), daemon=True)
+    t.start()
+    return t
 
 
 class Graph:

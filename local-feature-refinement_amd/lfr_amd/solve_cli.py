@@ -120,6 +120,8 @@ def main(argv=None):
         sys.stderr.write("FATAL: %s\n" % e)
         return 2
 
+    device = int(os.environ.get("LFR_DEVICE", "0"))
+    warm = capi.hip_warmup_async(device)          # HIP context creation overlaps the parse
     try:
         graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"])
     except capi.LfrError as e:
@@ -158,9 +160,10 @@ def main(argv=None):
             sys.stderr.write("note: %d component(s) above the size cap were split by the built-in bisection, "
                              "not by Graclus (see DESIGN.md)\n" % st["n_cut_components"])
         sys.stdout.flush()
+        warm.join()
         t1 = time.perf_counter()                                          # solve.cc:615
         try:
-            positions, sst = problem.solve_hip(int(os.environ.get("LFR_DEVICE", "0")),
+            positions, sst = problem.solve_hip(device,
                                                os.environ.get("LFR_TUKEY_VARIANT", "ceres1"))
         except (capi.LfrError, KeyError) as e:
             sys.stderr.write("FATAL: HIP solve failed: %s\n" % e)
