@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstring>
 #include <set>
+#include <thread>
+#include <cstdlib>
+#include <algorithm>
 
 #include "lfr_internal.hpp"
 
@@ -137,7 +140,26 @@ static bool parse_displacements(Cursor c, float *out, int &n) {   // one Displac
     return true;
 }
 
-static int parse_match(Cursor c, Graph &g, int32_t img1, int32_t img2) {
+// ---- parallel scanner -----------------------------------------------------------------------
+// Pass A (sequential): split the top level into ImagePair cursors.  Pass B (one thread per chunk
+// of pairs, balanced by bytes): decode pairs and matches into thread-local SoA buffers.  Pass C
+// (sequential, order-dependent): banned-image filter, image interning (first fact wins), node
+// numbering in order of first appearance (solve.cc:444-451,474-475).  Pass D (parallel): move the
+// similarities and flow grids into the graph's arrays.
+struct MatchBuf {
+    std::vector<uint32_t> f1, f2;
+    std::vector<float> sim, d1, d2;      // 18 floats per match, zero padded
+    int rc = LFR_OK;
+};
+struct PairRec {
+    const char *name1 = nullptr, *name2 = nullptr;
+    uint32_t len1 = 0, len2 = 0;
+    float fact1 = 0.f, fact2 = 0.f;
+    int32_t buf = 0;                     // which MatchBuf
+    int64_t first = 0, count = 0;        // its matches inside that buffer
+};
+
+static int parse_match(Cursor c, MatchBuf &out) {
     uint32_t f1 = 0, f2 = 0; float sim = 0.f;
     float d1[18], d2[18]; int n1 = 0, n2 = 0;
     memset(d1, 0, sizeof d1); memset(d2, 0, sizeof d2);
@@ -153,54 +175,131 @@ static int parse_match(Cursor c, Graph &g, int32_t img1, int32_t img2) {
         else c.skip(wt);
     }
     if (!c.ok) return LFR_ERR_PARSE;
-    if (n1 > 9 || n2 > 9) {
-        set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
-        return LFR_ERR_UNSUPPORTED;
-    }
-    g.add_match(img1, img2, f1, f2, sim, d1, n1, d2, n2);
+    if (n1 > 9 || n2 > 9) return LFR_ERR_UNSUPPORTED;
+    out.f1.push_back(f1); out.f2.push_back(f2); out.sim.push_back(sim);
+    out.d1.insert(out.d1.end(), d1, d1 + 18); out.d2.insert(out.d2.end(), d2, d2 + 18);
     return LFR_OK;
 }
 
-static int parse_pair(Cursor c, Graph &g, const std::set<std::string> &banned) {
-    std::string name1, name2; float fact1 = 0.f, fact2 = 0.f;
-    std::vector<Cursor> matches;
+static int parse_pair(Cursor c, PairRec &rec, MatchBuf &out) {
+    rec.first = (int64_t)out.sim.size();
     while (!c.done() && c.ok) {
         const uint64_t key = c.varint();
         const int field = (int)(key >> 3), wt = (int)(key & 7);
         if (field == 0) return LFR_ERR_PARSE;
-        if (field == 1 && wt == 2) { Cursor s = c.sub(); name1.assign((const char *)s.p, s.end - s.p); }
-        else if (field == 2 && wt == 5) fact1 = c.f32();
-        else if (field == 3 && wt == 2) { Cursor s = c.sub(); name2.assign((const char *)s.p, s.end - s.p); }
-        else if (field == 4 && wt == 5) fact2 = c.f32();
-        else if (field == 5 && wt == 2) matches.push_back(c.sub());
-        else c.skip(wt);
-    }
-    if (!c.ok) return LFR_ERR_PARSE;
-    if (banned.count(name1) || banned.count(name2)) return LFR_OK;       // solve.cc:444-446
-    const int32_t i1 = g.intern_image(name1, fact1);                     // solve.cc:448-451
-    const int32_t i2 = g.intern_image(name2, fact2);
-    for (Cursor &m : matches) {
-        if (!m.ok) return LFR_ERR_PARSE;
-        const int rc = parse_match(m, g, i1, i2);
-        if (rc != LFR_OK) return rc;
-    }
-    return LFR_OK;
-}
-
-static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, const std::set<std::string> &banned) {
-    Cursor c{data, data + size};
-    while (!c.done() && c.ok) {
-        const uint64_t key = c.varint();
-        const int field = (int)(key >> 3), wt = (int)(key & 7);
-        if (!c.ok || field == 0) return LFR_ERR_PARSE;
-        if (field == 1 && wt == 2) {
-            Cursor pc = c.sub();
+        if (field == 1 && wt == 2) { Cursor s = c.sub(); rec.name1 = (const char *)s.p; rec.len1 = (uint32_t)(s.end - s.p); }
+        else if (field == 2 && wt == 5) rec.fact1 = c.f32();
+        else if (field == 3 && wt == 2) { Cursor s = c.sub(); rec.name2 = (const char *)s.p; rec.len2 = (uint32_t)(s.end - s.p); }
+        else if (field == 4 && wt == 5) rec.fact2 = c.f32();
+        else if (field == 5 && wt == 2) {
+            Cursor m = c.sub();
             if (!c.ok) return LFR_ERR_PARSE;
-            const int rc = parse_pair(pc, g, banned);
+            const int rc = parse_match(m, out);
             if (rc != LFR_OK) return rc;
         } else c.skip(wt);
     }
-    return c.ok ? LFR_OK : LFR_ERR_PARSE;
+    if (!c.ok) return LFR_ERR_PARSE;
+    rec.count = (int64_t)out.sim.size() - rec.first;
+    return LFR_OK;
+}
+
+static int scan_threads() {
+    if (const char *e = getenv("LFR_HOST_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 256); }
+    const unsigned h = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(h ? h : 1u, 32u));
+}
+
+static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, const std::set<std::string> &banned) {
+    // pass A
+    std::vector<Cursor> pairs;
+    {
+        Cursor c{data, data + size};
+        while (!c.done() && c.ok) {
+            const uint64_t key = c.varint();
+            const int field = (int)(key >> 3), wt = (int)(key & 7);
+            if (!c.ok || field == 0) return LFR_ERR_PARSE;
+            if (field == 1 && wt == 2) {
+                Cursor pc = c.sub();
+                if (!c.ok) return LFR_ERR_PARSE;
+                pairs.push_back(pc);
+            } else c.skip(wt);
+        }
+        if (!c.ok) return LFR_ERR_PARSE;
+    }
+    const int64_t P = (int64_t)pairs.size();
+    if (P == 0) return LFR_OK;
+    // pass B
+    int T = (int)std::max<int64_t>(1, std::min<int64_t>(scan_threads(), (int64_t)(size >> 22) + 1));
+    std::vector<int64_t> cuts(T + 1, P);
+    cuts[0] = 0;
+    for (int t = 1; t < T; ++t) {           // balance by bytes: first pair starting at/after the byte target
+        const uint8_t *target = data + size / T * t;
+        int64_t lo = cuts[t - 1], hi = P;
+        while (lo < hi) { const int64_t mid = (lo + hi) / 2; if (pairs[mid].p < target) lo = mid + 1; else hi = mid; }
+        cuts[t] = lo;
+    }
+    std::vector<MatchBuf> bufs(T);
+    std::vector<PairRec> recs(P);
+    {
+        auto work = [&](int t) {
+            MatchBuf &b = bufs[t];
+            for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+                recs[i].buf = t;
+                const int rc = parse_pair(pairs[i], recs[i], b);
+                if (rc != LFR_OK) { b.rc = rc; return; }
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (auto &b : bufs) if (b.rc != LFR_OK) {
+        if (b.rc == LFR_ERR_UNSUPPORTED)
+            set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
+        return b.rc;
+    }
+    // pass C
+    struct Job { int32_t buf; int64_t src, dst, n; };
+    std::vector<Job> jobs;
+    int64_t M = g.n_matches();
+    for (int64_t i = 0; i < P; ++i) {
+        const PairRec &r = recs[i];
+        const std::string name1(r.name1 ? r.name1 : "", r.len1), name2(r.name2 ? r.name2 : "", r.len2);
+        if (banned.count(name1) || banned.count(name2)) continue;        // solve.cc:444-446
+        const int32_t i1 = g.intern_image(name1, r.fact1);                // solve.cc:448-451
+        const int32_t i2 = g.intern_image(name2, r.fact2);
+        const MatchBuf &b = bufs[r.buf];
+        for (int64_t m = r.first; m < r.first + r.count; ++m) {
+            const uint32_t a = g.find_or_create_node(i1, b.f1[m]);        // node1 before node2 (solve.cc:474-475)
+            const uint32_t c2 = g.find_or_create_node(i2, b.f2[m]);
+            g.m_node1.push_back(a); g.m_node2.push_back(c2);
+        }
+        if (r.count) {
+            if (!jobs.empty() && jobs.back().buf == r.buf && jobs.back().src + jobs.back().n == r.first) jobs.back().n += r.count;
+            else jobs.push_back(Job{r.buf, r.first, M, r.count});
+            M += r.count;
+        }
+    }
+    // pass D
+    g.m_sim.resize(M); g.m_disp1.resize(18 * M); g.m_disp2.resize(18 * M);
+    {
+        const int TJ = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, jobs.size()));
+        auto work = [&](int t) {
+            for (size_t j = t; j < jobs.size(); j += TJ) {
+                const Job &jb = jobs[j];
+                const MatchBuf &b = bufs[jb.buf];
+                memcpy(&g.m_sim[jb.dst], &b.sim[jb.src], sizeof(float) * jb.n);
+                memcpy(&g.m_disp1[18 * jb.dst], &b.d1[18 * jb.src], sizeof(float) * 18 * jb.n);
+                memcpy(&g.m_disp2[18 * jb.dst], &b.d2[18 * jb.src], sizeof(float) * 18 * jb.n);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < TJ; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    return LFR_OK;
 }
 
 static int parse_matching_path(const char *path, Graph &g, const std::set<std::string> &banned) {
