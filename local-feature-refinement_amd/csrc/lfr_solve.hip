@@ -849,6 +849,8 @@ struct lfr_batch {
 
 extern "C" {
 
+namespace { __global__ void lfr_warmup_kernel(int *p) { if (p) *p = 0; } }
+
 int lfr_hip_warmup(int device) {
     // Creating the HIP context costs a few hundred ms; a host program can call this from a side
     // thread while it parses its input (the `solve` launcher does).
@@ -857,6 +859,9 @@ int lfr_hip_warmup(int device) {
     if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
+    hipLaunchKernelGGL(lfr_warmup_kernel, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);   // loads the code object
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return LFR_OK;
 }
 
@@ -874,7 +879,7 @@ void lfr_batch_free(lfr_batch *b) {
     if (b->d_prof) (void)hipFree(b->d_prof);
     if (b->d_node_inc) (void)hipFree(b->d_node_inc);
     if (b->d_in_idx) (void)hipFree(b->d_in_idx);
-    if (b->events) for (auto &e : b->ev_ring) (void)hipEventDestroy(e);
+    if (b->events) for (auto &e : b->ev_ring) if (e) (void)hipEventDestroy(e);
     if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
     if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
     if (b->side_stream2) (void)hipStreamDestroy(b->side_stream2);
@@ -982,7 +987,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     b->h2d_ms = ms;
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (auto &e : b->ev_ring) HIP_TRY(hipEventCreate(&e));
+    for (auto &e : b->ev_ring) e = nullptr;      // created lazily, one slot per solve
     b->events = true;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
@@ -1013,6 +1018,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
     ++b->n_solves;
+    if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
     HIP_TRY(hipEventRecord(b->ev[0], st));
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
