@@ -81,7 +81,7 @@ enum KernelClass : int {
     KC_GLOBAL,      // workgroup per component, normal matrix in HBM workspace
     KC_COUNT
 };
-constexpr int kBlockMaxRows = 176;   // packed lower triangle 176*177/2*8 B = 124.6 KB of LDS
+constexpr int kBlockMaxRows = 192;   // packed lower triangle 192*193/2*8 B = 148.2 KB + 15.4 KB of vectors <= 160 KiB of LDS
 
 struct Problem {
     const Graph *g = nullptr;

@@ -445,7 +445,11 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_packed_kernel(Kern
 // =============================================================================================
 // workgroup-per-component kernel (packed lower-triangular normal matrix in LDS or HBM)
 // =============================================================================================
-constexpr int kBlockThreads = 256;
+#ifndef LFR_BLOCK_THREADS
+#define LFR_BLOCK_THREADS 512
+#endif
+constexpr int kBlockThreads = LFR_BLOCK_THREADS;   // one workgroup per component
+constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
 
 __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // j <= i
 
@@ -628,9 +632,9 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         }
         reuse_diagonal = true;
         __syncthreads();
-        // 16 x 16 thread tiling over (row, column): no index inversion, balanced trailing updates
+        // (kTileRows x 16) thread tiling over (row, column): no index inversion, balanced trailing updates
         const int ti = tid >> 4, tj = tid & 15;
-        for (int i = ti; i < n; i += 16) {
+        for (int i = ti; i < n; i += kTileRows) {
             const double si = vscale[i];
             for (int j = tj; j <= i; j += 16) {
                 double v = Mat[tri(i, j)] * si * vscale[j];
@@ -649,7 +653,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             if (!(dk > 0.0)) { if (tid == 0) sh.flag = 1; break; }       // uniform: every thread reads the same dk
             const double inv = 1.0 / dk;
             // trailing update with the UNSCALED column k: A[i][j] -= a_ik * a_jk / d_k, k < j <= i
-            for (int i = k + 1 + ti; i < n; i += 16) {
+            for (int i = k + 1 + ti; i < n; i += kTileRows) {
                 const double aik = Mat[tri(i, k)] * inv;
                 for (int j = k + 1 + tj; j <= i; j += 16) Mat[tri(i, j)] -= aik * Mat[tri(j, k)];
             }

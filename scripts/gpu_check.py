@@ -30,3 +30,4 @@ if "mid" in which: run("mid", synthetic.generate(seed=12, n_images=200, n_tracks
 if "long" in which: run("long", synthetic.generate(seed=3, n_images=96, n_tracks=200, len_dist="uniform", len_lo=20, len_hi=60, eps_out=0.0005))
 if "c2" in which: run("config2", synthetic.config2())
 if "c4" in which: run("config4", synthetic.config4())
+if "c5" in which: run("config5", synthetic.config5(), threads=64)
