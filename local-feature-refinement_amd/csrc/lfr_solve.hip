@@ -721,8 +721,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
                 __syncthreads();
                 PROF_MARK(4);
-                cost_c = sweep(vxc, vgn, false);
-                PROF_MARK(2);                         // 2: line-search sweeps (cost + gradient)
+                cost_c = sweep(vxc, vgn, true);       // also assembles J^T J at the trial point into Mat
+                PROF_MARK(2);                         // 2: line-search sweeps
                 ++exec_passes; ++n_ls_evals;
                 current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
                 current.gradient = 0.0; current.gradient_valid = false;
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         if (!ls_ok) {
             for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
             __syncthreads();
-            cost_c = sweep(vxc, vgn, false);
+            cost_c = sweep(vxc, vgn, true);
             ++exec_passes;
         }
         ++n_cand;
@@ -759,10 +759,11 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             __syncthreads();
             for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; }
             x_norm = sqrt(block_sum(xn, sh));
-            PROF_MARK(4);
-            cost = sweep(vx, vg, true);               // J^T J at the new point
-            PROF_MARK(0);
-            ++exec_passes;
+            // the accepted candidate is the last evaluated point: its cost, gradient and J^T J (in Mat,
+            // the factorization was no longer needed) are already there - no extra sweep
+            for (int i = tid; i < n; i += kBlockThreads) vg[i] = vgn[i];
+            __syncthreads();
+            cost = cost_cand;
             matrix_valid = true;
             gmax = grad_max(vx, vg);
             step_successful = true;
