@@ -139,3 +139,22 @@ def test_huge_component_hbm_matrix(lfr_lib):
     assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
     info = b.component_info()
     assert info["n_var_nodes"][0] == 1099 and info["termination"][0] == ref["infos"]["termination"][info["component"][0]]
+
+
+def test_every_kernel_class_is_exercised(lfr_lib):
+    """One graph with track lengths 2..17 plus long tracks: all five packed classes and both
+    workgroup kernels run, and each agrees with the oracle."""
+    parts = [synthetic.generate(seed=95, n_images=400, n_tracks=3000),                                   # packed classes
+             synthetic.generate(seed=96, n_images=400, n_tracks=40, len_dist="uniform", len_lo=18, len_hi=90),   # LDS matrix
+             synthetic.generate(seed=97, n_images=400, n_tracks=3, len_dist="uniform", len_lo=100, len_hi=130)]  # HBM matrix
+    seen = set()
+    for ma in parts:
+        g, p, b, st, pos, ref = solve_both(ma)
+        assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
+        info = b.component_info()
+        rows, edges = 2 * info["n_var_nodes"], info["n_edges"]
+        for r, e in zip(rows, edges):
+            cls = ("G8" if r <= 8 and e <= 24 else "G16" if r <= 16 and e <= 48 else "G32" if r <= 16 and e <= 96 else
+                   "G64_2" if r <= 32 and e <= 128 else "G64_4" if r <= 32 and e <= 256 else "BLOCK" if r <= 192 else "GLOBAL")
+            seen.add(cls)
+    assert seen == {"G8", "G16", "G32", "G64_2", "G64_4", "BLOCK", "GLOBAL"}, seen
