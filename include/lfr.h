@@ -177,6 +177,14 @@ int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *p
 /* Writes types.proto:30-46; returns through n_outside the count printed at solve.cc:666-670. */
 int lfr_write_solution(const lfr_graph *g, const double *positions, const char *path, int64_t *n_outside);
 
+/* The consumer's arithmetic as a library call (colmap_utils.py:126-137) — lets a caller skip the
+ * SolutionFile round trip: for every node of `image_name`, keypoints[feature_idx][0] += dj*fact*16,
+ * keypoints[feature_idx][1] += di*fact*16 (float32, same operation order), then +0.5 on both
+ * coordinates of all `num_features` rows.  An image the graph does not know only gets the +0.5
+ * (colmap_utils.py:127-128).  keypoints: num_features rows of `stride` floats (x, y, ...). */
+int lfr_apply_displacements(const lfr_graph *g, const double *positions, const char *image_name, float *keypoints,
+                            int64_t num_features, int64_t stride);
+
 #ifdef __cplusplus
 }
 #endif

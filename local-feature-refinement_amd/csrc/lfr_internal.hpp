@@ -33,6 +33,10 @@ struct Graph {
     uint64_t hmask = 0;
     int64_t hcount = 0;
 
+    // nodes grouped by image (built on first use by lfr_apply_displacements)
+    mutable std::vector<int64_t> img_off;
+    mutable std::vector<uint32_t> img_nodes;
+
     int64_t n_nodes() const { return (int64_t)node_image.size(); }
     int64_t n_matches() const { return (int64_t)m_sim.size(); }
     int32_t intern_image(const std::string &name, float fact);

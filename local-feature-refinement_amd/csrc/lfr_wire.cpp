@@ -471,6 +471,44 @@ int lfr_write_matching_file(const char *path, int32_t n_images, const char *cons
     return LFR_OK;
 }
 
+int lfr_apply_displacements(const lfr_graph *gh, const double *positions, const char *image_name, float *keypoints,
+                            int64_t num_features, int64_t stride) {
+    if (!gh || !image_name || (!keypoints && num_features > 0) || num_features < 0 || stride < 2 || (!positions && gh->g.n_nodes() > 0)) {
+        set_error("bad argument"); return LFR_ERR_ARG;
+    }
+    const Graph &g = gh->g;
+    if (g.img_off.empty()) {        // nodes grouped by image, in node order (not thread safe on first call)
+        const size_t ni = g.image_names.size();
+        g.img_off.assign(ni + 1, 0);
+        for (int32_t im : g.node_image) ++g.img_off[im + 1];
+        for (size_t i = 0; i < ni; ++i) g.img_off[i + 1] += g.img_off[i];
+        g.img_nodes.resize(g.node_image.size());
+        std::vector<int64_t> cur(g.img_off.begin(), g.img_off.end() - 1);
+        for (size_t n = 0; n < g.node_image.size(); ++n) g.img_nodes[cur[g.node_image[n]]++] = (uint32_t)n;
+    }
+    const auto it = g.image_index.find(image_name);
+    if (it != g.image_index.end()) {
+        const int32_t im = it->second;
+        const float fact = g.image_fact[im];
+        for (int64_t k = g.img_off[im]; k < g.img_off[im + 1]; ++k) {
+            const uint32_t n = g.img_nodes[k];
+            const uint32_t f = g.node_feat[n];
+            if ((int64_t)f >= num_features) { set_error("feature_idx %u out of range (%lld keypoints)", f, (long long)num_features); return LFR_ERR_ARG; }
+            // float32 arithmetic of colmap_utils.py:129-136: displacements[f] = [dj, di]; *= fact; keypoints += displacements * 16
+            const float dj = (float)positions[2 * n + 1], di = (float)positions[2 * n];
+            float *kp = keypoints + (size_t)f * stride;
+            volatile float tx = dj * fact, ty = di * fact;      // volatile: keep every product rounded to float32
+            volatile float ux = tx * 16.0f, uy = ty * 16.0f;
+            kp[0] = kp[0] + ux; kp[1] = kp[1] + uy;
+        }
+    }
+    for (int64_t f = 0; f < num_features; ++f) {                 // colmap_utils.py:137
+        float *kp = keypoints + (size_t)f * stride;
+        kp[0] = kp[0] + 0.5f; kp[1] = kp[1] + 0.5f;
+    }
+    return LFR_OK;
+}
+
 int lfr_write_solution(const lfr_graph *gh, const double *positions, const char *path, int64_t *n_outside) {
     if (!gh || !path || (!positions && gh->g.n_nodes() > 0)) { set_error("bad argument"); return LFR_ERR_ARG; }
     const Graph &g = gh->g;

@@ -89,6 +89,7 @@ def lib():
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
+        "lfr_apply_displacements": (C.c_int, [vp, vp, C.c_char_p, vp, i64, i64]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)       # AttributeError here = the .so does not export the ABI
@@ -103,7 +104,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -192,6 +193,14 @@ class Graph:
 
     def image_facts(self):
         return [lib().lfr_graph_image_fact(self._h, i) for i in range(self.n_images)]
+
+    def apply_displacements(self, positions, image_name, keypoints):
+        """In-place consumer arithmetic of colmap_utils.py:126-137 on a float32 [num_features, >=2] array."""
+        assert keypoints.dtype == np.float32 and keypoints.ndim == 2 and keypoints.flags.c_contiguous
+        pos = np.ascontiguousarray(positions, np.float64)
+        _check(lib().lfr_apply_displacements(self._h, _ptr(pos), image_name.encode("utf-8"), _ptr(keypoints),
+                                             keypoints.shape[0], keypoints.shape[1]))
+        return keypoints
 
     def write_solution(self, positions, path):
         """SolutionFile emit (solve.cc:644-679); returns the '> 0.5' count of solve.cc:666-670."""

@@ -158,3 +158,25 @@ def test_every_kernel_class_is_exercised(lfr_lib):
                    "G64_2" if r <= 32 and e <= 128 else "G64_4" if r <= 32 and e <= 256 else "BLOCK" if r <= 192 else "GLOBAL")
             seen.add(cls)
     assert seen == {"G8", "G16", "G32", "G64_2", "G64_4", "BLOCK", "GLOBAL"}, seen
+
+
+def test_fuzz_small_irregular_graphs(lfr_lib):
+    """Hand-style irregular inputs (duplicate matches, similarity ties, image conflicts, singleton
+    tracks inside multi-track components, zero flows): HIP vs the C oracle on 150 tiny graphs."""
+    from test_graph_stage import fuzz_pairs
+    checked = 0
+    for seed in range(1000, 1150):
+        pairs = fuzz_pairs(seed)
+        ma = synthetic.pairs_to_arrays(pairs)
+        if ma.n_matches == 0:
+            continue
+        g = capi.Graph.from_arrays(ma)
+        p = capi.Problem(g)
+        pos, st = p.solve_hip(0)
+        ref = O.run(ma, n_threads=1)
+        if ref["rc"] != 0:
+            ref = O.run(ma, n_threads=1, comp_override=p.labels()[2])
+        assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS, seed
+        assert st["n_failed"] == int((ref["infos"]["termination"][ref["comp_nvar"] > 0] == 2).sum())
+        checked += 1
+    assert checked >= 120

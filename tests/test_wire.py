@@ -149,3 +149,30 @@ def test_solution_emit(lfr_lib, pb, tmp_path):
     msg = SolutionFile()
     msg.ParseFromString(data)
     assert [im.image_name for im in msg.images] == [e["image_name"] for e in expect]
+
+
+def test_apply_displacements_matches_the_consumer_arithmetic(lfr_lib):
+    """colmap_utils.py:126-137 restated with numpy float32 ops vs lfr_apply_displacements."""
+    ma = synthetic.generate(seed=26, n_images=10, n_tracks=60, fact=1.0)
+    ma.facts[:] = np.float32([1.0, 0.5, 2.0, 1.0, 0.25, 1.0, 1.5, 1.0, 1.0, 3.0])
+    g = capi.Graph.from_arrays(ma)
+    rng = np.random.default_rng(3)
+    pos = rng.uniform(-1, 1, size=(g.n_nodes, 2))
+    img, feat = g.nodes()
+    names = g.image_names()
+    facts = g.image_facts()
+    for im, name in enumerate(names + ["unknown.png"]):
+        nf = 80
+        kp = rng.uniform(0, 1000, size=(nf, 4)).astype(np.float32)
+        want = kp.copy()
+        disp = np.zeros([nf, 2]).astype(np.float32)
+        if im < len(names):
+            for n in np.nonzero(img == im)[0]:
+                disp[feat[n], :] = [np.float32(pos[n, 1]), np.float32(pos[n, 0])]      # [dj, di]
+            disp *= facts[im]
+        want[:, :2] += disp * 16
+        want[:, :2] += 0.5
+        got = g.apply_displacements(pos, name, kp)
+        assert (got == want).all()
+    with pytest.raises(capi.LfrError):
+        g.apply_displacements(pos, names[0], np.zeros((1, 2), np.float32))       # feature_idx out of range
