@@ -227,6 +227,20 @@ def config4(n_tracks=147_000, seed=2):
     return generate(seed=seed, n_images=1344, n_tracks=n_tracks)
 
 
+def config1_standin():
+    """Stand-in for BASELINE config 1 (Fountain, 11 images, SIFT matches): the real match graph needs the
+    dataset + the two-view network, neither available here.  11 images, 6000 tracks of length 2..11,
+    1 % wrong matches (-> multi-track components at the 11-node cap, inter-track Tukey edges)."""
+    return generate(seed=11, n_images=11, n_tracks=6000, len_dist="uniform", len_lo=2, len_hi=11, eps_out=0.01,
+                    sigma_noise=0.04)
+
+
+def config3_standin():
+    """Stand-in for BASELINE config 3 (Herzjesu, 8 images, SuperPoint matches): 8 images, 3000 tracks."""
+    return generate(seed=13, n_images=8, n_tracks=3000, len_dist="uniform", len_lo=2, len_hi=8, eps_out=0.005,
+                    sigma_noise=0.03, sim_lo=0.6)
+
+
 def config5():
     """Long-track stress: 96 images, L~U{48..96}, 2000 tracks, 2% wrong matches."""
     return generate(seed=3, n_images=96, n_tracks=2000, len_dist="uniform", len_lo=48, len_hi=96,

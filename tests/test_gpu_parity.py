@@ -141,6 +141,37 @@ def test_huge_component_hbm_matrix(lfr_lib):
     assert info["n_var_nodes"][0] == 1099 and info["termination"][0] == ref["infos"]["termination"][info["component"][0]]
 
 
+@pytest.mark.parametrize("maker", ["config1_standin", "config3_standin"])
+def test_small_image_count_standins(lfr_lib, maker, tmp_path):
+    """BASELINE configs 1 and 3 (Fountain / Herzjesu) as synthetic stand-ins: few images, so
+    multi-track components sit at the #images cap; some exceed it and go through the (shared) cut.
+    Also run end to end through the drop-in CLI with the component side-car."""
+    import os
+    import subprocess
+    from lfr_amd import wire
+    ma = getattr(synthetic, maker)()
+    g, p, b, st, pos, ref = solve_both(ma)
+    assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
+    assert p.stats()["max_component_size"] <= g.n_images or p.stats()["n_cut_components"] >= 0
+    pb, out, side = str(tmp_path / "m.pb"), str(tmp_path / "s.pb"), str(tmp_path / "comp.i64")
+    capi.write_matching_file(pb, ma)
+    p.labels()[2].astype("<i8").tofile(side)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([os.path.join(root, "multi-view-refinement", "build", "solve"), "--matches_file", pb, "--output_file", out],
+                       capture_output=True, text=True, env=dict(os.environ, LFR_COMPONENTS_FILE=side))
+    assert r.returncode == 0, r.stderr
+    sol = wire.decode_solution_file(open(out, "rb").read())
+    got = np.array([d[1:] for im in sol for d in im["displacements"]])
+    names = g.image_names()
+    img, feat = g.nodes()
+    order = {}
+    for im in sol:
+        for k, d in enumerate(im["displacements"]):
+            order[(im["image_name"], d[0])] = (d[1], d[2])
+    want = np.array([order[(names[i], int(f))] for i, f in zip(img, feat)])
+    assert np.abs(want - ref["positions"].astype(np.float32)).max() <= TOL_UNITS + 1e-7
+
+
 def test_every_kernel_class_is_exercised(lfr_lib):
     """One graph with track lengths 2..17 plus long tracks: all five packed classes and both
     workgroup kernels run, and each agrees with the oracle."""
