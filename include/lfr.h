@@ -110,6 +110,12 @@ typedef struct lfr_problem_stats {
  * exceeded the cap (Graclus' cut is not reproducible). */
 int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
                       lfr_problem **out);
+/* Same graph stage (tracks, roots, components) without the host-side batch assembly: the 80-byte
+ * edge records, descriptors and incidence lists are then built on the GPU by lfr_batch_create
+ * (whole problems only, shard_world = 1): the flows cross PCIe once in match order and no host-side
+ * record array is ever materialised.  Results are bit-identical to the host-assembled batch. */
+int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                             lfr_problem **out);
 void lfr_problem_free(lfr_problem *p);
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */

@@ -1,0 +1,31 @@
+// Device-side batch assembly (lfr_assemble.hip): builds the HBM batch layout of a whole problem on
+// the GPU from the match graph + the host graph stage's labels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lfr_internal.hpp"
+
+namespace lfr {
+
+struct DeviceAssembly {
+    // device arrays (handed over to the batch)
+    CompDesc *d_descs = nullptr;
+    EdgeRec *d_edges = nullptr;
+    uint32_t *d_node_ids = nullptr;
+    NodeInc *d_node_inc = nullptr;
+    uint32_t *d_in_idx = nullptr;
+    // host mirrors
+    std::vector<CompDesc> descs;
+    std::vector<int64_t> desc_component;
+    std::vector<int32_t> desc_class, desc_tracks;
+    std::vector<uint32_t> node_ids;
+    int64_t n_edges = 0, n_nodes = 0;
+    void release();
+};
+
+// dev_disp1/dev_disp2: optional device pointers to the flows in match order (n_matches x 18 floats
+// each, disp1 = flow 2->1, disp2 = flow 1->2); when null the graph's host arrays are uploaded.
+int assemble_on_device(const Graph &g, const Problem &labels, hipStream_t stream, const float *dev_disp1,
+                       const float *dev_disp2, DeviceAssembly &out);
+
+}  // namespace lfr

@@ -175,7 +175,7 @@ static int classify(int rows, int64_t n_edges) {
     return KC_GLOBAL;
 }
 
-int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p) {
+int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p, bool host_batch) {
     using clock = std::chrono::steady_clock;
     p.g = &g;
     const int64_t N = g.n_nodes(), M = g.n_matches();
@@ -330,6 +330,13 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     }
     p.stats.n_components = n_components;
     p.stats.graph_cut_ms = ms_since(t0);
+    p.host_batch = host_batch;
+    if (!host_batch) {                    // labels only: lfr_batch_create assembles the batch on the GPU
+        std::vector<int64_t> csz(n_components, 0);
+        for (int64_t i = 0; i < N; ++i) ++csz[p.comp[i]];
+        p.stats.max_component_size = *std::max_element(csz.begin(), csz.end());
+        return LFR_OK;
+    }
 
     // ------------------------------------------------------------------ assembly (solve.cc:594-606, 94-143)
     t0 = clock::now();
@@ -500,14 +507,24 @@ using namespace lfr;
 
 extern "C" {
 
-int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
-                      lfr_problem **out) {
+static int problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                         bool host_batch, lfr_problem **out) {
     if (!g || !out) { set_error("bad argument"); return LFR_ERR_ARG; }
     lfr_problem *h = new lfr_problem();
-    const int rc = build_problem(g->g, max_nodes_in_component, component_override, h->p);
+    const int rc = build_problem(g->g, max_nodes_in_component, component_override, h->p, host_batch);
     if (rc != LFR_OK) { delete h; *out = nullptr; return rc; }
     *out = h;
     return LFR_OK;
+}
+
+int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                      lfr_problem **out) {
+    return problem_build(g, max_nodes_in_component, component_override, true, out);
+}
+
+int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
+                             lfr_problem **out) {
+    return problem_build(g, max_nodes_in_component, component_override, false, out);
 }
 
 void lfr_problem_free(lfr_problem *p) { delete p; }

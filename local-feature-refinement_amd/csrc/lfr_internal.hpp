@@ -92,6 +92,7 @@ struct Problem {
     std::vector<int64_t> track, comp;      // per node
     std::vector<uint8_t> is_root;
     lfr_problem_stats stats{};
+    bool host_batch = true;                // false: labels only, the batch is assembled on the device
     // batch (all solvable components, sorted by kernel class then size descending)
     std::vector<CompDesc> descs;
     std::vector<int64_t> desc_component;   // original component id per desc
@@ -107,7 +108,7 @@ struct Problem {
 // loaded shard; mirrors the largest-first task order of solve.cc:599-634).  Returns shard per desc.
 std::vector<int32_t> assign_shards(const Problem &p, int world);
 
-int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p);
+int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p, bool host_batch = true);
 
 // deterministic substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
 // (solve.cc:192): returns part (0/1) per node id appearing in `edges`.

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <vector>
 
+#include "lfr_assemble.hpp"
 #include "lfr_device.hpp"
 #include "lfr_internal.hpp"
 
@@ -847,7 +848,7 @@ struct lfr_batch {
     hipEvent_t ev_fork = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // workgroup-per-component kernels run beside the packed launch
     int packed_slot = 0;                               // class slot that carries the packed launch's events
-    double h2d_ms = 0.0;
+    double h2d_ms = 0.0;             // upload (+ device assembly when the batch is built on the GPU)
     std::vector<CompInfoDev> infos;      // last downloaded
     bool infos_valid = false;
 };
@@ -907,9 +908,31 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     { const char *e = getenv("LFR_SERIAL_CLASSES"); b->serial = e && e[0] == '1'; }
     b->n_graph_nodes = (int64_t)p.track.size();
 
+    // Labels-only problem: the batch layout is assembled on the GPU (lfr_assemble.hip) - the flows
+    // cross PCIe once in match order, no host-side record array exists.
+    lfr::DeviceAssembly dev;
+    const bool on_device = !p.host_batch;
+    if (on_device) {
+        if (shard_world != 1) { delete b; lfr::set_error("device-side assembly builds whole problems only (shard_world must be 1)"); return LFR_ERR_ARG; }
+        hipEvent_t a0, a1;
+        HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
+        HIP_TRY(hipEventRecord(a0, nullptr));
+        const int rc = lfr::assemble_on_device(*p.g, p, nullptr, nullptr, nullptr, dev);
+        if (rc != LFR_OK) { dev.release(); delete b; return rc; }
+        HIP_TRY(hipEventRecord(a1, nullptr));
+        HIP_TRY(hipEventSynchronize(a1));
+        float ams = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ams, a0, a1));
+        b->h2d_ms = ams;
+        (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
+    }
+    const std::vector<CompDesc> &src_descs = on_device ? dev.descs : p.descs;
+    const std::vector<int32_t> &src_class = on_device ? dev.desc_class : p.desc_class;
+    const std::vector<int32_t> &src_tracks = on_device ? dev.desc_tracks : p.desc_tracks;
     // LPT sharding (lfr::assign_shards); the shard keeps the class/size order of the batch
     std::vector<size_t> mine;
-    {
+    if (on_device) { mine.resize(src_descs.size()); for (size_t i = 0; i < mine.size(); ++i) mine[i] = i; }
+    else {
         const std::vector<int32_t> shard = lfr::assign_shards(p, shard_world);
         for (size_t i = 0; i < p.descs.size(); ++i) if (shard[i] == shard_rank) mine.push_back(i);
     }
@@ -918,14 +941,18 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     std::vector<EdgeRec> edges_copy;
     std::vector<uint32_t> in_idx_copy;
     uint64_t ws = 0;
-    if (whole) {
+    if (on_device) {
+        b->node_ids = dev.node_ids;
+        b->descs = dev.descs; b->desc_component = dev.desc_component; b->desc_class = dev.desc_class; b->desc_tracks = dev.desc_tracks;
+        b->es_off.resize(dev.descs.size()); b->ws_off.assign(dev.descs.size(), 0);
+    } else if (whole) {
         b->node_ids = p.node_ids; b->node_inc = p.node_inc;
         b->descs = p.descs; b->desc_component = p.desc_component; b->desc_class = p.desc_class; b->desc_tracks = p.desc_tracks;
         b->es_off.resize(p.descs.size()); b->ws_off.assign(p.descs.size(), 0);
     }
     for (size_t k = 0; k < mine.size(); ++k) {
         const size_t i = mine[k];
-        CompDesc d = p.descs[i];
+        CompDesc d = src_descs[i];
         if (!whole) {
             const uint32_t eo = (uint32_t)edges_copy.size(), no = (uint32_t)b->node_ids.size();
             edges_copy.insert(edges_copy.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
@@ -937,12 +964,12 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
             b->desc_class.push_back(p.desc_class[i]); b->desc_tracks.push_back(p.desc_tracks[i]);
             b->es_off.push_back(0); b->ws_off.push_back(0);
         }
-        const int cls = p.desc_class[i], rows = 2 * d.n_var;
+        const int cls = src_class[i], rows = 2 * d.n_var;
         b->es_off[k] = ws;
         if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
         if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
         if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
-        b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
+        b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += src_tracks[i];
     }
     const std::vector<EdgeRec> &edges = whole ? p.edges : edges_copy;
     const std::vector<uint32_t> &in_idx = whole ? p.in_idx : in_idx_copy;
@@ -965,32 +992,40 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, nullptr));
     const size_t nd = std::max<size_t>(b->descs.size(), 1), ne = std::max<size_t>(edges.size(), 1), nn = std::max<size_t>(b->node_ids.size(), 1);
-    HIP_TRY(hipMalloc(&b->d_descs, nd * sizeof(CompDesc)));
-    HIP_TRY(hipMalloc(&b->d_edges, ne * sizeof(EdgeRec)));
-    HIP_TRY(hipMalloc(&b->d_node_ids, nn * sizeof(uint32_t)));
+    if (on_device) {         // the assembly already produced the big arrays in HBM: adopt them
+        b->d_descs = dev.d_descs; b->d_edges = dev.d_edges; b->d_node_ids = dev.d_node_ids;
+        b->d_node_inc = dev.d_node_inc; b->d_in_idx = dev.d_in_idx;
+        dev.d_descs = nullptr; dev.d_edges = nullptr; dev.d_node_ids = nullptr; dev.d_node_inc = nullptr; dev.d_in_idx = nullptr;
+    } else {
+        HIP_TRY(hipMalloc(&b->d_descs, nd * sizeof(CompDesc)));
+        HIP_TRY(hipMalloc(&b->d_edges, ne * sizeof(EdgeRec)));
+        HIP_TRY(hipMalloc(&b->d_node_ids, nn * sizeof(uint32_t)));
+        HIP_TRY(hipMalloc(&b->d_node_inc, nn * sizeof(lfr::NodeInc)));
+        HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
+    }
     HIP_TRY(hipMalloc(&b->d_positions, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
     HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_es_off, nd * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_prof, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
-    HIP_TRY(hipMalloc(&b->d_node_inc, nn * sizeof(lfr::NodeInc)));
-    HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
     if (ws) HIP_TRY(hipMalloc(&b->d_workspace, ws * sizeof(double)));
     if (!b->descs.empty()) {
-        HIP_TRY(hipMemcpy(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_ws_off, b->ws_off.data(), b->ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(b->d_es_off, b->es_off.data(), b->es_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_node_inc, b->node_inc.data(), b->node_inc.size() * sizeof(lfr::NodeInc), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_in_idx, in_idx.data(), in_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!on_device) {
+            HIP_TRY(hipMemcpy(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->d_node_inc, b->node_inc.data(), b->node_inc.size() * sizeof(lfr::NodeInc), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(b->d_in_idx, in_idx.data(), in_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    b->h2d_ms = ms;
+    b->h2d_ms += ms;             // (device assembly: its upload + kernels were timed above)
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     for (auto &e : b->ev_ring) e = nullptr;      // created lazily, one slot per solve
     b->events = true;

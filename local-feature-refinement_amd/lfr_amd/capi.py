@@ -76,6 +76,7 @@ def lib():
         "lfr_graph_image_fact": (C.c_float, [vp, i32]),
         "lfr_write_matching_file": (C.c_int, [C.c_char_p, i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfr_problem_build": (C.c_int, [vp, i64, vp, pp]),
+        "lfr_problem_build_labels": (C.c_int, [vp, i64, vp, pp]),
         "lfr_problem_free": (None, [vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
@@ -102,7 +103,7 @@ def lib():
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
-           "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_free", "lfr_problem_get_stats",
+           "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
            "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution", "lfr_apply_displacements"]
 
@@ -233,11 +234,13 @@ def write_matching_file(path, ma):
 class Problem:
     """Tracks, roots, components and the device batch layout (solve.cc:487-606, 79-143)."""
 
-    def __init__(self, graph, max_nodes_in_component=0, component_override=None):
+    def __init__(self, graph, max_nodes_in_component=0, component_override=None, device_assembly=False):
+        """device_assembly=True: graph stage only; the batch is assembled on the GPU by Batch / solve_hip."""
         self.graph = graph
         h = C.c_void_p()
         co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
-        _check(lib().lfr_problem_build(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
+        fn = lib().lfr_problem_build_labels if device_assembly else lib().lfr_problem_build
+        _check(fn(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
         self._h = h
 
     def close(self):

@@ -211,3 +211,22 @@ def test_fuzz_small_irregular_graphs(lfr_lib):
         assert st["n_failed"] == int((ref["infos"]["termination"][ref["comp_nvar"] > 0] == 2).sum())
         checked += 1
     assert checked >= 120
+
+
+@pytest.mark.parametrize("name", ["tracks_only", "outliers_tukey", "long_tracks_block", "config5_like_cut", "very_long_tracks_global"])
+def test_device_assembly_equals_host_assembly(lfr_lib, name):
+    """lfr_problem_build_labels + GPU-side batch assembly (lfr_assemble.hip) must produce the same
+    batch as the host assembly: same component order, sizes, and bit-identical solutions."""
+    ma = synthetic.generate(**CASES[name])
+    g = capi.Graph.from_arrays(ma)
+    ph = capi.Problem(g)
+    pd = capi.Problem(g, device_assembly=True)
+    assert (ph.labels()[2] == pd.labels()[2]).all()
+    bh, bd = capi.Batch(ph, 0), capi.Batch(pd, 0)
+    sh, sd = bh.solve(), bd.solve()
+    ih, idv = bh.component_info(), bd.component_info()
+    for k in ("component", "n_var_nodes", "n_edges", "iterations", "termination"):
+        assert (ih[k] == idv[k]).all(), k
+    for k in ("n_components", "n_edges", "n_nodes", "n_tracks", "ref_jacobian_passes_edges", "exec_passes_edges"):
+        assert sh[k] == sd[k], k
+    assert (bh.download() == bd.download()).all()
