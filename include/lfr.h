@@ -116,6 +116,13 @@ int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const 
  * record array is ever materialised.  Results are bit-identical to the host-assembled batch. */
 int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
                              lfr_problem **out);
+/* As lfr_problem_build_labels, with the graph stage itself on HIP device `device`: radix sort of the
+ * matches, connected components, one GPU thread per connected component for the order-dependent
+ * constrained union-find (solve.cc:499-523), roots, components.  Bit-identical labels.  Falls back
+ * to the host stage when a component exceeds the size cap (graph cut), when a connected component
+ * is too large to be processed by one thread, or when component_override is given. */
+int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component,
+                          const int64_t *component_override, lfr_problem **out);
 void lfr_problem_free(lfr_problem *p);
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */

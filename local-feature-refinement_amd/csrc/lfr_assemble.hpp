@@ -28,4 +28,11 @@ struct DeviceAssembly {
 int assemble_on_device(const Graph &g, const Problem &labels, hipStream_t stream, const float *dev_disp1,
                        const float *dev_disp2, DeviceAssembly &out);
 
+// Tracks, roots and components on the GPU (lfr_graphstage.hip): fills p.track / p.comp / p.is_root and
+// the stage statistics exactly as the host stage does.  Returns LFR_GRAPHSTAGE_USE_HOST when the
+// input needs something only the host stage has (graph cut above the size cap, a huge connected
+// component): the caller then runs build_problem().
+constexpr int LFR_GRAPHSTAGE_USE_HOST = 1;
+int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem &p);
+
 }  // namespace lfr

@@ -855,6 +855,19 @@ struct lfr_batch {
 
 extern "C" {
 
+int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component, const int64_t *component_override,
+                          lfr_problem **out) {
+    if (!g || !out) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (!component_override) {
+        lfr_problem *h = new lfr_problem();
+        const int rc = lfr::graph_stage_on_device(g->g, max_nodes_in_component, device, h->p);
+        if (rc == LFR_OK) { *out = h; return LFR_OK; }
+        delete h;
+        if (rc != lfr::LFR_GRAPHSTAGE_USE_HOST) { *out = nullptr; return rc; }
+    }
+    return lfr_problem_build_labels(g, max_nodes_in_component, component_override, out);   // host graph stage
+}
+
 namespace { __global__ void lfr_warmup_kernel(int *p) { if (p) *p = 0; } }
 
 int lfr_hip_warmup(int device) {

@@ -77,6 +77,7 @@ def lib():
         "lfr_write_matching_file": (C.c_int, [C.c_char_p, i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfr_problem_build": (C.c_int, [vp, i64, vp, pp]),
         "lfr_problem_build_labels": (C.c_int, [vp, i64, vp, pp]),
+        "lfr_problem_build_hip": (C.c_int, [vp, C.c_int, i64, vp, pp]),
         "lfr_problem_free": (None, [vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
@@ -103,7 +104,7 @@ def lib():
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
-           "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_free", "lfr_problem_get_stats",
+           "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
            "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution", "lfr_apply_displacements"]
 
@@ -234,13 +235,18 @@ def write_matching_file(path, ma):
 class Problem:
     """Tracks, roots, components and the device batch layout (solve.cc:487-606, 79-143)."""
 
-    def __init__(self, graph, max_nodes_in_component=0, component_override=None, device_assembly=False):
-        """device_assembly=True: graph stage only; the batch is assembled on the GPU by Batch / solve_hip."""
+    def __init__(self, graph, max_nodes_in_component=0, component_override=None, device_assembly=False,
+                 device_graph_stage=None):
+        """device_assembly=True: graph stage only; the batch is assembled on the GPU by Batch / solve_hip.
+        device_graph_stage=<device ordinal>: tracks/roots/components on that GPU too (implies device_assembly)."""
         self.graph = graph
         h = C.c_void_p()
         co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
-        fn = lib().lfr_problem_build_labels if device_assembly else lib().lfr_problem_build
-        _check(fn(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
+        if device_graph_stage is not None:
+            _check(lib().lfr_problem_build_hip(graph._h, int(device_graph_stage), int(max_nodes_in_component), _ptr(co), C.byref(h)))
+        else:
+            fn = lib().lfr_problem_build_labels if device_assembly else lib().lfr_problem_build
+            _check(fn(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
         self._h = h
 
     def close(self):

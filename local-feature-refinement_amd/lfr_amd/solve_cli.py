@@ -11,7 +11,8 @@ Environment (additions that default so the reference's scripts run unchanged):
   LFR_TUKEY_VARIANT     ceres1 (default; Ceres <= 1.14) | ceres2 (Ceres >= 2.0)
   LFR_COMPONENTS_FILE   raw little-endian int64[n_nodes] component ids replacing the size-cap
                         graph cut (side-car for exact parity with a reference run)
-  LFR_HOST_ASSEMBLY     1: build the batch layout on the host instead of on the GPU
+  LFR_HOST_GRAPH_STAGE  1: tracks/roots/components on the host (batch assembly stays on the GPU)
+  LFR_HOST_ASSEMBLY     1: graph stage and batch layout on the host
   LFR_HOST_THREADS      worker threads of the host graph stage / scanner (default min(cores, 32))
 """
 import os
@@ -148,8 +149,15 @@ def main(argv=None):
     positions = np.zeros((n_nodes, 2), np.float64)                        # solve.cc:609-612
     if n_nodes > 0:
         try:
-            # graph stage on the host; the 80-byte edge records are assembled on the GPU
-            problem = capi.Problem(graph, 0, override, device_assembly=os.environ.get("LFR_HOST_ASSEMBLY") != "1")
+            # graph stage + batch assembly on the GPU (falls back to the host stage for the graph cut /
+            # huge connected components); LFR_HOST_GRAPH_STAGE=1 / LFR_HOST_ASSEMBLY=1 force the host paths
+            if os.environ.get("LFR_HOST_ASSEMBLY") == "1":
+                problem = capi.Problem(graph, 0, override)
+            elif os.environ.get("LFR_HOST_GRAPH_STAGE") == "1":
+                problem = capi.Problem(graph, 0, override, device_assembly=True)
+            else:
+                warm.join()
+                problem = capi.Problem(graph, 0, override, device_graph_stage=device)
         except capi.LfrError as e:
             sys.stderr.write("FATAL: %s\n" % e)
             return 2

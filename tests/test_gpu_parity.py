@@ -230,3 +230,43 @@ def test_device_assembly_equals_host_assembly(lfr_lib, name):
     for k in ("n_components", "n_edges", "n_nodes", "n_tracks", "ref_jacobian_passes_edges", "exec_passes_edges"):
         assert sh[k] == sd[k], k
     assert (bh.download() == bd.download()).all()
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=71, n_images=64, n_tracks=3000),
+    dict(seed=72, n_images=400, n_tracks=3000, eps_out=0.004),
+    dict(seed=98, n_images=30, n_tracks=2000, eps_out=0.0005, sim_lo=0.5),
+    dict(seed=76, n_images=96, n_tracks=60, len_dist="uniform", len_lo=20, len_hi=80),
+])
+def test_device_graph_stage_equals_host(lfr_lib, kw):
+    """lfr_problem_build_hip: GPU tracks / roots / components vs the host stage, label for label."""
+    ma = synthetic.generate(**kw)
+    g = capi.Graph.from_arrays(ma)
+    ph = capi.Problem(g)
+    pd = capi.Problem(g, device_graph_stage=0)
+    th, rh, ch = ph.labels()
+    td, rd, cd = pd.labels()
+    assert (th == td).all() and (rh == rd).all() and (ch == cd).all()
+    for k in ("n_tracks", "max_track_size", "n_components", "max_component_size"):
+        assert ph.stats()[k] == pd.stats()[k], k
+    a, _ = ph.solve_hip(0)
+    b, _ = pd.solve_hip(0)
+    assert (a == b).all()
+
+
+def test_device_graph_stage_fuzz_and_fallback(lfr_lib):
+    """Ties, duplicates and image conflicts (the order-dependent part) + the host fallback when a
+    component exceeds the cap."""
+    from test_graph_stage import fuzz_pairs
+    n_ok = 0
+    for seed in range(2000, 2120):
+        ma = synthetic.pairs_to_arrays(fuzz_pairs(seed))
+        if ma.n_matches == 0:
+            continue
+        g = capi.Graph.from_arrays(ma)
+        ph, pd = capi.Problem(g), capi.Problem(g, device_graph_stage=0)
+        for x, y in zip(ph.labels(), pd.labels()):
+            assert (x == y).all(), seed
+        assert ph.stats()["n_cut_components"] == pd.stats()["n_cut_components"]
+        n_ok += 1
+    assert n_ok >= 100
