@@ -184,6 +184,13 @@ int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iter
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
                   lfr_solve_stats *stats);
 
+/* The same over several GPUs of one node from ONE process: the host-assembled batch is dealt to
+ * `n_devices` shards (lfr_problem_shard_components), one host thread per device uploads, solves and
+ * downloads its shard; shards write disjoint node sets of `positions` (the thread pool of
+ * solve.cc:617-635 with GPUs as workers).  The problem must come from lfr_problem_build. */
+int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices, int tukey_variant, double *positions,
+                        lfr_solve_stats *stats);
+
 /* ---------------------------------------------------------------------------------------------
  * A12  SolutionFile emit.                                                     solve.cc:644-679
  * ------------------------------------------------------------------------------------------- */

@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <string>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -118,8 +120,6 @@ struct GroupLds {
     double g[NV];              // J^T r of the last evaluation
     double x[NV + 2];          // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
     double scale[NV];          // jacobi scaling (fixed at iteration 0)
-    double prow[NV + 2];       // Gauss-Jordan: pivot row (NV columns) + its right-hand side
-    double fcol[NV];           // Gauss-Jordan: pivot column (only when a row is split over 2 lanes)
     // cold per-group state (line-search bookkeeping, counters): lives here, not in VGPRs
     double ls_prev_x, ls_prev_value, ls_prev_gradient, dir_max;
     int ls_prev_flags, ls_iter, n_successful, n_ls_evals, n_cand, exec_passes;
@@ -1281,6 +1281,45 @@ int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *p
     }
     lfr_batch_free(b);
     return rc;
+}
+
+int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices, int tukey_variant, double *positions,
+                        lfr_solve_stats *stats) {
+    if (!p || !devices || n_devices < 1 || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (n_devices == 1) return lfr_solve_hip(p, devices[0], tukey_variant, positions, stats);
+    if (!p->p.host_batch) { lfr::set_error("multi-device solves shard the host-assembled batch: build the problem with lfr_problem_build"); return LFR_ERR_ARG; }
+    // one host thread per device (components are independent: no exchange between shards)
+    std::vector<lfr_batch *> batches(n_devices, nullptr);
+    std::vector<int> rcs(n_devices, LFR_OK);
+    std::vector<lfr_solve_stats> sts(n_devices);
+    std::vector<std::string> errs(n_devices);
+    const size_t n = p->p.track.size();
+    memset(positions, 0, sizeof(double) * 2 * n);
+    auto work = [&](int k) {
+        rcs[k] = lfr_batch_create(p, devices[k], k, n_devices, tukey_variant, &batches[k]);
+        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_solve(batches[k], nullptr, &sts[k]);
+        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_download(batches[k], positions);       // disjoint node sets per shard
+        if (rcs[k] != LFR_OK) errs[k] = lfr_last_error();
+        if (batches[k]) lfr_batch_free(batches[k]);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_devices; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; ++k) if (rcs[k] != LFR_OK) { lfr::set_error("device %d: %s", devices[k], errs[k].c_str()); return rcs[k]; }
+    if (stats) {
+        *stats = sts[0];
+        for (int k = 1; k < n_devices; ++k) {
+            const lfr_solve_stats &s = sts[k];
+            stats->n_components += s.n_components; stats->n_edges += s.n_edges; stats->n_nodes += s.n_nodes; stats->n_tracks += s.n_tracks;
+            stats->n_converged += s.n_converged; stats->n_no_convergence += s.n_no_convergence; stats->n_failed += s.n_failed;
+            stats->sum_iterations += s.sum_iterations; stats->ref_jacobian_passes_edges += s.ref_jacobian_passes_edges;
+            stats->ref_cost_passes_edges += s.ref_cost_passes_edges; stats->exec_passes_edges += s.exec_passes_edges;
+            stats->ref_passes_nodes += s.ref_passes_nodes; stats->sum_final_cost += s.sum_final_cost;
+            stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); stats->h2d_ms = std::max(stats->h2d_ms, s.h2d_ms);
+        }
+    }
+    return LFR_OK;
 }
 
 }  // extern "C"

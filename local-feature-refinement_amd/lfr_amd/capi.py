@@ -90,6 +90,7 @@ def lib():
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
+        "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
         "lfr_apply_displacements": (C.c_int, [vp, vp, C.c_char_p, vp, i64, i64]),
     }
@@ -106,7 +107,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_write_solution", "lfr_apply_displacements"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -286,6 +287,16 @@ class Problem:
         st = SolveStats()
         _check(lib().lfr_solve_hip(self._h, device, TUKEY[tukey_variant], _ptr(pos), C.byref(st)))
         return pos, st.as_dict()
+
+
+def solve_hip_multi(problem, devices, tukey_variant="ceres1"):
+    """Shard a host-assembled problem over several GPUs from this process (one host thread per device)."""
+    n = problem.graph.n_nodes
+    pos = np.zeros((n, 2), np.float64)
+    st = SolveStats()
+    dev = np.ascontiguousarray(devices, np.int32)
+    _check(lib().lfr_solve_hip_multi(problem._h, _ptr(dev), len(dev), TUKEY[tukey_variant], _ptr(pos), C.byref(st)))
+    return pos, st.as_dict()
 
 
 class Batch:

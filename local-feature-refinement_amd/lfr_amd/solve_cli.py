@@ -8,6 +8,8 @@ MI355X; there is no CPU fallback — a missing library or GPU is a loud error (e
 
 Environment (additions that default so the reference's scripts run unchanged):
   LFR_DEVICE            HIP device ordinal (default 0)
+  LFR_GPUS              comma-separated device ordinals: shard the components over several GPUs of the
+                        node from this one process (e.g. 0,1,2,3,4,5,6,7)
   LFR_TUKEY_VARIANT     ceres1 (default; Ceres <= 1.14) | ceres2 (Ceres >= 2.0)
   LFR_COMPONENTS_FILE   raw little-endian int64[n_nodes] component ids replacing the size-cap
                         graph cut (side-car for exact parity with a reference run)
@@ -151,8 +153,9 @@ def main(argv=None):
         try:
             # graph stage + batch assembly on the GPU (falls back to the host stage for the graph cut /
             # huge connected components); LFR_HOST_GRAPH_STAGE=1 / LFR_HOST_ASSEMBLY=1 force the host paths
-            if os.environ.get("LFR_HOST_ASSEMBLY") == "1":
-                problem = capi.Problem(graph, 0, override)
+            gpus = [int(x) for x in os.environ.get("LFR_GPUS", "").split(",") if x.strip() != ""]
+            if len(gpus) > 1 or os.environ.get("LFR_HOST_ASSEMBLY") == "1":
+                problem = capi.Problem(graph, 0, override)          # multi-GPU shards are cut from the host batch
             elif os.environ.get("LFR_HOST_GRAPH_STAGE") == "1":
                 problem = capi.Problem(graph, 0, override, device_assembly=True)
             else:
@@ -174,8 +177,11 @@ def main(argv=None):
         warm.join()
         t1 = time.perf_counter()                                          # solve.cc:615
         try:
-            positions, sst = problem.solve_hip(device,
-                                               os.environ.get("LFR_TUKEY_VARIANT", "ceres1"))
+            variant = os.environ.get("LFR_TUKEY_VARIANT", "ceres1")
+            if len(gpus) > 1:
+                positions, sst = capi.solve_hip_multi(problem, gpus, variant)
+            else:
+                positions, sst = problem.solve_hip(device, variant)
         except (capi.LfrError, KeyError) as e:
             sys.stderr.write("FATAL: HIP solve failed: %s\n" % e)
             return 2

@@ -270,3 +270,15 @@ def test_device_graph_stage_fuzz_and_fallback(lfr_lib):
         assert ph.stats()["n_cut_components"] == pd.stats()["n_cut_components"]
         n_ok += 1
     assert n_ok >= 100
+
+
+def test_multi_device_entry_point_on_one_gpu(lfr_lib):
+    """lfr_solve_hip_multi with the device list [0, 0, 0]: three host threads, three shards, one GPU -
+    the sharded result must be bit-identical to the single-batch solve."""
+    ma = synthetic.generate(seed=99, n_images=64, n_tracks=3000, eps_out=0.001)
+    p = capi.Problem(capi.Graph.from_arrays(ma))
+    full, st1 = p.solve_hip(0)
+    multi, stm = capi.solve_hip_multi(p, [0, 0, 0])
+    assert (full == multi).all()
+    for k in ("n_components", "n_edges", "n_tracks", "n_converged", "sum_iterations", "ref_jacobian_passes_edges"):
+        assert st1[k] == stm[k], k
