@@ -72,6 +72,17 @@ int lfr_graph_from_arrays(int32_t n_images, const char *const *image_names, cons
                           const float *sim, const float *disp1, const float *disp2,
                           const char *const *banned, int n_banned, lfr_graph **out);
 
+/* Producer contract without the host hop for the flows (compute_match_graph.py:163-187 keeps
+ * grid_displacements12/21 on the GPU): as lfr_graph_from_arrays, but disp1/disp2 are DEVICE pointers
+ * (n_matches x 18 float32 on HIP device `device`, owned by the caller, alive until the batch has been
+ * created).  Such a graph is solved through lfr_problem_build_labels / lfr_problem_build_hip +
+ * lfr_batch_create on the same device; lfr_problem_build (host assembly) rejects it. */
+int lfr_graph_from_arrays_device_flows(int32_t n_images, const char *const *image_names, const float *image_facts,
+                                       int64_t n_pairs, const int32_t *pair_img1, const int32_t *pair_img2,
+                                       const int64_t *pair_off, const uint32_t *feat1, const uint32_t *feat2,
+                                       const float *sim, const void *disp1_device, const void *disp2_device, int device,
+                                       const char *const *banned, int n_banned, lfr_graph **out);
+
 void lfr_graph_free(lfr_graph *g);
 int64_t lfr_graph_num_nodes(const lfr_graph *g);      /* "# graph nodes"  solve.cc:484 */
 int64_t lfr_graph_num_edges(const lfr_graph *g);      /* "# graph edges" = 2 x matches  solve.cc:485 */

@@ -156,7 +156,8 @@ __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t
 __global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
                              const int32_t *comp, const int32_t *di_of_comp, const uint32_t *edge_off, const uint32_t *node_off,
-                             const uint32_t *local_of, uint4 *records, NodeInc *inc, uint64_t *in_keys, uint32_t *in_vals) {
+                             const uint32_t *local_of, const uint32_t *flow_row, uint4 *records, NodeInc *inc, uint64_t *in_keys,
+                             uint32_t *in_vals) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / 5;
     const int chunk = (int)(t - 5 * p);
@@ -164,7 +165,8 @@ __global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, c
     const uint32_t e = edge_sorted[p];
     uint32_t s, d;
     edge_ends(node1, node2, e, s, d);
-    const float *fl = ((e & 1) ? disp1 : disp2) + 18 * (size_t)(e >> 1);
+    const size_t frow = flow_row ? flow_row[e >> 1] : (size_t)(e >> 1);
+    const float *fl = ((e & 1) ? disp1 : disp2) + 18 * frow;
     uint4 q;
     if (chunk < 4) {
         q.x = __float_as_uint(fl[4 * chunk]); q.y = __float_as_uint(fl[4 * chunk + 1]);
@@ -267,7 +269,14 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     HIP_TRY(hipMemcpyAsync(b_track.p, track32.data(), 4 * N, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b_comp.p, comp32.data(), 4 * N, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(b_root.p, p.is_root.data(), N, hipMemcpyHostToDevice, st));
-    const float *disp1 = dev_disp1, *disp2 = dev_disp2;
+    const float *disp1 = dev_disp1 ? dev_disp1 : g.dev_disp1, *disp2 = dev_disp2 ? dev_disp2 : g.dev_disp2;
+    DevBuf b_frow;
+    const uint32_t *flow_row = nullptr;
+    if (disp1 && disp2 && !g.m_flow_row.empty()) {      // caller-owned device flows, indexed by their original row
+        DEV_ALLOC(b_frow, 4 * M);
+        HIP_TRY(hipMemcpyAsync(b_frow.p, g.m_flow_row.data(), 4 * M, hipMemcpyHostToDevice, st));
+        flow_row = b_frow.as<uint32_t>();
+    }
     if (!disp1 || !disp2) {
         DEV_ALLOC(b_d1, 72 * M); DEV_ALLOC(b_d2, 72 * M);
         HIP_TRY(hipMemcpyAsync(b_d1.p, g.m_disp1.data(), 72 * M, hipMemcpyHostToDevice, st));
@@ -352,7 +361,7 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     uint32_t *in_v0 = b_ei0.as<uint32_t>();
     hipLaunchKernelGGL(k_emit_edges, grid_for(5 * total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2,
                        b_sim.as<float>(), disp1, disp2, track, comp, b_di.as<int32_t>(), b_eo.as<uint32_t>(), b_no.as<uint32_t>(),
-                       b_local.as<uint32_t>(), reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
+                       b_local.as<uint32_t>(), flow_row, reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
     if ((rc = sort_pairs(in_k0, in_k1, in_v0, out.d_in_idx, total_edges, 0, 48, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_in_begin, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, in_k1, b_eo.as<uint32_t>(), b_no.as<uint32_t>(), out.d_node_inc);
 

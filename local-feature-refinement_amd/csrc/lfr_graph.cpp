@@ -331,6 +331,10 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     p.stats.n_components = n_components;
     p.stats.graph_cut_ms = ms_since(t0);
     p.host_batch = host_batch;
+    if (host_batch && g.dev_disp1) {
+        set_error("the flows of this graph live on the GPU: use lfr_problem_build_labels or lfr_problem_build_hip");
+        return LFR_ERR_ARG;
+    }
     if (!host_batch) {                    // labels only: lfr_batch_create assembles the batch on the GPU
         std::vector<int64_t> csz(n_components, 0);
         for (int64_t i = 0; i < N; ++i) ++csz[p.comp[i]];

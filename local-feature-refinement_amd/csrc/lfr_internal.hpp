@@ -24,6 +24,11 @@ struct Graph {
     std::vector<uint32_t> m_node1, m_node2;    // per match
     std::vector<float> m_sim;
     std::vector<float> m_disp1, m_disp2;       // 18 floats per match, zero padded (solve.cc:460-472)
+    // flows that never left the GPU (lfr_graph_from_arrays_device_flows): device arrays of
+    // n_rows x 18 floats owned by the caller; match m uses row m_flow_row[m] (identity when empty)
+    const float *dev_disp1 = nullptr, *dev_disp2 = nullptr;
+    int dev_flows_device = -1;
+    std::vector<uint32_t> m_flow_row;
     std::vector<int32_t> node_image;
     std::vector<uint32_t> node_feat;
 

@@ -927,6 +927,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     const bool on_device = !p.host_batch;
     if (on_device) {
         if (shard_world != 1) { delete b; lfr::set_error("device-side assembly builds whole problems only (shard_world must be 1)"); return LFR_ERR_ARG; }
+        if (p.g->dev_disp1 && p.g->dev_flows_device != device) { delete b; lfr::set_error("the graph's flows live on device %d, the batch was requested on device %d", p.g->dev_flows_device, device); return LFR_ERR_ARG; }
         hipEvent_t a0, a1;
         HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
         HIP_TRY(hipEventRecord(a0, nullptr));

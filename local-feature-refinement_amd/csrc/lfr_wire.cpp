@@ -413,6 +413,38 @@ int lfr_graph_from_arrays(int32_t n_images, const char *const *image_names, cons
     return LFR_OK;
 }
 
+int lfr_graph_from_arrays_device_flows(int32_t n_images, const char *const *image_names, const float *image_facts,
+                                       int64_t n_pairs, const int32_t *pair_img1, const int32_t *pair_img2,
+                                       const int64_t *pair_off, const uint32_t *feat1, const uint32_t *feat2,
+                                       const float *sim, const void *disp1_device, const void *disp2_device, int device,
+                                       const char *const *banned, int n_banned, lfr_graph **out) {
+    if (!out || n_images < 0 || n_pairs < 0 || !disp1_device || !disp2_device || device < 0) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::set<std::string> ban;
+    for (int i = 0; i < n_banned; ++i) ban.insert(banned[i]);
+    lfr_graph *h = new lfr_graph();
+    Graph &g = h->g;
+    const int64_t M = n_pairs ? pair_off[n_pairs] : 0;
+    g.m_node1.reserve(M); g.m_node2.reserve(M); g.m_sim.reserve(M); g.m_flow_row.reserve(M);
+    for (int64_t p = 0; p < n_pairs; ++p) {
+        const int32_t a = pair_img1[p], b = pair_img2[p];
+        if (a < 0 || a >= n_images || b < 0 || b >= n_images) { delete h; set_error("image index out of range"); return LFR_ERR_ARG; }
+        const std::string na = image_names[a], nb = image_names[b];
+        if (ban.count(na) || ban.count(nb)) continue;
+        const int32_t i1 = g.intern_image(na, image_facts[a]);
+        const int32_t i2 = g.intern_image(nb, image_facts[b]);
+        for (int64_t m = pair_off[p]; m < pair_off[p + 1]; ++m) {
+            const uint32_t n1 = g.find_or_create_node(i1, feat1[m]);      // node1 before node2 (solve.cc:474-475)
+            const uint32_t n2 = g.find_or_create_node(i2, feat2[m]);
+            g.m_node1.push_back(n1); g.m_node2.push_back(n2); g.m_sim.push_back(sim[m]);
+            g.m_flow_row.push_back((uint32_t)m);
+        }
+    }
+    g.dev_disp1 = (const float *)disp1_device; g.dev_disp2 = (const float *)disp2_device; g.dev_flows_device = device;
+    g.finish();
+    *out = h;
+    return LFR_OK;
+}
+
 void lfr_graph_free(lfr_graph *g) { delete g; }
 int64_t lfr_graph_num_nodes(const lfr_graph *g) { return g ? g->g.n_nodes() : 0; }
 int64_t lfr_graph_num_edges(const lfr_graph *g) { return g ? 2 * g->g.n_matches() : 0; }

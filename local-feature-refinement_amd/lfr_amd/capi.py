@@ -67,6 +67,7 @@ def lib():
         "lfr_graph_from_files": (C.c_int, [cpp, C.c_int, cpp, C.c_int, pp]),
         "lfr_graph_from_matches_file": (C.c_int, [C.c_char_p, cpp, C.c_int, pp]),
         "lfr_graph_from_arrays": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cpp, C.c_int, pp]),
+        "lfr_graph_from_arrays_device_flows": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, cpp, C.c_int, pp]),
         "lfr_graph_free": (None, [vp]),
         "lfr_graph_num_nodes": (i64, [vp]),
         "lfr_graph_num_edges": (i64, [vp]),
@@ -103,7 +104,7 @@ def lib():
 
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
-           "lfr_graph_from_arrays", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -165,6 +166,19 @@ class Graph:
                                            _ptr(a["d2"]), _cstrs(list(banned)), len(banned), C.byref(h)))
         return cls(h)
 
+    @classmethod
+    def from_device_flows(cls, ma, disp1_ptr, disp2_ptr, device=0, banned=()):
+        """ma: MatchArrays (its disp1/disp2 are ignored); disp*_ptr: device addresses (int) of float32
+        [n_matches, 18] arrays on HIP device `device`, e.g. tensor.data_ptr().  The caller keeps them alive
+        until the Batch exists."""
+        h = C.c_void_p()
+        a = _contig(ma, flows=False)
+        _check(lib().lfr_graph_from_arrays_device_flows(
+            len(ma.image_names), _cstrs(ma.image_names), _ptr(a["facts"]), len(a["p1"]), _ptr(a["p1"]), _ptr(a["p2"]),
+            _ptr(a["off"]), _ptr(a["f1"]), _ptr(a["f2"]), _ptr(a["sim"]), C.c_void_p(disp1_ptr), C.c_void_p(disp2_ptr),
+            device, _cstrs(list(banned)), len(banned), C.byref(h)))
+        return cls(h)
+
     def close(self):
         if self._h:
             lib().lfr_graph_free(self._h)
@@ -213,8 +227,14 @@ class Graph:
         return n_out.value
 
 
-def _contig(ma):
+def _contig(ma, flows=True):
     M = ma.n_matches
+    if not flows:
+        return {"facts": np.ascontiguousarray(ma.facts, np.float32),
+                "p1": np.ascontiguousarray(ma.pair_img1, np.int32), "p2": np.ascontiguousarray(ma.pair_img2, np.int32),
+                "off": np.ascontiguousarray(ma.pair_off, np.int64),
+                "f1": np.ascontiguousarray(ma.feat1, np.uint32), "f2": np.ascontiguousarray(ma.feat2, np.uint32),
+                "sim": np.ascontiguousarray(ma.sim, np.float32)}
     return {"facts": np.ascontiguousarray(ma.facts, np.float32),
             "p1": np.ascontiguousarray(ma.pair_img1, np.int32), "p2": np.ascontiguousarray(ma.pair_img2, np.int32),
             "off": np.ascontiguousarray(ma.pair_off, np.int64),

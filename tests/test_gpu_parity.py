@@ -282,3 +282,40 @@ def test_multi_device_entry_point_on_one_gpu(lfr_lib):
     assert (full == multi).all()
     for k in ("n_components", "n_edges", "n_tracks", "n_converged", "sum_iterations", "ref_jacobian_passes_edges"):
         assert st1[k] == stm[k], k
+
+
+def test_device_resident_flows_producer_contract(lfr_lib):
+    """lfr_graph_from_arrays_device_flows: the flow grids stay on the GPU (torch tensors standing in
+    for the two-view network's output, compute_match_graph.py:163-187); results are bit-identical to
+    the host-array path, also with banned images (row indirection)."""
+    import ctypes
+    ma = synthetic.generate(seed=93, n_images=50, n_tracks=2500, eps_out=0.001)
+    # device buffers through the same HIP runtime the library is linked against (a producer such as the
+    # two-view network would hand over tensor.data_ptr(); see INTEGRATION.md for the torch import order)
+    hip = ctypes.CDLL("libamdhip64.so")
+    ptrs = []
+    for arr in (ma.disp1, ma.disp2):
+        host = np.ascontiguousarray(arr, np.float32).reshape(-1, 18)
+        dptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(dptr), ctypes.c_size_t(host.nbytes)) == 0
+        assert hip.hipMemcpy(dptr, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(host.nbytes), 1) == 0   # H2D
+        ptrs.append(dptr)
+
+    class _P:      # mimic tensor.data_ptr()
+        def __init__(self, v):
+            self.v = v
+
+        def data_ptr(self):
+            return self.v.value
+    d1, d2 = _P(ptrs[0]), _P(ptrs[1])
+    for banned in ((), (ma.image_names[2], ma.image_names[31])):
+        g_host = capi.Graph.from_arrays(ma, banned)
+        g_dev = capi.Graph.from_device_flows(ma, d1.data_ptr(), d2.data_ptr(), 0, banned)
+        assert g_host.n_nodes == g_dev.n_nodes and g_host.n_edges == g_dev.n_edges
+        want, _ = capi.Problem(g_host).solve_hip(0)
+        got, _ = capi.Problem(g_dev, device_graph_stage=0).solve_hip(0)
+        assert (want == got).all()
+        with pytest.raises(capi.LfrError):
+            capi.Problem(g_dev)          # host assembly needs host flows
+    for p_ in ptrs:
+        hip.hipFree(p_)
