@@ -142,13 +142,20 @@ __global__ void k_node_locals(int64_t total_nodes, const uint32_t *node_sorted, 
 }
 
 __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t *node2, const int32_t *comp,
-                            const int32_t *di_of_comp, const uint8_t *kept, uint64_t *keys, uint32_t *ids) {
+                            const int32_t *di_of_comp, const uint32_t *class_of_desc, const uint8_t *kept, uint64_t *keys,
+                            uint32_t *ids) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_dir) return;
     uint32_t s, d;
     edge_ends(node1, node2, e, s, d);
     const int32_t di = kept[e] ? di_of_comp[comp[s]] : -1;
-    keys[e] = di < 0 ? ~0ull : (((uint64_t)(uint32_t)di << 32) | s);     // residual-block order: by source node, then edge id
+    // workgroup classes: residual-block order (by source node, then edge id); packed classes: edge id only
+    // (the sort is stable), so the two directions 2m, 2m+1 of a match become neighbouring records
+    // (written with an early return + mask: the one-expression form `(di >= 0 && class < KC_BLOCK) ? 0 : s` was
+    // miscompiled by hipcc 7.2 -O3 for gfx950 - the register holding s was reused before the select)
+    if (di < 0) { keys[e] = ~0ull; ids[e] = (uint32_t)e; return; }
+    const uint32_t by_source = class_of_desc[di] >= (uint32_t)KC_BLOCK ? 0xffffffffu : 0u;
+    keys[e] = ((uint64_t)(uint32_t)di << 32) | (s & by_source);
     ids[e] = (uint32_t)e;
 }
 
@@ -345,10 +352,10 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     hipLaunchKernelGGL(k_node_locals, grid_for(total_nodes), dim3(kThreads), 0, st, total_nodes, b_ni1.as<uint32_t>(), comp, b_di.as<int32_t>(),
                        b_no.as<uint32_t>(), out.d_node_ids, b_local.as<uint32_t>());
 
-    // ---- edge order: kept edges by (desc, source node, edge id) ----
+    // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
     DevBuf b_ek0, b_ek1, b_ei0, b_ei1;
     DEV_ALLOC(b_ek0, 8 * E2); DEV_ALLOC(b_ek1, 8 * E2); DEV_ALLOC(b_ei0, 4 * E2); DEV_ALLOC(b_ei1, 4 * E2);
-    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_di.as<int32_t>(), b_kept.as<uint8_t>(),
+    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_di.as<int32_t>(), class_sorted, b_kept.as<uint8_t>(),
                        b_ek0.as<uint64_t>(), b_ei0.as<uint32_t>());
     if ((rc = sort_pairs(b_ek0.as<uint64_t>(), b_ek1.as<uint64_t>(), b_ei0.as<uint32_t>(), b_ei1.as<uint32_t>(), E2, 0, 64, st)) != LFR_OK) return rc;
 

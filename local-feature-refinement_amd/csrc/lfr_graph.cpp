@@ -248,6 +248,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
         for (int64_t m = 0; m < M; ++m) { out_eid[cur[g.m_node1[m]]++] = 2 * m; out_eid[cur[g.m_node2[m]]++] = 2 * m + 1; }
     }
     auto edge_dst = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node1[e >> 1] : g.m_node2[e >> 1]; };
+    auto edge_src = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node2[e >> 1] : g.m_node1[e >> 1]; };
 
     // ------------------------------------------------------------------ components (solve.cc:252-373)
     t0 = clock::now();
@@ -434,6 +435,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
         dcuts.push_back((int64_t)metas.size());
     }
     parallel_chunks(dcuts, [&](int, int64_t dlo, int64_t dhi) {
+        std::vector<int64_t> kept;
         for (int64_t di = dlo; di < dhi; ++di) {
             const Meta &mt = metas[di];
             const int64_t lo = comp_off[mt.comp], hi = comp_off[mt.comp + 1];
@@ -450,26 +452,34 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
             d.edge_off = (uint32_t)eo0; d.n_edges = (uint32_t)mt.n_edges; d.node_off = (uint32_t)no;
             d.n_nodes = (uint16_t)mt.n_nodes; d.n_var = (uint16_t)mt.n_var;
             p.desc_component[di] = mt.comp; p.desc_class[di] = mt.cls; p.desc_tracks[di] = mt.n_tracks;
-            for (int64_t k = lo; k < hi; ++k) {           // residual-block order of solve.cc:98-102
+            // Workgroup classes: residual-block order of solve.cc:98-102 (by source node: the owner-computes
+            // kernels walk out-edge runs).  Packed classes: edge-id order, so that the two directions of a
+            // match (ids 2m, 2m+1; both are kept or both dropped) sit in neighbouring records / lanes.
+            const bool by_edge_id = mt.cls < KC_BLOCK;
+            kept.clear();
+            for (int64_t k = lo; k < hi; ++k) {
                 const int64_t n = comp_nodes[k];
-                p.node_inc[no + local_of[n]].out_begin = (uint32_t)(eo - eo0);
+                p.node_inc[no + local_of[n]].out_begin = (uint32_t)(eo - eo0 + (int64_t)kept.size());
                 for (int64_t q = out_off[n]; q < out_off[n + 1]; ++q) {
                     const int64_t e = out_eid[q];
                     const uint32_t dn = edge_dst(e);
-                    int kind;
-                    if (p.track[n] == p.track[dn]) kind = 0;
-                    else if (p.comp[n] == p.comp[dn]) kind = 1;
-                    else continue;
+                    if (!(p.track[n] == p.track[dn] || p.comp[n] == p.comp[dn])) continue;
                     if (!is_var[n] && !is_var[dn]) continue;
-                    EdgeRec &r = p.edges[eo++];
-                    const float *fl = ((e & 1) ? g.m_disp1.data() : g.m_disp2.data()) + 18 * (e >> 1);
-                    memcpy(r.flow, fl, sizeof r.flow);
-                    r.sim = g.m_sim[e >> 1];
-                    r.src = (uint16_t)local_of[n];
-                    r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
-                    ++p.node_inc[no + local_of[n]].out_count;
-                    ++p.node_inc[no + local_of[dn]].in_count;
+                    kept.push_back(e);
                 }
+            }
+            if (by_edge_id) std::sort(kept.begin(), kept.end());
+            for (const int64_t e : kept) {
+                const uint32_t n = edge_src(e), dn = edge_dst(e);
+                const int kind = p.track[n] == p.track[dn] ? 0 : 1;
+                EdgeRec &r = p.edges[eo++];
+                const float *fl = ((e & 1) ? g.m_disp1.data() : g.m_disp2.data()) + 18 * (e >> 1);
+                memcpy(r.flow, fl, sizeof r.flow);
+                r.sim = g.m_sim[e >> 1];
+                r.src = (uint16_t)local_of[n];
+                r.dst_kind = (uint16_t)(local_of[dn] | (kind << 15));
+                ++p.node_inc[no + local_of[n]].out_count;
+                ++p.node_inc[no + local_of[dn]].in_count;
             }
             {   // in-edge lists: counting sort of the component's edges by destination (stable)
                 uint32_t acc = 0;

@@ -96,9 +96,18 @@ __global__ void k_iota(int64_t n, uint32_t *p) {
 }
 
 // ---- lock-free union-find (hook the larger root under the smaller): labels = smallest member ----
+// Every access to parent[] is an agent-scope atomic: a plain load may be served from the CU's
+// non-coherent vector L1, and a stale "parent[a] == a" there makes the CAS loop spin forever.
+__device__ __forceinline__ uint32_t uf_load(const uint32_t *parent, uint32_t x) {
+    return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    uint32_t p = parent[x];
-    while (p != x) { const uint32_t gp = parent[p]; if (gp != p) parent[x] = gp; x = p; p = gp; }    // path halving
+    uint32_t p = uf_load(parent, x);
+    while (p != x) {                                           // path halving (parents only ever decrease)
+        const uint32_t gp = uf_load(parent, p);
+        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p; p = gp;
+    }
     return x;
 }
 __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t b) {
@@ -106,7 +115,9 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
         a = uf_find(parent, a); b = uf_find(parent, b);
         if (a == b) return;
         if (a < b) { const uint32_t t = a; a = b; b = t; }      // a > b: hook a under b
-        if (atomicCAS(&parent[a], a, b) == a) return;
+        const uint32_t seen = atomicCAS(&parent[a], a, b);
+        if (seen == a) return;
+        a = seen;                                               // a was hooked meanwhile: continue from its new parent
     }
 }
 __global__ void k_cc_union(int64_t M, const uint32_t *n1, const uint32_t *n2, uint32_t *parent) {

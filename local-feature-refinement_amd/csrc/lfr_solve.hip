@@ -277,31 +277,30 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
             eval_edge<true>(flow[k], sim[k], ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
             cost_l += o.cost;
             double *A = L.A, *g = L.g;
+            // The neighbouring lane (lane ^ 1) holds the opposite direction of the same match (packed classes
+            // are assembled in edge-id order: records 2m, 2m+1), so its d r / d x_dst = sq' * I terms land on
+            // THIS lane's source block and the two cross blocks coincide: exchange them through DPP and issue
+            // 7 LDS atomics per edge instead of 17.
+            const int q = sl & 1;
+            const double p_w = dpp_f64<kDppQuadXor1>(o.sq * o.sq);
+            const double p_g0 = dpp_f64<kDppQuadXor1>(o.sq * o.r0);
+            const double p_g1 = dpp_f64<kDppQuadXor1>(o.sq * o.r1);
+            // cross block M[rb+i][ra+j] = sq*J_ij + sq'*J'_ji: the even lane owns (0,0),(1,1), the odd lane (1,0),(0,1)
+            const double c_send1 = o.sq * (q ? o.j00 : o.j01), c_send2 = o.sq * (q ? o.j11 : o.j10);
+            const double c_own1 = o.sq * (q ? o.j10 : o.j00), c_own2 = o.sq * (q ? o.j01 : o.j11);
+            const double c1 = c_own1 + dpp_f64<kDppQuadXor1>(c_send1);
+            const double c2 = c_own2 + dpp_f64<kDppQuadXor1>(c_send2);
             if (ra >= 0) {
-                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10);
+                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10 + p_w);
                 atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
-                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11);
-                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1);
-                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1);
-            }
-            if (rb >= 0) {
-                atomicAdd(&A[rb * LD + rb], o.sq * o.sq);
-                atomicAdd(&A[(rb + 1) * LD + rb + 1], o.sq * o.sq);
-                atomicAdd(&g[rb], o.sq * o.r0);
-                atomicAdd(&g[rb + 1], o.sq * o.r1);
+                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11 + p_w);
+                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1 + p_g0);
+                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1 + p_g1);
             }
             if (ra >= 0 && rb >= 0) {
-                if (rb > ra) {
-                    atomicAdd(&A[rb * LD + ra], o.sq * o.j00);
-                    atomicAdd(&A[rb * LD + ra + 1], o.sq * o.j01);
-                    atomicAdd(&A[(rb + 1) * LD + ra], o.sq * o.j10);
-                    atomicAdd(&A[(rb + 1) * LD + ra + 1], o.sq * o.j11);
-                } else {
-                    atomicAdd(&A[ra * LD + rb], o.j00 * o.sq);
-                    atomicAdd(&A[ra * LD + rb + 1], o.j10 * o.sq);
-                    atomicAdd(&A[(ra + 1) * LD + rb], o.j01 * o.sq);
-                    atomicAdd(&A[(ra + 1) * LD + rb + 1], o.j11 * o.sq);
-                }
+                const int r1 = rb + q, k1 = ra, r2 = rb + 1 - q, k2 = ra + 1;
+                atomicAdd(&A[rb > ra ? r1 * LD + k1 : k1 * LD + r1], c1);
+                atomicAdd(&A[rb > ra ? r2 * LD + k2 : k2 * LD + r2], c2);
             }
         }
         wave_lds_sync();
@@ -842,6 +841,7 @@ struct lfr_batch {
     static constexpr int kEvPerSlot = 2 * (lfr::KC_COUNT + 1);
     hipEvent_t ev_ring[kSlots * kEvPerSlot];
     hipEvent_t *ev = ev_ring;                            // slot of the current solve
+    uint32_t ev_recorded[kSlots] = {};                   // per slot: classes whose start/end events were recorded
     int64_t n_solves = 0;
     bool events = false;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
@@ -1071,6 +1071,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.es_off = b->d_es_off;
     a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
+    uint32_t &recorded = b->ev_recorded[b->n_solves % lfr_batch::kSlots];
+    recorded = 0;
     ++b->n_solves;
     if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
     HIP_TRY(hipEventRecord(b->ev[0], st));
@@ -1097,8 +1099,10 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
             a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
             const int n = a.desc_end - a.desc_begin;
+            if (n <= 0) continue;
+            recorded |= 1u << cls;
             HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
-            if (n > 0) {
+            {
                 const dim3 grid((n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls]);
                 switch (cls) {
                     case lfr::KC_G8:    hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), grid, blk, 0, st, a); break;
@@ -1113,15 +1117,19 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
         }
     } else {
+        // events (each one is a barrier packet on its stream): only the launches that exist are bracketed
+        bool side_used[lfr::KC_COUNT] = {};
         if (have_side) {
             HIP_TRY(hipEventRecord(b->ev_fork, st));
             for (int cls = lfr::KC_GLOBAL; cls >= lfr::KC_BLOCK; --cls) {
+                if (b->class_begin[cls + 1] <= b->class_begin[cls]) continue;
                 hipStream_t ss = cls == lfr::KC_GLOBAL ? b->side_stream2 : b->side_stream;
                 HIP_TRY(hipStreamWaitEvent(ss, b->ev_fork, 0));
                 HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], ss));
                 const int rc = launch_block(cls, ss);
                 if (rc != LFR_OK) return rc;
                 HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], ss));
+                side_used[cls] = true; recorded |= 1u << cls;
             }
         }
         PackedRanges r;
@@ -1134,16 +1142,14 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             nb += (n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls];
         }
         r.blk_begin[5] = nb;
-        // the packed launch is timed as one unit: its events sit in the slot of the largest class
-        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st));
-        if (nb > 0) {
+        if (nb > 0) {      // the packed launch is timed as one unit: its events sit in the slot of the largest class
+            HIP_TRY(hipEventRecord(b->ev[2 + 2 * b->packed_slot], st));
             hipLaunchKernelGGL(solve_packed_kernel, dim3(nb), blk, 0, st, a, r);
             HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], st));
+            recorded |= 1u << b->packed_slot;
         }
-        HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], st));
-        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) if (cls != b->packed_slot) HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
-        if (!have_side) for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls) { HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], st)); HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st)); }
-        if (have_side) { HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0)); HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_GLOBAL], 0)); }
+        for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls) if (side_used[cls]) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * cls], 0));
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;
@@ -1195,7 +1201,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         }
         if (merged && cls != lfr::KC_BLOCK - 1) continue;
         const int slot = merged ? b->packed_slot : cls;
-        HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 + 2 * slot], b->ev[3 + 2 * slot]));
+        ms = 0.f;
+        if (recorded >> slot & 1u) HIP_TRY(hipEventElapsedTime(&ms, b->ev[2 + 2 * slot], b->ev[3 + 2 * slot]));
         if (edges > 0 && ms > best_ms) {
             best_ms = ms;
             stats->dominant_kernel_ms = ms; stats->dominant_kernel_edges = edges; stats->dominant_kernel_nodes = nodes;
@@ -1208,13 +1215,19 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges) {
     if (!b || solves_back < 0 || solves_back >= lfr_batch::kSlots || solves_back >= b->n_solves) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     HIP_TRY(hipSetDevice(b->device));
-    hipEvent_t *ev = b->ev_ring + ((b->n_solves - 1 - solves_back) % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
+    const int ring_slot = (b->n_solves - 1 - solves_back) % lfr_batch::kSlots;
+    hipEvent_t *ev = b->ev_ring + ring_slot * lfr_batch::kEvPerSlot;
+    const uint32_t recorded = b->ev_recorded[ring_slot];
     HIP_TRY(hipEventSynchronize(ev[1]));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1]));
     if (total_ms) *total_ms = ms;
     for (int cls = 0; cls < lfr::KC_COUNT; ++cls) {
-        if (class_ms) { HIP_TRY(hipEventElapsedTime(&ms, ev[2 + 2 * cls], ev[3 + 2 * cls])); class_ms[cls] = ms; }
+        if (class_ms) {
+            ms = 0.f;
+            if (recorded >> cls & 1u) HIP_TRY(hipEventElapsedTime(&ms, ev[2 + 2 * cls], ev[3 + 2 * cls]));
+            class_ms[cls] = ms;
+        }
         if (class_edges) {      // edges of the LAUNCH timed in this slot (the packed launch carries all packed classes)
             int64_t e = 0;
             const bool packed = !b->serial && cls < lfr::KC_BLOCK;

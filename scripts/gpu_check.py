@@ -7,7 +7,7 @@ from lfr_amd import capi, synthetic
 import lfr_oracle as O
 
 def run(name, ma, threads=8):
-    g = capi.Graph.from_arrays(ma); p = capi.Problem(g)
+    g = capi.Graph.from_arrays(ma); p = capi.Problem(g, device_assembly=bool(os.environ.get('LFR_CHECK_DEVICE')))
     t = time.time(); pos, st = p.solve_hip(0); t_gpu = time.time() - t
     ref = O.run(ma, n_threads=threads)
     if ref["rc"] != 0:      # oversized components: hand the product's cut to the oracle (Graclus is not restatable)
