@@ -155,6 +155,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     for (int m = 32; m >= 1; m >>= 1) nv2_max = max(nv2_max, __shfl_xor(nv2_max, m, 64));
     nv2_max = __builtin_amdgcn_readfirstlane(nv2_max);
 
+#ifndef LFR_STREAM_EDGES
     // ---- edges -> registers (the only HBM read of the solve) ----
     float flow[EPL][18];
     float sim[EPL];
@@ -176,6 +177,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         sim[k] = __uint_as_float(q[4].z);
         idx[k] = q[4].w;
     }
+#endif
     if (sl < NV) { L.x[sl] = 0.0; L.scale[sl] = 1.0; }
     if (sl < 2) L.x[NV + sl] = 0.0;
 
@@ -265,16 +267,38 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         wave_lds_sync();
         PROF_MARK(6);                                 // 6: zero J^T J
         double cost_l = 0.0;
+#ifdef LFR_STREAM_EDGES
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int k = 0; k < EPL; ++k) {
             if (!(pe && sl + S * k < E)) continue;
+#ifdef LFR_STREAM_EDGES
+            float flow_k[18]; float sim_k; uint32_t pk;
+            {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
+                uint4 q[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) q[i] = rp[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
+                    flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
+                }
+                flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
+                sim_k = __uint_as_float(q[4].z); pk = q[4].w;
+            }
+#else
+            const float (&flow_k)[18] = flow[k]; const float sim_k = sim[k];
             uint32_t pk = idx[k];
+#endif
             asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
             const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
             const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
             const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
             EdgeOut o;
-            eval_edge<true>(flow[k], sim[k], ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+            eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
             cost_l += o.cost;
             double *A = L.A, *g = L.g;
             // The neighbouring lane (lane ^ 1) holds the opposite direction of the same match (packed classes
@@ -1117,21 +1141,12 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], st));
         }
     } else {
-        // events (each one is a barrier packet on its stream): only the launches that exist are bracketed
-        bool side_used[lfr::KC_COUNT] = {};
-        if (have_side) {
-            HIP_TRY(hipEventRecord(b->ev_fork, st));
-            for (int cls = lfr::KC_GLOBAL; cls >= lfr::KC_BLOCK; --cls) {
-                if (b->class_begin[cls + 1] <= b->class_begin[cls]) continue;
-                hipStream_t ss = cls == lfr::KC_GLOBAL ? b->side_stream2 : b->side_stream;
-                HIP_TRY(hipStreamWaitEvent(ss, b->ev_fork, 0));
-                HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], ss));
-                const int rc = launch_block(cls, ss);
-                if (rc != LFR_OK) return rc;
-                HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], ss));
-                side_used[cls] = true; recorded |= 1u << cls;
-            }
-        }
+        // Launch plan.  A workgroup-per-component kernel needs a (nearly) empty CU for each of its
+        // 512-thread workgroups; once the packed launch has flooded the chip such a workgroup only gets a
+        // CU at the packed launch's tail, i.e. the two kernels would run back to back.  So when big-workgroup
+        // classes exist THEY go first, on the caller's stream, and the packed launch follows from a side
+        // stream (its cross-queue wait makes it the later dispatch) and fills the remaining CUs.
+        // Events are barrier packets on their stream: only the launches that exist are bracketed.
         PackedRanges r;
         int nb = 0;
         for (int i = 0; i < 5; ++i) {
@@ -1142,14 +1157,45 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             nb += (n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls];
         }
         r.blk_begin[5] = nb;
-        if (nb > 0) {      // the packed launch is timed as one unit: its events sit in the slot of the largest class
-            HIP_TRY(hipEventRecord(b->ev[2 + 2 * b->packed_slot], st));
-            hipLaunchKernelGGL(solve_packed_kernel, dim3(nb), blk, 0, st, a, r);
+        // the packed launch is timed as one unit: its events sit in the slot of the largest class
+        auto launch_packed = [&](hipStream_t cs) -> int {
+            HIP_TRY(hipEventRecord(b->ev[2 + 2 * b->packed_slot], cs));
+            hipLaunchKernelGGL(solve_packed_kernel, dim3(nb), blk, 0, cs, a, r);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], st));
+            HIP_TRY(hipEventRecord(b->ev[3 + 2 * b->packed_slot], cs));
             recorded |= 1u << b->packed_slot;
+            return LFR_OK;
+        };
+        auto launch_big = [&](int cls, hipStream_t cs) -> int {
+            HIP_TRY(hipEventRecord(b->ev[2 + 2 * cls], cs));
+            const int rc = launch_block(cls, cs);
+            if (rc != LFR_OK) return rc;
+            HIP_TRY(hipEventRecord(b->ev[3 + 2 * cls], cs));
+            recorded |= 1u << cls;
+            return LFR_OK;
+        };
+        const bool have_block = b->class_begin[lfr::KC_BLOCK + 1] > b->class_begin[lfr::KC_BLOCK];
+        const bool have_global = b->class_begin[lfr::KC_GLOBAL + 1] > b->class_begin[lfr::KC_GLOBAL];
+        if (!have_side) {
+            if (nb > 0) { const int rc = launch_packed(st); if (rc != LFR_OK) return rc; }
+        } else {
+            const int first = have_global ? lfr::KC_GLOBAL : lfr::KC_BLOCK;        // longest-running class on the caller's stream
+            const bool second = have_global && have_block;
+            if (second || nb > 0) HIP_TRY(hipEventRecord(b->ev_fork, st));
+            { const int rc = launch_big(first, st); if (rc != LFR_OK) return rc; }
+            if (second) {
+                HIP_TRY(hipStreamWaitEvent(b->side_stream2, b->ev_fork, 0));
+                const int rc = launch_big(lfr::KC_BLOCK, b->side_stream2);
+                if (rc != LFR_OK) return rc;
+            }
+            if (nb > 0) {
+                HIP_TRY(hipStreamWaitEvent(b->side_stream, b->ev_fork, 0));
+                const int rc = launch_packed(b->side_stream);
+                if (rc != LFR_OK) return rc;
+                HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * b->packed_slot], 0));
+            }
+            if (second) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0));
         }
-        for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls) if (side_used[cls]) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * cls], 0));
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfr_hip.so")
+LIB_PATH = os.environ.get("LFR_LIB_OVERRIDE") or os.path.join(_HERE, "liblfr_hip.so")   # override: A/B of kernel variants
 
 TUKEY = {"ceres1": 1, "ceres2": 2}
 TERM_CONVERGENCE, TERM_NO_CONVERGENCE, TERM_FAILURE = 0, 1, 2
