@@ -3,7 +3,7 @@
 match graph of BASELINE.json (configs[3] / SURVEY.md §8(d) "config 4": 1344 images, ~147k tracks,
 ~5.0M directed edges), inputs resident in HBM when the timed region starts.
 
-A step = one pass of the hot path (memset positions + every solve kernel) over one batch.
+A step = one pass of the hot path (every solve kernel; the output array is fully rewritten) over one batch.
 N > 1: one process per GPU (torch.distributed / RCCL); every rank solves its OWN 5M-edge graph
 (seed 2 + rank) — weak scaling, no data-path collective (components are independent,
 solve.cc:594-597); the statistics vector is all-reduced once for reporting.

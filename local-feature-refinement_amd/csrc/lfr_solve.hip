@@ -75,19 +75,23 @@ struct KernelArgs {
 #endif
 enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
 
-// Gauss-Jordan elimination of the damped normal equations held one row per lane (h[CPL] = the
-// lane's columns), no pivoting (SPD); padded rows are identity.  Step K: ONE burst of ds_swizzle
+// Gauss-Jordan elimination of the damped normal equations held one row per lane, no pivoting (SPD);
+// padded rows are identity.  The LPR lanes of a row hold its columns INTERLEAVED (lane part p owns
+// columns LPR*c + p in h[c]), so the columns already eliminated (j <= K) fall off both parts evenly
+// and the register loops of step K start at c0 = (K+1)/LPR.  Step K: ONE burst of ds_swizzle
 // broadcasts of the pivot row into distinct registers (a single LDS-crossbar round trip), a Newton
 // reciprocal of the pivot, then the rank-1 update.  Written as a compile-time recursion of nested
 // `if (K+1 < n)` so the unrolled steps share one exit and no copies of h[] are made at merges.
+// (Also skipping the columns beyond the wave's largest system behind scalar branches was measured:
+// the extra control flow costs ~150 spilled VGPRs and 25 % of the kernel.)
 template <int NV, int LPR, int K>
 struct GaussJordan {
     static constexpr int S = NV * LPR, CPL = NV / LPR;
     static constexpr int kPartAnd = (NV == 8) ? 0x18 : (NV == 16) ? 0x10 : 0x00;
     static __device__ __forceinline__ void run(double (&h)[NV / LPR], double &rhs, double &piv_own, double &minpiv,
                                                int row, int part, int n_steps) {
-        constexpr int pk = K / CPL, ck = K % CPL;                      // part / register holding column K
-        constexpr int c0 = (K - CPL * (LPR - 1) + 1 > 0) ? K - CPL * (LPR - 1) + 1 : 0;   // first column still live
+        constexpr int pk = K % LPR, ck = K / LPR;                      // part / register holding column K
+        constexpr int c0 = (K + 1) / LPR;                              // first register with a live column (> K)
         double pr[CPL];
 #pragma unroll
         for (int c = c0; c < CPL; ++c) pr[c] = swz_bcast<kPartAnd, K % 32>(h[c]);
@@ -155,7 +159,6 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     for (int m = 32; m >= 1; m >>= 1) nv2_max = max(nv2_max, __shfl_xor(nv2_max, m, 64));
     nv2_max = __builtin_amdgcn_readfirstlane(nv2_max);
 
-#ifndef LFR_STREAM_EDGES
     // ---- edges -> registers (the only HBM read of the solve) ----
     float flow[EPL][18];
     float sim[EPL];
@@ -177,7 +180,6 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         sim[k] = __uint_as_float(q[4].z);
         idx[k] = q[4].w;
     }
-#endif
     if (sl < NV) { L.x[sl] = 0.0; L.scale[sl] = 1.0; }
     if (sl < 2) L.x[NV + sl] = 0.0;
 
@@ -212,10 +214,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double aii = is_row ? A[row * LD + row] : 1.0;
                 if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
                 const double Dl = sqrt(diag / radius);
-                double h[CPL];                        // columns part*CPL .. part*CPL+CPL-1 of the own row
+                double h[CPL];                        // columns LPR*c + part of the own row
 #pragma unroll
                 for (int c = 0; c < CPL; ++c) {
-                    const int j = part * CPL + c;
+                    const int j = LPR * c + part;
                     double v = 0.0;
                     if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]) * scale * L.scale[j];
                     if (j == row) v = is_row ? v + Dl * Dl : 1.0;
@@ -267,32 +269,11 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         wave_lds_sync();
         PROF_MARK(6);                                 // 6: zero J^T J
         double cost_l = 0.0;
-#ifdef LFR_STREAM_EDGES
-#pragma unroll 1
-#else
 #pragma unroll
-#endif
         for (int k = 0; k < EPL; ++k) {
             if (!(pe && sl + S * k < E)) continue;
-#ifdef LFR_STREAM_EDGES
-            float flow_k[18]; float sim_k; uint32_t pk;
-            {
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
-                uint4 q[5];
-#pragma unroll
-                for (int i = 0; i < 5; ++i) q[i] = rp[i];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
-                    flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
-                }
-                flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
-                sim_k = __uint_as_float(q[4].z); pk = q[4].w;
-            }
-#else
             const float (&flow_k)[18] = flow[k]; const float sim_k = sim[k];
             uint32_t pk = idx[k];
-#endif
             asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
             const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
             const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
@@ -342,17 +323,16 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         // ======================= C: transitions (no cross-lane operations below) =======================
         bool decide = false;
         double cost_cand = 0.0;
+        if (pe && sl == 0) atomicAdd(&L.exec_passes, 1);          // statistics live in LDS: fire-and-forget ds_add
         if (phase == PH_EVAL_INIT) {
-            if (sl == 0) ++L.exec_passes;
             cost = cost_e; gi = gnew; gmax = gmax_new;
             scale = is_row ? 1.0 / (1.0 + sqrt(L.A[row * LD + row])) : 1.0;        // jacobi scaling, once
             if (own) L.scale[row] = scale;
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_REEVAL) {
-            if (sl == 0) ++L.exec_passes;
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_EVAL_LS) {
-            if (sl == 0) { ++L.exec_passes; ++L.n_ls_evals; }
+            if (sl == 0) atomicAdd(&L.n_ls_evals, 1);
             const bool value_valid = isfinite(cost_e);
             if (value_valid && !(cost_e > cost + kLsSufficientDecrease * g_dot_delta * alpha)) {
                 decide = true; cost_cand = cost_e;                                   // candidate == this sample
@@ -385,11 +365,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 }
             }
         } else if (phase == PH_EVAL_CAND) {
-            if (sl == 0) ++L.exec_passes;
             decide = true; cost_cand = isfinite(cost_e) ? cost_e : DBL_MAX;
         }
         if (decide) {
-            if (sl == 0) ++L.n_cand;
+            if (sl == 0) atomicAdd(&L.n_cand, 1);
             const double step_norm = sqrt(step_norm2);
             const double cost_change = cost - cost_cand;
             if (step_norm <= kParameterTol * (x_norm + kParameterTol)) phase = PH_DONE;          // candidate discarded
@@ -399,7 +378,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 if (rel > kMinRelDecrease) {
                     xi = xt; x_norm = sqrt(xnorm2_new); cost = cost_cand; gi = gnew; gmax = gmax_new;
                     step_successful = true;
-                    if (sl == 0) ++L.n_successful;
+                    if (sl == 0) atomicAdd(&L.n_successful, 1);
                     const double t = 2.0 * rel - 1.0;
                     radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
                     n_reject = 0; reuse_diagonal = false; a_dirty = false;
@@ -415,8 +394,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     PROF_FLUSH();
 
     if (have) {
-        if (own && term != LFR_TERM_FAILURE)
-            a.positions[2 * (size_t)a.node_ids[d.node_off + (row >> 1)] + (row & 1)] = xi;
+        if (own)       // every variable is written by every solve (a failed solve leaves 0, solve.cc:609-612)
+            a.positions[2 * (size_t)a.node_ids[d.node_off + (row >> 1)] + (row & 1)] = term != LFR_TERM_FAILURE ? xi : 0.0;
         if (sl == 0) {
             CompInfoDev inf;
             inf.iterations = iteration; inf.termination = term; inf.n_successful = L.n_successful;
@@ -804,9 +783,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     __syncthreads();
     PROF_MARK(4);
     PROF_FLUSH();
-    if (term != LFR_TERM_FAILURE)
-        for (int i = tid; i < n; i += kBlockThreads)
-            a.positions[2 * (size_t)a.node_ids[d.node_off + (i >> 1)] + (i & 1)] = vx[i];
+    for (int i = tid; i < n; i += kBlockThreads)
+        a.positions[2 * (size_t)a.node_ids[d.node_off + (i >> 1)] + (i & 1)] = term != LFR_TERM_FAILURE ? vx[i] : 0.0;
     if (tid == 0) {
         CompInfoDev inf;
         inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
@@ -1042,6 +1020,9 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
     }
     HIP_TRY(hipMalloc(&b->d_positions, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
+    // Roots, constants and nodes outside every solved component stay at 0 for the life of the batch
+    // (solve.cc:609-612); the kernels overwrite every variable on every solve, so no per-solve memset.
+    HIP_TRY(hipMemset(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
     HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
     HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
     HIP_TRY(hipMalloc(&b->d_es_off, nd * sizeof(uint64_t)));
@@ -1100,7 +1081,6 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     ++b->n_solves;
     if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
     HIP_TRY(hipEventRecord(b->ev[0], st));
-    HIP_TRY(hipMemsetAsync(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double), st));   // solve.cc:609-612
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
