@@ -160,11 +160,17 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     nv2_max = __builtin_amdgcn_readfirstlane(nv2_max);
 
     // ---- edges -> registers (the only HBM read of the solve) ----
-    float flow[EPL][18];
-    float sim[EPL];
-    uint32_t idx[EPL];          // src | (dst|kind<<15) << 16, decoded at every use (keeps 5 VGPRs/slot free)
+    // Slots beyond the third are re-read from HBM/L2 by every sweep instead of being held: only the
+    // <=256-edge class has them, and 80 resident flow registers there cost more in spills than the loads.
+#ifndef LFR_RES4
+#define LFR_RES4 2
+#endif
+    constexpr int RES = EPL <= 3 ? EPL : LFR_RES4;
+    float flow[RES][18];
+    float sim[RES];
+    uint32_t idx[RES];          // src | (dst|kind<<15) << 16, decoded at every use (keeps 5 VGPRs/slot free)
 #pragma unroll
-    for (int k = 0; k < EPL; ++k) {
+    for (int k = 0; k < RES; ++k) {
         const int e = sl + S * k;
         const bool on = e < E;
         const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (on ? e : 0));
@@ -272,8 +278,24 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
 #pragma unroll
         for (int k = 0; k < EPL; ++k) {
             if (!(pe && sl + S * k < E)) continue;
-            const float (&flow_k)[18] = flow[k]; const float sim_k = sim[k];
-            uint32_t pk = idx[k];
+            float flow_k[18]; float sim_k; uint32_t pk;
+            if (k < RES) {
+#pragma unroll
+                for (int i = 0; i < 18; ++i) flow_k[i] = flow[k < RES ? k : 0][i];
+                sim_k = sim[k < RES ? k : 0]; pk = idx[k < RES ? k : 0];
+            } else {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
+                uint4 q[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) q[i] = rp[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
+                    flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
+                }
+                flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
+                sim_k = __uint_as_float(q[4].z); pk = q[4].w;
+            }
             asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
             const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
             const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
