@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -82,19 +83,22 @@ enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, P
 // broadcasts of the pivot row into distinct registers (a single LDS-crossbar round trip), a Newton
 // reciprocal of the pivot, then the rank-1 update.  Written as a compile-time recursion of nested
 // `if (K+1 < n)` so the unrolled steps share one exit and no copies of h[] are made at merges.
-// (Also skipping the columns beyond the wave's largest system behind scalar branches was measured:
-// the extra control flow costs ~150 spilled VGPRs and 25 % of the kernel.)
-template <int NV, int LPR, int K>
+// (Skipping the columns beyond the wave's largest system behind scalar branches inside the steps was
+// measured: the extra control flow costs ~150 spilled VGPRs and 25 % of the kernel - hence the CL
+// instantiations below, selected once per step.)
+// CL = registers per lane that can hold live columns: the caller picks the smallest instantiation that
+// covers the largest system of the wave (wave-uniform), so columns beyond it cost nothing.
+template <int NV, int LPR, int K, int CL>
 struct GaussJordan {
-    static constexpr int S = NV * LPR, CPL = NV / LPR;
+    static constexpr int S = NV * LPR;
     static constexpr int kPartAnd = (NV == 8) ? 0x18 : (NV == 16) ? 0x10 : 0x00;
-    static __device__ __forceinline__ void run(double (&h)[NV / LPR], double &rhs, double &piv_own, double &minpiv,
+    static __device__ __forceinline__ void run(double (&h)[CL], double &rhs, double &piv_own, double &minpiv,
                                                int row, int part, int n_steps) {
         constexpr int pk = K % LPR, ck = K / LPR;                      // part / register holding column K
         constexpr int c0 = (K + 1) / LPR;                              // first register with a live column (> K)
-        double pr[CPL];
+        double pr[CL];
 #pragma unroll
-        for (int c = c0; c < CPL; ++c) pr[c] = swz_bcast<kPartAnd, K % 32>(h[c]);
+        for (int c = c0; c < CL; ++c) pr[c] = swz_bcast<kPartAnd, K % 32>(h[c]);
         const double prhs = swz_bcast<kPartAnd, K % 32>(rhs);
         const double piv = (S == 64) ? readlane_f64(h[ck], K + NV * pk)
                                      : swz_bcast<(S == 8) ? 0x18 : (S == 16) ? 0x10 : 0x00, (K + NV * pk) % 32>(h[ck]);
@@ -109,10 +113,10 @@ struct GaussJordan {
         f = is_k ? 0.0 : f;
         piv_own = is_k ? piv : piv_own;
 #pragma unroll
-        for (int c = c0; c < CPL; ++c) h[c] = fma(-f, pr[c], h[c]);
+        for (int c = c0; c < CL; ++c) h[c] = fma(-f, pr[c], h[c]);
         rhs = fma(-f, prhs, rhs);
-        if constexpr (K + 1 < NV) {
-            if (K + 1 < n_steps) GaussJordan<NV, LPR, K + 1>::run(h, rhs, piv_own, minpiv, row, part, n_steps);
+        if constexpr (K + 1 < CL * LPR && K + 1 < NV) {
+            if (K + 1 < n_steps) GaussJordan<NV, LPR, K + 1, CL>::run(h, rhs, piv_own, minpiv, row, part, n_steps);
         }
     }
 };
@@ -220,22 +224,39 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double aii = is_row ? A[row * LD + row] : 1.0;
                 if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
                 const double Dl = sqrt(diag / radius);
-                double h[CPL];                        // columns LPR*c + part of the own row
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) {
-                    const int j = LPR * c + part;
-                    double v = 0.0;
-                    if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]) * scale * L.scale[j];
-                    if (j == row) v = is_row ? v + Dl * Dl : 1.0;
-                    h[c] = v;
-                }
                 double rhs = is_row ? scale * gi : 0.0;
                 const double rhs0 = rhs;
                 double piv_own = 1.0;
                 bool fail = false;
-                PROF_MARK(5);                         // 5: step setup (diagonal, h build)
                 double minpiv = 1.0;
-                GaussJordan<NV, LPR, 0>::run(h, rhs, piv_own, minpiv, row, part, nv2_max);
+                // build the lane's columns (LPR*c + part of the own row) and eliminate, in the instantiation
+                // sized for the largest system of the wave
+                auto lm_solve = [&](auto cl_tag) {
+                    constexpr int CL = decltype(cl_tag)::value;
+                    double h[CL];
+#pragma unroll
+                    for (int c = 0; c < CL; ++c) {
+                        const int j = LPR * c + part;
+                        double v = 0.0;
+                        if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]) * scale * L.scale[j];
+                        if (j == row) v = is_row ? v + Dl * Dl : 1.0;
+                        h[c] = v;
+                    }
+                    PROF_MARK(5);                     // 5: step setup (diagonal, h build)
+                    GaussJordan<NV, LPR, 0, CL>::run(h, rhs, piv_own, minpiv, row, part, nv2_max);
+                };
+                const int c_hi = (nv2_max + LPR - 1) / LPR;          // wave-uniform
+#define LFR_CL(n) lm_solve(std::integral_constant<int, n>{})
+                if constexpr (CPL == 8 && LPR == 1) {             // rows come in pairs: even sizes only
+                    if (c_hi <= 2) LFR_CL(2); else if (c_hi <= 4) LFR_CL(4); else if (c_hi <= 6) LFR_CL(6); else LFR_CL(8);
+                } else if constexpr (CPL == 8) {
+                    if (c_hi <= 4) LFR_CL(4); else if (c_hi <= 6) LFR_CL(6); else if (c_hi <= 7) LFR_CL(7); else LFR_CL(8);
+                } else if constexpr (LPR == 1) {
+                    if (c_hi <= 10) LFR_CL(10); else if (c_hi <= 12) LFR_CL(12); else if (c_hi <= 14) LFR_CL(14); else LFR_CL(16);
+                } else {
+                    if (c_hi <= 10) LFR_CL(10); else if (c_hi <= 12) LFR_CL(12); else if (c_hi <= 14) LFR_CL(14); else LFR_CL(16);
+                }
+#undef LFR_CL
                 fail = !(minpiv > 0.0);
                 const double step = is_row ? -(rhs * fast_rcp(piv_own)) : 0.0;
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
