@@ -290,7 +290,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         const bool pe = phase == PH_EVAL_INIT || phase == PH_EVAL_LS || phase == PH_EVAL_CAND || phase == PH_REEVAL;
         if (!__any(pe)) continue;
         if (pe) {
-            for (int i = sl; i < NV * LD; i += S) L.A[i] = 0.0;
+            for (int i = sl; i < nv2 * LD; i += S) L.A[i] = 0.0;       // rows >= nv2 are never touched
             if (sl < NV) L.g[sl] = 0.0;
         }
         wave_lds_sync();
@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_packed_kernel(Kern
     const int b = (int)blockIdx.x;
     if (b < r.blk_begin[1]) {
         a.desc_begin = r.desc_begin[0]; a.desc_end = r.desc_end[0]; a.cls = lfr::KC_G64_4;
-        solve_group_body<32, 2, 4>(a, b - r.blk_begin[0], lds_raw);
+        solve_group_body<32, 2, 5>(a, b - r.blk_begin[0], lds_raw);
     } else if (b < r.blk_begin[2]) {
         a.desc_begin = r.desc_begin[1]; a.desc_end = r.desc_end[1]; a.cls = lfr::KC_G64_2;
         solve_group_body<32, 2, 2>(a, b - r.blk_begin[1], lds_raw);
@@ -1156,7 +1156,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                     case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G32:   hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 2, 2>), grid, blk, 0, st, a); break;
-                    case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 4>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 5>), grid, blk, 0, st, a); break;
                     default: { const int rc = launch_block(cls, st); if (rc != LFR_OK) return rc; }
                 }
                 HIP_TRY(hipGetLastError());
