@@ -141,7 +141,7 @@ def main():
             "passes_per_edge_reference": st["dominant_ref_passes_edges"] / max(1, st["dominant_kernel_edges"]),
             "read_once_bytes": int(b_once), "read_once_achieved": b_once / dur_s / 1e9,
             "note": "achieved = SURVEY 8(d) streaming bytes (84 B/edge + 32 B/node per evaluation pass Ceres performs) "
-                    "/ launch time; the kernel keeps edges in VGPRs so it reads HBM once (read_once_*)",
+                    "/ launch time; the kernel keeps edges in VGPRs so it reads HBM about once (read_once_*; traffic = PMC-measured bytes)",
         }
         res["all_kernels_ms"] = tot_ms
         keep = range(7) if serial else [dom if dom < 5 else 0, 5, 6]
