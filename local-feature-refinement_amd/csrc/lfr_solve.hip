@@ -136,6 +136,11 @@ struct GroupLds {
 #ifndef LFR_GROUP_WAVES
 #define LFR_GROUP_WAVES 2          // waves per SIMD the packed kernel is register-budgeted for
 #endif
+#ifndef LFR_PACKED_WAVES
+#define LFR_PACKED_WAVES 1         // waves per workgroup of the packed kernel: the waves are independent, and a
+                                  // one-wave workgroup frees its slot the moment it finishes (4 -> 1: -7 %)
+#endif
+constexpr int kPackedWaves = LFR_PACKED_WAVES;
 template <int NV, int LPR, int EPL>
 __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int block_in_class, unsigned char *lds_raw) {
     constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
@@ -145,7 +150,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = lane / S, sl = lane % S;
     const int row = sl % NV, part = sl / NV;
-    const int ci0 = a.desc_begin + (block_in_class * 4 + wave) * G;
+    const int ci0 = a.desc_begin + (block_in_class * kPackedWaves + wave) * G;
     if (ci0 >= a.desc_end) return;                    // wave-uniform
     const int ci = ci0 + gid;
     const bool have = ci < a.desc_end;
@@ -449,13 +454,13 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     }
 }
 
-constexpr size_t kPackedLdsBytes = 4 * sizeof(GroupLds<16>) * 4 > 4 * sizeof(GroupLds<32>) ? 4 * sizeof(GroupLds<16>) * 4 : 4 * sizeof(GroupLds<32>);
-static_assert(kPackedLdsBytes >= 4 * 8 * sizeof(GroupLds<8>) && kPackedLdsBytes >= 4 * 2 * sizeof(GroupLds<16>), "LDS budget");
+constexpr size_t kPackedLdsBytes = kPackedWaves * (sizeof(GroupLds<16>) * 4 > sizeof(GroupLds<32>) ? sizeof(GroupLds<16>) * 4 : sizeof(GroupLds<32>));
+static_assert(kPackedLdsBytes >= kPackedWaves * 8 * sizeof(GroupLds<8>) && kPackedLdsBytes >= kPackedWaves * 2 * sizeof(GroupLds<16>), "LDS budget");
 
 // one class per launch (diagnostics: LFR_SERIAL_CLASSES=1 gives per-class timings)
 template <int NV, int LPR, int EPL>
-__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_group_kernel(const KernelArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[4 * (64 / (NV * LPR)) * sizeof(GroupLds<NV>)];
+__global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_group_kernel(const KernelArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kPackedWaves * (64 / (NV * LPR)) * sizeof(GroupLds<NV>)];
     solve_group_body<NV, LPR, EPL>(a, (int)blockIdx.x, lds_raw);
 }
 
@@ -467,7 +472,7 @@ struct PackedRanges {
     int blk_begin[6];          // G64_4, G64_2, G32, G16, G8 in dispatch order
     int desc_begin[5], desc_end[5];
 };
-__global__ __launch_bounds__(256, LFR_GROUP_WAVES) void solve_packed_kernel(KernelArgs a, const PackedRanges r) {
+__global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_packed_kernel(KernelArgs a, const PackedRanges r) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kPackedLdsBytes];
     const int b = (int)blockIdx.x;
     if (b < r.blk_begin[1]) {
@@ -1128,8 +1133,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
     static const int kPackedOrder[5] = {lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
-    static const int kCompsPerBlock[lfr::KC_COUNT] = {32, 16, 8, 4, 4, 1, 1};
-    const dim3 blk(256);
+    static const int kCompsPerBlock[lfr::KC_COUNT] = {8 * kPackedWaves, 4 * kPackedWaves, 2 * kPackedWaves, kPackedWaves, kPackedWaves, 1, 1};
+    const dim3 blk(64 * kPackedWaves);
     auto launch_block = [&](int cls, hipStream_t cs) -> int {
         a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
         const int n = a.desc_end - a.desc_begin;
