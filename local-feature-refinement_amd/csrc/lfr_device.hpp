@@ -43,6 +43,19 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     g = fma(g, e, g);
     return fma(fma(-g, g, x), h, g);                   // final residual correction
 }
+// A literal pinned into an SGPR pair at the point of use: without it the compiler hoists the ten
+// series coefficients below out of the solve loop and parks them in 20 VGPRs for the whole kernel
+// (plus a v_mov_b64 in front of every v_fmac).  SALU moves issue beside the other wave's VALU work.
+__device__ __forceinline__ double sgpr_const(double c) {
+    asm volatile("" : "+s"(c));
+    return c;
+}
+// f32 -> f64 that can be neither hoisted nor CSE'd (see eval_edge) and needs no copy of its source
+__device__ __forceinline__ double cvt_pinned(float x) {
+    double d;
+    asm volatile("v_cvt_f64_f32_e32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
+}
 // log(x) for finite x >= 1 (the Cauchy loss evaluates log(1 + s/b)): x = m * 2^e with m in
 // [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) by its odd series (|z| <= 0.1716, 11 terms),
 // e*ln2 added in two pieces.  ~35 instructions instead of ~90 of the generic libm log; error ~1 ulp.
@@ -52,10 +65,11 @@ __device__ __forceinline__ double log_ge1(double x) {
     if (m < 0.70710678118654752440) { m *= 2.0; --e; }
     const double z = (m - 1.0) * fast_rcp(m + 1.0);
     const double w = z * z;
-    double p = 1.0 / 23.0;
-    p = fma(p, w, 1.0 / 21.0); p = fma(p, w, 1.0 / 19.0); p = fma(p, w, 1.0 / 17.0); p = fma(p, w, 1.0 / 15.0);
-    p = fma(p, w, 1.0 / 13.0); p = fma(p, w, 1.0 / 11.0); p = fma(p, w, 1.0 / 9.0); p = fma(p, w, 1.0 / 7.0);
-    p = fma(p, w, 1.0 / 5.0); p = fma(p, w, 1.0 / 3.0);
+    double p = sgpr_const(1.0 / 23.0);
+    p = fma(p, w, sgpr_const(1.0 / 21.0)); p = fma(p, w, sgpr_const(1.0 / 19.0)); p = fma(p, w, sgpr_const(1.0 / 17.0));
+    p = fma(p, w, sgpr_const(1.0 / 15.0)); p = fma(p, w, sgpr_const(1.0 / 13.0)); p = fma(p, w, sgpr_const(1.0 / 11.0));
+    p = fma(p, w, sgpr_const(1.0 / 9.0)); p = fma(p, w, sgpr_const(1.0 / 7.0)); p = fma(p, w, sgpr_const(1.0 / 5.0));
+    p = fma(p, w, sgpr_const(1.0 / 3.0));
     const double lm = fma(2.0 * z * w, p, 2.0 * z);    // log(m)
     const double ed = (double)e;
     return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
@@ -73,6 +87,8 @@ struct EdgeOut {
 // f_k = sum_i Lr_i (sum_j Lc_j d_ijk): same 54 FMAs for value + both partials but no table of 27
 // weight products, so the live set stays ~45 VGPRs (the association differs from the reference's
 // (Lr_i*Lc_j)*d by rounding only, ~1e-16 relative).
+// WANT_JAC = false evaluates the cost only: no derivative sums, no rho', no corrected residual/jacobian
+// (o.cost is the only valid output).
 template <bool WANT_JAC>
 __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, int kind, int tukey_variant,
                                           double x1r, double x1c, double x2r, double x2c, EdgeOut &o) {
@@ -85,17 +101,17 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     for (int i = 0; i < 3; ++i) {
         // The flows never change during a solve, so the compiler would hoist the f32->f64
         // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
-        // The empty asm makes the values opaque: the conversions stay next to their use.
-        float a0 = flow[6 * i], a1 = flow[6 * i + 1], b0 = flow[6 * i + 2], b1 = flow[6 * i + 3],
-              c0 = flow[6 * i + 4], c1 = flow[6 * i + 5];
-        asm volatile("" : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1), "+v"(c0), "+v"(c1));
-        const double t0 = lc[0] * (double)a0 + lc[1] * (double)b0 + lc[2] * (double)c0;
-        const double t1 = lc[0] * (double)a1 + lc[1] * (double)b1 + lc[2] * (double)c1;
+        // The conversions are volatile asm: they stay next to their use (and read the resident
+        // float registers directly).
+        const double a0 = cvt_pinned(flow[6 * i]), a1 = cvt_pinned(flow[6 * i + 1]), b0 = cvt_pinned(flow[6 * i + 2]),
+                     b1 = cvt_pinned(flow[6 * i + 3]), c0 = cvt_pinned(flow[6 * i + 4]), c1 = cvt_pinned(flow[6 * i + 5]);
+        const double t0 = lc[0] * a0 + lc[1] * b0 + lc[2] * c0;
+        const double t1 = lc[0] * a1 + lc[1] * b1 + lc[2] * c1;
         const double lri = (i == 0) ? 2. * row * (row - .5) : (i == 1) ? (-4.) * (row - .5) * (row + .5) : 2. * row * (row + .5);
         f0 += lri * t0; f1 += lri * t1;
         if (WANT_JAC) {
-            const double u0 = dlc[0] * (double)a0 + dlc[1] * (double)b0 + dlc[2] * (double)c0;
-            const double u1 = dlc[0] * (double)a1 + dlc[1] * (double)b1 + dlc[2] * (double)c1;
+            const double u0 = dlc[0] * a0 + dlc[1] * b0 + dlc[2] * c0;
+            const double u1 = dlc[0] * a1 + dlc[1] * b1 + dlc[2] * c1;
             const double dlri = (i == 0) ? 2. * row + 2. * (row - .5) : (i == 1) ? (-4.) * (row - .5) + (-4.) * (row + .5)
                                                                                  : 2. * row + 2. * (row + .5);
             dr0 += dlri * t0; dr1 += dlri * t1;
@@ -108,14 +124,12 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     }
     const double r0 = x2r - x1r - f0, r1 = x2c - x1c - f1;       // cost.cc:87
     const double s = r0 * r0 + r1 * r1;
-    float simo = simf;
-    asm volatile("" : "+v"(simo));
-    const double w = (double)simo;
+    const double w = cvt_pinned(simf);
     double rho0, rho1;
     if (kind == 0) {                                              // CauchyLoss(0.25)
-        const double sum = 1.0 + s * kCauchyC, inv = fast_rcp(sum);
+        const double sum = 1.0 + s * kCauchyC;
         rho0 = kCauchyB * log_ge1(sum);
-        rho1 = fmax(DBL_MIN, inv);
+        rho1 = WANT_JAC ? fmax(DBL_MIN, fast_rcp(sum)) : 1.0;
     } else {                                                      // TukeyLoss(0.0625)
         const double k0 = (tukey_variant == 1) ? kTukeyA2 / 6.0 : kTukeyA2 / 3.0;
         const double k1 = (tukey_variant == 1) ? 0.5 : 1.0;
@@ -125,9 +139,11 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
             rho1 = k1 * v2;
         } else { rho0 = k0; rho1 = 0.0; }
     }
-    rho0 *= w; rho1 *= w;
-    const double sq = fast_sqrt(rho1);  // Corrector, rho'' <= 0 branch
+    rho0 *= w;
     o.cost = 0.5 * rho0;
+    if (!WANT_JAC) return;
+    rho1 *= w;
+    const double sq = fast_sqrt(rho1);  // Corrector, rho'' <= 0 branch
     o.r0 = r0 * sq; o.r1 = r1 * sq; o.sq = sq;
     if (WANT_JAC) {
         o.j00 = (-1.0 - dr0) * sq; o.j01 = (-dc0) * sq;

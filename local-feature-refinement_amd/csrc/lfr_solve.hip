@@ -206,6 +206,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     double g_dot_delta = 0.0, model_cost_change = 0.0, alpha = 1.0;
     int n_reject = 0;                                 // decrease_factor = 2^(1 + n_reject)  (Ceres: 2, 4, 8, ...)
     bool reuse_diagonal = false, step_successful = true, a_dirty = false;
+    bool cost_only = false;                           // this round evaluates the cost only (predicted last iteration)
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
     if (sl == 0) { L.n_successful = 0; L.n_ls_evals = 0; L.n_cand = 0; L.exec_passes = 0; L.ls_iter = 0; L.ls_prev_flags = 0; }
 
@@ -281,6 +282,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                         n_invalid = 0;
                         model_cost_change = mcc; delta = dl; g_dot_delta = gdd;
                         alpha = 1.0;
+                        // A predicted decrease below the function tolerance almost always ends the solve at the
+                        // next test (config 4: every final iteration, 0.1 % of the others): evaluate the cost only;
+                        // if the solve does not stop there, the same point is evaluated again in full.
+                        cost_only = mcc <= kFunctionTol * cost;
                         if (sl == 0) { L.dir_max = dmx; L.ls_iter = 0; L.ls_prev_flags = 0; }
                         xt = clampb(__dadd_rn(xi, delta));
                         if (own) L.x[row] = xt;
@@ -294,66 +299,103 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         // ======================= B: one sweep over the edges of the evaluating groups =======================
         const bool pe = phase == PH_EVAL_INIT || phase == PH_EVAL_LS || phase == PH_EVAL_CAND || phase == PH_REEVAL;
         if (!__any(pe)) continue;
-        if (pe) {
+        const bool jac = !cost_only;                  // (cost_only is only ever set in PH_EVAL_LS)
+        if (pe && jac) {
             for (int i = sl; i < nv2 * LD; i += S) L.A[i] = 0.0;       // rows >= nv2 are never touched
             if (sl < NV) L.g[sl] = 0.0;
         }
         wave_lds_sync();
         PROF_MARK(6);                                 // 6: zero J^T J
         double cost_l = 0.0;
+        if (__any(pe && jac)) {
+            // full sweep (a cost-only group riding in this wave evaluates in full too, but assembles nothing)
 #pragma unroll
-        for (int k = 0; k < EPL; ++k) {
-            if (!(pe && sl + S * k < E)) continue;
-            float flow_k[18]; float sim_k; uint32_t pk;
-            if (k < RES) {
+            for (int k = 0; k < EPL; ++k) {
+                if (!(pe && sl + S * k < E)) continue;
+                float flow_k[18]; float sim_k; uint32_t pk;
+                if (k < RES) {
 #pragma unroll
-                for (int i = 0; i < 18; ++i) flow_k[i] = flow[k < RES ? k : 0][i];
-                sim_k = sim[k < RES ? k : 0]; pk = idx[k < RES ? k : 0];
-            } else {
-                const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
-                uint4 q[5];
+                    for (int i = 0; i < 18; ++i) flow_k[i] = flow[k < RES ? k : 0][i];
+                    sim_k = sim[k < RES ? k : 0]; pk = idx[k < RES ? k : 0];
+                } else {
+                    const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
+                    uint4 q[5];
 #pragma unroll
-                for (int i = 0; i < 5; ++i) q[i] = rp[i];
+                    for (int i = 0; i < 5; ++i) q[i] = rp[i];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
-                    flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
+                    for (int i = 0; i < 4; ++i) {
+                        flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
+                        flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
+                    }
+                    flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
+                    sim_k = __uint_as_float(q[4].z); pk = q[4].w;
                 }
-                flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
-                sim_k = __uint_as_float(q[4].z); pk = q[4].w;
+                asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
+                const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
+                const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
+                const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
+                EdgeOut o;
+                eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                cost_l += o.cost;
+                if (!jac) continue;
+                double *A = L.A, *g = L.g;
+                // The neighbouring lane (lane ^ 1) holds the opposite direction of the same match (packed classes
+                // are assembled in edge-id order: records 2m, 2m+1), so its d r / d x_dst = sq' * I terms land on
+                // THIS lane's source block and the two cross blocks coincide: exchange them through DPP and issue
+                // 7 LDS atomics per edge instead of 17.
+                const int q = sl & 1;
+                const double p_w = dpp_f64<kDppQuadXor1>(o.sq * o.sq);
+                const double p_g0 = dpp_f64<kDppQuadXor1>(o.sq * o.r0);
+                const double p_g1 = dpp_f64<kDppQuadXor1>(o.sq * o.r1);
+                // cross block M[rb+i][ra+j] = sq*J_ij + sq'*J'_ji: the even lane owns (0,0),(1,1), the odd lane (1,0),(0,1)
+                const double c_send1 = o.sq * (q ? o.j00 : o.j01), c_send2 = o.sq * (q ? o.j11 : o.j10);
+                const double c_own1 = o.sq * (q ? o.j10 : o.j00), c_own2 = o.sq * (q ? o.j01 : o.j11);
+                const double c1 = c_own1 + dpp_f64<kDppQuadXor1>(c_send1);
+                const double c2 = c_own2 + dpp_f64<kDppQuadXor1>(c_send2);
+                if (ra >= 0) {
+                    atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10 + p_w);
+                    atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
+                    atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11 + p_w);
+                    atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1 + p_g0);
+                    atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1 + p_g1);
+                }
+                if (ra >= 0 && rb >= 0) {
+                    const int r1 = rb + q, k1 = ra, r2 = rb + 1 - q, k2 = ra + 1;
+                    atomicAdd(&A[rb > ra ? r1 * LD + k1 : k1 * LD + r1], c1);
+                    atomicAdd(&A[rb > ra ? r2 * LD + k2 : k2 * LD + r2], c2);
+                }
             }
-            asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
-            const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
-            const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
-            const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
-            EdgeOut o;
-            eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
-            cost_l += o.cost;
-            double *A = L.A, *g = L.g;
-            // The neighbouring lane (lane ^ 1) holds the opposite direction of the same match (packed classes
-            // are assembled in edge-id order: records 2m, 2m+1), so its d r / d x_dst = sq' * I terms land on
-            // THIS lane's source block and the two cross blocks coincide: exchange them through DPP and issue
-            // 7 LDS atomics per edge instead of 17.
-            const int q = sl & 1;
-            const double p_w = dpp_f64<kDppQuadXor1>(o.sq * o.sq);
-            const double p_g0 = dpp_f64<kDppQuadXor1>(o.sq * o.r0);
-            const double p_g1 = dpp_f64<kDppQuadXor1>(o.sq * o.r1);
-            // cross block M[rb+i][ra+j] = sq*J_ij + sq'*J'_ji: the even lane owns (0,0),(1,1), the odd lane (1,0),(0,1)
-            const double c_send1 = o.sq * (q ? o.j00 : o.j01), c_send2 = o.sq * (q ? o.j11 : o.j10);
-            const double c_own1 = o.sq * (q ? o.j10 : o.j00), c_own2 = o.sq * (q ? o.j01 : o.j11);
-            const double c1 = c_own1 + dpp_f64<kDppQuadXor1>(c_send1);
-            const double c2 = c_own2 + dpp_f64<kDppQuadXor1>(c_send2);
-            if (ra >= 0) {
-                atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10 + p_w);
-                atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
-                atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11 + p_w);
-                atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1 + p_g0);
-                atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1 + p_g1);
-            }
-            if (ra >= 0 && rb >= 0) {
-                const int r1 = rb + q, k1 = ra, r2 = rb + 1 - q, k2 = ra + 1;
-                atomicAdd(&A[rb > ra ? r1 * LD + k1 : k1 * LD + r1], c1);
-                atomicAdd(&A[rb > ra ? r2 * LD + k2 : k2 * LD + r2], c2);
+        } else {
+            // every evaluating group of the wave wants the cost only: no derivatives, no assembly
+#pragma unroll
+            for (int k = 0; k < EPL; ++k) {
+                if (!(pe && sl + S * k < E)) continue;
+                float flow_k[18]; float sim_k; uint32_t pk;
+                if (k < RES) {
+#pragma unroll
+                    for (int i = 0; i < 18; ++i) flow_k[i] = flow[k < RES ? k : 0][i];
+                    sim_k = sim[k < RES ? k : 0]; pk = idx[k < RES ? k : 0];
+                } else {
+                    const uint4 *rp = reinterpret_cast<const uint4 *>(a.edges + d.edge_off + (sl + S * k));
+                    uint4 q[5];
+#pragma unroll
+                    for (int i = 0; i < 5; ++i) q[i] = rp[i];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        flow_k[4 * i] = __uint_as_float(q[i].x); flow_k[4 * i + 1] = __uint_as_float(q[i].y);
+                        flow_k[4 * i + 2] = __uint_as_float(q[i].z); flow_k[4 * i + 3] = __uint_as_float(q[i].w);
+                    }
+                    flow_k[16] = __uint_as_float(q[4].x); flow_k[17] = __uint_as_float(q[4].y);
+                    sim_k = __uint_as_float(q[4].z); pk = q[4].w;
+                }
+                asm volatile("" : "+v"(pk));              // decode here, do not hoist 5 derived values per slot
+                const int es = (int)(pk & 0xffffu), ed = (int)((pk >> 16) & 0x7fffu), ekind = (int)(pk >> 31);
+                const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
+                const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
+                EdgeOut o;
+                (void)ra; (void)rb;
+                eval_edge<false>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                cost_l += o.cost;
             }
         }
         wave_lds_sync();
@@ -379,6 +421,18 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_REEVAL) {
             a_dirty = false; phase = PH_SOLVE;
+        } else if (phase == PH_EVAL_LS && cost_only) {
+            // Speculative cost-only round: without the jacobian only the two "converged, candidate discarded"
+            // outcomes can be taken.  Anything else (accept, reject, Armijo contraction) repeats the
+            // evaluation of the same point in full next round; nothing is counted for this one.
+            cost_only = false;
+            const bool armijo = isfinite(cost_e) && !(cost_e > cost + kLsSufficientDecrease * g_dot_delta * alpha);
+            const bool stop = armijo && (sqrt(step_norm2) <= kParameterTol * (x_norm + kParameterTol) ||
+                                         fabs(cost - cost_e) <= kFunctionTol * cost);
+            if (stop) {
+                if (sl == 0) atomicAdd(&L.n_ls_evals, 1);
+                decide = true; cost_cand = cost_e;
+            }
         } else if (phase == PH_EVAL_LS) {
             if (sl == 0) atomicAdd(&L.n_ls_evals, 1);
             const bool value_valid = isfinite(cost_e);
