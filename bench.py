@@ -157,11 +157,14 @@ def main():
             import lfr_oracle
             cores = args.cpu_threads or os.cpu_count() or 1
             ref = lfr_oracle.run(ma, n_threads=cores)
+            ref2 = lfr_oracle.run(ma, n_threads=cores)          # best of two: the host side of a GPU box is noisy
+            if ref2["solver_ms"] < ref["solver_ms"]:
+                ref = ref2
             err = float(np.abs(batch.download() - ref["positions"]).max())
             res["cpu_baseline"] = {
                 "value": st["n_edges"] / (ref["solver_ms"] * 1e-3), "unit": "edges/s", "cores": cores, "kind": "port",
-                "sample": "the whole rank-0 graph (%d edges), Solver span only, C restatement of the Ceres path "
-                          "(oracle/lfr_oracle.c, -O2), not Ceres" % st["n_edges"],
+                "sample": "the whole rank-0 graph (%d edges), Solver span only, best of two runs, C restatement of the "
+                          "Ceres path (oracle/lfr_oracle.c, -O2), not Ceres" % st["n_edges"],
                 "solver_ms": ref["solver_ms"], "graph_stage_ms": ref["graph_ms"],
                 "max_abs_diff_vs_gpu_units": err,
             }
