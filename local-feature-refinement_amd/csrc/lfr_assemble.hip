@@ -159,6 +159,23 @@ __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t
     ids[e] = (uint32_t)e;
 }
 
+// packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
+// kernel's pair exchange relies on it)
+__global__ void k_check_pairs(int64_t total_edges, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
+                              const int32_t *comp, const int32_t *di_of_comp, const uint32_t *class_of_desc,
+                              const uint32_t *edge_off, int *flag) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= total_edges) return;
+    const uint32_t e = edge_sorted[p];
+    uint32_t s, d;
+    edge_ends(node1, node2, e, s, d);
+    const uint32_t di = (uint32_t)di_of_comp[comp[s]];
+    if (class_of_desc[di] >= (uint32_t)KC_BLOCK) return;
+    const uint32_t local = (uint32_t)p - edge_off[di];
+    const int64_t q = (local & 1u) ? p - 1 : p + 1;
+    if (q < 0 || q >= total_edges || edge_sorted[q] != (e ^ 1u)) *flag = 1;
+}
+
 // one thread per (edge record, 16-byte chunk): writes EdgeRec, counts degrees, records run starts
 __global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
@@ -358,6 +375,16 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_di.as<int32_t>(), class_sorted, b_kept.as<uint8_t>(),
                        b_ek0.as<uint64_t>(), b_ei0.as<uint32_t>());
     if ((rc = sort_pairs(b_ek0.as<uint64_t>(), b_ek1.as<uint64_t>(), b_ei0.as<uint32_t>(), b_ei1.as<uint32_t>(), E2, 0, 64, st)) != LFR_OK) return rc;
+
+    HIP_TRY(hipMemsetAsync(b_flag.p, 0, 4, st));
+    hipLaunchKernelGGL(k_check_pairs, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2, comp,
+                       b_di.as<int32_t>(), class_sorted, b_eo.as<uint32_t>(), b_flag.as<int>());
+    {
+        int unpaired = 0;
+        HIP_TRY(hipMemcpyAsync(&unpaired, b_flag.p, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
+    }
 
     // ---- records, degrees, in-edge lists ----
     HIP_TRY(hipMalloc(&out.d_edges, std::max<size_t>(sizeof(EdgeRec) * total_edges, 16)));

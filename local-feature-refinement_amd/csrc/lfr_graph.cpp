@@ -6,6 +6,7 @@
 // Image names are interned to integers at ingest: every use in the reference is an equality
 // test (std::set<std::string> intersection/union, solve.cc:493-519).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstring>
 #include <numeric>
@@ -434,6 +435,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
         }
         dcuts.push_back((int64_t)metas.size());
     }
+    std::atomic<int> pair_err{0};
     parallel_chunks(dcuts, [&](int, int64_t dlo, int64_t dhi) {
         std::vector<int64_t> kept;
         for (int64_t di = dlo; di < dhi; ++di) {
@@ -468,7 +470,13 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
                     kept.push_back(e);
                 }
             }
-            if (by_edge_id) std::sort(kept.begin(), kept.end());
+            if (by_edge_id) {
+                std::sort(kept.begin(), kept.end());
+                // the packed kernel's pair exchange relies on it: both directions of every match are present
+                bool paired = kept.size() % 2 == 0;
+                for (size_t q = 0; paired && q < kept.size(); q += 2) paired = (kept[q] ^ 1) == kept[q + 1];
+                if (!paired) { pair_err.store(1); return; }
+            }
             for (const int64_t e : kept) {
                 const uint32_t n = edge_src(e), dn = edge_dst(e);
                 const int kind = p.track[n] == p.track[dn] ? 0 : 1;
@@ -491,6 +499,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
             }
         }
     });
+    if (pair_err.load()) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
     for (const Meta &mt : metas) p.stats.n_solved_tracks += mt.n_tracks;
     p.stats.n_solved_components = (int64_t)metas.size();
     p.stats.n_solved_edges = total_edges;

@@ -750,38 +750,128 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         matrix_valid = false;
         __syncthreads();
         PROF_MARK(5);                                 // 5: scaling
-        // ---- LDL^T in place (right-looking), d on the diagonal, unit L below ----
+        // ---- blocked LDL^T in place (right-looking, panels of kPanel columns) ----
+        // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal and 1/d_k
+        // goes to vinv[k].  Every sequential step of a factorization costs an LDS round trip (~10^3 cycles
+        // with its barrier) whatever it computes, so the work is cut into n/kPanel steps: (1) one thread
+        // factors the kPanel x kPanel diagonal block IN REGISTERS, (2) one thread per row below finishes the
+        // row's panel entries in registers, (3) the trailing matrix takes the rank-kPanel update in 4x4
+        // register tiles.
+        constexpr int kPanel = 8;
+        constexpr int kPT = kPanel * (kPanel + 1) / 2;
+        double *vinv = vgn;            // free until the line search
         if (tid == 0) sh.flag = 0;
         __syncthreads();
-        for (int k = 0; k < n; ++k) {
-            const double dk = Mat[tri(k, k)];
-            if (!(dk > 0.0)) { if (tid == 0) sh.flag = 1; break; }       // uniform: every thread reads the same dk
-            const double inv = 1.0 / dk;
-            // trailing update with the UNSCALED column k: A[i][j] -= a_ik * a_jk / d_k, k < j <= i
-            for (int i = k + 1 + ti; i < n; i += kTileRows) {
-                const double aik = Mat[tri(i, k)] * inv;
-                for (int j = k + 1 + tj; j <= i; j += 16) Mat[tri(i, j)] -= aik * Mat[tri(j, k)];
+        // the diagonal block [kb, kb+nb) as packed lower registers; rows/columns >= nb are identity padding
+        auto load_block = [&](int kb, int nb, double (&B)[kPT]) {
+#pragma unroll
+            for (int i = 0; i < kPanel; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j)
+                    B[i * (i + 1) / 2 + j] = (i < nb) ? Mat[tri(kb + i, kb + j)] : (i == j ? 1.0 : 0.0);
+        };
+        for (int kb = 0; kb < n; kb += kPanel) {
+            const int nb = min(kPanel, n - kb), ke = kb + nb;
+            if (tid == 0) {
+                double B[kPT], inv[kPanel];
+                load_block(kb, nb, B);
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < kPanel; ++k) {
+                    const double dk = B[k * (k + 1) / 2 + k];
+                    bad = bad || !(dk > 0.0);
+                    inv[k] = fast_rcp(dk);
+#pragma unroll
+                    for (int i = k + 1; i < kPanel; ++i) {
+                        const double lik = B[i * (i + 1) / 2 + k] * inv[k];
+#pragma unroll
+                        for (int j = k + 1; j <= i; ++j) B[i * (i + 1) / 2 + j] -= lik * B[j * (j + 1) / 2 + k];
+                    }
+                }
+                if (bad) sh.flag = 1;
+#pragma unroll
+                for (int i = 0; i < kPanel; ++i) {
+                    if (i < nb) {
+                        vinv[kb + i] = inv[i];
+#pragma unroll
+                        for (int j = 1; j <= i; ++j) Mat[tri(kb + i, kb + j)] = B[i * (i + 1) / 2 + j];
+                    }
+                }
             }
             __syncthreads();
-            for (int i = k + 1 + tid; i < n; i += kBlockThreads) Mat[tri(i, k)] *= inv;
+            if (sh.flag) break;                                           // uniform
+            if (ke < n) {
+                double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
+                load_block(kb, nb, B);
+#pragma unroll
+                for (int k = 0; k < kPanel; ++k) inv[k] = k < nb ? vinv[kb + k] : 1.0;
+                for (int i = ke + tid; i < n; i += kBlockThreads) {       // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
+                    double r[kPanel];
+#pragma unroll
+                    for (int c = 0; c < kPanel; ++c) r[c] = c < nb ? Mat[tri(i, kb + c)] : 0.0;
+#pragma unroll
+                    for (int c = 1; c < kPanel; ++c) {
+#pragma unroll
+                        for (int k = 0; k < c; ++k) r[c] -= (r[k] * inv[k]) * B[c * (c + 1) / 2 + k];
+                    }
+#pragma unroll
+                    for (int c = 1; c < kPanel; ++c) if (c < nb) Mat[tri(i, kb + c)] = r[c];
+                }
+            }
+            __syncthreads();
+            const int mt = (n - ke + 3) / 4, n_tiles = mt * (mt + 1) / 2;
+            for (int t = tid; t < n_tiles; t += kBlockThreads) {
+                int I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
+                while (I * (I + 1) / 2 > t) --I;
+                while ((I + 1) * (I + 2) / 2 <= t) ++I;
+                const int J = t - I * (I + 1) / 2;
+                const int i0 = ke + 4 * I, j0 = ke + 4 * J;
+                double acc[4][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+#pragma unroll
+                for (int k = 0; k < kPanel; ++k) {
+                    if (k < nb) {
+                        const double inv = vinv[kb + k];
+                        double ai[4], wj[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) ai[u] = (i0 + u < n) ? Mat[tri(i0 + u, kb + k)] : 0.0;
+#pragma unroll
+                        for (int v = 0; v < 4; ++v) wj[v] = (j0 + v < n) ? Mat[tri(j0 + v, kb + k)] * inv : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+#pragma unroll
+                            for (int v = 0; v < 4; ++v) acc[u][v] = fma(ai[u], wj[v], acc[u][v]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int i = i0 + u, j = j0 + v;
+                        if (i < n && j <= i) Mat[tri(i, j)] -= acc[u][v];
+                    }
+            }
             __syncthreads();
         }
         __syncthreads();
         PROF_MARK(1);                                 // 1: factorization
         bool valid = sh.flag == 0;
         if (valid) {
-            // forward: L z = rhs (column oriented)
-            for (int k = 0; k < n; ++k) {
-                const double zk = vstep[k];
-                for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * zk;
+            // triangular solves, one column per step (a step is one barrier + one LDS round trip, ~200 cycles:
+            // cheaper than panel steps with a single-thread block solve, which were measured at 2.7k each)
+            for (int k = 0; k < n; ++k) {                                 // forward: L z = rhs
+                const double t = vstep[k] * vinv[k];
+                for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * t;
                 __syncthreads();
             }
-            for (int i = tid; i < n; i += kBlockThreads) vstep[i] /= Mat[tri(i, i)];
+            for (int i = tid; i < n; i += kBlockThreads) vstep[i] *= vinv[i];
             __syncthreads();
-            // backward: L^T y = z (column oriented over rows of L)
-            for (int k = n - 1; k >= 0; --k) {
+            for (int k = n - 1; k > 0; --k) {                             // backward: L^T y = w
                 const double yk = vstep[k];
-                for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * yk;
+                for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * vinv[j] * yk;
                 __syncthreads();
             }
         }

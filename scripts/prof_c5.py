@@ -1,0 +1,15 @@
+"""config 5 (long tracks, workgroup kernels): timing + optional phase profile (LFR_LIB_OVERRIDE=<-DLFR_PROFILE_PHASES build>)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "local-feature-refinement_amd"))
+import numpy as np
+from lfr_amd import capi, synthetic
+ma = synthetic.config5()
+g = capi.Graph.from_arrays(ma)
+p = capi.Problem(g)
+b = capi.Batch(p, 0)
+for i in range(3):
+    st = b.solve()
+    print("config5: edges %d comps %d kernel %.3f ms dominant %.3f ms  noconv %d fail %d" % (st["n_edges"], st["n_components"], st["kernel_ms"], st["dominant_kernel_ms"], st["n_no_convergence"], st["n_failed"]), flush=True)
+info = b.component_info()
+print("rows: min %d max %d mean %.1f; iterations mean %.2f max %d" % (2 * info["n_var_nodes"].min(), 2 * info["n_var_nodes"].max(), 2 * info["n_var_nodes"].mean(), info["iterations"].mean(), info["iterations"].max()))
