@@ -654,34 +654,64 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             const lfr::NodeInc ni = inc[v];
             if (want_matrix) for (int j = 0; j <= row; ++j) Mat[tri(row, j)] = 0.0;
             double gacc = 0.0, dsame = 0.0, dlow = 0.0;     // A[row][row], A[2v+1][2v] (c == 1 only)
-            for (uint32_t k = 0; k < ni.out_count; ++k) {   // edges v -> w : J1 = d r / d x_v
-                const uint32_t e = ni.out_begin + k;
-                const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
-                const double2 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-                const double jc0 = c ? a0.y : a0.x, jc1 = c ? a1.y : a1.x;    // column c of J1
-                gacc += jc0 * a2.y + jc1 * a3.x;
-                if (want_matrix) {
-                    dsame += jc0 * jc0 + jc1 * jc1;
-                    if (c) dlow += a0.y * a0.x + a1.y * a1.x;
-                    const int wn = (int)(edges[e].dst_kind & 0x7fff);
-                    if (wn < v) {                           // block (v, w) += J1^T * sq
-                        Mat[tri(row, 2 * wn)] += jc0 * a2.x;
-                        Mat[tri(row, 2 * wn + 1)] += jc1 * a2.x;
+            // The scratch and the edge records live in HBM/L2: the loads of kAhead edges are issued together
+            // (one latency per batch instead of one per edge), then consumed in the fixed order.
+#ifndef LFR_AHEAD
+#define LFR_AHEAD 8
+#endif
+            constexpr int kAhead = LFR_AHEAD;
+            for (uint32_t k0 = 0; k0 < ni.out_count; k0 += kAhead) {   // edges v -> w : J1 = d r / d x_v
+                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
+                int wn_[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const uint32_t e = ni.out_begin + min(k0 + u, ni.out_count - 1);
+                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
+                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
+                    wn_[u] = (int)(edges[e].dst_kind & 0x7fff);
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (k0 + u >= ni.out_count) break;
+                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
+                    const double jc0 = c ? a0.y : a0.x, jc1 = c ? a1.y : a1.x;    // column c of J1
+                    gacc += jc0 * a2.y + jc1 * a3.x;
+                    if (want_matrix) {
+                        dsame += jc0 * jc0 + jc1 * jc1;
+                        if (c) dlow += a0.y * a0.x + a1.y * a1.x;
+                        const int wn = wn_[u];
+                        if (wn < v) {                           // block (v, w) += J1^T * sq
+                            Mat[tri(row, 2 * wn)] += jc0 * a2.x;
+                            Mat[tri(row, 2 * wn + 1)] += jc1 * a2.x;
+                        }
                     }
                 }
             }
-            for (uint32_t k = 0; k < ni.in_count; ++k) {    // edges w -> v : d r / d x_v = sq * I
-                const uint32_t e = in_idx[ni.in_begin + k];
-                const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
-                const double2 a0 = w[0], a1 = w[1], a2 = w[2], a3 = w[3];
-                const double sq = a2.x, rc = c ? a3.x : a2.y;
-                gacc += sq * rc;
-                if (want_matrix) {
-                    dsame += sq * sq;
-                    const int wn = (int)edges[e].src;
-                    if (wn < v) {                           // block (v, w) += sq * J1'
-                        Mat[tri(row, 2 * wn)] += sq * (c ? a1.x : a0.x);
-                        Mat[tri(row, 2 * wn + 1)] += sq * (c ? a1.y : a0.y);
+            for (uint32_t k0 = 0; k0 < ni.in_count; k0 += kAhead) {    // edges w -> v : d r / d x_v = sq * I
+                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
+                int wn_[kAhead];
+                uint32_t e_[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) e_[u] = in_idx[ni.in_begin + min(k0 + u, ni.in_count - 1)];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e_[u]);
+                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
+                    wn_[u] = (int)edges[e_[u]].src;
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (k0 + u >= ni.in_count) break;
+                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
+                    const double sq = a2.x, rc = c ? a3.x : a2.y;
+                    gacc += sq * rc;
+                    if (want_matrix) {
+                        dsame += sq * sq;
+                        const int wn = wn_[u];
+                        if (wn < v) {                           // block (v, w) += sq * J1'
+                            Mat[tri(row, 2 * wn)] += sq * (c ? a1.x : a0.x);
+                            Mat[tri(row, 2 * wn + 1)] += sq * (c ? a1.y : a0.y);
+                        }
                     }
                 }
             }
