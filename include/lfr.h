@@ -166,8 +166,9 @@ typedef struct lfr_solve_stats {
     int64_t dominant_ref_passes_nodes;
 } lfr_solve_stats;
 
-/* Create the HIP context of `device` (a few hundred ms the first time); safe to call from a side
- * thread while the caller parses its input. */
+/* Create the HIP context of `device` (a few hundred ms the first time) and run a toy graph through the
+ * device pipeline once, so that every kernel is resolved before the real input arrives; safe to call
+ * from a side thread while the caller parses its input. */
 int lfr_hip_warmup(int device);
 
 /* Upload shard `shard_rank` of `shard_world` (components dealt largest-first to the least
@@ -181,7 +182,7 @@ void lfr_batch_free(lfr_batch *b);
 int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
 /* HIP-event timings of one of the last 64 lfr_batch_solve calls (solves_back = 0: the latest);
  * waits for that solve to finish.  class_ms / class_edges: LFR_NUM_KERNEL_CLASSES entries, one
- * per kernel launch (packed <8,1,3>, <16,1,3>, <16,2,3>, <32,2,2>, <32,2,4>, block, global-matrix). */
+ * per kernel launch (packed <8,1,3>, <16,1,3>, <16,2,3>, <32,2,2>, <32,2,5>, block, global-matrix). */
 #define LFR_NUM_KERNEL_CLASSES 7
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written. */

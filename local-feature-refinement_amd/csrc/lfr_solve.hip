@@ -1102,9 +1102,40 @@ int lfr_hip_warmup(int device) {
     if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
-    hipLaunchKernelGGL(lfr_warmup_kernel, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);   // loads the code object
+    hipLaunchKernelGGL(lfr_warmup_kernel, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);   // loads this unit's code object
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    // HIP also resolves every kernel on its first launch (~1 ms each; the graph stage and the assembly launch
+    // about forty different ones, rocPRIM's included): push a toy graph - one 18-node track (workgroup kernel)
+    // and one 3-node track (packed kernel) - through the whole device pipeline once.  Best effort.
+    {
+        constexpr int kImg = 18;
+        std::vector<std::string> names(kImg);
+        std::vector<const char *> name_ptrs(kImg);
+        std::vector<float> facts(kImg, 1.0f);
+        for (int i = 0; i < kImg; ++i) { names[i] = "warmup" + std::to_string(i); name_ptrs[i] = names[i].c_str(); }
+        std::vector<int32_t> p1, p2;
+        std::vector<int64_t> off{0};
+        std::vector<uint32_t> f1, f2;
+        for (int a = 0; a < kImg; ++a)
+            for (int b = a + 1; b < kImg; ++b) {
+                p1.push_back(a); p2.push_back(b);
+                f1.push_back(0); f2.push_back(0);                                  // the 18-node track
+                if (b < 3) { f1.push_back(1); f2.push_back(1); }                   // the 3-node track
+                off.push_back((int64_t)f1.size());
+            }
+        const size_t M = f1.size();
+        std::vector<float> sim(M, 0.9f), flows(18 * M, 0.01f);
+        lfr_graph *g = nullptr; lfr_problem *pr = nullptr; lfr_batch *bt = nullptr;
+        if (lfr_graph_from_arrays(kImg, name_ptrs.data(), facts.data(), (int64_t)p1.size(), p1.data(), p2.data(), off.data(),
+                                  f1.data(), f2.data(), sim.data(), flows.data(), flows.data(), nullptr, 0, &g) == LFR_OK &&
+            lfr_problem_build_hip(g, device, 0, nullptr, &pr) == LFR_OK &&
+            lfr_batch_create(pr, device, 0, 1, LFR_TUKEY_CERES1, &bt) == LFR_OK) {
+            lfr_solve_stats st;
+            (void)lfr_batch_solve(bt, nullptr, &st);
+        }
+        lfr_batch_free(bt); lfr_problem_free(pr); lfr_graph_free(g);
+    }
     return LFR_OK;
 }
 
