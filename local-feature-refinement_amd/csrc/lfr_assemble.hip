@@ -243,31 +243,26 @@ __global__ void k_fill_descs(int64_t n_desc, const uint32_t *perm, const uint32_
     desc_tracks[i] = c_tracks[c];
 }
 
-struct DevBuf {          // tiny RAII for the many temporaries
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    template <class T> T *as() { return (T *)p; }
-};
-#define DEV_ALLOC(buf, bytes) HIP_TRY(hipMalloc(&(buf).p, std::max<size_t>((size_t)(bytes), 16)))
+#define DEV_ALLOC(buf, bytes) HIP_TRY(dev_alloc(arena, buf, (size_t)(bytes), false))
 
 template <class K, class V>
-int sort_pairs(const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
+int sort_pairs(DevArena *arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     DevBuf tmp;
-    DEV_ALLOC(tmp, bytes);
+    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LFR_OK;
 }
 
-int exclusive_sum(const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
+int exclusive_sum(DevArena *arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
     DevBuf tmp;
-    DEV_ALLOC(tmp, bytes);
+    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LFR_OK;
@@ -280,6 +275,10 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     const int64_t N = g.n_nodes(), M = g.n_matches(), E2 = 2 * M;
     const int64_t C = p.stats.n_components, T = p.stats.n_tracks;
     if (E2 >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) { set_error("graph too large for the device assembly"); return LFR_ERR_UNSUPPORTED; }
+
+    DevArena slab;                                   // declared first: the buffers below must die before it
+    DevArena *arena = &slab;
+    if (slab.init((size_t)240 * M + (size_t)64 * N + (size_t)64 * C + ((size_t)16 << 20)) != hipSuccess) { (void)hipGetLastError(); slab.base = nullptr; arena = nullptr; }
 
     // ---- uploads: endpoints, similarities, labels (small) and the flows (2 x 72 B per match) ----
     std::vector<int32_t> track32(N), comp32(N);
@@ -333,11 +332,11 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
                        b_kv.as<uint32_t>(), b_ke.as<uint32_t>(), b_kc.as<uint32_t>(), b_id0.as<uint32_t>(), b_flag.as<int>());
     int rc;
     // LSD over the three keys (each pass stable): variables, edges, class
-    if ((rc = sort_pairs(b_kv.as<uint32_t>(), b_k0.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 16, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_kv.as<uint32_t>(), b_k0.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 16, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, b_id1.as<uint32_t>(), b_ke.as<uint32_t>(), b_k0.as<uint32_t>());
-    if ((rc = sort_pairs(b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), C, 0, 32, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), C, 0, 32, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, b_id0.as<uint32_t>(), b_kc.as<uint32_t>(), b_k0.as<uint32_t>());
-    if ((rc = sort_pairs(b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 3, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 3, st)) != LFR_OK) return rc;
     const uint32_t *perm = b_id1.as<uint32_t>();             // perm[i] = component of desc i
     const uint32_t *class_sorted = b_k1.as<uint32_t>();
 
@@ -346,8 +345,8 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     HIP_TRY(hipMemsetAsync(b_dn.p, 0, 4 * (C + 1), st)); HIP_TRY(hipMemsetAsync(b_de.p, 0, 4 * (C + 1), st));
     hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, b_cn.as<uint32_t>(), b_ce.as<uint32_t>(),
                        b_dn.as<uint32_t>(), b_de.as<uint32_t>(), b_di.as<int32_t>());
-    if ((rc = exclusive_sum(b_dn.as<uint32_t>(), b_no.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
-    if ((rc = exclusive_sum(b_de.as<uint32_t>(), b_eo.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, b_dn.as<uint32_t>(), b_no.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, b_de.as<uint32_t>(), b_eo.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
     uint32_t totals[2];
     int too_big = 0;
     HIP_TRY(hipMemcpy(&totals[0], b_no.as<uint32_t>() + C, 4, hipMemcpyDeviceToHost));
@@ -364,7 +363,7 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     DevBuf b_nk0, b_nk1, b_ni0, b_ni1, b_local;
     DEV_ALLOC(b_nk0, 4 * N); DEV_ALLOC(b_nk1, 4 * N); DEV_ALLOC(b_ni0, 4 * N); DEV_ALLOC(b_ni1, 4 * N); DEV_ALLOC(b_local, 4 * N);
     hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, b_di.as<int32_t>(), b_var.as<uint8_t>(), b_nk0.as<uint32_t>(), b_ni0.as<uint32_t>());
-    if ((rc = sort_pairs(b_nk0.as<uint32_t>(), b_nk1.as<uint32_t>(), b_ni0.as<uint32_t>(), b_ni1.as<uint32_t>(), N, 0, 32, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_nk0.as<uint32_t>(), b_nk1.as<uint32_t>(), b_ni0.as<uint32_t>(), b_ni1.as<uint32_t>(), N, 0, 32, st)) != LFR_OK) return rc;
     HIP_TRY(hipMalloc(&out.d_node_ids, std::max<size_t>(4 * total_nodes, 16)));
     hipLaunchKernelGGL(k_node_locals, grid_for(total_nodes), dim3(kThreads), 0, st, total_nodes, b_ni1.as<uint32_t>(), comp, b_di.as<int32_t>(),
                        b_no.as<uint32_t>(), out.d_node_ids, b_local.as<uint32_t>());
@@ -374,7 +373,7 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     DEV_ALLOC(b_ek0, 8 * E2); DEV_ALLOC(b_ek1, 8 * E2); DEV_ALLOC(b_ei0, 4 * E2); DEV_ALLOC(b_ei1, 4 * E2);
     hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_di.as<int32_t>(), class_sorted, b_kept.as<uint8_t>(),
                        b_ek0.as<uint64_t>(), b_ei0.as<uint32_t>());
-    if ((rc = sort_pairs(b_ek0.as<uint64_t>(), b_ek1.as<uint64_t>(), b_ei0.as<uint32_t>(), b_ei1.as<uint32_t>(), E2, 0, 64, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_ek0.as<uint64_t>(), b_ek1.as<uint64_t>(), b_ei0.as<uint32_t>(), b_ei1.as<uint32_t>(), E2, 0, 64, st)) != LFR_OK) return rc;
 
     HIP_TRY(hipMemsetAsync(b_flag.p, 0, 4, st));
     hipLaunchKernelGGL(k_check_pairs, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2, comp,
@@ -396,7 +395,7 @@ int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const f
     hipLaunchKernelGGL(k_emit_edges, grid_for(5 * total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2,
                        b_sim.as<float>(), disp1, disp2, track, comp, b_di.as<int32_t>(), b_eo.as<uint32_t>(), b_no.as<uint32_t>(),
                        b_local.as<uint32_t>(), flow_row, reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
-    if ((rc = sort_pairs(in_k0, in_k1, in_v0, out.d_in_idx, total_edges, 0, 48, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, in_k0, in_k1, in_v0, out.d_in_idx, total_edges, 0, 48, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_in_begin, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, in_k1, b_eo.as<uint32_t>(), b_no.as<uint32_t>(), out.d_node_inc);
 
     // ---- descriptors ----

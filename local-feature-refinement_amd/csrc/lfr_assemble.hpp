@@ -25,6 +25,42 @@ struct DeviceAssembly {
 
 // dev_disp1/dev_disp2: optional device pointers to the flows in match order (n_matches x 18 floats
 // each, disp1 = flow 2->1, disp2 = flow 1->2); when null the graph's host arrays are uploaded.
+// One slab per pipeline stage: hipFree costs ~0.2 ms (it synchronises the device) and each stage uses ~40
+// temporaries.  A buffer that does not fit falls back to its own hipMalloc/hipFree.
+struct DevArena {
+    char *base = nullptr;
+    size_t cap = 0, top = 0;
+    ~DevArena() { if (base) (void)hipFree(base); }
+    hipError_t init(size_t bytes) { cap = bytes; return hipMalloc((void **)&base, bytes); }
+    void *take(size_t bytes) {
+        const size_t b = (bytes + 255) & ~(size_t)255;
+        if (!base || top + b > cap) return nullptr;
+        void *p = base + top;
+        top += b;
+        return p;
+    }
+};
+struct DevBuf {          // tiny RAII for the many temporaries
+    void *p = nullptr;
+    DevArena *arena = nullptr;
+    size_t mark = 0;
+    bool temp = false;       // released at scope end (stack discipline: nothing is taken while it lives)
+    ~DevBuf() {
+        if (!p) return;
+        if (!arena) (void)hipFree(p);
+        else if (temp) arena->top = mark;
+    }
+    template <class T> T *as() { return (T *)p; }
+};
+inline hipError_t dev_alloc(DevArena *ar, DevBuf &b, size_t bytes, bool temp) {
+    bytes = bytes < 16 ? 16 : bytes;
+    if (ar) {
+        const size_t m = ar->top;
+        if (void *q = ar->take(bytes)) { b.p = q; b.arena = ar; b.mark = m; b.temp = temp; return hipSuccess; }
+    }
+    return hipMalloc(&b.p, bytes);
+}
+
 int assemble_on_device(const Graph &g, const Problem &labels, hipStream_t stream, const float *dev_disp1,
                        const float *dev_disp2, DeviceAssembly &out);
 

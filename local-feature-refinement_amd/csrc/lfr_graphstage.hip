@@ -42,30 +42,25 @@ constexpr int kThreads = 256;
 constexpr int64_t kMaxSegmentEdges = 1 << 16;     // larger connected components: host stage
 inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + kThreads - 1) / kThreads)); }
 
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    template <class T> T *as() { return (T *)p; }
-};
-#define DEV_ALLOC(buf, bytes) HIP_TRY(hipMalloc(&(buf).p, std::max<size_t>((size_t)(bytes), 16)))
+#define DEV_ALLOC(buf, bytes) HIP_TRY(dev_alloc(arena, buf, (size_t)(bytes), false))
 
 template <class K, class V>
-int sort_pairs(const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
+int sort_pairs(DevArena *arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     DevBuf tmp;
-    DEV_ALLOC(tmp, bytes);
+    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
     HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LFR_OK;
 }
-int exclusive_sum(const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
+int exclusive_sum(DevArena *arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
     DevBuf tmp;
-    DEV_ALLOC(tmp, bytes);
+    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
     HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, st));
     HIP_TRY(hipStreamSynchronize(st));
     return LFR_OK;
@@ -259,6 +254,9 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem
     HIP_TRY(hipSetDevice(device));
     hipStream_t st = nullptr;
     auto t0 = clock::now();
+    DevArena slab;                                   // declared first: the buffers below must die before it
+    DevArena *arena = &slab;
+    if (slab.init((size_t)80 * M + (size_t)96 * N + ((size_t)16 << 20)) != hipSuccess) { (void)hipGetLastError(); slab.base = nullptr; arena = nullptr; }
 
     DevBuf b_n1, b_n2, b_sim, b_img;
     DEV_ALLOC(b_n1, 4 * M); DEV_ALLOC(b_n2, 4 * M); DEV_ALLOC(b_sim, 4 * M); DEV_ALLOC(b_img, 4 * N);
@@ -275,9 +273,9 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem
     DEV_ALLOC(b_id0, 4 * M); DEV_ALLOC(b_id1, 4 * M);
     hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, b_khi.as<uint64_t>(), b_klo.as<uint32_t>(), b_id0.as<uint32_t>());
     int rc;
-    if ((rc = sort_pairs(b_klo.as<uint32_t>(), b_klo2.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_klo.as<uint32_t>(), b_klo2.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, b_id1.as<uint32_t>(), b_khi.as<uint64_t>(), b_khi2.as<uint64_t>());
-    if ((rc = sort_pairs(b_khi2.as<uint64_t>(), b_khi.as<uint64_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), M, 0, 64, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_khi2.as<uint64_t>(), b_khi.as<uint64_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), M, 0, 64, st)) != LFR_OK) return rc;
     uint32_t *order = b_id0.as<uint32_t>();
 
     // 2. connected components of the match graph (conflicts ignored)
@@ -291,11 +289,11 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem
     DevBuf b_ck0, b_ck1, b_flags, b_segid, b_starts;
     DEV_ALLOC(b_ck0, 4 * M); DEV_ALLOC(b_ck1, 4 * M); DEV_ALLOC(b_flags, 4 * (M + 1)); DEV_ALLOC(b_segid, 4 * (M + 1));
     hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, order, n1, b_cc.as<uint32_t>(), b_ck0.as<uint32_t>());
-    if ((rc = sort_pairs(b_ck0.as<uint32_t>(), b_ck1.as<uint32_t>(), order, b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, b_ck0.as<uint32_t>(), b_ck1.as<uint32_t>(), order, b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
     order = b_id1.as<uint32_t>();
     HIP_TRY(hipMemsetAsync(b_flags.p, 0, 4 * (M + 1), st));
     hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, b_ck1.as<uint32_t>(), b_flags.as<uint32_t>());
-    if ((rc = exclusive_sum(b_flags.as<uint32_t>(), b_segid.as<uint32_t>(), M + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, b_flags.as<uint32_t>(), b_segid.as<uint32_t>(), M + 1, st)) != LFR_OK) return rc;
     uint32_t n_seg = 0;
     HIP_TRY(hipMemcpy(&n_seg, b_segid.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost));
     DEV_ALLOC(b_starts, 4 * ((int64_t)n_seg + 1));
@@ -321,7 +319,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem
     DEV_ALLOC(b_rflag, 4 * (N + 1)); DEV_ALLOC(b_rrank, 4 * (N + 1)); DEV_ALLOC(b_track, 4 * N); DEV_ALLOC(b_max, 8);
     HIP_TRY(hipMemsetAsync(b_rflag.p, 0, 4 * (N + 1), st));
     hipLaunchKernelGGL(k_root_flags, grid_for(N), dim3(kThreads), 0, st, N, b_par.as<int32_t>(), b_rflag.as<uint32_t>());
-    if ((rc = exclusive_sum(b_rflag.as<uint32_t>(), b_rrank.as<uint32_t>(), N + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, b_rflag.as<uint32_t>(), b_rrank.as<uint32_t>(), N + 1, st)) != LFR_OK) return rc;
     uint32_t n_tracks = 0;
     HIP_TRY(hipMemcpy(&n_tracks, b_rrank.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost));
     DEV_ALLOC(b_tsize, 4 * (int64_t)n_tracks);
@@ -357,7 +355,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem
     hipLaunchKernelGGL(k_cc_flatten, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>());
     HIP_TRY(hipMemsetAsync(b_cflag.p, 0, 4 * ((size_t)n_tracks + 1), st));
     hipLaunchKernelGGL(k_comp_flags, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>(), b_cflag.as<uint32_t>());
-    if ((rc = exclusive_sum(b_cflag.as<uint32_t>(), b_crank.as<uint32_t>(), (int64_t)n_tracks + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, b_cflag.as<uint32_t>(), b_crank.as<uint32_t>(), (int64_t)n_tracks + 1, st)) != LFR_OK) return rc;
     uint32_t n_comp = 0;
     HIP_TRY(hipMemcpy(&n_comp, b_crank.as<uint32_t>() + n_tracks, 4, hipMemcpyDeviceToHost));
     DEV_ALLOC(b_csize, 4 * (int64_t)n_comp);
