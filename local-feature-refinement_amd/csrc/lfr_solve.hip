@@ -257,6 +257,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                     if (c_hi <= 2) LFR_CL(2); else if (c_hi <= 4) LFR_CL(4); else if (c_hi <= 6) LFR_CL(6); else LFR_CL(8);
                 } else if constexpr (CPL == 8) {
                     if (c_hi <= 4) LFR_CL(4); else if (c_hi <= 6) LFR_CL(6); else if (c_hi <= 7) LFR_CL(7); else LFR_CL(8);
+                } else if constexpr (CPL == 32) {                  // two <=32-row systems per wave
+                    if (c_hi <= 18) LFR_CL(18); else if (c_hi <= 20) LFR_CL(20); else if (c_hi <= 22) LFR_CL(22);
+                    else LFR_CL(24);                              // the class holds <= 24 rows (classify())
                 } else if constexpr (LPR == 1) {
                     if (c_hi <= 10) LFR_CL(10); else if (c_hi <= 12) LFR_CL(12); else if (c_hi <= 14) LFR_CL(14); else LFR_CL(16);
                 } else {
@@ -508,7 +511,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     }
 }
 
-constexpr size_t kPackedLdsBytes = kPackedWaves * (sizeof(GroupLds<16>) * 4 > sizeof(GroupLds<32>) ? sizeof(GroupLds<16>) * 4 : sizeof(GroupLds<32>));
+constexpr size_t kPackedLdsBytes = kPackedWaves * (sizeof(GroupLds<16>) * 4 > 2 * sizeof(GroupLds<32>) ? sizeof(GroupLds<16>) * 4 : 2 * sizeof(GroupLds<32>));
 static_assert(kPackedLdsBytes >= kPackedWaves * 8 * sizeof(GroupLds<8>) && kPackedLdsBytes >= kPackedWaves * 2 * sizeof(GroupLds<16>), "LDS budget");
 
 // one class per launch (diagnostics: LFR_SERIAL_CLASSES=1 gives per-class timings)
@@ -534,7 +537,7 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
         solve_group_body<32, 2, 5>(a, b - r.blk_begin[0], lds_raw);
     } else if (b < r.blk_begin[2]) {
         a.desc_begin = r.desc_begin[1]; a.desc_end = r.desc_end[1]; a.cls = lfr::KC_G64_2;
-        solve_group_body<32, 2, 2>(a, b - r.blk_begin[1], lds_raw);
+        solve_group_body<32, 1, 4>(a, b - r.blk_begin[1], lds_raw);
     } else if (b < r.blk_begin[3]) {
         a.desc_begin = r.desc_begin[2]; a.desc_end = r.desc_end[2]; a.cls = lfr::KC_G32;
         solve_group_body<16, 2, 3>(a, b - r.blk_begin[2], lds_raw);
@@ -1338,7 +1341,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
     static const int kPackedOrder[5] = {lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
-    static const int kCompsPerBlock[lfr::KC_COUNT] = {8 * kPackedWaves, 4 * kPackedWaves, 2 * kPackedWaves, kPackedWaves, kPackedWaves, 1, 1};
+    static const int kCompsPerBlock[lfr::KC_COUNT] = {8 * kPackedWaves, 4 * kPackedWaves, 2 * kPackedWaves, 2 * kPackedWaves, kPackedWaves, 1, 1};
     const dim3 blk(64 * kPackedWaves);
     auto launch_block = [&](int cls, hipStream_t cs) -> int {
         a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
@@ -1365,7 +1368,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                     case lfr::KC_G8:    hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G32:   hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), grid, blk, 0, st, a); break;
-                    case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 2, 2>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 1, 4>), grid, blk, 0, st, a); break;
                     case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 5>), grid, blk, 0, st, a); break;
                     default: { const int rc = launch_block(cls, st); if (rc != LFR_OK) return rc; }
                 }
