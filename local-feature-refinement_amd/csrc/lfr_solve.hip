@@ -537,7 +537,7 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
         solve_group_body<32, 2, 5>(a, b - r.blk_begin[0], lds_raw);
     } else if (b < r.blk_begin[2]) {
         a.desc_begin = r.desc_begin[1]; a.desc_end = r.desc_end[1]; a.cls = lfr::KC_G64_2;
-        solve_group_body<32, 1, 4>(a, b - r.blk_begin[1], lds_raw);
+        solve_group_body<32, 1, 6>(a, b - r.blk_begin[1], lds_raw);
     } else if (b < r.blk_begin[3]) {
         a.desc_begin = r.desc_begin[2]; a.desc_end = r.desc_end[2]; a.cls = lfr::KC_G32;
         solve_group_body<16, 2, 3>(a, b - r.blk_begin[2], lds_raw);
@@ -1368,7 +1368,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                     case lfr::KC_G8:    hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), grid, blk, 0, st, a); break;
                     case lfr::KC_G32:   hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), grid, blk, 0, st, a); break;
-                    case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 1, 4>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 1, 6>), grid, blk, 0, st, a); break;
                     case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 5>), grid, blk, 0, st, a); break;
                     default: { const int rc = launch_block(cls, st); if (rc != LFR_OK) return rc; }
                 }
