@@ -124,7 +124,7 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel launch (SURVEY §8(d) accounting)
         serial = os.environ.get("LFR_SERIAL_CLASSES") == "1"
-        kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,3>", "solve_group_kernel<16,2,3>",
+        kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,6>", "(retired)",
                         "solve_group_kernel<32,1,6>", "solve_group_kernel<32,2,5>", "solve_block_kernel<lds>",
                         "solve_block_kernel<hbm>"]
         if not serial:      # one launch for all packed classes; its events sit in the slot of the largest class

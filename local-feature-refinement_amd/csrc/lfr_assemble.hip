@@ -85,8 +85,7 @@ __global__ void k_count_tracks(int64_t n_tracks, const uint32_t *t_size, const i
 
 __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
-    if (rows <= 16 && n_edges <= 48) return KC_G16;
-    if (rows <= 16 && n_edges <= 96) return KC_G32;
+    if (rows <= 16 && n_edges <= 96) return KC_G16;
     if (rows <= 24 && n_edges <= 192) return KC_G64_2;
     if (rows <= 32 && n_edges <= 320) return KC_G64_4;
     if (rows <= (uint32_t)kBlockMaxRows) return KC_BLOCK;

@@ -168,8 +168,7 @@ static std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<in
 
 static int classify(int rows, int64_t n_edges) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
-    if (rows <= 16 && n_edges <= 48) return KC_G16;
-    if (rows <= 16 && n_edges <= 96) return KC_G32;
+    if (rows <= 16 && n_edges <= 96) return KC_G16;
     if (rows <= 24 && n_edges <= 192) return KC_G64_2;
     if (rows <= 32 && n_edges <= 320) return KC_G64_4;
     if (rows <= kBlockMaxRows) return KC_BLOCK;

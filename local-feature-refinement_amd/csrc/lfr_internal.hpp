@@ -82,8 +82,8 @@ static_assert(sizeof(NodeInc) == 16, "NodeInc must be 16 bytes");
 // kernel classes
 enum KernelClass : int {
     KC_G8 = 0,      // packed <NV=8, LPR=1, EPL=3>:  8 comps/wave, <=8 rows,  <=24 edges
-    KC_G16,         // packed <16,1,3>: 4 comps/wave, <=16 rows, <=48 edges
-    KC_G32,         // packed <16,2,3>: 2 comps/wave, <=16 rows, <=96 edges (2 lanes per row)
+    KC_G16,         // packed <16,1,6>: 4 comps/wave, <=16 rows, <=96 edges (3 slots resident, 3 re-read per sweep)
+    KC_G32,         // retired (was <16,2,3>: 2 comps/wave); kept so that the class indices of the C ABI stay put
     KC_G64_2,       // packed <32,1,6>: 2 comps/wave, <=24 rows, <=192 edges (2 slots resident, 4 re-read per sweep)
     KC_G64_4,       // packed <32,2,5>: 1 comp/wave,  <=32 rows, <=320 edges (2 slots resident, 3 re-read per sweep)
     KC_BLOCK,       // workgroup per component, normal matrix in LDS

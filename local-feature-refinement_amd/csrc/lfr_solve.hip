@@ -174,7 +174,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
 #ifndef LFR_RES4
 #define LFR_RES4 2
 #endif
-    constexpr int RES = EPL <= 3 ? EPL : LFR_RES4;
+    constexpr int RES = EPL <= 3 ? EPL : (NV == 16 ? 3 : LFR_RES4);
     float flow[RES][18];
     float sim[RES];
     uint32_t idx[RES];          // src | (dst|kind<<15) << 16, decoded at every use (keeps 5 VGPRs/slot free)
@@ -540,10 +540,10 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
         solve_group_body<32, 1, 6>(a, b - r.blk_begin[1], lds_raw);
     } else if (b < r.blk_begin[3]) {
         a.desc_begin = r.desc_begin[2]; a.desc_end = r.desc_end[2]; a.cls = lfr::KC_G32;
-        solve_group_body<16, 2, 3>(a, b - r.blk_begin[2], lds_raw);
+        // (KC_G32, formerly <16,2,3>, is retired: <16,1,6> takes every <=16-row component up to 96 edges)
     } else if (b < r.blk_begin[4]) {
         a.desc_begin = r.desc_begin[3]; a.desc_end = r.desc_end[3]; a.cls = lfr::KC_G16;
-        solve_group_body<16, 1, 3>(a, b - r.blk_begin[3], lds_raw);
+        solve_group_body<16, 1, 6>(a, b - r.blk_begin[3], lds_raw);
     } else {
         a.desc_begin = r.desc_begin[4]; a.desc_end = r.desc_end[4]; a.cls = lfr::KC_G8;
         solve_group_body<8, 1, 3>(a, b - r.blk_begin[4], lds_raw);
@@ -1366,8 +1366,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                 const dim3 grid((n + kCompsPerBlock[cls] - 1) / kCompsPerBlock[cls]);
                 switch (cls) {
                     case lfr::KC_G8:    hipLaunchKernelGGL((solve_group_kernel<8, 1, 3>), grid, blk, 0, st, a); break;
-                    case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 3>), grid, blk, 0, st, a); break;
-                    case lfr::KC_G32:   hipLaunchKernelGGL((solve_group_kernel<16, 2, 3>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G16:   hipLaunchKernelGGL((solve_group_kernel<16, 1, 6>), grid, blk, 0, st, a); break;
+                    case lfr::KC_G32:   break;     // retired class, never assigned
                     case lfr::KC_G64_2: hipLaunchKernelGGL((solve_group_kernel<32, 1, 6>), grid, blk, 0, st, a); break;
                     case lfr::KC_G64_4: hipLaunchKernelGGL((solve_group_kernel<32, 2, 5>), grid, blk, 0, st, a); break;
                     default: { const int rc = launch_block(cls, st); if (rc != LFR_OK) return rc; }
