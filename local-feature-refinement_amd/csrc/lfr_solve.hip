@@ -174,7 +174,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
 #ifndef LFR_RES4
 #define LFR_RES4 2
 #endif
-    constexpr int RES = EPL <= 3 ? EPL : (NV == 16 ? 3 : LFR_RES4);
+#ifndef LFR_RES16
+#define LFR_RES16 3
+#endif
+    constexpr int RES = EPL <= 3 ? EPL : (NV == 16 ? LFR_RES16 : LFR_RES4);
     float flow[RES][18];
     float sim[RES];
     uint32_t idx[RES];          // src | (dst|kind<<15) << 16, decoded at every use (keeps 5 VGPRs/slot free)
