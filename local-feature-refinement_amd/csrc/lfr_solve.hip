@@ -127,7 +127,6 @@ struct GroupLds {
     double A[NV * LD];         // J^T J (lower triangle) of the last evaluation
     double g[NV];              // J^T r of the last evaluation
     double x[NV + 2];          // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
-    double scale[NV];          // jacobi scaling (fixed at iteration 0)
     // cold per-group state (line-search bookkeeping, counters): lives here, not in VGPRs
     double ls_prev_x, ls_prev_value, ls_prev_gradient, dir_max;
     int ls_prev_flags, ls_iter, n_successful, n_ls_evals, n_cand, exec_passes;
@@ -198,12 +197,13 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         sim[k] = __uint_as_float(q[4].z);
         idx[k] = q[4].w;
     }
-    if (sl < NV) { L.x[sl] = 0.0; L.scale[sl] = 1.0; }
+    if (sl < NV) L.x[sl] = 0.0;
     if (sl < 2) L.x[NV + sl] = 0.0;
 
     // ---- group state (uniform inside a group; 'row' values are identical in the LPR lanes of a row) ----
     int phase = have ? PH_EVAL_INIT : PH_DONE;
     double xi = 0.0, gi = 0.0, scale = 1.0, diag = 1.0;            // row
+    double inv_scale = 1.0;                                          // row: 1 / scale = 1 + sqrt(a_ii at iteration 0)
     double xt = 0.0, delta = 0.0;                                    // row
     double cost = 0.0, radius = kInitialRadius, x_norm = 0.0, gmax = 0.0;
     double g_dot_delta = 0.0, model_cost_change = 0.0, alpha = 1.0;
@@ -233,7 +233,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double aii = is_row ? A[row * LD + row] : 1.0;
                 if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
                 const double Dl = sqrt(diag / radius);
-                double rhs = is_row ? scale * gi : 0.0;
+                // (S A S + D^2) y = S g  <=>  (A + S^-1 D^2 S^-1) (S y) = g: the unscaled system with the same Jacobi-
+                // scaled LM diagonal gives the step directly and saves two multiplies and an LDS read per element
+                const double dd = Dl * Dl * inv_scale * inv_scale;
+                double rhs = is_row ? gi : 0.0;
                 const double rhs0 = rhs;
                 double piv_own = 1.0;
                 bool fail = false;
@@ -247,8 +250,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                     for (int c = 0; c < CL; ++c) {
                         const int j = LPR * c + part;
                         double v = 0.0;
-                        if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]) * scale * L.scale[j];
-                        if (j == row) v = is_row ? v + Dl * Dl : 1.0;
+                        if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]);
+                        if (j == row) v = is_row ? v + dd : 1.0;
                         h[c] = v;
                     }
                     PROF_MARK(5);                     // 5: step setup (diagonal, h build)
@@ -274,8 +277,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
                 const unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << (S & 63)) - 1);
                 const bool bad = ((badmask >> ((gid * S) & 63)) & gmask) != 0;
-                const double mcc = 0.5 * group_sum<S>(own ? (-rhs0 * step + Dl * Dl * step * step) : 0.0);
-                const double dl = step * scale;
+                const double mcc = 0.5 * group_sum<S>(own ? (-rhs0 * step + dd * step * step) : 0.0);
+                const double dl = step;
                 const double gdd = group_sum<S>(own ? gi * dl : 0.0);
                 const double dmx = group_max<S>(fabs(dl));
                 if (ps) {
@@ -422,8 +425,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         if (pe && sl == 0) atomicAdd(&L.exec_passes, 1);          // statistics live in LDS: fire-and-forget ds_add
         if (phase == PH_EVAL_INIT) {
             cost = cost_e; gi = gnew; gmax = gmax_new;
-            scale = is_row ? 1.0 / (1.0 + sqrt(L.A[row * LD + row])) : 1.0;        // jacobi scaling, once
-            if (own) L.scale[row] = scale;
+            inv_scale = is_row ? 1.0 + sqrt(L.A[row * LD + row]) : 1.0;
+            scale = 1.0 / inv_scale;                                                // jacobi scaling, once
             a_dirty = false; phase = PH_SOLVE;
         } else if (phase == PH_REEVAL) {
             a_dirty = false; phase = PH_SOLVE;
