@@ -3,14 +3,16 @@
 // with the cost model of cost.cc:13-48,78-90.  Control flow mirrors Ceres' trust-region loop
 // decision for decision; fp64 throughout; no MFMA (2N-variable blocks are tiny).
 //
-// Kernel classes:
-//   solve_wave_kernel<NV,EPL>  one wave64 per component; edges live in VGPRs for the whole solve
-//                              (HBM is read exactly once), J^T J assembled in LDS by ds_add_f64,
-//                              damped system solved in registers (lane = row) with v_readlane
-//                              broadcasts.  No barriers: a wave is its own synchronisation domain.
-//   solve_block_kernel         one workgroup per component; packed J^T J in LDS (<=176 rows) or in
-//                              an HBM workspace (GLOBAL variant); edges re-streamed from L2/HBM
-//                              per pass.
+// Kernels:
+//   solve_packed_kernel        ONE launch for every component of up to 32 rows: a wave64 hosts 64/S components
+//                              (S = 8, 16, 32 or 64 lanes each), one wave per workgroup, no barriers.  Edge slots
+//                              live in VGPRs (or are re-read per sweep beyond the resident ones), the two directions
+//                              of a match sit in neighbouring lanes and exchange their terms through DPP before
+//                              7 ds_add_f64 per edge assemble J^T J in LDS, the damped system is eliminated in
+//                              registers (lane = row) with ds_swizzle broadcasts, sized per wave.
+//   solve_block_kernel         one 512-thread workgroup per larger component; packed J^T J in LDS (<=192 rows)
+//                              or in an HBM workspace (GLOBAL variant), owner-computes assembly, blocked LDL^T;
+//                              edges re-streamed from L2/HBM per pass.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -57,9 +59,11 @@ struct KernelArgs {
 
 // =============================================================================================
 // packed sub-group kernel: a wave64 hosts G = 64/S components, S = NV*LPR lanes each.
-//   evaluation : lane = edge slot, EPL edges per lane resident in VGPRs (HBM is read once)
-//   solve      : NV rows; a row is held by LPR lanes with CPL = NV/LPR columns each (h[CPL] in
-//                registers), Gauss-Jordan with ds_swizzle / v_readlane broadcasts inside the group
+//   evaluation : lane = edge slot, EPL edge slots per lane: the first RES resident in VGPRs, the rest re-read
+//                from L2/HBM by every sweep
+//   solve      : NV rows; a row is held by LPR lanes with its columns interleaved (h[c] = column LPR*c + part),
+//                Gauss-Jordan with ds_swizzle / v_readlane broadcasts inside the group, instantiated per
+//                live-column count
 // Groups advance through the same LM state machine in lockstep rounds (solve -> evaluate ->
 // decide); rare paths (invalid step, line-search contraction, rejected step) just take extra
 // rounds for their group.  Reductions are DPP butterflies; no barriers (a wave is its own
