@@ -83,6 +83,14 @@ int lfr_graph_from_arrays_device_flows(int32_t n_images, const char *const *imag
                                        const float *sim, const void *disp1_device, const void *disp2_device, int device,
                                        const char *const *banned, int n_banned, lfr_graph **out);
 
+/* Device residency of the graph (the GPU-side counterpart of the Graph object solve.cc:405-481 builds while it
+ * parses).  lfr_graph_to_device starts copying endpoints, similarities and flows to HBM
+ * asynchronously and returns; the device pipeline (lfr_problem_build_hip, lfr_batch_create) continues from that
+ * copy, and creates it itself - inside the caller's "Total time" span - when it does not exist.  The copy stays
+ * cached on the handle until lfr_graph_evict_device / lfr_graph_free. */
+int lfr_graph_to_device(const lfr_graph *g, int device);
+int lfr_graph_evict_device(const lfr_graph *g);
+
 void lfr_graph_free(lfr_graph *g);
 int64_t lfr_graph_num_nodes(const lfr_graph *g);      /* "# graph nodes"  solve.cc:484 */
 int64_t lfr_graph_num_edges(const lfr_graph *g);      /* "# graph edges" = 2 x matches  solve.cc:485 */
@@ -134,13 +142,20 @@ int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component,
  * is too large to be processed by one thread, or when component_override is given. */
 int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component,
                           const int64_t *component_override, lfr_problem **out);
+/* flags: LFR_BUILD_FLOWS_STAY_ON_HOST - do not stage the flows in HBM; a sharded lfr_batch_create then gathers
+ * only its shard's rows zero-copy from the graph's pinned host arrays (multi-GPU: every GPU pulls 1/world of the
+ * flow bytes over its own PCIe link). */
+#define LFR_BUILD_FLOWS_STAY_ON_HOST 1
+int lfr_problem_build_hip_ex(const lfr_graph *g, int device, int64_t max_nodes_in_component,
+                             const int64_t *component_override, int flags, lfr_problem **out);
 void lfr_problem_free(lfr_problem *p);
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component);
 
-/* Solvable components dealt to shard `shard_rank` of `shard_world` (largest edge count first to
- * the least-loaded shard; the multi-GPU analogue of the largest-first task order, solve.cc:599-634).
+/* Solvable components dealt to shard `shard_rank` of `shard_world`: the batch order (kernel class, then
+ * edge count descending - the largest-first task order of solve.cc:599-634) dealt out and back
+ * (0..W-1, W-1..0, ...), so every shard gets the same mix of classes and sizes.  Needs a host-assembled problem.
  * Fills original component ids / edge counts (either may be NULL); returns the count. */
 int64_t lfr_problem_shard_components(const lfr_problem *p, int shard_rank, int shard_world, int64_t *components,
                                      int64_t *n_edges);
@@ -170,23 +185,34 @@ typedef struct lfr_solve_stats {
  * device pipeline once, so that every kernel is resolved before the real input arrives; safe to call
  * from a side thread while the caller parses its input. */
 int lfr_hip_warmup(int device);
+/* Pre-populate the per-device caches (device slabs, pinned staging) with what a pipeline run over a graph of
+ * n_nodes / n_matches will ask for, so that a one-shot caller's timed span pays no allocation; lfr_hip_trim
+ * returns every cached slab to the driver. */
+int lfr_hip_reserve(int device, int64_t n_nodes, int64_t n_matches);
+int lfr_hip_trim(int device);
 
-/* Upload shard `shard_rank` of `shard_world` (components dealt largest-first to the least
- * loaded shard, mirroring solve.cc:599-604) to HIP device `device`. */
+/* Shard `shard_rank` of `shard_world` (see lfr_problem_shard_components) resident on HIP device `device`:
+ * assembled there from the labels (lfr_problem_build_labels / _hip), or uploaded (lfr_problem_build).
+ * Limits: <= 32767 nodes per component (16-bit local indices in the 80-byte edge record), < 2^30 matches. */
 int lfr_batch_create(const lfr_problem *p, int device, int shard_rank, int shard_world, int tukey_variant,
                      lfr_batch **out);
 void lfr_batch_free(lfr_batch *b);
 /* Run every solve kernel of the batch on `hip_stream` (a hipStream_t, NULL = default stream).
- * Positions are reset to zero first (solve.cc:609-612).  Asynchronous unless stats != NULL, in
- * which case the call synchronizes the stream and fills stats. */
+ * The position array is zeroed once, when the batch is created (solve.cc:609-612); every solve rewrites every
+ * variable node (a failed solve writes 0), roots and nodes outside solved components stay 0.  Asynchronous
+ * unless stats != NULL, in which case the call synchronizes the stream and fills stats. */
 int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
 /* HIP-event timings of one of the last 64 lfr_batch_solve calls (solves_back = 0: the latest);
  * waits for that solve to finish.  class_ms / class_edges: LFR_NUM_KERNEL_CLASSES entries, one
  * per kernel launch (packed <8,1,3>, <16,1,6>, a retired slot, <32,1,6>, <32,2,5>, block, global-matrix). */
 #define LFR_NUM_KERNEL_CLASSES 7
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges);
-/* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written. */
+/* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written.  Waits for the
+ * latest lfr_batch_solve of this batch, whatever stream it was issued on. */
 int lfr_batch_download(lfr_batch *b, double *positions);
+/* The same without the final host copy: *positions points at the batch's pinned staging buffer (2 * n_nodes
+ * doubles, nodes outside the shard read 0), valid until the next solve / download / free of this batch. */
+int lfr_batch_positions_view(lfr_batch *b, const double **positions);
 /* per solved component of the shard, in batch order: original component id, iterations,
  * termination, final cost (any pointer may be NULL). Returns the count. */
 int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
@@ -196,10 +222,10 @@ int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iter
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
                   lfr_solve_stats *stats);
 
-/* The same over several GPUs of one node from ONE process: the host-assembled batch is dealt to
- * `n_devices` shards (lfr_problem_shard_components), one host thread per device uploads, solves and
- * downloads its shard; shards write disjoint node sets of `positions` (the thread pool of
- * solve.cc:617-635 with GPUs as workers).  The problem must come from lfr_problem_build. */
+/* The same over several GPUs of one node from ONE process: the solvable components are dealt to
+ * `n_devices` shards (lfr_problem_shard_components), one host thread per device assembles (on its GPU, for a
+ * labels-only problem) or uploads (host-assembled problem), solves and downloads its shard; shards write
+ * disjoint node sets of `positions` (the thread pool of solve.cc:617-635 with GPUs as workers). */
 int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices, int tukey_variant, double *positions,
                         lfr_solve_stats *stats);
 

@@ -1,13 +1,17 @@
 // Device-side batch assembly (reference: create_and_solve_problem's problem construction,
 // solve.cc:94-143, and the largest-first ordering of solve.cc:599-604).
 //
-// Input: the match graph (per-match endpoints, similarity, two 3x3x2 flow grids) and the host
-// graph stage's per-node labels (track, component, is_root).  Output, built entirely on the GPU
-// and bit-identical to the host assembly of lfr_graph.cpp: CompDesc[], 80-byte EdgeRec[] in the
-// reference's residual-block order, node_ids[], NodeInc[], in_idx[] — sorted by kernel class, then
-// edge count descending.  The 2 x 180 MB of flows cross PCIe once, in match order, and are gathered
-// into edge records at HBM speed; no 400 MB host-side record array is ever built.
+// Input: the match graph in HBM (DevGraph: per-match endpoints, similarity, two 3x3x2 flow grids) and the
+// per-node labels in HBM (DevProblem: track, component, is_root - left there by the device graph stage).
+// Output, built entirely on the GPU and bit-identical to the host assembly of lfr_graph.cpp: CompDesc[],
+// 80-byte EdgeRec[] in the reference's residual-block order, node_ids[], NodeInc[], in_idx[] - sorted by
+// kernel class, then edge count descending - plus the per-component workspace offsets and the launch
+// geometry of the solve kernels (AsmSummary).  The flows are gathered into edge records at HBM speed from
+// their staged copy (uploaded on the copy stream while the graph stage ran), from the caller's device
+// arrays, or - sharded batches - zero-copy from pinned host memory (only the shard's rows cross PCIe).
 //
+// No host round trips: every launch is sized by an upper bound (N, 2M, C) and bounded on the device by the
+// counts the previous kernels left there; one read-back of the 160-byte summary ends the stage.
 // Everything is integer/byte work: radix sorts (hipCUB), scans, histograms with integer atomics
 // (exact and order-independent), gathers.  HBM-bound; no LDS tiling to speak of.
 #include <hip/hip_runtime.h>
@@ -21,19 +25,10 @@
 
 namespace lfr {
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t _e = (expr);                                                               \
-        if (_e != hipSuccess) {                                                               \
-            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                         \
-            return LFR_ERR_HIP;                                                               \
-        }                                                                                     \
-    } while (0)
-
 namespace {
 
-constexpr int kThreads = 256;
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + kThreads - 1) / kThreads)); }
+constexpr int kThreads = kPipeThreads;
+inline dim3 grid_for(int64_t n) { return pipe_grid(n); }
 
 __device__ __forceinline__ void edge_ends(const uint32_t *node1, const uint32_t *node2, int64_t e, uint32_t &src, uint32_t &dst) {
     const int64_t m = e >> 1;
@@ -94,11 +89,11 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges) {
 
 // per component: solvable? class; the three sort keys of the batch order
 __global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges,
-                            uint32_t *key_var, uint32_t *key_edges, uint32_t *key_class, uint32_t *ids, int *too_big) {
+                            uint32_t *key_var, uint32_t *key_edges, uint32_t *key_class, uint32_t *ids, uint32_t *too_big) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
-    if (solvable && c_nodes[c] > 32767) *too_big = 1;
+    if (solvable && c_nodes[c] > 32767) *too_big = 1u;
     key_var[c] = 0xffffu - min(c_var[c], 0xffffu);             // descending
     key_edges[c] = 0xffffffffu - c_edges[c];                   // descending
     key_class[c] = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c]) : 7u;
@@ -131,10 +126,10 @@ __global__ void k_node_keys(int64_t n_nodes, const int32_t *comp, const int32_t 
     ids[n] = (uint32_t)n;
 }
 
-__global__ void k_node_locals(int64_t total_nodes, const uint32_t *node_sorted, const int32_t *comp, const int32_t *di_of_comp,
+__global__ void k_node_locals(int64_t cap, const uint32_t *total_nodes, const uint32_t *node_sorted, const int32_t *comp, const int32_t *di_of_comp,
                               const uint32_t *node_off, uint32_t *node_ids, uint32_t *local_of) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total_nodes) return;
+    if (p >= cap || p >= (int64_t)*total_nodes) return;
     const uint32_t n = node_sorted[p];
     node_ids[p] = n;
     local_of[n] = (uint32_t)p - node_off[di_of_comp[comp[n]]];
@@ -160,11 +155,12 @@ __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t
 
 // packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
 // kernel's pair exchange relies on it)
-__global__ void k_check_pairs(int64_t total_edges, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
+__global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                               const int32_t *comp, const int32_t *di_of_comp, const uint32_t *class_of_desc,
-                              const uint32_t *edge_off, int *flag) {
+                              const uint32_t *edge_off, uint32_t *flag) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total_edges) return;
+    const int64_t total_edges = (int64_t)*total_edges_p;
+    if (p >= cap || p >= total_edges) return;
     const uint32_t e = edge_sorted[p];
     uint32_t s, d;
     edge_ends(node1, node2, e, s, d);
@@ -172,11 +168,11 @@ __global__ void k_check_pairs(int64_t total_edges, const uint32_t *edge_sorted, 
     if (class_of_desc[di] >= (uint32_t)KC_BLOCK) return;
     const uint32_t local = (uint32_t)p - edge_off[di];
     const int64_t q = (local & 1u) ? p - 1 : p + 1;
-    if (q < 0 || q >= total_edges || edge_sorted[q] != (e ^ 1u)) *flag = 1;
+    if (q < 0 || q >= total_edges || edge_sorted[q] != (e ^ 1u)) *flag = 1u;
 }
 
 // one thread per (edge record, 16-byte chunk): writes EdgeRec, counts degrees, records run starts
-__global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
+__global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
                              const int32_t *comp, const int32_t *di_of_comp, const uint32_t *edge_off, const uint32_t *node_off,
                              const uint32_t *local_of, const uint32_t *flow_row, uint4 *records, NodeInc *inc, uint64_t *in_keys,
@@ -184,7 +180,12 @@ __global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, c
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / 5;
     const int chunk = (int)(t - 5 * p);
-    if (p >= total_edges) return;
+    if (p >= cap) return;
+    const int64_t total_edges = (int64_t)*total_edges_p;
+    if (p >= total_edges) {                                  // padding of the in-edge sort: sorts behind every real key
+        if (chunk == 4) { in_keys[p] = 0x0000ffffffffffffull; in_vals[p] = 0u; }
+        return;
+    }
     const uint32_t e = edge_sorted[p];
     uint32_t s, d;
     edge_ends(node1, node2, e, s, d);
@@ -218,10 +219,10 @@ __global__ void k_emit_edges(int64_t total_edges, const uint32_t *edge_sorted, c
     records[5 * p + chunk] = q;
 }
 
-__global__ void k_in_begin(int64_t total_edges, const uint64_t *in_keys_sorted, const uint32_t *edge_off, const uint32_t *node_off,
+__global__ void k_in_begin(int64_t cap, const uint32_t *total_edges_p, const uint64_t *in_keys_sorted, const uint32_t *edge_off, const uint32_t *node_off,
                            NodeInc *inc) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= total_edges) return;
+    if (p >= cap || p >= (int64_t)*total_edges_p) return;
     const uint64_t k = in_keys_sorted[p];
     if (p == 0 || in_keys_sorted[p - 1] != k) {
         const uint32_t di = (uint32_t)(k >> 16), ld = (uint32_t)(k & 0xffffu);
@@ -229,11 +230,11 @@ __global__ void k_in_begin(int64_t total_edges, const uint64_t *in_keys_sorted, 
     }
 }
 
-__global__ void k_fill_descs(int64_t n_desc, const uint32_t *perm, const uint32_t *edge_off, const uint32_t *node_off,
+__global__ void k_fill_descs(int64_t cap, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *edge_off, const uint32_t *node_off,
                              const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges, const uint32_t *c_tracks,
                              CompDesc *descs, uint32_t *desc_tracks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_desc) return;
+    if (i >= cap || class_sorted[i] == 7u) return;
     const uint32_t c = perm[i];
     CompDesc d;
     d.edge_off = edge_off[i]; d.n_edges = c_edges[c]; d.node_off = node_off[i];
@@ -242,194 +243,214 @@ __global__ void k_fill_descs(int64_t n_desc, const uint32_t *perm, const uint32_
     desc_tracks[i] = c_tracks[c];
 }
 
-#define DEV_ALLOC(buf, bytes) HIP_TRY(dev_alloc(arena, buf, (size_t)(bytes), false))
-
-template <class K, class V>
-int sort_pairs(DevArena *arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
-    if (n <= 0) return LFR_OK;
-    size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
-    DevBuf tmp;
-    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    return LFR_OK;
+// sharded batches: the i-th solvable component in batch order goes to shard snake_shard(i); the others are
+// marked unsolvable (class 7) for this shard and drop out of everything downstream
+__global__ void k_shard_class(int64_t n_comp, const uint32_t *class_sorted, int shard_rank, int shard_world, uint32_t *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_comp) return;
+    const uint32_t c = class_sorted[i];
+    out[i] = (c != 7u && snake_shard(i, shard_world) == shard_rank) ? c : 7u;
 }
 
-int exclusive_sum(DevArena *arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
+// class ranges, per-class edge totals, largest workgroup-class systems, per-edge scratch sizes
+__global__ void k_summary(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
+                          const uint32_t *c_edges, const uint32_t *c_tracks, AsmSummary *sum, unsigned long long *es_size) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_comp) return;
+    const int prev = i > 0 ? (int)class_sorted[i - 1] : -1;
+    const int cur = i < n_comp ? (int)class_sorted[i] : 7;
+    for (int kc = prev + 1; kc <= cur; ++kc) sum->class_begin[kc] = (uint32_t)i;     // first index with class >= kc
+    if (i == n_comp) return;
+    es_size[i] = 0ull;
+    if (cur == 7) return;
+    const uint32_t c = perm[i];
+    atomicAdd((unsigned long long *)&sum->class_edges[cur], (unsigned long long)c_edges[c]);
+    atomicAdd(&sum->n_tracks, c_tracks[c]);
+    if (cur == KC_BLOCK) atomicMax(&sum->block_max_rows, 2u * c_var[c]);
+    if (cur == KC_GLOBAL) atomicMax(&sum->global_max_rows, 2u * c_var[c]);
+    if (cur == KC_BLOCK || cur == KC_GLOBAL) es_size[i] = 8ull * c_edges[c];          // 64 B of Jacobian scratch per edge
+}
+// global-matrix class: packed lower triangle + the vectors of the largest system of the class, per component
+__global__ void k_ws_sizes(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
+                           const AsmSummary *sum, unsigned long long *ws_size) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_comp) return;
+    unsigned long long v = 0ull;
+    if (class_sorted[i] == (uint32_t)KC_GLOBAL) {
+        const unsigned long long rows = 2ull * c_var[perm[i]], mat = rows * (rows + 1) / 2;
+        v = mat + (mat & 1ull) + (10ull * sum->global_max_rows + 4ull);              // block_vector_doubles(global_max_rows)
+    }
+    ws_size[i] = v;
+}
+// es_scan / ws_scan: exclusive scans over C+1 entries (the last entry holds the total)
+__global__ void k_offsets(int64_t n_comp, const uint32_t *class_sorted, const unsigned long long *es_scan, const unsigned long long *ws_scan,
+                          const uint32_t *node_off, const uint32_t *edge_off, AsmSummary *sum, uint64_t *es_off, uint64_t *ws_off) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_comp) return;
+    if (i == n_comp) {
+        sum->es_doubles = es_scan[n_comp]; sum->ws_doubles = ws_scan[n_comp];
+        sum->n_desc = sum->class_begin[7];
+        sum->total_nodes = node_off[n_comp]; sum->total_edges = edge_off[n_comp];
+        return;
+    }
+    es_off[i] = es_scan[i];
+    ws_off[i] = class_sorted[i] == (uint32_t)KC_GLOBAL ? es_scan[n_comp] + ws_scan[i] : 0ull;
+}
+
+struct ArenaMark {                                 // temporaries: released at scope end (reuse is stream ordered)
+    DevArena &a; size_t m;
+    explicit ArenaMark(DevArena &ar) : a(ar), m(ar.top) {}
+    ~ArenaMark() { a.top = m; }
+};
+#define TAKE(ptr, T, count)                                                                                   \
+    T *ptr = arena.take_n<T>((size_t)(count));                                                                \
+    if (!ptr) { set_error("assembly: device arena exhausted (%s)", #ptr); return LFR_ERR_NOMEM; }
+#define TAKE_OUT(dst, T, count)                                                                               \
+    dst = slab.take_n<T>((size_t)(count));                                                                    \
+    if (!dst) { set_error("assembly: batch slab exhausted (%s)", #dst); return LFR_ERR_NOMEM; }
+
+template <class K, class V>
+int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
-    DevBuf tmp;
-    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    ArenaMark mark(arena);
+    void *tmp = arena.take(bytes);
+    if (!tmp) { set_error("assembly: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    return LFR_OK;
+}
+template <class T>
+int exclusive_sum(DevArena &arena, const T *in, T *out, int64_t n, hipStream_t st) {
+    if (n <= 0) return LFR_OK;
+    size_t bytes = 0;
+    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
+    ArenaMark mark(arena);
+    void *tmp = arena.take(bytes);
+    if (!tmp) { set_error("assembly: device arena exhausted (scan of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st));
     return LFR_OK;
 }
 
 }  // namespace
 
-int assemble_on_device(const Graph &g, const Problem &p, hipStream_t st, const float *dev_disp1, const float *dev_disp2,
-                       DeviceAssembly &out) {
-    const int64_t N = g.n_nodes(), M = g.n_matches(), E2 = 2 * M;
-    const int64_t C = p.stats.n_components, T = p.stats.n_tracks;
-    if (E2 >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) { set_error("graph too large for the device assembly"); return LFR_ERR_UNSUPPORTED; }
-
-    DevArena slab;                                   // declared first: the buffers below must die before it
-    DevArena *arena = &slab;
-    if (slab.init((size_t)240 * M + (size_t)64 * N + (size_t)64 * C + ((size_t)16 << 20)) != hipSuccess) { (void)hipGetLastError(); slab.base = nullptr; arena = nullptr; }
-
-    // ---- uploads: endpoints, similarities, labels (small) and the flows (2 x 72 B per match) ----
-    std::vector<int32_t> track32(N), comp32(N);
-    for (int64_t i = 0; i < N; ++i) { track32[i] = (int32_t)p.track[i]; comp32[i] = (int32_t)p.comp[i]; }
-    DevBuf b_n1, b_n2, b_sim, b_track, b_comp, b_root, b_d1, b_d2;
-    DEV_ALLOC(b_n1, 4 * M); DEV_ALLOC(b_n2, 4 * M); DEV_ALLOC(b_sim, 4 * M);
-    DEV_ALLOC(b_track, 4 * N); DEV_ALLOC(b_comp, 4 * N); DEV_ALLOC(b_root, N);
-    HIP_TRY(hipMemcpyAsync(b_n1.p, g.m_node1.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_n2.p, g.m_node2.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_sim.p, g.m_sim.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_track.p, track32.data(), 4 * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_comp.p, comp32.data(), 4 * N, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_root.p, p.is_root.data(), N, hipMemcpyHostToDevice, st));
-    const float *disp1 = dev_disp1 ? dev_disp1 : g.dev_disp1, *disp2 = dev_disp2 ? dev_disp2 : g.dev_disp2;
-    DevBuf b_frow;
-    const uint32_t *flow_row = nullptr;
-    if (disp1 && disp2 && !g.m_flow_row.empty()) {      // caller-owned device flows, indexed by their original row
-        DEV_ALLOC(b_frow, 4 * M);
-        HIP_TRY(hipMemcpyAsync(b_frow.p, g.m_flow_row.data(), 4 * M, hipMemcpyHostToDevice, st));
-        flow_row = b_frow.as<uint32_t>();
-    }
-    if (!disp1 || !disp2) {
-        DEV_ALLOC(b_d1, 72 * M); DEV_ALLOC(b_d2, 72 * M);
-        HIP_TRY(hipMemcpyAsync(b_d1.p, g.m_disp1.data(), 72 * M, hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(b_d2.p, g.m_disp2.data(), 72 * M, hipMemcpyHostToDevice, st));
-        disp1 = b_d1.as<float>(); disp2 = b_d2.as<float>();
-    }
-    const uint32_t *node1 = b_n1.as<uint32_t>(), *node2 = b_n2.as<uint32_t>();
-    const int32_t *track = b_track.as<int32_t>(), *comp = b_comp.as<int32_t>();
-
-    // ---- which edges are kept, which nodes are variables, per-component sizes ----
-    DevBuf b_kept, b_opt, b_var, b_cn, b_cv, b_ce, b_ct, b_ts, b_tc, b_flag;
-    DEV_ALLOC(b_kept, E2); DEV_ALLOC(b_opt, N); DEV_ALLOC(b_var, N);
-    DEV_ALLOC(b_cn, 4 * C); DEV_ALLOC(b_cv, 4 * C); DEV_ALLOC(b_ce, 4 * C); DEV_ALLOC(b_ct, 4 * C);
-    DEV_ALLOC(b_ts, 4 * T); DEV_ALLOC(b_tc, 4 * T); DEV_ALLOC(b_flag, 4);
-    HIP_TRY(hipMemsetAsync(b_opt.p, 0, N, st));
-    HIP_TRY(hipMemsetAsync(b_cn.p, 0, 4 * C, st)); HIP_TRY(hipMemsetAsync(b_cv.p, 0, 4 * C, st));
-    HIP_TRY(hipMemsetAsync(b_ce.p, 0, 4 * C, st)); HIP_TRY(hipMemsetAsync(b_ct.p, 0, 4 * C, st));
-    HIP_TRY(hipMemsetAsync(b_ts.p, 0, 4 * T, st)); HIP_TRY(hipMemsetAsync(b_flag.p, 0, 4, st));
-    hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, b_kept.as<uint8_t>(), b_opt.as<uint8_t>());
-    hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, b_opt.as<uint8_t>(), b_root.as<uint8_t>(), track, comp,
-                       b_var.as<uint8_t>(), b_cn.as<uint32_t>(), b_cv.as<uint32_t>(), b_ts.as<uint32_t>(), b_tc.as<int32_t>());
-    hipLaunchKernelGGL(k_count_edges, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_var.as<uint8_t>(), b_kept.as<uint8_t>(), b_ce.as<uint32_t>());
-    hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, b_ts.as<uint32_t>(), b_tc.as<int32_t>(), b_ct.as<uint32_t>());
-
-    // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
-    DevBuf b_kv, b_ke, b_kc, b_id0, b_id1, b_k0, b_k1;
-    DEV_ALLOC(b_kv, 4 * C); DEV_ALLOC(b_ke, 4 * C); DEV_ALLOC(b_kc, 4 * C);
-    DEV_ALLOC(b_id0, 4 * C); DEV_ALLOC(b_id1, 4 * C); DEV_ALLOC(b_k0, 4 * C); DEV_ALLOC(b_k1, 4 * C);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, b_cn.as<uint32_t>(), b_cv.as<uint32_t>(), b_ce.as<uint32_t>(),
-                       b_kv.as<uint32_t>(), b_ke.as<uint32_t>(), b_kc.as<uint32_t>(), b_id0.as<uint32_t>(), b_flag.as<int>());
-    int rc;
-    // LSD over the three keys (each pass stable): variables, edges, class
-    if ((rc = sort_pairs(arena, b_kv.as<uint32_t>(), b_k0.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 16, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, b_id1.as<uint32_t>(), b_ke.as<uint32_t>(), b_k0.as<uint32_t>());
-    if ((rc = sort_pairs(arena, b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), C, 0, 32, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, b_id0.as<uint32_t>(), b_kc.as<uint32_t>(), b_k0.as<uint32_t>());
-    if ((rc = sort_pairs(arena, b_k0.as<uint32_t>(), b_k1.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), C, 0, 3, st)) != LFR_OK) return rc;
-    const uint32_t *perm = b_id1.as<uint32_t>();             // perm[i] = component of desc i
-    const uint32_t *class_sorted = b_k1.as<uint32_t>();
-
-    DevBuf b_dn, b_de, b_no, b_eo, b_di;
-    DEV_ALLOC(b_dn, 4 * (C + 1)); DEV_ALLOC(b_de, 4 * (C + 1)); DEV_ALLOC(b_no, 4 * (C + 1)); DEV_ALLOC(b_eo, 4 * (C + 1)); DEV_ALLOC(b_di, 4 * C);
-    HIP_TRY(hipMemsetAsync(b_dn.p, 0, 4 * (C + 1), st)); HIP_TRY(hipMemsetAsync(b_de.p, 0, 4 * (C + 1), st));
-    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, b_cn.as<uint32_t>(), b_ce.as<uint32_t>(),
-                       b_dn.as<uint32_t>(), b_de.as<uint32_t>(), b_di.as<int32_t>());
-    if ((rc = exclusive_sum(arena, b_dn.as<uint32_t>(), b_no.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
-    if ((rc = exclusive_sum(arena, b_de.as<uint32_t>(), b_eo.as<uint32_t>(), C + 1, st)) != LFR_OK) return rc;
-    uint32_t totals[2];
-    int too_big = 0;
-    HIP_TRY(hipMemcpy(&totals[0], b_no.as<uint32_t>() + C, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&totals[1], b_eo.as<uint32_t>() + C, 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(&too_big, b_flag.p, 4, hipMemcpyDeviceToHost));
-    if (too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
-    const int64_t total_nodes = totals[0], total_edges = totals[1];
-    std::vector<uint32_t> h_class(C);
-    HIP_TRY(hipMemcpy(h_class.data(), class_sorted, 4 * C, hipMemcpyDeviceToHost));
-    int64_t n_desc = 0;
-    while (n_desc < C && h_class[n_desc] != 7u) ++n_desc;
-
-    // ---- local node numbering: nodes by (desc, variable first, node id) ----
-    DevBuf b_nk0, b_nk1, b_ni0, b_ni1, b_local;
-    DEV_ALLOC(b_nk0, 4 * N); DEV_ALLOC(b_nk1, 4 * N); DEV_ALLOC(b_ni0, 4 * N); DEV_ALLOC(b_ni1, 4 * N); DEV_ALLOC(b_local, 4 * N);
-    hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, b_di.as<int32_t>(), b_var.as<uint8_t>(), b_nk0.as<uint32_t>(), b_ni0.as<uint32_t>());
-    if ((rc = sort_pairs(arena, b_nk0.as<uint32_t>(), b_nk1.as<uint32_t>(), b_ni0.as<uint32_t>(), b_ni1.as<uint32_t>(), N, 0, 32, st)) != LFR_OK) return rc;
-    HIP_TRY(hipMalloc(&out.d_node_ids, std::max<size_t>(4 * total_nodes, 16)));
-    hipLaunchKernelGGL(k_node_locals, grid_for(total_nodes), dim3(kThreads), 0, st, total_nodes, b_ni1.as<uint32_t>(), comp, b_di.as<int32_t>(),
-                       b_no.as<uint32_t>(), out.d_node_ids, b_local.as<uint32_t>());
-
-    // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
-    DevBuf b_ek0, b_ek1, b_ei0, b_ei1;
-    DEV_ALLOC(b_ek0, 8 * E2); DEV_ALLOC(b_ek1, 8 * E2); DEV_ALLOC(b_ei0, 4 * E2); DEV_ALLOC(b_ei1, 4 * E2);
-    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, b_di.as<int32_t>(), class_sorted, b_kept.as<uint8_t>(),
-                       b_ek0.as<uint64_t>(), b_ei0.as<uint32_t>());
-    if ((rc = sort_pairs(arena, b_ek0.as<uint64_t>(), b_ek1.as<uint64_t>(), b_ei0.as<uint32_t>(), b_ei1.as<uint32_t>(), E2, 0, 64, st)) != LFR_OK) return rc;
-
-    HIP_TRY(hipMemsetAsync(b_flag.p, 0, 4, st));
-    hipLaunchKernelGGL(k_check_pairs, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2, comp,
-                       b_di.as<int32_t>(), class_sorted, b_eo.as<uint32_t>(), b_flag.as<int>());
-    {
-        int unpaired = 0;
-        HIP_TRY(hipMemcpyAsync(&unpaired, b_flag.p, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
-    }
-
-    // ---- records, degrees, in-edge lists ----
-    HIP_TRY(hipMalloc(&out.d_edges, std::max<size_t>(sizeof(EdgeRec) * total_edges, 16)));
-    HIP_TRY(hipMalloc(&out.d_node_inc, std::max<size_t>(sizeof(NodeInc) * total_nodes, 16)));
-    HIP_TRY(hipMalloc(&out.d_in_idx, std::max<size_t>(4 * total_edges, 16)));
-    HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * total_nodes, 16), st));
-    uint64_t *in_k0 = b_ek0.as<uint64_t>(), *in_k1 = b_ek1.as<uint64_t>();   // reuse the key buffers
-    uint32_t *in_v0 = b_ei0.as<uint32_t>();
-    hipLaunchKernelGGL(k_emit_edges, grid_for(5 * total_edges), dim3(kThreads), 0, st, total_edges, b_ei1.as<uint32_t>(), node1, node2,
-                       b_sim.as<float>(), disp1, disp2, track, comp, b_di.as<int32_t>(), b_eo.as<uint32_t>(), b_no.as<uint32_t>(),
-                       b_local.as<uint32_t>(), flow_row, reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
-    if ((rc = sort_pairs(arena, in_k0, in_k1, in_v0, out.d_in_idx, total_edges, 0, 48, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_in_begin, grid_for(total_edges), dim3(kThreads), 0, st, total_edges, in_k1, b_eo.as<uint32_t>(), b_no.as<uint32_t>(), out.d_node_inc);
-
-    // ---- descriptors ----
-    DevBuf b_dt;
-    DEV_ALLOC(b_dt, 4 * std::max<int64_t>(n_desc, 1));
-    HIP_TRY(hipMalloc(&out.d_descs, std::max<size_t>(sizeof(CompDesc) * n_desc, 16)));
-    hipLaunchKernelGGL(k_fill_descs, grid_for(n_desc), dim3(kThreads), 0, st, n_desc, perm, b_eo.as<uint32_t>(), b_no.as<uint32_t>(),
-                       b_cn.as<uint32_t>(), b_cv.as<uint32_t>(), b_ce.as<uint32_t>(), b_ct.as<uint32_t>(), out.d_descs, b_dt.as<uint32_t>());
-    HIP_TRY(hipGetLastError());
-    HIP_TRY(hipStreamSynchronize(st));
-
-    // ---- host mirrors the batch needs (descriptors, component ids, node ids) ----
-    out.descs.resize(n_desc); out.desc_component.resize(n_desc); out.desc_class.resize(n_desc); out.desc_tracks.resize(n_desc);
-    out.node_ids.resize(total_nodes);
-    std::vector<uint32_t> h_perm(n_desc), h_tracks(n_desc);
-    if (n_desc) {
-        HIP_TRY(hipMemcpy(out.descs.data(), out.d_descs, sizeof(CompDesc) * n_desc, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_perm.data(), perm, 4 * n_desc, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(h_tracks.data(), b_dt.p, 4 * n_desc, hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(out.node_ids.data(), out.d_node_ids, 4 * total_nodes, hipMemcpyDeviceToHost));
-    }
-    for (int64_t i = 0; i < n_desc; ++i) {
-        out.desc_component[i] = h_perm[i]; out.desc_class[i] = (int32_t)h_class[i]; out.desc_tracks[i] = (int32_t)h_tracks[i];
-    }
-    out.n_edges = total_edges; out.n_nodes = total_nodes;
-    return LFR_OK;
+size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C) {
+    const size_t E2 = (size_t)2 * M, n = (size_t)N, c = (size_t)C + 1;
+    return sizeof(CompDesc) * c + sizeof(EdgeRec) * E2 + 4 * n + sizeof(NodeInc) * n + 4 * E2 + 16 * c + 12 * c + 256 * 16;
 }
 
-void DeviceAssembly::release() {
-    if (d_descs) (void)hipFree(d_descs);
-    if (d_edges) (void)hipFree(d_edges);
-    if (d_node_ids) (void)hipFree(d_node_ids);
-    if (d_node_inc) (void)hipFree(d_node_inc);
-    if (d_in_idx) (void)hipFree(d_in_idx);
-    d_descs = nullptr; d_edges = nullptr; d_node_ids = nullptr; d_node_inc = nullptr; d_in_idx = nullptr;
+int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, int shard_world, DevArena &slab, DeviceAssembly &out) {
+    const DevGraph &dg = *dp.graph;
+    DevCtx *ctx = dp.ctx;
+    hipStream_t st = ctx->s_main;
+    const int64_t N = dg.N, M = dg.M, E2 = 2 * M;
+    const int64_t C = p.stats.n_components, T = p.stats.n_tracks;
+    if (E2 >= ((int64_t)1 << 31) || N >= ((int64_t)1 << 31)) { set_error("graph too large for the device assembly"); return LFR_ERR_UNSUPPORTED; }
+    LFR_HIP_TRY(hipSetDevice(ctx->device));
+
+    DevArena arena;                                   // temporaries of this call
+    if (!arena.init(ctx, (size_t)96 * M + (size_t)48 * N + (size_t)128 * (C + 1) + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
+    size_t pin_bytes = 0;
+    AsmSummary *h_sum = (AsmSummary *)ctx->pinned_acquire(sizeof(AsmSummary), &pin_bytes);
+    if (!h_sum) return LFR_ERR_NOMEM;
+    struct PinGuard { DevCtx *c; void *p; size_t b; ~PinGuard() { c->pinned_release(p, b); } } pin_guard{ctx, h_sum, pin_bytes};
+
+    const uint32_t *node1 = dg.n1, *node2 = dg.n2;
+    const int32_t *track = dp.track, *comp = dp.comp;
+
+    // ---- outputs (capacities are upper bounds: every edge kept, every node in a solved component) ----
+    TAKE_OUT(out.d_descs, CompDesc, C + 1); TAKE_OUT(out.d_edges, EdgeRec, E2);
+    TAKE_OUT(out.d_node_ids, uint32_t, N); TAKE_OUT(out.d_node_inc, NodeInc, N); TAKE_OUT(out.d_in_idx, uint32_t, E2);
+    TAKE_OUT(out.d_ws_off, uint64_t, C + 1); TAKE_OUT(out.d_es_off, uint64_t, C + 1);
+    TAKE_OUT(out.d_desc_class, uint32_t, C + 1); TAKE_OUT(out.d_desc_tracks, uint32_t, C + 1); TAKE_OUT(out.d_desc_component, uint32_t, C + 1);
+
+    // ---- which edges are kept, which nodes are variables, per-component sizes ----
+    TAKE(sum, AsmSummary, 1);
+    TAKE(kept, uint8_t, E2); TAKE(opt, uint8_t, N); TAKE(is_var, uint8_t, N);
+    TAKE(cn, uint32_t, C + 1); TAKE(cv, uint32_t, C + 1); TAKE(ce, uint32_t, C + 1); TAKE(ct, uint32_t, C + 1);
+    TAKE(ts, uint32_t, T + 1); TAKE(tc, int32_t, T + 1);
+    LFR_HIP_TRY(hipMemsetAsync(sum, 0, sizeof(AsmSummary), st));
+    LFR_HIP_TRY(hipMemsetAsync(opt, 0, (size_t)N, st));
+    LFR_HIP_TRY(hipMemsetAsync(cn, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(cv, 0, 4 * (size_t)(C + 1), st));
+    LFR_HIP_TRY(hipMemsetAsync(ce, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(ct, 0, 4 * (size_t)(C + 1), st));
+    LFR_HIP_TRY(hipMemsetAsync(ts, 0, 4 * (size_t)(T + 1), st));
+    hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
+    hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
+    hipLaunchKernelGGL(k_count_edges, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, is_var, kept, ce);
+    hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, ts, tc, ct);
+
+    // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
+    TAKE(kv, uint32_t, C + 1); TAKE(ke, uint32_t, C + 1); TAKE(kc, uint32_t, C + 1);
+    TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
+    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, kv, ke, kc, id0, &sum->too_big);
+    int rc;
+    // LSD over the three keys (each pass stable): variables, edges, class
+    if ((rc = sort_pairs(arena, kv, k0, id0, id1, C, 0, 16, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id1, ke, k0);
+    if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, 32, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id0, kc, k0);
+    if ((rc = sort_pairs(arena, k0, k1, id0, id1, C, 0, 3, st)) != LFR_OK) return rc;
+    uint32_t *perm = id1;                  // perm[i] = component of desc i
+    uint32_t *class_sorted = k1;
+    if (shard_world > 1) {                 // keep this shard's components (same relative order), the rest becomes class 7
+        hipLaunchKernelGGL(k_shard_class, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, shard_rank, shard_world, k0);
+        if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, 3, st)) != LFR_OK) return rc;
+        perm = id0; class_sorted = k1;     // (k1 is rewritten by the sort after k_shard_class has read it: stream ordered)
+    }
+
+    TAKE(dn, uint32_t, C + 1); TAKE(de, uint32_t, C + 1); TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
+    LFR_HIP_TRY(hipMemsetAsync(dn, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(de, 0, 4 * (size_t)(C + 1), st));
+    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, cn, ce, dn, de, di);
+    if ((rc = exclusive_sum(arena, dn, no, C + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, de, eo, C + 1, st)) != LFR_OK) return rc;
+    const uint32_t *total_nodes_p = no + C, *total_edges_p = eo + C;
+
+    // ---- launch geometry + workspace offsets ----
+    TAKE(es_size, unsigned long long, C + 1); TAKE(ws_size, unsigned long long, C + 1);
+    TAKE(es_scan, unsigned long long, C + 1); TAKE(ws_scan, unsigned long long, C + 1);
+    LFR_HIP_TRY(hipMemsetAsync(ws_size, 0, 8 * (size_t)(C + 1), st));
+    hipLaunchKernelGGL(k_summary, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, perm, cv, ce, ct, sum, es_size);
+    hipLaunchKernelGGL(k_ws_sizes, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, cv, sum, ws_size);
+    if ((rc = exclusive_sum(arena, es_size, es_scan, C + 1, st)) != LFR_OK) return rc;
+    if ((rc = exclusive_sum(arena, ws_size, ws_scan, C + 1, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_offsets, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, es_scan, ws_scan, no, eo, sum, out.d_es_off, out.d_ws_off);
+
+    // ---- local node numbering: nodes by (desc, variable first, node id) ----
+    TAKE(nk0, uint32_t, N); TAKE(nk1, uint32_t, N); TAKE(ni0, uint32_t, N); TAKE(ni1, uint32_t, N); TAKE(local, uint32_t, N);
+    hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, di, is_var, nk0, ni0);
+    if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, 32, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_node_locals, grid_for(N), dim3(kThreads), 0, st, N, total_nodes_p, ni1, comp, di, no, out.d_node_ids, local);
+
+    // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
+    TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);
+    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, ek0, ei0);
+    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, 64, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_check_pairs, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted, eo, &sum->unpaired);
+
+    // ---- records, degrees, in-edge lists (the first consumer of the flows: wait for their upload) ----
+    if (dg.flows_staged && dg.ev_flows) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows, 0));
+    LFR_HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * (size_t)N, 16), st));
+    uint64_t *in_k0 = ek0, *in_k1 = ek1;   // reuse the key buffers
+    uint32_t *in_v0 = ei0;
+    hipLaunchKernelGGL(k_emit_edges, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
+                       dg.sim, dg.disp1, dg.disp2, track, comp, di, eo, no, local, dg.flow_row,
+                       reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
+    if ((rc = sort_pairs(arena, in_k0, in_k1, in_v0, out.d_in_idx, E2, 0, 48, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, in_k1, eo, no, out.d_node_inc);
+
+    // ---- descriptors + the device copies behind the lazily fetched host mirrors ----
+    hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks);
+    LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_class, class_sorted, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
+    LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_component, perm, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
+    LFR_HIP_TRY(hipGetLastError());
+
+    // the one read-back of the stage
+    LFR_HIP_TRY(hipMemcpyAsync(h_sum, sum, sizeof(AsmSummary), hipMemcpyDeviceToHost, st));
+    LFR_HIP_TRY(hipStreamSynchronize(st));
+    out.summary = *h_sum;
+    if (out.summary.too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
+    if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
+    return LFR_OK;
 }
 
 }  // namespace lfr

@@ -1,74 +1,101 @@
-// Device-side batch assembly (lfr_assemble.hip): builds the HBM batch layout of a whole problem on
-// the GPU from the match graph + the host graph stage's labels.
+// Device pipeline between the parsed match graph and the solve kernels:
+//   DevGraph    the match graph in HBM (endpoints, similarities, node images; flows staged, caller-owned or zero-copy)
+//   DevProblem  tracks / roots / components in HBM (lfr_graphstage.hip)
+//   device assembly of the batch layout (lfr_assemble.hip)
+// One stream (DevCtx::s_main) carries the whole chain without host round trips: the graph stage ends with one
+// 64-byte read-back (counts for the stdout lines + the host-fallback decision), the assembly with one
+// (launch geometry of the solve kernels).  The flows travel on DevCtx::s_copy beside it.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <memory>
+
+#include "lfr_devctx.hpp"
 #include "lfr_internal.hpp"
 
 namespace lfr {
 
-struct DeviceAssembly {
-    // device arrays (handed over to the batch)
+#define LFR_HIP_TRY(expr)                                                                     \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::lfr::set_error("%s failed: %s", #expr, hipGetErrorString(_e));                  \
+            return LFR_ERR_HIP;                                                               \
+        }                                                                                     \
+    } while (0)
+
+struct DevGraph {
+    DevCtx *ctx = nullptr;
+    int64_t N = 0, M = 0;
+    DevArena slab;                       // endpoints, similarities, node images [, flow rows] [, staged flows]
+    uint32_t *n1 = nullptr, *n2 = nullptr;
+    float *sim = nullptr;
+    int32_t *node_image = nullptr;
+    uint32_t *flow_row = nullptr;        // caller-owned device flows are indexed by their original row
+    const float *disp1 = nullptr, *disp2 = nullptr;   // flows in match order: HBM (staged / caller-owned) or pinned host (zero copy)
+    bool flows_staged = false, flows_zero_copy = false, flows_external = false;
+    hipEvent_t ev_flows = nullptr;       // recorded on s_copy after the staged upload
+    ~DevGraph();
+};
+// The graph's device copy (created on first use, cached on the graph until lfr_graph_evict_device).
+// stage_flows: copy the flows to HBM asynchronously on s_copy; otherwise leave them where they are
+// (pinned host memory is read zero-copy by the assembly; pageable memory is staged after all).
+int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_ptr<DevGraph> &out);
+
+struct DevProblem {
+    DevCtx *ctx = nullptr;
+    std::shared_ptr<DevGraph> graph;
+    int64_t N = 0;
+    DevArena slab;
+    int32_t *track = nullptr, *comp = nullptr;
+    uint8_t *is_root = nullptr;
+    ~DevProblem();
+};
+// labels computed on the host (graph cut, side-car, fallbacks) -> HBM
+int upload_labels(const Problem &p, int device, bool stage_flows, std::shared_ptr<DevProblem> &out);
+
+// Tracks, roots and components on the GPU (lfr_graphstage.hip): fills p.dev and the stage statistics; the
+// host copies of the labels are fetched on demand (Problem::ensure_host_labels).  Returns
+// LFR_GRAPHSTAGE_USE_HOST when the input needs something only the host stage has.
+constexpr int LFR_GRAPHSTAGE_USE_HOST = 1;
+int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p);
+
+// What the host needs to launch the solve kernels, read back once at the end of the assembly.
+struct AsmSummary {
+    uint32_t n_desc, total_nodes, total_edges, n_tracks;
+    uint32_t class_begin[KC_COUNT + 1];
+    uint32_t block_max_rows, global_max_rows;
+    uint32_t too_big, unpaired;
+    uint64_t class_edges[KC_COUNT];
+    uint64_t es_doubles, ws_doubles;     // per-edge scratch, + HBM matrices of the global class
+};
+
+struct DeviceAssembly {                  // arrays inside the batch's slab (capacities are upper bounds)
     CompDesc *d_descs = nullptr;
     EdgeRec *d_edges = nullptr;
     uint32_t *d_node_ids = nullptr;
     NodeInc *d_node_inc = nullptr;
     uint32_t *d_in_idx = nullptr;
-    // host mirrors
-    std::vector<CompDesc> descs;
-    std::vector<int64_t> desc_component;
-    std::vector<int32_t> desc_class, desc_tracks;
-    std::vector<uint32_t> node_ids;
-    int64_t n_edges = 0, n_nodes = 0;
-    void release();
+    uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
+    uint32_t *d_desc_component = nullptr, *d_desc_class = nullptr, *d_desc_tracks = nullptr;
+    AsmSummary summary{};
 };
+// bytes of batch slab the assembly's outputs need for a graph of N nodes, M matches, C components
+size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C);
+// Builds the batch layout of shard `shard_rank` of `shard_world` (snake deal in batch order, see assign_shards)
+// out of `slab`; synchronises s_main once, at the end.
+int assemble_on_device(const Problem &p, const DevProblem &labels, int shard_rank, int shard_world, DevArena &slab, DeviceAssembly &out);
 
-// dev_disp1/dev_disp2: optional device pointers to the flows in match order (n_matches x 18 floats
-// each, disp1 = flow 2->1, disp2 = flow 1->2); when null the graph's host arrays are uploaded.
-// One slab per pipeline stage: hipFree costs ~0.2 ms (it synchronises the device) and each stage uses ~40
-// temporaries.  A buffer that does not fit falls back to its own hipMalloc/hipFree.
-struct DevArena {
-    char *base = nullptr;
-    size_t cap = 0, top = 0;
-    ~DevArena() { if (base) (void)hipFree(base); }
-    hipError_t init(size_t bytes) { cap = bytes; return hipMalloc((void **)&base, bytes); }
-    void *take(size_t bytes) {
-        const size_t b = (bytes + 255) & ~(size_t)255;
-        if (!base || top + b > cap) return nullptr;
-        void *p = base + top;
-        top += b;
-        return p;
-    }
-};
-struct DevBuf {          // tiny RAII for the many temporaries
-    void *p = nullptr;
-    DevArena *arena = nullptr;
-    size_t mark = 0;
-    bool temp = false;       // released at scope end (stack discipline: nothing is taken while it lives)
-    ~DevBuf() {
-        if (!p) return;
-        if (!arena) (void)hipFree(p);
-        else if (temp) arena->top = mark;
-    }
-    template <class T> T *as() { return (T *)p; }
-};
-inline hipError_t dev_alloc(DevArena *ar, DevBuf &b, size_t bytes, bool temp) {
-    bytes = bytes < 16 ? 16 : bytes;
-    if (ar) {
-        const size_t m = ar->top;
-        if (void *q = ar->take(bytes)) { b.p = q; b.arena = ar; b.mark = m; b.temp = temp; return hipSuccess; }
-    }
-    return hipMalloc(&b.p, bytes);
+// shard of the i-th solvable component in batch order (class, edges descending, ...): dealt out and back
+// (0..W-1, W-1..0, ...), so every shard receives the same mix of kernel classes and sizes
+__host__ __device__ inline int snake_shard(int64_t i, int world) {
+    const int64_t round = i / world;
+    const int pos = (int)(i - round * world);
+    return (round & 1) ? world - 1 - pos : pos;
 }
 
-int assemble_on_device(const Graph &g, const Problem &labels, hipStream_t stream, const float *dev_disp1,
-                       const float *dev_disp2, DeviceAssembly &out);
-
-// Tracks, roots and components on the GPU (lfr_graphstage.hip): fills p.track / p.comp / p.is_root and
-// the stage statistics exactly as the host stage does.  Returns LFR_GRAPHSTAGE_USE_HOST when the
-// input needs something only the host stage has (graph cut above the size cap, a huge connected
-// component): the caller then runs build_problem().
-constexpr int LFR_GRAPHSTAGE_USE_HOST = 1;
-int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem &p);
+// small helpers shared by the two pipeline stages (all asynchronous on `st`)
+constexpr int kPipeThreads = 256;
+inline dim3 pipe_grid(int64_t n) { return dim3((unsigned)((n < 1 ? 1 : n) + kPipeThreads - 1) / kPipeThreads); }
 
 }  // namespace lfr

@@ -1,0 +1,168 @@
+// Per-device streams + slab caches, pinned host arrays (see lfr_devctx.hpp).
+#include "lfr_devctx.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+
+#include "lfr_internal.hpp"
+
+namespace lfr {
+
+namespace {
+
+constexpr size_t kPinThreshold = (size_t)1 << 20;      // smaller arrays: plain malloc (tests build thousands of toy graphs)
+
+int hip_device_count() {                                // cached; 0 without a GPU (CPU-only test runs)
+    static const int n = [] {
+        if (const char *e = getenv("LFR_NO_PINNED")) if (e[0] == '1') return 0;
+        int c = 0;
+        if (hipGetDeviceCount(&c) != hipSuccess) { (void)hipGetLastError(); c = 0; }
+        return c;
+    }();
+    return n;
+}
+
+size_t env_mb(const char *name, size_t dflt_bytes) {
+    if (const char *e = getenv(name)) { const long long v = atoll(e); if (v >= 0) return (size_t)v << 20; }
+    return dflt_bytes;
+}
+
+}  // namespace
+
+void *host_alloc(size_t bytes, bool *pinned) {
+    *pinned = false;
+    if (bytes >= kPinThreshold && hip_device_count() > 0) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p) { *pinned = true; return p; }
+        (void)hipGetLastError();
+    }
+    void *p = malloc(bytes ? bytes : 1);
+    if (!p) { fprintf(stderr, "lfr: out of host memory (%zu bytes)\n", bytes); abort(); }
+    return p;
+}
+
+void host_free(void *p, bool pinned) {
+    if (!p) return;
+    if (pinned) (void)hipHostFree(p); else free(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+void *DevCtx::dev_acquire(size_t bytes, size_t *got) {
+    bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)free_dev.size(); ++i)
+            if (free_dev[i].bytes >= bytes && free_dev[i].bytes <= 2 * bytes + ((size_t)64 << 20) &&
+                (best < 0 || free_dev[i].bytes < free_dev[best].bytes)) best = i;
+        if (best >= 0) {
+            Slab s = free_dev[best];
+            free_dev.erase(free_dev.begin() + best);
+            cached_dev -= s.bytes;
+            if (got) *got = s.bytes;
+            return s.p;
+        }
+    }
+    (void)hipSetDevice(device);
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        trim();                                         // cached slabs of the wrong size may be what is in the way
+        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc of %zu bytes failed on device %d", bytes, device); return nullptr; }
+    }
+    if (got) *got = bytes;
+    return p;
+}
+
+void DevCtx::dev_release(void *p, size_t bytes) {
+    if (!p) return;
+    std::vector<Slab> drop;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        free_dev.push_back(Slab{p, bytes});
+        cached_dev += bytes;
+        while (cached_dev > limit_dev && !free_dev.empty()) {       // oldest first
+            drop.push_back(free_dev.front());
+            cached_dev -= free_dev.front().bytes;
+            free_dev.erase(free_dev.begin());
+        }
+    }
+    if (!drop.empty()) { (void)hipSetDevice(device); for (auto &s : drop) (void)hipFree(s.p); }
+}
+
+void *DevCtx::pinned_acquire(size_t bytes, size_t *got) {
+    bytes = (bytes + 4095) & ~(size_t)4095;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)free_pinned.size(); ++i)
+            if (free_pinned[i].bytes >= bytes && free_pinned[i].bytes <= 2 * bytes + ((size_t)1 << 20) &&
+                (best < 0 || free_pinned[i].bytes < free_pinned[best].bytes)) best = i;
+        if (best >= 0) {
+            Slab s = free_pinned[best];
+            free_pinned.erase(free_pinned.begin() + best);
+            cached_pinned -= s.bytes;
+            if (got) *got = s.bytes;
+            return s.p;
+        }
+    }
+    (void)hipSetDevice(device);
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); set_error("hipHostMalloc of %zu bytes failed", bytes); return nullptr; }
+    if (got) *got = bytes;
+    return p;
+}
+
+void DevCtx::pinned_release(void *p, size_t bytes) {
+    if (!p) return;
+    std::vector<Slab> drop;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        free_pinned.push_back(Slab{p, bytes});
+        cached_pinned += bytes;
+        while (cached_pinned > limit_pinned && !free_pinned.empty()) {
+            drop.push_back(free_pinned.front());
+            cached_pinned -= free_pinned.front().bytes;
+            free_pinned.erase(free_pinned.begin());
+        }
+    }
+    for (auto &s : drop) (void)hipHostFree(s.p);
+}
+
+void DevCtx::trim() {
+    std::vector<Slab> d, h;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        d.swap(free_dev); h.swap(free_pinned);
+        cached_dev = cached_pinned = 0;
+    }
+    (void)hipSetDevice(device);
+    for (auto &s : d) (void)hipFree(s.p);
+    for (auto &s : h) (void)hipHostFree(s.p);
+}
+
+DevCtx *dev_ctx(int device) {
+    static std::mutex mu;
+    static std::vector<DevCtx *> ctxs;                   // never destroyed: the HIP runtime may be gone at exit
+    std::lock_guard<std::mutex> lk(mu);
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess) { (void)hipGetLastError(); n_dev = 0; }
+    if (device < 0 || device >= n_dev) { set_error("HIP device %d not available (%d devices)", device, n_dev); return nullptr; }
+    if ((int)ctxs.size() <= device) ctxs.resize(device + 1, nullptr);
+    if (ctxs[device]) return ctxs[device];
+    if (hipSetDevice(device) != hipSuccess) { set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    std::unique_ptr<DevCtx> c(new DevCtx());
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->s_main, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->s_copy, hipStreamNonBlocking) != hipSuccess) {
+        set_error("hipStreamCreate failed on device %d: %s", device, hipGetErrorString(hipGetLastError()));
+        return nullptr;
+    }
+    c->limit_dev = env_mb("LFR_SLAB_CACHE_MB", c->limit_dev);
+    c->limit_pinned = env_mb("LFR_PINNED_CACHE_MB", c->limit_pinned);
+    ctxs[device] = c.release();
+    return ctxs[device];
+}
+
+}  // namespace lfr

@@ -510,15 +510,9 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
 std::vector<int32_t> assign_shards(const Problem &p, int world) {
     std::vector<int32_t> shard(p.descs.size(), 0);
     if (world <= 1) return shard;
-    std::vector<size_t> order(p.descs.size());
-    std::iota(order.begin(), order.end(), (size_t)0);
-    std::stable_sort(order.begin(), order.end(), [&](size_t x, size_t y) { return p.descs[x].n_edges > p.descs[y].n_edges; });
-    std::vector<int64_t> load(world, 0);
-    for (size_t i : order) {
-        int best = 0;
-        for (int s = 1; s < world; ++s) if (load[s] < load[best]) best = s;
-        load[best] += (int64_t)p.descs[i].n_edges + 8;      // +8: fixed per-component cost
-        shard[i] = best;
+    for (size_t i = 0; i < shard.size(); ++i) {          // snake_shard() of lfr_assemble.hpp (host-only file: restated)
+        const size_t round = i / (size_t)world, pos = i % (size_t)world;
+        shard[i] = (int32_t)((round & 1) ? (size_t)world - 1 - pos : pos);
     }
     return shard;
 }
@@ -560,6 +554,7 @@ int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats) {
 int64_t lfr_problem_shard_components(const lfr_problem *p, int shard_rank, int shard_world, int64_t *components,
                                      int64_t *n_edges) {
     if (!p || shard_world < 1 || shard_rank < 0 || shard_rank >= shard_world) return LFR_ERR_ARG;
+    if (!p->p.host_batch) { set_error("lfr_problem_shard_components needs a host-assembled problem (lfr_problem_build)"); return LFR_ERR_ARG; }
     const std::vector<int32_t> shard = assign_shards(p->p, shard_world);
     int64_t n = 0;
     for (size_t i = 0; i < shard.size(); ++i)
@@ -573,6 +568,8 @@ int64_t lfr_problem_shard_components(const lfr_problem *p, int shard_rank, int s
 
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component) {
     if (!p) return LFR_ERR_ARG;
+    const int rc = p->p.ensure_host_labels();       // after the device graph stage the labels are still in HBM
+    if (rc != LFR_OK) return rc;
     const size_t n = p->p.track.size();
     if (track && n) memcpy(track, p->p.track.data(), sizeof(int64_t) * n);
     if (is_root && n) memcpy(is_root, p->p.is_root.data(), n);

@@ -1,5 +1,6 @@
 // Device-side graph stage: tracks (solve.cc:489-549), roots (solve.cc:552-582) and components
-// (solve.cc:252-308) on the GPU, bit-identical to the host stage of lfr_graph.cpp.
+// (solve.cc:252-308) on the GPU, bit-identical to the host stage of lfr_graph.cpp; plus the device copies of
+// the match graph (DevGraph) and of the labels (DevProblem) that the batch assembly continues from.
 //
 // The constrained maximum spanning forest is greedy over the globally sorted match list, i.e.
 // order dependent — but only INSIDE a connected component of the match graph: two matches of
@@ -11,10 +12,13 @@
 //      image-conflict test over its own matches, in order
 //   5. track ids = rank of the root nodes; roots = arg-max (score, node) per track; components =
 //      connected components of the track meta-graph, numbered by their smallest track.
-// Components above the size cap need the graph cut, and very large connected components would
-// serialise step 4 on one thread: both cases return LFR_GRAPHSTAGE_USE_HOST and the caller runs the
-// host stage instead.  Integer work throughout; the only floating-point accumulation (root scores,
-// sums of float32 similarities in fp64) is exact for any realistic input, hence order independent.
+// The whole chain is enqueued on ONE stream without host round trips: counts that size later steps
+// (segments, tracks, components) stay on the device and bound the kernels there; every array is sized
+// by its upper bound (N or M).  One 64-byte read-back at the end delivers the counts for the stdout lines
+// and the two conditions under which the caller must use the host stage instead (a component above the
+// size cap needs the graph cut; a very large connected component would serialise step 4 on one thread).
+// Integer work throughout; the only floating-point accumulation (root scores, sums of float32
+// similarities in fp64) is exact for any realistic input, hence order independent.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -27,42 +31,40 @@
 
 namespace lfr {
 
-#define HIP_TRY(expr)                                                                         \
-    do {                                                                                      \
-        hipError_t _e = (expr);                                                               \
-        if (_e != hipSuccess) {                                                               \
-            set_error("%s failed: %s", #expr, hipGetErrorString(_e));                         \
-            return LFR_ERR_HIP;                                                               \
-        }                                                                                     \
-    } while (0)
-
 namespace {
 
-constexpr int kThreads = 256;
+constexpr int kThreads = kPipeThreads;
 constexpr int64_t kMaxSegmentEdges = 1 << 16;     // larger connected components: host stage
-inline dim3 grid_for(int64_t n) { return dim3((unsigned)std::max<int64_t>(1, (n + kThreads - 1) / kThreads)); }
+inline dim3 grid_for(int64_t n) { return pipe_grid(n); }
 
-#define DEV_ALLOC(buf, bytes) HIP_TRY(dev_alloc(arena, buf, (size_t)(bytes), false))
+struct ArenaMark {                                 // temporaries: released at scope end (reuse is stream ordered)
+    DevArena &a; size_t m;
+    explicit ArenaMark(DevArena &ar) : a(ar), m(ar.top) {}
+    ~ArenaMark() { a.top = m; }
+};
+#define TAKE(ptr, T, count)                                                                                   \
+    T *ptr = arena.take_n<T>((size_t)(count));                                                                \
+    if (!ptr) { set_error("graph stage: device arena exhausted (%s)", #ptr); return LFR_ERR_NOMEM; }
 
 template <class K, class V>
-int sort_pairs(DevArena *arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
+int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
-    DevBuf tmp;
-    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp.p, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    ArenaMark mark(arena);
+    void *tmp = arena.take(bytes);
+    if (!tmp) { set_error("graph stage: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     return LFR_OK;
 }
-int exclusive_sum(DevArena *arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
+int exclusive_sum(DevArena &arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
-    DevBuf tmp;
-    HIP_TRY(dev_alloc(arena, tmp, bytes, true));
-    HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp.p, bytes, in, out, (int)n, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
+    ArenaMark mark(arena);
+    void *tmp = arena.take(bytes);
+    if (!tmp) { set_error("graph stage: device arena exhausted (scan of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st));
     return LFR_OK;
 }
 
@@ -131,9 +133,17 @@ __global__ void k_seg_flags(int64_t M, const uint32_t *keys, uint32_t *flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
-__global__ void k_seg_starts(int64_t M, const uint32_t *flags, const uint32_t *seg_id, uint32_t *starts) {
+// counts[] layout (device): what the host reads back at the end of the stage
+enum { CNT_SEG = 0, CNT_TRACKS, CNT_COMPS, CNT_MAX_TRACK, CNT_MAX_COMP, CNT_MAX_SEG, CNT_WORDS = 16 };
+// seg_id[i] = exclusive count of flags; seg_id[M] = number of segments
+__global__ void k_seg_starts(int64_t M, const uint32_t *flags, const uint32_t *seg_id, uint32_t *starts, uint32_t *counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M && flags[i]) starts[seg_id[i]] = (uint32_t)i;
+    if (i == 0) { starts[seg_id[M]] = (uint32_t)M; counts[CNT_SEG] = seg_id[M]; }
+}
+__global__ void k_seg_maxlen(int64_t cap, const uint32_t *starts, uint32_t *counts) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < cap && s < (int64_t)counts[CNT_SEG]) atomicMax(&counts[CNT_MAX_SEG], starts[s + 1] - starts[s]);
 }
 
 // ---- the reference's greedy constrained union-find, one thread per connected component ----
@@ -145,12 +155,13 @@ __device__ __forceinline__ int32_t seq_root(int32_t *parent, int32_t i) {
     while (parent[i] >= 0) { const int32_t nx = parent[i]; parent[i] = r; i = nx; }
     return r;
 }
-__global__ void k_kruskal(int64_t n_seg, const uint32_t *starts, int64_t M, const uint32_t *order, const uint32_t *n1,
+__global__ void k_kruskal(int64_t cap, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
                           const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
                           int32_t *count) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_seg) return;
-    const int64_t lo = starts[s], hi = (s + 1 < n_seg) ? starts[s + 1] : M;
+    if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
+    const int64_t lo = starts[s], hi = starts[s + 1];
+    if (hi - lo > kMaxSegmentEdges) return;                  // the host stage takes this input (CNT_MAX_SEG tells the caller)
     for (int64_t k = lo; k < hi; ++k) {
         const uint32_t m = order[k];
         const int32_t r1 = seq_root(parent, (int32_t)n1[m]), r2 = seq_root(parent, (int32_t)n2[m]);
@@ -175,9 +186,11 @@ __global__ void k_root_flags(int64_t n, const int32_t *parent, uint32_t *flags) 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) flags[i] = parent[i] < 0 ? 1u : 0u;
 }
-__global__ void k_track_ids(int64_t n, const int32_t *parent, const uint32_t *rank, int32_t *track, uint32_t *tsize) {
+// rank[] = exclusive scan of the root flags over N+1 entries: rank[N] = number of tracks
+__global__ void k_track_ids(int64_t n, const int32_t *parent, const uint32_t *rank, int32_t *track, uint32_t *tsize, uint32_t *counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (i == 0) counts[CNT_TRACKS] = rank[n];
     int32_t r = (int32_t)i;
     while (parent[r] >= 0) r = parent[r];
     track[i] = (int32_t)rank[r];                              // solve.cc:528-541
@@ -203,9 +216,9 @@ __global__ void k_best_node(int64_t n, const int32_t *track, const double *score
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n && ordered_bits(score[i]) == best[track[i]]) atomicMax(&node[track[i]], (int32_t)i);   // ties: larger node idx
 }
-__global__ void k_mark_roots(int64_t n_tracks, const int32_t *node, uint8_t *is_root) {
+__global__ void k_mark_roots(int64_t cap, const uint32_t *counts, const int32_t *node, uint8_t *is_root) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_tracks) is_root[node[t]] = 1;
+    if (t < cap && t < (int64_t)counts[CNT_TRACKS]) is_root[node[t]] = 1;
 }
 
 // ---- components of the track meta-graph ----
@@ -215,170 +228,305 @@ __global__ void k_meta_union(int64_t M, const uint32_t *n1, const uint32_t *n2, 
     const int32_t ta = track[n1[m]], tb = track[n2[m]];
     if (ta != tb) uf_union(parent, (uint32_t)ta, (uint32_t)tb);
 }
-__global__ void k_comp_flags(int64_t n_tracks, const uint32_t *parent, uint32_t *flags) {
+__global__ void k_comp_flags(int64_t cap, const uint32_t *counts, const uint32_t *parent, uint32_t *flags) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_tracks) flags[t] = parent[t] == (uint32_t)t ? 1u : 0u;      // representative = smallest track of the component
+    if (t < cap && t < (int64_t)counts[CNT_TRACKS]) flags[t] = parent[t] == (uint32_t)t ? 1u : 0u;      // representative = smallest track of the component
 }
-__global__ void k_comp_sizes(int64_t n_tracks, const uint32_t *parent, const uint32_t *rank, const uint32_t *tsize, uint32_t *csize) {
+// rank[] = exclusive scan of the component flags over N+1 entries (flags beyond the tracks are 0): rank[N] = #components
+__global__ void k_comp_sizes(int64_t cap, uint32_t *counts, const uint32_t *parent, const uint32_t *rank, const uint32_t *tsize, uint32_t *csize) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n_tracks) atomicAdd(&csize[rank[parent[t]]], tsize[t]);
+    if (t == 0) counts[CNT_COMPS] = rank[cap];
+    if (t < cap && t < (int64_t)counts[CNT_TRACKS]) {
+        atomicAdd(&csize[rank[parent[t]]], tsize[t]);
+        atomicMax(&counts[CNT_MAX_TRACK], tsize[t]);
+    }
 }
 __global__ void k_node_comp(int64_t n, const int32_t *track, const uint32_t *parent, const uint32_t *rank, int32_t *comp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) comp[i] = (int32_t)rank[parent[track[i]]];
 }
-__global__ void k_max_u32(int64_t n, const uint32_t *v, uint32_t *out) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicMax(out, v[i]);
-}
-
-double ms_since(std::chrono::steady_clock::time_point t0) {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+__global__ void k_max_csize(int64_t cap, uint32_t *counts, const uint32_t *csize) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < cap && c < (int64_t)counts[CNT_COMPS]) atomicMax(&counts[CNT_MAX_COMP], csize[c]);
 }
 
 }  // namespace
 
-int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, Problem &p) {
-    using clock = std::chrono::steady_clock;
+// =================================================================================================
+// device copies of the graph and of the labels
+// =================================================================================================
+DevGraph::~DevGraph() {
+    if (ctx) {      // nothing of ours may still be reading the slab when it goes back to the cache
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->s_copy);
+        (void)hipStreamSynchronize(ctx->s_main);
+    }
+    if (ev_flows) (void)hipEventDestroy(ev_flows);
+}
+DevProblem::~DevProblem() {
+    if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->s_main); }
+}
+
+static int stage_flows_now(const Graph &g, DevGraph &dg) {
+    // 2 x 72 B per match, in match order, on the copy stream: travels beside the graph stage
+    DevCtx *ctx = dg.ctx;
+    const int64_t M = dg.M;
+    float *d1 = dg.slab.take_n<float>((size_t)18 * M), *d2 = dg.slab.take_n<float>((size_t)18 * M);
+    if (!d1 || !d2) { set_error("device graph: slab too small for the flows"); return LFR_ERR_NOMEM; }
+    if (M > 0) {
+        LFR_HIP_TRY(hipMemcpyAsync(d1, g.m_disp1.data(), (size_t)72 * M, hipMemcpyHostToDevice, ctx->s_copy));
+        LFR_HIP_TRY(hipMemcpyAsync(d2, g.m_disp2.data(), (size_t)72 * M, hipMemcpyHostToDevice, ctx->s_copy));
+    }
+    if (!dg.ev_flows) LFR_HIP_TRY(hipEventCreateWithFlags(&dg.ev_flows, hipEventDisableTiming));
+    LFR_HIP_TRY(hipEventRecord(dg.ev_flows, ctx->s_copy));
+    dg.disp1 = d1; dg.disp2 = d2;
+    dg.flows_staged = true; dg.flows_zero_copy = false;
+    return LFR_OK;
+}
+
+int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_ptr<DevGraph> &out) {
+    if (device < 0) { set_error("bad device ordinal %d", device); return LFR_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g.dev_mu);
+    if ((int)g.devgs.size() <= device) g.devgs.resize(device + 1);
+    if (g.devgs[device]) {
+        if (stage_flows && g.devgs[device]->flows_zero_copy) g.devgs[device].reset();   // a whole-problem batch after a sharded one: rebuild with staged flows
+        else { out = g.devgs[device]; return LFR_OK; }
+    }
+    if (g.dev_disp1 && g.dev_flows_device != device) {
+        set_error("the graph's flows live on device %d, the pipeline was requested on device %d", g.dev_flows_device, device);
+        return LFR_ERR_ARG;
+    }
+    DevCtx *ctx = dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    LFR_HIP_TRY(hipSetDevice(device));
+    const int64_t N = g.n_nodes(), M = g.n_matches();
+    if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) { set_error("graph too large for the device pipeline"); return LFR_ERR_UNSUPPORTED; }
+    std::shared_ptr<DevGraph> dg(new DevGraph());
+    dg->ctx = ctx; dg->N = N; dg->M = M;
+    const bool external = g.dev_disp1 && g.dev_disp2;
+    const bool host_pinned = g.m_disp1.pinned() && g.m_disp2.pinned();
+    const bool stage = !external && (stage_flows || !host_pinned);      // pageable flows cannot be read zero-copy
+    const size_t bytes = (size_t)16 * M + (size_t)4 * N + (stage ? (size_t)144 * M : 0) + ((size_t)1 << 16);
+    if (!dg->slab.init(ctx, bytes)) return LFR_ERR_NOMEM;
+    dg->n1 = dg->slab.take_n<uint32_t>(M); dg->n2 = dg->slab.take_n<uint32_t>(M);
+    dg->sim = dg->slab.take_n<float>(M); dg->node_image = dg->slab.take_n<int32_t>(N);
+    hipStream_t st = ctx->s_main;
+    if (M > 0) {
+        LFR_HIP_TRY(hipMemcpyAsync(dg->n1, g.m_node1.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+        LFR_HIP_TRY(hipMemcpyAsync(dg->n2, g.m_node2.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+        LFR_HIP_TRY(hipMemcpyAsync(dg->sim, g.m_sim.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+    }
+    if (N > 0) LFR_HIP_TRY(hipMemcpyAsync(dg->node_image, g.node_image.data(), (size_t)4 * N, hipMemcpyHostToDevice, st));
+    if (external) {
+        dg->disp1 = g.dev_disp1; dg->disp2 = g.dev_disp2; dg->flows_external = true;
+        if (!g.m_flow_row.empty()) {
+            dg->flow_row = dg->slab.take_n<uint32_t>(M);
+            LFR_HIP_TRY(hipMemcpyAsync(dg->flow_row, g.m_flow_row.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+        }
+    } else if (stage) {
+        const int rc = stage_flows_now(g, *dg);
+        if (rc != LFR_OK) return rc;
+    } else {
+        dg->disp1 = g.m_disp1.data(); dg->disp2 = g.m_disp2.data(); dg->flows_zero_copy = true;   // pinned + portable: device visible
+    }
+    g.devgs[device] = dg;
+    out = dg;
+    return LFR_OK;
+}
+
+int upload_labels(const Problem &p, int device, bool stage_flows, std::shared_ptr<DevProblem> &out) {
+    std::shared_ptr<DevGraph> dg;
+    int rc = ensure_dev_graph(*p.g, device, stage_flows, dg);
+    if (rc != LFR_OK) return rc;
+    DevCtx *ctx = dg->ctx;
+    const int64_t N = dg->N;
+    std::shared_ptr<DevProblem> dp(new DevProblem());
+    dp->ctx = ctx; dp->graph = dg; dp->N = N;
+    if (!dp->slab.init(ctx, (size_t)9 * N + 4096)) return LFR_ERR_NOMEM;
+    dp->track = dp->slab.take_n<int32_t>(N); dp->comp = dp->slab.take_n<int32_t>(N); dp->is_root = dp->slab.take_n<uint8_t>(N);
+    if (N > 0) {
+        std::vector<int32_t> t32(N), c32(N);
+        for (int64_t i = 0; i < N; ++i) { t32[i] = (int32_t)p.track[i]; c32[i] = (int32_t)p.comp[i]; }
+        LFR_HIP_TRY(hipMemcpyAsync(dp->track, t32.data(), (size_t)4 * N, hipMemcpyHostToDevice, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyAsync(dp->comp, c32.data(), (size_t)4 * N, hipMemcpyHostToDevice, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyAsync(dp->is_root, p.is_root.data(), (size_t)N, hipMemcpyHostToDevice, ctx->s_main));
+        LFR_HIP_TRY(hipStreamSynchronize(ctx->s_main));         // the staging vectors die here
+    }
+    out = dp;
+    return LFR_OK;
+}
+
+int Problem::ensure_host_labels() const {
+    std::lock_guard<std::mutex> lk(label_mu);
+    if (host_labels_valid) return LFR_OK;
+    std::shared_ptr<DevProblem> dev;
+    for (auto &d : devs) if (d) { dev = d; break; }
+    if (!dev) { set_error("internal: labels neither on the host nor on the device"); return LFR_ERR_ARG; }
+    const int64_t N = dev->N;
+    DevCtx *ctx = dev->ctx;
+    LFR_HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int32_t> t32(N), c32(N);
+    track.resize(N); comp.resize(N); is_root.resize(N);
+    if (N > 0) {
+        LFR_HIP_TRY(hipMemcpyAsync(t32.data(), dev->track, (size_t)4 * N, hipMemcpyDeviceToHost, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyAsync(c32.data(), dev->comp, (size_t)4 * N, hipMemcpyDeviceToHost, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyAsync(is_root.data(), dev->is_root, (size_t)N, hipMemcpyDeviceToHost, ctx->s_main));
+        LFR_HIP_TRY(hipStreamSynchronize(ctx->s_main));
+    }
+    for (int64_t i = 0; i < N; ++i) { track[i] = t32[i]; comp[i] = c32[i]; }
+    host_labels_valid = true;
+    return LFR_OK;
+}
+
+// =================================================================================================
+// the stage
+// =================================================================================================
+int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p) {
     const int64_t N = g.n_nodes(), M = g.n_matches();
     p.g = &g;
-    p.track.assign(N, -1); p.comp.assign(N, -1); p.is_root.assign(N, 0);
     p.stats = lfr_problem_stats{};
     p.host_batch = false;
-    if (N == 0) return LFR_OK;
+    { std::lock_guard<std::mutex> lk(p.label_mu); p.devs.clear(); }
+    if (N == 0) { p.track.clear(); p.comp.clear(); p.is_root.clear(); p.host_labels_valid = true; return LFR_OK; }
     if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) return LFR_GRAPHSTAGE_USE_HOST;
     if (max_nodes <= 0) max_nodes = (int64_t)g.image_names.size();
-    int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
-    if (device < 0 || device >= n_dev) { set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
-    HIP_TRY(hipSetDevice(device));
-    hipStream_t st = nullptr;
-    auto t0 = clock::now();
-    DevArena slab;                                   // declared first: the buffers below must die before it
-    DevArena *arena = &slab;
-    if (slab.init((size_t)80 * M + (size_t)96 * N + ((size_t)16 << 20)) != hipSuccess) { (void)hipGetLastError(); slab.base = nullptr; arena = nullptr; }
+    std::shared_ptr<DevGraph> dg;
+    int rc = ensure_dev_graph(g, device, stage_flows, dg);       // endpoints on s_main now; the flows start travelling on s_copy
+    if (rc != LFR_OK) return rc;
+    DevCtx *ctx = dg->ctx;
+    LFR_HIP_TRY(hipSetDevice(device));
+    hipStream_t st = ctx->s_main;
 
-    DevBuf b_n1, b_n2, b_sim, b_img;
-    DEV_ALLOC(b_n1, 4 * M); DEV_ALLOC(b_n2, 4 * M); DEV_ALLOC(b_sim, 4 * M); DEV_ALLOC(b_img, 4 * N);
-    HIP_TRY(hipMemcpyAsync(b_n1.p, g.m_node1.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_n2.p, g.m_node2.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_sim.p, g.m_sim.data(), 4 * M, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(b_img.p, g.node_image.data(), 4 * N, hipMemcpyHostToDevice, st));
-    const uint32_t *n1 = b_n1.as<uint32_t>(), *n2 = b_n2.as<uint32_t>();
-    const float *sim = b_sim.as<float>();
+    std::shared_ptr<DevProblem> dp(new DevProblem());
+    dp->ctx = ctx; dp->graph = dg; dp->N = N;
+    if (!dp->slab.init(ctx, (size_t)9 * N + 4096)) return LFR_ERR_NOMEM;
+    dp->track = dp->slab.take_n<int32_t>(N); dp->comp = dp->slab.take_n<int32_t>(N); dp->is_root = dp->slab.take_n<uint8_t>(N);
+
+    DevArena arena;                                   // temporaries of this call
+    if (!arena.init(ctx, (size_t)96 * M + (size_t)96 * N + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
+    size_t pin_bytes = 0;
+    uint32_t *h_counts = (uint32_t *)ctx->pinned_acquire(4 * CNT_WORDS, &pin_bytes);
+    if (!h_counts) return LFR_ERR_NOMEM;
+    struct PinGuard { DevCtx *c; void *p; size_t b; ~PinGuard() { c->pinned_release(p, b); } } pin_guard{ctx, h_counts, pin_bytes};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
+    for (auto &e : ev) LFR_HIP_TRY(hipEventCreate(&e));
+
+    const uint32_t *n1 = dg->n1, *n2 = dg->n2;
+    const float *sim = dg->sim;
+    TAKE(counts, uint32_t, CNT_WORDS);
+    LFR_HIP_TRY(hipMemsetAsync(counts, 0, 4 * CNT_WORDS, st));
+    LFR_HIP_TRY(hipEventRecord(ev[0], st));
 
     // 1. matches in the reference's order: descending (sim, n1, n2)
-    DevBuf b_khi, b_khi2, b_klo, b_klo2, b_id0, b_id1;
-    DEV_ALLOC(b_khi, 8 * M); DEV_ALLOC(b_khi2, 8 * M); DEV_ALLOC(b_klo, 4 * M); DEV_ALLOC(b_klo2, 4 * M);
-    DEV_ALLOC(b_id0, 4 * M); DEV_ALLOC(b_id1, 4 * M);
-    hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, b_khi.as<uint64_t>(), b_klo.as<uint32_t>(), b_id0.as<uint32_t>());
-    int rc;
-    if ((rc = sort_pairs(arena, b_klo.as<uint32_t>(), b_klo2.as<uint32_t>(), b_id0.as<uint32_t>(), b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, b_id1.as<uint32_t>(), b_khi.as<uint64_t>(), b_khi2.as<uint64_t>());
-    if ((rc = sort_pairs(arena, b_khi2.as<uint64_t>(), b_khi.as<uint64_t>(), b_id1.as<uint32_t>(), b_id0.as<uint32_t>(), M, 0, 64, st)) != LFR_OK) return rc;
-    uint32_t *order = b_id0.as<uint32_t>();
+    TAKE(khi, uint64_t, M); TAKE(khi2, uint64_t, M); TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
+    TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
+    hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, khi, klo, id0);
+    if ((rc = sort_pairs(arena, klo, klo2, id0, id1, M, 0, 32, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, id1, khi, khi2);
+    if ((rc = sort_pairs(arena, khi2, khi, id1, id0, M, 0, 64, st)) != LFR_OK) return rc;
+    uint32_t *order = id0;
 
     // 2. connected components of the match graph (conflicts ignored)
-    DevBuf b_cc;
-    DEV_ALLOC(b_cc, 4 * N);
-    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, b_cc.as<uint32_t>());
-    hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, b_cc.as<uint32_t>());
-    hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, b_cc.as<uint32_t>());
+    TAKE(cc, uint32_t, N);
+    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, cc);
+    hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, cc);
+    hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, cc);
 
     // 3. ordered matches grouped by connected component (stable)
-    DevBuf b_ck0, b_ck1, b_flags, b_segid, b_starts;
-    DEV_ALLOC(b_ck0, 4 * M); DEV_ALLOC(b_ck1, 4 * M); DEV_ALLOC(b_flags, 4 * (M + 1)); DEV_ALLOC(b_segid, 4 * (M + 1));
-    hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, order, n1, b_cc.as<uint32_t>(), b_ck0.as<uint32_t>());
-    if ((rc = sort_pairs(arena, b_ck0.as<uint32_t>(), b_ck1.as<uint32_t>(), order, b_id1.as<uint32_t>(), M, 0, 32, st)) != LFR_OK) return rc;
-    order = b_id1.as<uint32_t>();
-    HIP_TRY(hipMemsetAsync(b_flags.p, 0, 4 * (M + 1), st));
-    hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, b_ck1.as<uint32_t>(), b_flags.as<uint32_t>());
-    if ((rc = exclusive_sum(arena, b_flags.as<uint32_t>(), b_segid.as<uint32_t>(), M + 1, st)) != LFR_OK) return rc;
-    uint32_t n_seg = 0;
-    HIP_TRY(hipMemcpy(&n_seg, b_segid.as<uint32_t>() + M, 4, hipMemcpyDeviceToHost));
-    DEV_ALLOC(b_starts, 4 * ((int64_t)n_seg + 1));
-    hipLaunchKernelGGL(k_seg_starts, grid_for(M), dim3(kThreads), 0, st, M, b_flags.as<uint32_t>(), b_segid.as<uint32_t>(), b_starts.as<uint32_t>());
-    {   // a huge connected component would run on ONE thread: let the host do those inputs
-        std::vector<uint32_t> h_starts(n_seg);
-        if (n_seg) HIP_TRY(hipMemcpy(h_starts.data(), b_starts.p, 4 * (size_t)n_seg, hipMemcpyDeviceToHost));
-        for (uint32_t s = 0; s < n_seg; ++s) {
-            const int64_t len = (s + 1 < n_seg ? (int64_t)h_starts[s + 1] : M) - h_starts[s];
-            if (len > kMaxSegmentEdges) return LFR_GRAPHSTAGE_USE_HOST;
-        }
-    }
+    TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(flags, uint32_t, M + 1); TAKE(segid, uint32_t, M + 1);
+    TAKE(starts, uint32_t, std::min(N, M) + 2);
+    hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, order, n1, cc, ck0);
+    if ((rc = sort_pairs(arena, ck0, ck1, order, id1, M, 0, 32, st)) != LFR_OK) return rc;
+    order = id1;
+    LFR_HIP_TRY(hipMemsetAsync(flags, 0, 4 * (size_t)(M + 1), st));
+    hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
+    if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc;
+    const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
+    hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
+    hipLaunchKernelGGL(k_seg_maxlen, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
 
     // 4. greedy constrained union-find per connected component
-    DevBuf b_par, b_next, b_tail, b_cnt;
-    DEV_ALLOC(b_par, 4 * N); DEV_ALLOC(b_next, 4 * N); DEV_ALLOC(b_tail, 4 * N); DEV_ALLOC(b_cnt, 4 * N);
-    hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, b_par.as<int32_t>(), b_next.as<int32_t>(), b_tail.as<int32_t>(), b_cnt.as<int32_t>());
-    hipLaunchKernelGGL(k_kruskal, grid_for(n_seg), dim3(kThreads), 0, st, (int64_t)n_seg, b_starts.as<uint32_t>(), M, order, n1, n2,
-                       b_img.as<int32_t>(), b_par.as<int32_t>(), b_next.as<int32_t>(), b_tail.as<int32_t>(), b_cnt.as<int32_t>());
+    TAKE(par, int32_t, N); TAKE(next, int32_t, N); TAKE(tail, int32_t, N); TAKE(cnt, int32_t, N);
+    hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, par, next, tail, cnt);
+    hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, counts, starts, order, n1, n2,
+                       dg->node_image, par, next, tail, cnt);
 
     // 5. track ids (roots in ascending node index), sizes
-    DevBuf b_rflag, b_rrank, b_track, b_tsize, b_max;
-    DEV_ALLOC(b_rflag, 4 * (N + 1)); DEV_ALLOC(b_rrank, 4 * (N + 1)); DEV_ALLOC(b_track, 4 * N); DEV_ALLOC(b_max, 8);
-    HIP_TRY(hipMemsetAsync(b_rflag.p, 0, 4 * (N + 1), st));
-    hipLaunchKernelGGL(k_root_flags, grid_for(N), dim3(kThreads), 0, st, N, b_par.as<int32_t>(), b_rflag.as<uint32_t>());
-    if ((rc = exclusive_sum(arena, b_rflag.as<uint32_t>(), b_rrank.as<uint32_t>(), N + 1, st)) != LFR_OK) return rc;
-    uint32_t n_tracks = 0;
-    HIP_TRY(hipMemcpy(&n_tracks, b_rrank.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost));
-    DEV_ALLOC(b_tsize, 4 * (int64_t)n_tracks);
-    HIP_TRY(hipMemsetAsync(b_tsize.p, 0, 4 * (size_t)n_tracks, st));
-    HIP_TRY(hipMemsetAsync(b_max.p, 0, 8, st));
-    hipLaunchKernelGGL(k_track_ids, grid_for(N), dim3(kThreads), 0, st, N, b_par.as<int32_t>(), b_rrank.as<uint32_t>(), b_track.as<int32_t>(), b_tsize.as<uint32_t>());
-    hipLaunchKernelGGL(k_max_u32, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_tsize.as<uint32_t>(), b_max.as<uint32_t>());
-    HIP_TRY(hipStreamSynchronize(st));
-    p.stats.tracks_ms = ms_since(t0);
+    TAKE(rflag, uint32_t, N + 1); TAKE(rrank, uint32_t, N + 1); TAKE(tsize, uint32_t, N);
+    LFR_HIP_TRY(hipMemsetAsync(rflag, 0, 4 * (size_t)(N + 1), st));
+    LFR_HIP_TRY(hipMemsetAsync(tsize, 0, 4 * (size_t)N, st));
+    hipLaunchKernelGGL(k_root_flags, grid_for(N), dim3(kThreads), 0, st, N, par, rflag);
+    if ((rc = exclusive_sum(arena, rflag, rrank, N + 1, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_track_ids, grid_for(N), dim3(kThreads), 0, st, N, par, rrank, dp->track, tsize, counts);
+    LFR_HIP_TRY(hipEventRecord(ev[1], st));
 
     // roots
-    t0 = clock::now();
-    DevBuf b_score, b_best, b_bnode, b_root;
-    DEV_ALLOC(b_score, 8 * N); DEV_ALLOC(b_best, 8 * (int64_t)n_tracks); DEV_ALLOC(b_bnode, 4 * (int64_t)n_tracks); DEV_ALLOC(b_root, N);
-    HIP_TRY(hipMemsetAsync(b_score.p, 0, 8 * N, st));
-    HIP_TRY(hipMemsetAsync(b_best.p, 0, 8 * (size_t)n_tracks, st));
-    HIP_TRY(hipMemsetAsync(b_bnode.p, 0xff, 4 * (size_t)n_tracks, st));          // -1
-    HIP_TRY(hipMemsetAsync(b_root.p, 0, N, st));
-    hipLaunchKernelGGL(k_scores, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, b_track.as<int32_t>(), b_score.as<double>());
-    hipLaunchKernelGGL(k_best_score, grid_for(N), dim3(kThreads), 0, st, N, b_track.as<int32_t>(), b_score.as<double>(), b_best.as<unsigned long long>());
-    hipLaunchKernelGGL(k_best_node, grid_for(N), dim3(kThreads), 0, st, N, b_track.as<int32_t>(), b_score.as<double>(), b_best.as<unsigned long long>(), b_bnode.as<int32_t>());
-    hipLaunchKernelGGL(k_mark_roots, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_bnode.as<int32_t>(), b_root.as<uint8_t>());
-    HIP_TRY(hipStreamSynchronize(st));
-    p.stats.roots_ms = ms_since(t0);
+    TAKE(score, double, N); TAKE(best, unsigned long long, N); TAKE(bnode, int32_t, N);
+    LFR_HIP_TRY(hipMemsetAsync(score, 0, 8 * (size_t)N, st));
+    LFR_HIP_TRY(hipMemsetAsync(best, 0, 8 * (size_t)N, st));
+    LFR_HIP_TRY(hipMemsetAsync(bnode, 0xff, 4 * (size_t)N, st));          // -1
+    LFR_HIP_TRY(hipMemsetAsync(dp->is_root, 0, (size_t)N, st));
+    hipLaunchKernelGGL(k_scores, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, score);
+    hipLaunchKernelGGL(k_best_score, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best);
+    hipLaunchKernelGGL(k_best_node, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best, bnode);
+    hipLaunchKernelGGL(k_mark_roots, grid_for(N), dim3(kThreads), 0, st, N, counts, bnode, dp->is_root);
+    LFR_HIP_TRY(hipEventRecord(ev[2], st));
 
     // components of the track meta-graph, numbered by their smallest track (solve.cc:292-300)
-    t0 = clock::now();
-    DevBuf b_mp, b_cflag, b_crank, b_csize, b_comp;
-    DEV_ALLOC(b_mp, 4 * (int64_t)n_tracks); DEV_ALLOC(b_cflag, 4 * ((int64_t)n_tracks + 1)); DEV_ALLOC(b_crank, 4 * ((int64_t)n_tracks + 1));
-    DEV_ALLOC(b_comp, 4 * N);
-    hipLaunchKernelGGL(k_iota, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>());
-    hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, b_track.as<int32_t>(), b_mp.as<uint32_t>());
-    hipLaunchKernelGGL(k_cc_flatten, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>());
-    HIP_TRY(hipMemsetAsync(b_cflag.p, 0, 4 * ((size_t)n_tracks + 1), st));
-    hipLaunchKernelGGL(k_comp_flags, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>(), b_cflag.as<uint32_t>());
-    if ((rc = exclusive_sum(arena, b_cflag.as<uint32_t>(), b_crank.as<uint32_t>(), (int64_t)n_tracks + 1, st)) != LFR_OK) return rc;
-    uint32_t n_comp = 0;
-    HIP_TRY(hipMemcpy(&n_comp, b_crank.as<uint32_t>() + n_tracks, 4, hipMemcpyDeviceToHost));
-    DEV_ALLOC(b_csize, 4 * (int64_t)n_comp);
-    HIP_TRY(hipMemsetAsync(b_csize.p, 0, 4 * (size_t)n_comp, st));
-    hipLaunchKernelGGL(k_comp_sizes, grid_for(n_tracks), dim3(kThreads), 0, st, (int64_t)n_tracks, b_mp.as<uint32_t>(), b_crank.as<uint32_t>(),
-                       b_tsize.as<uint32_t>(), b_csize.as<uint32_t>());
-    hipLaunchKernelGGL(k_max_u32, grid_for(n_comp), dim3(kThreads), 0, st, (int64_t)n_comp, b_csize.as<uint32_t>(), b_max.as<uint32_t>() + 1);
-    hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, b_track.as<int32_t>(), b_mp.as<uint32_t>(), b_crank.as<uint32_t>(), b_comp.as<int32_t>());
-    HIP_TRY(hipGetLastError());
-    uint32_t maxes[2] = {0, 0};
-    HIP_TRY(hipMemcpy(maxes, b_max.p, 8, hipMemcpyDeviceToHost));
-    if ((int64_t)maxes[1] > max_nodes) return LFR_GRAPHSTAGE_USE_HOST;      // needs the graph cut (solve.cc:311-343)
+    TAKE(mp, uint32_t, N); TAKE(cflag, uint32_t, N + 1); TAKE(crank, uint32_t, N + 1); TAKE(csize, uint32_t, N);
+    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp);
+    hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, mp);
+    hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, mp);
+    LFR_HIP_TRY(hipMemsetAsync(cflag, 0, 4 * (size_t)(N + 1), st));
+    LFR_HIP_TRY(hipMemsetAsync(csize, 0, 4 * (size_t)N, st));
+    hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
+    if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
+    hipLaunchKernelGGL(k_max_csize, grid_for(N), dim3(kThreads), 0, st, N, counts, csize);
+    hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, dp->track, mp, crank, dp->comp);
+    LFR_HIP_TRY(hipGetLastError());
+    LFR_HIP_TRY(hipEventRecord(ev[3], st));
 
-    // labels back to the host (the Problem's public labels; the assembly re-uploads 10 MB)
-    std::vector<int32_t> h_track(N), h_comp(N);
-    HIP_TRY(hipMemcpy(h_track.data(), b_track.p, 4 * N, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(h_comp.data(), b_comp.p, 4 * N, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(p.is_root.data(), b_root.p, N, hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < N; ++i) { p.track[i] = h_track[i]; p.comp[i] = h_comp[i]; }
-    p.stats.n_tracks = n_tracks; p.stats.max_track_size = maxes[0];
-    p.stats.n_components = n_comp; p.stats.max_component_size = maxes[1];
-    p.stats.graph_cut_ms = ms_since(t0);
+    // the one read-back of the stage
+    LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
+    LFR_HIP_TRY(hipStreamSynchronize(st));
+    if ((int64_t)h_counts[CNT_MAX_SEG] > kMaxSegmentEdges) return LFR_GRAPHSTAGE_USE_HOST;   // step 4 skipped that component
+    if ((int64_t)h_counts[CNT_MAX_COMP] > max_nodes) return LFR_GRAPHSTAGE_USE_HOST;          // needs the graph cut (solve.cc:311-343)
+    float ms = 0.f;
+    LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); p.stats.tracks_ms = ms;
+    LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); p.stats.roots_ms = ms;
+    LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); p.stats.graph_cut_ms = ms;
+    p.stats.n_tracks = h_counts[CNT_TRACKS]; p.stats.max_track_size = h_counts[CNT_MAX_TRACK];
+    p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
+    {
+        std::lock_guard<std::mutex> lk(p.label_mu);
+        p.track.clear(); p.comp.clear(); p.is_root.clear();
+        p.host_labels_valid = false;                  // fetched from HBM on demand
+        p.devs.assign((size_t)device + 1, nullptr);
+        p.devs[device] = dp;
+    }
     return LFR_OK;
 }
 
 }  // namespace lfr
+
+// =================================================================================================
+// C ABI: device residency of the graph
+// =================================================================================================
+extern "C" {
+
+int lfr_graph_to_device(const lfr_graph *g, int device) {
+    if (!g) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    std::shared_ptr<lfr::DevGraph> dg;
+    return lfr::ensure_dev_graph(g->g, device, true, dg);
+}
+
+int lfr_graph_evict_device(const lfr_graph *g) {
+    if (!g) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g->g.dev_mu);
+    g->g.devgs.clear();                               // problems / batches built from it keep their own reference
+    return LFR_OK;
+}
+
+}  // extern "C"

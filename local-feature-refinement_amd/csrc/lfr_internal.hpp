@@ -1,15 +1,20 @@
 // Internal data model of liblfr_hip.so (not part of the C ABI; see include/lfr.h).
 #pragma once
 #include <cstdint>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 #include "lfr.h"
+#include "lfr_devctx.hpp"
 
 namespace lfr {
 
 void set_error(const char *fmt, ...);
+struct DevGraph;
+struct DevProblem;
 
 // ------------------------------------------------------------------------------------------
 // Match graph (solve.cc:405-481).  Directed edge 2m   = node1(m) -> node2(m), flow disp2(m);
@@ -21,9 +26,11 @@ struct Graph {
     std::vector<std::string> image_names;      // seen (non-banned) images, order of first appearance
     std::vector<float> image_fact;             // first-wins (solve.cc:449,451)
     std::unordered_map<std::string, int32_t> image_index;
-    std::vector<uint32_t> m_node1, m_node2;    // per match
-    std::vector<float> m_sim;
-    std::vector<float> m_disp1, m_disp2;       // 18 floats per match, zero padded (solve.cc:460-472)
+    // per-match arrays: pinned host memory when a GPU is present (lfr_devctx.hpp), so that they cross PCIe at
+    // link speed and the flows can be gathered zero-copy by a sharded assembly
+    HostBuf<uint32_t> m_node1, m_node2;
+    HostBuf<float> m_sim;
+    HostBuf<float> m_disp1, m_disp2;           // 18 floats per match, zero padded (solve.cc:460-472)
     // flows that never left the GPU (lfr_graph_from_arrays_device_flows): device arrays of
     // n_rows x 18 floats owned by the caller; match m uses row m_flow_row[m] (identity when empty)
     const float *dev_disp1 = nullptr, *dev_disp2 = nullptr;
@@ -38,9 +45,14 @@ struct Graph {
     uint64_t hmask = 0;
     int64_t hcount = 0;
 
-    // nodes grouped by image (built on first use by lfr_apply_displacements)
-    mutable std::vector<int64_t> img_off;
-    mutable std::vector<uint32_t> img_nodes;
+    // nodes grouped by image (built by finish(); lfr_apply_displacements)
+    std::vector<int64_t> img_off;
+    std::vector<uint32_t> img_nodes;
+
+    // the graph's copy in HBM (lfr_assemble.hpp), created on first use by the device pipeline or by
+    // lfr_graph_to_device, dropped by lfr_graph_evict_device
+    mutable std::vector<std::shared_ptr<DevGraph>> devgs;      // indexed by HIP device ordinal
+    mutable std::mutex dev_mu;
 
     int64_t n_nodes() const { return (int64_t)node_image.size(); }
     int64_t n_matches() const { return (int64_t)m_sim.size(); }
@@ -48,7 +60,7 @@ struct Graph {
     uint32_t find_or_create_node(int32_t image, uint32_t feature);
     void add_match(int32_t img1, int32_t img2, uint32_t f1, uint32_t f2, float sim, const float *d1, int n1,
                    const float *d2, int n2);
-    void finish();   // drop the hash map
+    void finish();   // drop the hash map, group the nodes by image
 };
 
 // ------------------------------------------------------------------------------------------
@@ -94,8 +106,23 @@ constexpr int kBlockMaxRows = 192;   // packed lower triangle 192*193/2*8 B = 14
 
 struct Problem {
     const Graph *g = nullptr;
-    std::vector<int64_t> track, comp;      // per node
-    std::vector<uint8_t> is_root;
+    // per-node labels.  After the device graph stage they live in HBM (`dev`) and these host copies are
+    // fetched on first use (ensure_host_labels: lfr_problem_get_labels, host fallbacks).
+    mutable std::vector<int64_t> track, comp;
+    mutable std::vector<uint8_t> is_root;
+    mutable bool host_labels_valid = true;
+    mutable std::mutex label_mu;
+    mutable std::vector<std::shared_ptr<DevProblem>> devs;   // labels in HBM per device ordinal (device graph stage, or uploaded by the first device assembly there)
+    std::shared_ptr<DevProblem> dev_get(int device) const {
+        std::lock_guard<std::mutex> lk(label_mu);
+        return device >= 0 && device < (int)devs.size() ? devs[device] : nullptr;
+    }
+    void dev_set(int device, const std::shared_ptr<DevProblem> &d) const {
+        std::lock_guard<std::mutex> lk(label_mu);
+        if ((int)devs.size() <= device) devs.resize(device + 1);
+        devs[device] = d;
+    }
+    int ensure_host_labels() const;            // lfr_graphstage.hip
     lfr_problem_stats stats{};
     bool host_batch = true;                // false: labels only, the batch is assembled on the device
     // batch (all solvable components, sorted by kernel class then size descending)
@@ -109,8 +136,9 @@ struct Problem {
     std::vector<uint32_t> in_idx;          // parallel to edges (per component: edge indices sorted by dst)
 };
 
-// LPT deal of the solvable components to `world` shards (largest edge count first to the least
-// loaded shard; mirrors the largest-first task order of solve.cc:599-634).  Returns shard per desc.
+// Deal of the solvable components to `world` shards: the batch order (kernel class, then edge count
+// descending - the largest-first task order of solve.cc:599-634) dealt out and back (snake_shard in
+// lfr_assemble.hpp), so every shard gets the same mix of classes and sizes.  Returns shard per desc.
 std::vector<int32_t> assign_shards(const Problem &p, int world);
 
 int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p, bool host_batch = true);

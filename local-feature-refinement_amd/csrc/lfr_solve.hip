@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
+#include <memory>
 #include <string>
 #include <thread>
 #include <type_traits>
@@ -1051,19 +1053,18 @@ size_t block_lds_bytes(int max_rows, bool global_matrix) {
 // =============================================================================================
 struct lfr_batch {
     int device = 0;
+    lfr::DevCtx *ctx = nullptr;
     int tukey_variant = LFR_TUKEY_CERES1;
     int64_t n_graph_nodes = 0;
-    // shard content (host copies kept for stats / downloads)
-    std::vector<CompDesc> descs;
-    std::vector<int64_t> desc_component;
-    std::vector<int32_t> desc_class, desc_tracks;
-    std::vector<uint32_t> node_ids;
-    std::vector<uint64_t> ws_off, es_off;
-    std::vector<lfr::NodeInc> node_inc;
+    int shard_world = 1;
+    // launch geometry (device-assembled batches: read back once as AsmSummary)
+    int n_desc = 0;
     int class_begin[lfr::KC_COUNT + 1] = {0};
+    int64_t class_edges[lfr::KC_COUNT] = {0};
     int block_max_rows = 0, global_max_rows = 0;
     int64_t n_edges = 0, n_nodes = 0, n_tracks = 0;
-    // device
+    // device: everything lives in `slab` (+ the workgroup kernels' workspace in `ws_slab`)
+    lfr::DevArena slab, ws_slab;
     CompDesc *d_descs = nullptr;
     EdgeRec *d_edges = nullptr;
     uint32_t *d_node_ids = nullptr;
@@ -1074,30 +1075,229 @@ struct lfr_batch {
     unsigned long long *d_prof = nullptr;
     lfr::NodeInc *d_node_inc = nullptr;
     uint32_t *d_in_idx = nullptr;
+    uint32_t *d_desc_component = nullptr, *d_desc_class = nullptr, *d_desc_tracks = nullptr;   // device-assembled: behind the host mirrors
+    // host mirrors (host-assembled: filled at creation; device-assembled: fetched on first use)
+    bool mirrors_valid = false;
+    std::vector<CompDesc> descs;
+    std::vector<int64_t> desc_component;
+    std::vector<int32_t> desc_class, desc_tracks;
+    std::vector<uint32_t> node_ids;
+    // pinned staging of the positions (downloads, zero-copy view)
+    double *h_positions = nullptr;
+    size_t h_positions_bytes = 0;
+    // events / streams
     static constexpr int kSlots = 64;                    // event ring: timings of the last 64 solves
     static constexpr int kEvPerSlot = 2 * (lfr::KC_COUNT + 1);
     hipEvent_t ev_ring[kSlots * kEvPerSlot];
     hipEvent_t *ev = ev_ring;                            // slot of the current solve
     uint32_t ev_recorded[kSlots] = {};                   // per slot: classes whose start/end events were recorded
     int64_t n_solves = 0;
-    bool events = false;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // workgroup-per-component kernels run beside the packed launch
+    hipStream_t last_stream = nullptr;                 // stream of the latest solve (downloads wait for it)
     int packed_slot = 0;                               // class slot that carries the packed launch's events
-    double h2d_ms = 0.0;             // upload (+ device assembly when the batch is built on the GPU)
+    double h2d_ms = 0.0;             // upload (host-assembled) or device assembly incl. waiting for the flows
     std::vector<CompInfoDev> infos;      // last downloaded
     bool infos_valid = false;
+
+    lfr_batch() { for (auto &e : ev_ring) e = nullptr; }
+    ~lfr_batch() {
+        if (ctx) {
+            (void)hipSetDevice(device);
+            if (n_solves > 0) (void)hipStreamSynchronize(last_stream);      // nothing may still use the slab
+            if (side_stream) (void)hipStreamSynchronize(side_stream);
+            if (side_stream2) (void)hipStreamSynchronize(side_stream2);
+            (void)hipStreamSynchronize(ctx->s_main);
+            if (h_positions) ctx->pinned_release(h_positions, h_positions_bytes);
+        }
+        for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (side_stream) (void)hipStreamDestroy(side_stream);
+        if (side_stream2) (void)hipStreamDestroy(side_stream2);
+        // slab / ws_slab return to the context's cache in their destructors
+    }
 };
+
+namespace {
+
+#define TAKE_B(dst, T, count)                                                                                 \
+    b->dst = b->slab.take_n<T>((size_t)(count));                                                              \
+    if (!b->dst) { lfr::set_error("batch slab exhausted (%s)", #dst); return LFR_ERR_NOMEM; }
+
+// host mirrors of a device-assembled batch (descriptors, component ids, classes, node ids): 2-6 MB, fetched once
+int ensure_mirrors(lfr_batch *b) {
+    if (b->mirrors_valid) return LFR_OK;
+    HIP_TRY(hipSetDevice(b->device));
+    hipStream_t st = b->ctx->s_main;
+    const size_t nd = (size_t)b->n_desc, nn = (size_t)b->n_nodes;
+    b->descs.resize(nd); b->desc_component.resize(nd); b->desc_class.resize(nd); b->desc_tracks.resize(nd);
+    b->node_ids.resize(nn);
+    std::vector<uint32_t> comp(nd), cls(nd), trk(nd);
+    if (nd) {
+        HIP_TRY(hipMemcpyAsync(b->descs.data(), b->d_descs, nd * sizeof(CompDesc), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(comp.data(), b->d_desc_component, 4 * nd, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cls.data(), b->d_desc_class, 4 * nd, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(trk.data(), b->d_desc_tracks, 4 * nd, hipMemcpyDeviceToHost, st));
+    }
+    if (nn) HIP_TRY(hipMemcpyAsync(b->node_ids.data(), b->d_node_ids, 4 * nn, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (size_t i = 0; i < nd; ++i) { b->desc_component[i] = comp[i]; b->desc_class[i] = (int32_t)cls[i]; b->desc_tracks[i] = (int32_t)trk[i]; }
+    b->mirrors_valid = true;
+    return LFR_OK;
+}
+
+// device-assembled batch: labels (device graph stage) -> batch layout, all in HBM
+int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int shard_world) {
+    std::shared_ptr<lfr::DevProblem> dp = p.dev_get(b->device);
+    const bool stage_flows = shard_world == 1;          // a shard gathers its rows zero-copy from pinned host memory
+    if (!dp) {                                           // labels came from the host stage, or live on another GPU
+        int rc = p.ensure_host_labels();
+        if (rc != LFR_OK) return rc;
+        rc = lfr::upload_labels(p, b->device, stage_flows, dp);
+        if (rc != LFR_OK) return rc;
+        p.dev_set(b->device, dp);
+    }
+    const lfr::DevGraph &dg = *dp->graph;
+    const int64_t N = dg.N, M = dg.M, C = p.stats.n_components;
+    hipStream_t st = b->ctx->s_main;
+    hipEvent_t a0 = nullptr, a1 = nullptr;
+    struct EvGuard { hipEvent_t &x, &y; ~EvGuard() { if (x) (void)hipEventDestroy(x); if (y) (void)hipEventDestroy(y); } } guard{a0, a1};
+    HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
+    HIP_TRY(hipEventRecord(a0, st));
+    const size_t fixed = sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1) + sizeof(CompInfoDev) * (size_t)(C + 1) +
+                         8 * lfr::KC_COUNT * sizeof(unsigned long long) + ((size_t)1 << 16);
+    if (!b->slab.init(b->ctx, lfr::assembly_output_bytes(N, M, C) + fixed)) return LFR_ERR_NOMEM;
+    TAKE_B(d_positions, double, 2 * std::max<int64_t>(N, 1));
+    TAKE_B(d_infos, CompInfoDev, C + 1);
+    TAKE_B(d_prof, unsigned long long, 8 * lfr::KC_COUNT);
+    // Roots, constants and nodes outside every solved component stay at 0 for the life of the batch
+    // (solve.cc:609-612); the kernels overwrite every variable on every solve, so no per-solve memset.
+    HIP_TRY(hipMemsetAsync(b->d_positions, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1), st));
+    HIP_TRY(hipMemsetAsync(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long), st));
+    lfr::DeviceAssembly dev;
+    const int rc = lfr::assemble_on_device(p, *dp, shard_rank, shard_world, b->slab, dev);     // ends with the one synchronisation
+    if (rc != LFR_OK) return rc;
+    HIP_TRY(hipEventRecord(a1, st));
+    b->d_descs = dev.d_descs; b->d_edges = dev.d_edges; b->d_node_ids = dev.d_node_ids; b->d_node_inc = dev.d_node_inc;
+    b->d_in_idx = dev.d_in_idx; b->d_ws_off = dev.d_ws_off; b->d_es_off = dev.d_es_off;
+    b->d_desc_component = dev.d_desc_component; b->d_desc_class = dev.d_desc_class; b->d_desc_tracks = dev.d_desc_tracks;
+    const lfr::AsmSummary &s = dev.summary;
+    b->n_desc = (int)s.n_desc; b->n_edges = s.total_edges; b->n_nodes = s.total_nodes; b->n_tracks = s.n_tracks;
+    for (int c = 0; c <= lfr::KC_COUNT; ++c) b->class_begin[c] = (int)s.class_begin[c];
+    for (int c = 0; c < lfr::KC_COUNT; ++c) b->class_edges[c] = (int64_t)s.class_edges[c];
+    b->block_max_rows = (int)s.block_max_rows; b->global_max_rows = (int)s.global_max_rows;
+    const uint64_t ws = s.es_doubles + s.ws_doubles;
+    if (ws) {
+        if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
+        b->d_workspace = (double *)b->ws_slab.base;
+    }
+    HIP_TRY(hipEventSynchronize(a1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a0, a1));
+    b->h2d_ms = ms;
+    return LFR_OK;
+}
+
+// host-assembled batch (lfr_problem_build): shard the problem's arrays, upload
+int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int shard_world) {
+    const std::vector<int32_t> shard = lfr::assign_shards(p, shard_world);
+    const bool whole = shard_world == 1;
+    std::vector<EdgeRec> edges_copy;
+    std::vector<uint32_t> in_idx_copy;
+    std::vector<lfr::NodeInc> node_inc_copy;
+    std::vector<uint64_t> ws_off, es_off;
+    uint64_t ws = 0;
+    for (size_t i = 0; i < p.descs.size(); ++i) {
+        if (shard[i] != shard_rank) continue;
+        CompDesc d = p.descs[i];
+        if (!whole) {
+            const uint32_t eo = (uint32_t)edges_copy.size(), no = (uint32_t)b->node_ids.size();
+            edges_copy.insert(edges_copy.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
+            in_idx_copy.insert(in_idx_copy.end(), p.in_idx.begin() + d.edge_off, p.in_idx.begin() + d.edge_off + d.n_edges);
+            b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
+            node_inc_copy.insert(node_inc_copy.end(), p.node_inc.begin() + d.node_off, p.node_inc.begin() + d.node_off + d.n_nodes);
+            d.edge_off = eo; d.node_off = no;
+        }
+        b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
+        b->desc_class.push_back(p.desc_class[i]); b->desc_tracks.push_back(p.desc_tracks[i]);
+        const int cls = p.desc_class[i], rows = 2 * d.n_var;
+        es_off.push_back(ws); ws_off.push_back(0);
+        if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
+        if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
+        if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
+        b->class_edges[cls] += d.n_edges;
+        b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
+    }
+    if (whole) b->node_ids = p.node_ids;
+    const std::vector<EdgeRec> &edges = whole ? p.edges : edges_copy;
+    const std::vector<uint32_t> &in_idx = whole ? p.in_idx : in_idx_copy;
+    const std::vector<lfr::NodeInc> &node_inc = whole ? p.node_inc : node_inc_copy;
+    for (size_t i = 0; i < b->descs.size(); ++i)      // HBM variant: packed matrix + vectors per component
+        if (b->desc_class[i] == lfr::KC_GLOBAL) {
+            const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;
+            ws += ws & 1;
+            ws_off[i] = ws;
+            ws += mat + (mat & 1) + block_vector_doubles(b->global_max_rows);
+        }
+    b->n_desc = (int)b->descs.size();
+    {   // class ranges (descs are sorted by class)
+        int c = 0;
+        b->class_begin[0] = 0;
+        for (int i = 0; i <= b->n_desc; ++i) {
+            const int cls = i < b->n_desc ? b->desc_class[i] : lfr::KC_COUNT;
+            while (c < cls) b->class_begin[++c] = i;
+        }
+    }
+    b->mirrors_valid = true;
+    hipStream_t st = b->ctx->s_main;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    struct EvGuard { hipEvent_t &x, &y; ~EvGuard() { if (x) (void)hipEventDestroy(x); if (y) (void)hipEventDestroy(y); } } guard{e0, e1};
+    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, st));
+    const size_t nd = std::max<size_t>(b->descs.size(), 1), ne = std::max<size_t>(edges.size(), 1), nn = std::max<size_t>(b->node_ids.size(), 1);
+    const size_t npos = 2 * (size_t)std::max<int64_t>(b->n_graph_nodes, 1);
+    const size_t bytes = nd * (sizeof(CompDesc) + sizeof(CompInfoDev) + 16) + ne * (sizeof(EdgeRec) + 4) + nn * (4 + sizeof(lfr::NodeInc)) +
+                         npos * sizeof(double) + 8 * lfr::KC_COUNT * sizeof(unsigned long long) + ((size_t)1 << 16);
+    if (!b->slab.init(b->ctx, bytes)) return LFR_ERR_NOMEM;
+    TAKE_B(d_descs, CompDesc, nd); TAKE_B(d_edges, EdgeRec, ne); TAKE_B(d_node_ids, uint32_t, nn);
+    TAKE_B(d_node_inc, lfr::NodeInc, nn); TAKE_B(d_in_idx, uint32_t, ne);
+    TAKE_B(d_positions, double, npos); TAKE_B(d_infos, CompInfoDev, nd);
+    TAKE_B(d_ws_off, uint64_t, nd); TAKE_B(d_es_off, uint64_t, nd); TAKE_B(d_prof, unsigned long long, 8 * lfr::KC_COUNT);
+    HIP_TRY(hipMemsetAsync(b->d_positions, 0, npos * sizeof(double), st));        // solve.cc:609-612, see create_on_device
+    HIP_TRY(hipMemsetAsync(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long), st));
+    if (ws) {
+        if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
+        b->d_workspace = (double *)b->ws_slab.base;
+    }
+    if (!b->descs.empty()) {
+        HIP_TRY(hipMemcpyAsync(b->d_ws_off, ws_off.data(), ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_es_off, es_off.data(), es_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_node_inc, node_inc.data(), node_inc.size() * sizeof(lfr::NodeInc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(b->d_in_idx, in_idx.data(), in_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    }
+    HIP_TRY(hipEventRecord(e1, st));
+    HIP_TRY(hipEventSynchronize(e1));               // the staging vectors above die at return
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    b->h2d_ms = ms;
+    return LFR_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
-int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component, const int64_t *component_override,
-                          lfr_problem **out) {
+int lfr_problem_build_hip_ex(const lfr_graph *g, int device, int64_t max_nodes_in_component, const int64_t *component_override,
+                             int flags, lfr_problem **out) {
     if (!g || !out) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    const bool stage_flows = !(flags & LFR_BUILD_FLOWS_STAY_ON_HOST);
     if (!component_override) {
         lfr_problem *h = new lfr_problem();
-        const int rc = lfr::graph_stage_on_device(g->g, max_nodes_in_component, device, h->p);
+        const int rc = lfr::graph_stage_on_device(g->g, max_nodes_in_component, device, stage_flows, h->p);
         if (rc == LFR_OK) { *out = h; return LFR_OK; }
         delete h;
         if (rc != lfr::LFR_GRAPHSTAGE_USE_HOST) { *out = nullptr; return rc; }
@@ -1105,14 +1305,18 @@ int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_c
     return lfr_problem_build_labels(g, max_nodes_in_component, component_override, out);   // host graph stage
 }
 
+int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component, const int64_t *component_override,
+                          lfr_problem **out) {
+    return lfr_problem_build_hip_ex(g, device, max_nodes_in_component, component_override, 0, out);
+}
+
 namespace { __global__ void lfr_warmup_kernel(int *p) { if (p) *p = 0; } }
 
 int lfr_hip_warmup(int device) {
     // Creating the HIP context costs a few hundred ms; a host program can call this from a side
     // thread while it parses its input (the `solve` launcher does).
-    int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
-    if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
     HIP_TRY(hipSetDevice(device));
     HIP_TRY(hipFree(nullptr));
     hipLaunchKernelGGL(lfr_warmup_kernel, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);   // loads this unit's code object
@@ -1146,32 +1350,50 @@ int lfr_hip_warmup(int device) {
             lfr_batch_create(pr, device, 0, 1, LFR_TUKEY_CERES1, &bt) == LFR_OK) {
             lfr_solve_stats st;
             (void)lfr_batch_solve(bt, nullptr, &st);
+            const double *view = nullptr;
+            (void)lfr_batch_positions_view(bt, &view);
         }
         lfr_batch_free(bt); lfr_problem_free(pr); lfr_graph_free(g);
     }
     return LFR_OK;
 }
 
-void lfr_batch_free(lfr_batch *b) {
-    if (!b) return;
-    (void)hipSetDevice(b->device);
-    if (b->d_descs) (void)hipFree(b->d_descs);
-    if (b->d_edges) (void)hipFree(b->d_edges);
-    if (b->d_node_ids) (void)hipFree(b->d_node_ids);
-    if (b->d_positions) (void)hipFree(b->d_positions);
-    if (b->d_infos) (void)hipFree(b->d_infos);
-    if (b->d_workspace) (void)hipFree(b->d_workspace);
-    if (b->d_ws_off) (void)hipFree(b->d_ws_off);
-    if (b->d_es_off) (void)hipFree(b->d_es_off);
-    if (b->d_prof) (void)hipFree(b->d_prof);
-    if (b->d_node_inc) (void)hipFree(b->d_node_inc);
-    if (b->d_in_idx) (void)hipFree(b->d_in_idx);
-    if (b->events) for (auto &e : b->ev_ring) if (e) (void)hipEventDestroy(e);
-    if (b->ev_fork) (void)hipEventDestroy(b->ev_fork);
-    if (b->side_stream) (void)hipStreamDestroy(b->side_stream);
-    if (b->side_stream2) (void)hipStreamDestroy(b->side_stream2);
-    delete b;
+int lfr_hip_reserve(int device, int64_t n_nodes, int64_t n_matches) {
+    // Pre-populate the slab caches with what a pipeline run over a graph of this size will ask for, so that the
+    // timed span of a one-shot caller (the `solve` launcher knows the sizes once the file is parsed... or guesses
+    // them from the file size while it is still parsing) pays no hipMalloc / hipHostMalloc.
+    if (n_nodes < 0 || n_matches < 0) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    const int64_t N = n_nodes, M = n_matches;
+    const size_t want[5] = {
+        (size_t)16 * M + (size_t)4 * N + (size_t)144 * M + ((size_t)1 << 16),                              // DevGraph with staged flows
+        (size_t)9 * N + 4096,                                                                             // DevProblem
+        (size_t)96 * M + (size_t)96 * N + ((size_t)32 << 20),                                             // graph-stage temporaries
+        (size_t)96 * M + (size_t)48 * N + (size_t)128 * (N + 1) + ((size_t)32 << 20),                     // assembly temporaries (C <= N)
+        lfr::assembly_output_bytes(N, M, N) + (size_t)(16 + 32) * (size_t)(N + 1) + ((size_t)1 << 17)};   // batch slab
+    void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t got[5] = {0, 0, 0, 0, 0};
+    // (the graph-stage and assembly temporaries are never alive together: the larger of the two serves both)
+    for (int i = 0; i < 5; ++i) {
+        if (i == 2 && want[3] >= want[2]) continue;
+        if (i == 3 && want[2] > want[3]) continue;
+        p[i] = ctx->dev_acquire(want[i], &got[i]);
+    }
+    for (int i = 0; i < 5; ++i) if (p[i]) ctx->dev_release(p[i], got[i]);
+    size_t hb = 0;
+    if (void *h = ctx->pinned_acquire(sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1), &hb)) ctx->pinned_release(h, hb);
+    return LFR_OK;
 }
+
+int lfr_hip_trim(int device) {
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    ctx->trim();
+    return LFR_OK;
+}
+
+void lfr_batch_free(lfr_batch *b) { delete b; }
 
 int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shard_world, int tukey_variant,
                      lfr_batch **out) {
@@ -1179,157 +1401,31 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         (tukey_variant != LFR_TUKEY_CERES1 && tukey_variant != LFR_TUKEY_CERES2)) {
         lfr::set_error("bad argument"); return LFR_ERR_ARG;
     }
+    *out = nullptr;
     const lfr::Problem &p = ph->p;
-    int n_dev = 0;
-    HIP_TRY(hipGetDeviceCount(&n_dev));
-    if (device < 0 || device >= n_dev) { lfr::set_error("HIP device %d not available (%d devices)", device, n_dev); return LFR_ERR_HIP; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
     HIP_TRY(hipSetDevice(device));
-    lfr_batch *b = new lfr_batch();
-    b->device = device; b->tukey_variant = tukey_variant;
+    std::unique_ptr<lfr_batch> b(new lfr_batch());            // every error path below releases what was acquired
+    b->device = device; b->ctx = ctx; b->tukey_variant = tukey_variant; b->shard_world = shard_world;
     { const char *e = getenv("LFR_SERIAL_CLASSES"); b->serial = e && e[0] == '1'; }
-    b->n_graph_nodes = (int64_t)p.track.size();
-
-    // Labels-only problem: the batch layout is assembled on the GPU (lfr_assemble.hip) - the flows
-    // cross PCIe once in match order, no host-side record array exists.
-    lfr::DeviceAssembly dev;
-    const bool on_device = !p.host_batch;
-    if (on_device) {
-        if (shard_world != 1) { delete b; lfr::set_error("device-side assembly builds whole problems only (shard_world must be 1)"); return LFR_ERR_ARG; }
-        if (p.g->dev_disp1 && p.g->dev_flows_device != device) { delete b; lfr::set_error("the graph's flows live on device %d, the batch was requested on device %d", p.g->dev_flows_device, device); return LFR_ERR_ARG; }
-        hipEvent_t a0, a1;
-        HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
-        HIP_TRY(hipEventRecord(a0, nullptr));
-        const int rc = lfr::assemble_on_device(*p.g, p, nullptr, nullptr, nullptr, dev);
-        if (rc != LFR_OK) { dev.release(); delete b; return rc; }
-        HIP_TRY(hipEventRecord(a1, nullptr));
-        HIP_TRY(hipEventSynchronize(a1));
-        float ams = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ams, a0, a1));
-        b->h2d_ms = ams;
-        (void)hipEventDestroy(a0); (void)hipEventDestroy(a1);
-    }
-    const std::vector<CompDesc> &src_descs = on_device ? dev.descs : p.descs;
-    const std::vector<int32_t> &src_class = on_device ? dev.desc_class : p.desc_class;
-    const std::vector<int32_t> &src_tracks = on_device ? dev.desc_tracks : p.desc_tracks;
-    // LPT sharding (lfr::assign_shards); the shard keeps the class/size order of the batch
-    std::vector<size_t> mine;
-    if (on_device) { mine.resize(src_descs.size()); for (size_t i = 0; i < mine.size(); ++i) mine[i] = i; }
-    else {
-        const std::vector<int32_t> shard = lfr::assign_shards(p, shard_world);
-        for (size_t i = 0; i < p.descs.size(); ++i) if (shard[i] == shard_rank) mine.push_back(i);
-    }
-    // Whole problem on one GPU: upload straight from the problem's arrays (no 400 MB host copy).
-    const bool whole = shard_world == 1;
-    std::vector<EdgeRec> edges_copy;
-    std::vector<uint32_t> in_idx_copy;
-    uint64_t ws = 0;
-    if (on_device) {
-        b->node_ids = dev.node_ids;
-        b->descs = dev.descs; b->desc_component = dev.desc_component; b->desc_class = dev.desc_class; b->desc_tracks = dev.desc_tracks;
-        b->es_off.resize(dev.descs.size()); b->ws_off.assign(dev.descs.size(), 0);
-    } else if (whole) {
-        b->node_ids = p.node_ids; b->node_inc = p.node_inc;
-        b->descs = p.descs; b->desc_component = p.desc_component; b->desc_class = p.desc_class; b->desc_tracks = p.desc_tracks;
-        b->es_off.resize(p.descs.size()); b->ws_off.assign(p.descs.size(), 0);
-    }
-    for (size_t k = 0; k < mine.size(); ++k) {
-        const size_t i = mine[k];
-        CompDesc d = src_descs[i];
-        if (!whole) {
-            const uint32_t eo = (uint32_t)edges_copy.size(), no = (uint32_t)b->node_ids.size();
-            edges_copy.insert(edges_copy.end(), p.edges.begin() + d.edge_off, p.edges.begin() + d.edge_off + d.n_edges);
-            in_idx_copy.insert(in_idx_copy.end(), p.in_idx.begin() + d.edge_off, p.in_idx.begin() + d.edge_off + d.n_edges);
-            b->node_ids.insert(b->node_ids.end(), p.node_ids.begin() + d.node_off, p.node_ids.begin() + d.node_off + d.n_nodes);
-            b->node_inc.insert(b->node_inc.end(), p.node_inc.begin() + d.node_off, p.node_inc.begin() + d.node_off + d.n_nodes);
-            d.edge_off = eo; d.node_off = no;
-            b->descs.push_back(d); b->desc_component.push_back(p.desc_component[i]);
-            b->desc_class.push_back(p.desc_class[i]); b->desc_tracks.push_back(p.desc_tracks[i]);
-            b->es_off.push_back(0); b->ws_off.push_back(0);
-        }
-        const int cls = src_class[i], rows = 2 * d.n_var;
-        b->es_off[k] = ws;
-        if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
-        if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
-        if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
-        b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += src_tracks[i];
-    }
-    const std::vector<EdgeRec> &edges = whole ? p.edges : edges_copy;
-    const std::vector<uint32_t> &in_idx = whole ? p.in_idx : in_idx_copy;
-    for (size_t i = 0; i < b->descs.size(); ++i)      // HBM variant: packed matrix + vectors per component
-        if (b->desc_class[i] == lfr::KC_GLOBAL) {
-            const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;
-            ws += ws & 1;
-            b->ws_off[i] = ws;
-            ws += mat + (mat & 1) + block_vector_doubles(b->global_max_rows);
-        }
-    {   // class ranges (descs are sorted by class)
-        int c = 0;
-        b->class_begin[0] = 0;
-        for (int i = 0; i <= (int)b->descs.size(); ++i) {
-            const int cls = i < (int)b->descs.size() ? b->desc_class[i] : lfr::KC_COUNT;
-            while (c < cls) b->class_begin[++c] = i;
-        }
-    }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0)); HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    const size_t nd = std::max<size_t>(b->descs.size(), 1), ne = std::max<size_t>(edges.size(), 1), nn = std::max<size_t>(b->node_ids.size(), 1);
-    if (on_device) {         // the assembly already produced the big arrays in HBM: adopt them
-        b->d_descs = dev.d_descs; b->d_edges = dev.d_edges; b->d_node_ids = dev.d_node_ids;
-        b->d_node_inc = dev.d_node_inc; b->d_in_idx = dev.d_in_idx;
-        dev.d_descs = nullptr; dev.d_edges = nullptr; dev.d_node_ids = nullptr; dev.d_node_inc = nullptr; dev.d_in_idx = nullptr;
-    } else {
-        HIP_TRY(hipMalloc(&b->d_descs, nd * sizeof(CompDesc)));
-        HIP_TRY(hipMalloc(&b->d_edges, ne * sizeof(EdgeRec)));
-        HIP_TRY(hipMalloc(&b->d_node_ids, nn * sizeof(uint32_t)));
-        HIP_TRY(hipMalloc(&b->d_node_inc, nn * sizeof(lfr::NodeInc)));
-        HIP_TRY(hipMalloc(&b->d_in_idx, ne * sizeof(uint32_t)));
-    }
-    HIP_TRY(hipMalloc(&b->d_positions, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
-    // Roots, constants and nodes outside every solved component stay at 0 for the life of the batch
-    // (solve.cc:609-612); the kernels overwrite every variable on every solve, so no per-solve memset.
-    HIP_TRY(hipMemset(b->d_positions, 0, std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2) * sizeof(double)));
-    HIP_TRY(hipMalloc(&b->d_infos, nd * sizeof(CompInfoDev)));
-    HIP_TRY(hipMalloc(&b->d_ws_off, nd * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&b->d_es_off, nd * sizeof(uint64_t)));
-    HIP_TRY(hipMalloc(&b->d_prof, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
-    HIP_TRY(hipMemset(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long)));
-    if (ws) HIP_TRY(hipMalloc(&b->d_workspace, ws * sizeof(double)));
-    if (!b->descs.empty()) {
-        HIP_TRY(hipMemcpy(b->d_ws_off, b->ws_off.data(), b->ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(b->d_es_off, b->es_off.data(), b->es_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-        if (!on_device) {
-            HIP_TRY(hipMemcpy(b->d_descs, b->descs.data(), b->descs.size() * sizeof(CompDesc), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(b->d_edges, edges.data(), edges.size() * sizeof(EdgeRec), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(b->d_node_ids, b->node_ids.data(), b->node_ids.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(b->d_node_inc, b->node_inc.data(), b->node_inc.size() * sizeof(lfr::NodeInc), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(b->d_in_idx, in_idx.data(), in_idx.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        }
-    }
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
-    b->h2d_ms += ms;             // (device assembly: its upload + kernels were timed above)
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    for (auto &e : b->ev_ring) e = nullptr;      // created lazily, one slot per solve
-    b->events = true;
+    b->n_graph_nodes = p.g->n_nodes();
+    const int rc = p.host_batch ? create_from_host(b.get(), p, shard_rank, shard_world) : create_on_device(b.get(), p, shard_rank, shard_world);
+    if (rc != LFR_OK) return rc;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
-    HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&b->side_stream2, hipStreamNonBlocking));
+    if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
+        HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+        HIP_TRY(hipStreamCreateWithFlags(&b->side_stream2, hipStreamNonBlocking));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)block_lds_bytes(std::max(b->block_max_rows, 2), false)));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)block_lds_bytes(std::max(b->global_max_rows, 2), true)));
+    }
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
-        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) {
-            int64_t e = 0;
-            for (int i = b->class_begin[cls]; i < b->class_begin[cls + 1]; ++i) e += b->descs[i].n_edges;
-            if (e > best) { best = e; b->packed_slot = cls; }
-        }
+        for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) if (b->class_edges[cls] > best) { best = b->class_edges[cls]; b->packed_slot = cls; }
     }
-    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)block_lds_bytes(std::max(b->block_max_rows, 2), false)));
-    HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)block_lds_bytes(std::max(b->global_max_rows, 2), true)));
-    *out = b;
+    *out = b.release();
     return LFR_OK;
 }
 
@@ -1345,6 +1441,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     uint32_t &recorded = b->ev_recorded[b->n_solves % lfr_batch::kSlots];
     recorded = 0;
     ++b->n_solves;
+    b->last_stream = st;
     if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
     HIP_TRY(hipEventRecord(b->ev[0], st));
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
@@ -1464,9 +1561,12 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));
     stats->kernel_ms = ms;
     stats->h2d_ms = b->h2d_ms;
+    { const int rc = ensure_mirrors(b); if (rc != LFR_OK) return rc; }
     b->infos.resize(b->descs.size());
-    if (!b->descs.empty())
-        HIP_TRY(hipMemcpy(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost));
+    if (!b->descs.empty()) {
+        HIP_TRY(hipMemcpyAsync(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     b->infos_valid = true;
     stats->n_components = (int64_t)b->descs.size();
     stats->n_edges = b->n_edges; stats->n_nodes = b->n_nodes; stats->n_tracks = b->n_tracks;
@@ -1524,22 +1624,50 @@ int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *cl
             int64_t e = 0;
             const bool packed = !b->serial && cls < lfr::KC_BLOCK;
             const int lo = packed ? (cls == b->packed_slot ? 0 : cls + 1) : cls, hi = packed ? (cls == b->packed_slot ? lfr::KC_BLOCK : cls + 1) : cls + 1;
-            for (int c = lo; c < hi; ++c)
-                for (int i = b->class_begin[c]; i < b->class_begin[c + 1]; ++i) e += b->descs[i].n_edges;
+            for (int c = lo; c < hi; ++c) e += b->class_edges[c];
             class_edges[cls] = e;
         }
     }
     return LFR_OK;
 }
 
-int lfr_batch_download(lfr_batch *b, double *positions) {
+// The positions of the whole graph in pinned host memory, valid until the next solve / download / free of this
+// batch: waits for the latest solve, one D2H at link speed, no further copy.  Nodes outside this batch's shard
+// read 0.
+int lfr_batch_positions_view(lfr_batch *b, const double **positions) {
     if (!b || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     HIP_TRY(hipSetDevice(b->device));
-    std::vector<double> tmp(std::max<size_t>(2 * (size_t)b->n_graph_nodes, 2));
-    HIP_TRY(hipMemcpy(tmp.data(), b->d_positions, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
-    for (size_t i = 0; i < b->node_ids.size(); ++i) {
+    const size_t bytes = sizeof(double) * 2 * (size_t)std::max<int64_t>(b->n_graph_nodes, 1);
+    if (!b->h_positions) {
+        b->h_positions = (double *)b->ctx->pinned_acquire(bytes, &b->h_positions_bytes);
+        if (!b->h_positions) return LFR_ERR_NOMEM;
+    }
+    hipStream_t st = b->ctx->s_main;
+    if (b->n_solves > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev[1], 0));        // end of the latest solve, whatever stream it ran on
+    HIP_TRY(hipMemcpyAsync(b->h_positions, b->d_positions, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    *positions = b->h_positions;
+    return LFR_OK;
+}
+
+int lfr_batch_download(lfr_batch *b, double *positions) {
+    if (!b || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    const double *view = nullptr;
+    int rc = lfr_batch_positions_view(b, &view);
+    if (rc != LFR_OK) return rc;
+    if (b->shard_world == 1) {             // whole problem: every node the batch does not solve is 0 in the view as well
+        const size_t n = 2 * (size_t)b->n_graph_nodes;
+        const int T = n >= ((size_t)1 << 20) ? 4 : 1;
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back([=] { memcpy(positions + n * t / T, view + n * t / T, sizeof(double) * (n * (t + 1) / T - n * t / T)); });
+        memcpy(positions, view, sizeof(double) * (n / T));
+        for (auto &x : th) x.join();
+        return LFR_OK;
+    }
+    if ((rc = ensure_mirrors(b)) != LFR_OK) return rc;
+    for (size_t i = 0; i < b->node_ids.size(); ++i) {      // a shard writes its own nodes only
         const size_t n = b->node_ids[i];
-        positions[2 * n] = tmp[2 * n]; positions[2 * n + 1] = tmp[2 * n + 1];
+        positions[2 * n] = view[2 * n]; positions[2 * n + 1] = view[2 * n + 1];
     }
     return LFR_OK;
 }
@@ -1547,11 +1675,15 @@ int lfr_batch_download(lfr_batch *b, double *positions) {
 int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
                                  double *final_cost, int32_t *n_var_nodes, int32_t *n_edges) {
     if (!b) return LFR_ERR_ARG;
+    if (ensure_mirrors(b) != LFR_OK) return LFR_ERR_HIP;
     if (!b->infos_valid) {
         if (hipSetDevice(b->device) != hipSuccess) return LFR_ERR_HIP;
         b->infos.resize(b->descs.size());
+        hipStream_t st = b->ctx->s_main;
+        if (b->n_solves > 0 && hipStreamWaitEvent(st, b->ev[1], 0) != hipSuccess) return LFR_ERR_HIP;
         if (!b->descs.empty() &&
-            hipMemcpy(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost) != hipSuccess)
+            (hipMemcpyAsync(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost, st) != hipSuccess ||
+             hipStreamSynchronize(st) != hipSuccess))
             return LFR_ERR_HIP;
         b->infos_valid = true;
     }
@@ -1571,21 +1703,13 @@ int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *p
     lfr_batch *b = nullptr;
     int rc = lfr_batch_create(p, device, 0, 1, tukey_variant, &b);
     if (rc != LFR_OK) return rc;
+    std::unique_ptr<lfr_batch> guard(b);
     lfr_solve_stats local;
-    rc = lfr_batch_solve(b, nullptr, stats ? stats : &local);
-    if (rc == LFR_OK) {
-        const size_t n = p->p.track.size();
-        memset(positions, 0, sizeof(double) * 2 * n);
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-        (void)hipEventRecord(e0, nullptr);
-        rc = lfr_batch_download(b, positions);
-        (void)hipEventRecord(e1, nullptr); (void)hipEventSynchronize(e1);
-        float ms = 0.f; (void)hipEventElapsedTime(&ms, e0, e1);
-        if (stats) stats->d2h_ms = ms;
-        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    }
-    lfr_batch_free(b);
+    rc = lfr_batch_solve(b, b->ctx->s_main, stats ? stats : &local);
+    if (rc != LFR_OK) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    rc = lfr_batch_download(b, positions);
+    if (stats) stats->d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return rc;
 }
 
@@ -1593,20 +1717,20 @@ int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices,
                         lfr_solve_stats *stats) {
     if (!p || !devices || n_devices < 1 || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     if (n_devices == 1) return lfr_solve_hip(p, devices[0], tukey_variant, positions, stats);
-    if (!p->p.host_batch) { lfr::set_error("multi-device solves shard the host-assembled batch: build the problem with lfr_problem_build"); return LFR_ERR_ARG; }
     // one host thread per device (components are independent: no exchange between shards)
-    std::vector<lfr_batch *> batches(n_devices, nullptr);
     std::vector<int> rcs(n_devices, LFR_OK);
     std::vector<lfr_solve_stats> sts(n_devices);
     std::vector<std::string> errs(n_devices);
-    const size_t n = p->p.track.size();
+    const size_t n = (size_t)p->p.g->n_nodes();
     memset(positions, 0, sizeof(double) * 2 * n);
+    if (!p->p.host_batch) { const int rc = p->p.ensure_host_labels(); if (rc != LFR_OK) return rc; }   // once, before the threads fork
     auto work = [&](int k) {
-        rcs[k] = lfr_batch_create(p, devices[k], k, n_devices, tukey_variant, &batches[k]);
-        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_solve(batches[k], nullptr, &sts[k]);
-        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_download(batches[k], positions);       // disjoint node sets per shard
+        lfr_batch *bt = nullptr;
+        rcs[k] = lfr_batch_create(p, devices[k], k, n_devices, tukey_variant, &bt);
+        std::unique_ptr<lfr_batch> guard(bt);
+        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_solve(bt, bt->ctx->s_main, &sts[k]);
+        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_download(bt, positions);       // disjoint node sets per shard
         if (rcs[k] != LFR_OK) errs[k] = lfr_last_error();
-        if (batches[k]) lfr_batch_free(batches[k]);
     };
     std::vector<std::thread> th;
     for (int k = 1; k < n_devices; ++k) th.emplace_back(work, k);

@@ -78,7 +78,7 @@ void Graph::add_match(int32_t img1, int32_t img2, uint32_t f1, uint32_t f2, floa
     const uint32_t b = find_or_create_node(img2, f2);
     m_node1.push_back(a); m_node2.push_back(b); m_sim.push_back(sim);
     const size_t o = m_disp1.size();
-    m_disp1.resize(o + 18, 0.f); m_disp2.resize(o + 18, 0.f);
+    m_disp1.resize(o + 18); m_disp2.resize(o + 18);            // zero filled
     if (n1 > 0) memcpy(&m_disp1[o], d1, sizeof(float) * 2 * (size_t)n1);
     if (n2 > 0) memcpy(&m_disp2[o], d2, sizeof(float) * 2 * (size_t)n2);
 }
@@ -86,6 +86,15 @@ void Graph::add_match(int32_t img1, int32_t img2, uint32_t f1, uint32_t f2, floa
 void Graph::finish() {
     std::vector<uint64_t>().swap(hkeys);
     std::vector<int64_t>().swap(hvals);
+    // nodes grouped by image, in node order (lfr_apply_displacements; built here so that the handle is
+    // read-only - and therefore thread safe - afterwards)
+    const size_t ni = image_names.size();
+    img_off.assign(ni + 1, 0);
+    for (int32_t im : node_image) ++img_off[im + 1];
+    for (size_t i = 0; i < ni; ++i) img_off[i + 1] += img_off[i];
+    img_nodes.resize(node_image.size());
+    std::vector<int64_t> cur(img_off.begin(), img_off.end() - 1);
+    for (size_t n = 0; n < node_image.size(); ++n) img_nodes[cur[node_image[n]]++] = (uint32_t)n;
 }
 
 // ---------------------------------------------------------------------------- wire primitives
@@ -263,6 +272,11 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
     struct Job { int32_t buf; int64_t src, dst, n; };
     std::vector<Job> jobs;
     int64_t M = g.n_matches();
+    {   // one (pinned) allocation per array and file instead of geometric growth
+        int64_t add = 0;
+        for (int64_t i = 0; i < P; ++i) add += recs[i].count;
+        g.m_node1.reserve((size_t)(M + add)); g.m_node2.reserve((size_t)(M + add));
+    }
     for (int64_t i = 0; i < P; ++i) {
         const PairRec &r = recs[i];
         const std::string name1(r.name1 ? r.name1 : "", r.len1), name2(r.name2 ? r.name2 : "", r.len2);
@@ -509,15 +523,6 @@ int lfr_apply_displacements(const lfr_graph *gh, const double *positions, const 
         set_error("bad argument"); return LFR_ERR_ARG;
     }
     const Graph &g = gh->g;
-    if (g.img_off.empty()) {        // nodes grouped by image, in node order (not thread safe on first call)
-        const size_t ni = g.image_names.size();
-        g.img_off.assign(ni + 1, 0);
-        for (int32_t im : g.node_image) ++g.img_off[im + 1];
-        for (size_t i = 0; i < ni; ++i) g.img_off[i + 1] += g.img_off[i];
-        g.img_nodes.resize(g.node_image.size());
-        std::vector<int64_t> cur(g.img_off.begin(), g.img_off.end() - 1);
-        for (size_t n = 0; n < g.node_image.size(); ++n) g.img_nodes[cur[g.node_image[n]]++] = (uint32_t)n;
-    }
     const auto it = g.image_index.find(image_name);
     if (it != g.image_index.end()) {
         const int32_t im = it->second;

@@ -68,6 +68,8 @@ def lib():
         "lfr_graph_from_matches_file": (C.c_int, [C.c_char_p, cpp, C.c_int, pp]),
         "lfr_graph_from_arrays": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cpp, C.c_int, pp]),
         "lfr_graph_from_arrays_device_flows": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, cpp, C.c_int, pp]),
+        "lfr_graph_to_device": (C.c_int, [vp, C.c_int]),
+        "lfr_graph_evict_device": (C.c_int, [vp]),
         "lfr_graph_free": (None, [vp]),
         "lfr_graph_num_nodes": (i64, [vp]),
         "lfr_graph_num_edges": (i64, [vp]),
@@ -79,15 +81,19 @@ def lib():
         "lfr_problem_build": (C.c_int, [vp, i64, vp, pp]),
         "lfr_problem_build_labels": (C.c_int, [vp, i64, vp, pp]),
         "lfr_problem_build_hip": (C.c_int, [vp, C.c_int, i64, vp, pp]),
+        "lfr_problem_build_hip_ex": (C.c_int, [vp, C.c_int, i64, vp, C.c_int, pp]),
         "lfr_problem_free": (None, [vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
         "lfr_problem_shard_components": (i64, [vp, C.c_int, C.c_int, vp, vp]),
         "lfr_hip_warmup": (C.c_int, [C.c_int]),
+        "lfr_hip_reserve": (C.c_int, [C.c_int, i64, i64]),
+        "lfr_hip_trim": (C.c_int, [C.c_int]),
         "lfr_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, pp]),
         "lfr_batch_free": (None, [vp]),
         "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
         "lfr_batch_download": (C.c_int, [vp, vp]),
+        "lfr_batch_positions_view": (C.c_int, [vp, pp]),
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
@@ -104,7 +110,8 @@ def lib():
 
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
-           "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -127,13 +134,22 @@ def _cstrs(strings):
     return arr
 
 
-def hip_warmup_async(device=0):
-    """Start creating the HIP context on a side thread (ctypes releases the GIL); returns the thread."""
+def hip_warmup_async(device=0, n_nodes=0, n_matches=0):
+    """Start creating the HIP context on a side thread (ctypes releases the GIL); returns the thread.
+    n_nodes / n_matches > 0 also pre-populates the slab caches for a graph of (about) that size."""
     import threading
     L = lib()
-    t = threading.Thread(target=lambda: L.lfr_hip_warmup(device), daemon=True)
+
+    def work():
+        L.lfr_hip_warmup(device)
+        if n_matches > 0:
+            L.lfr_hip_reserve(device, n_nodes, n_matches)
+    t = threading.Thread(target=work, daemon=True)
     t.start()
     return t
+
+
+FLOWS_STAY_ON_HOST = 1      # LFR_BUILD_FLOWS_STAY_ON_HOST
 
 
 class Graph:
@@ -185,6 +201,14 @@ class Graph:
             self._h = None
 
     __del__ = close
+
+    def to_device(self, device=0):
+        """Start the asynchronous upload of the graph (endpoints, similarities, flows) to HBM."""
+        _check(lib().lfr_graph_to_device(self._h, device))
+
+    def evict_device(self):
+        """Drop the graph's cached copy in HBM (the next device pipeline run uploads it again)."""
+        _check(lib().lfr_graph_evict_device(self._h))
 
     @property
     def n_nodes(self):
@@ -257,14 +281,16 @@ class Problem:
     """Tracks, roots, components and the device batch layout (solve.cc:487-606, 79-143)."""
 
     def __init__(self, graph, max_nodes_in_component=0, component_override=None, device_assembly=False,
-                 device_graph_stage=None):
+                 device_graph_stage=None, flags=0):
         """device_assembly=True: graph stage only; the batch is assembled on the GPU by Batch / solve_hip.
-        device_graph_stage=<device ordinal>: tracks/roots/components on that GPU too (implies device_assembly)."""
+        device_graph_stage=<device ordinal>: tracks/roots/components on that GPU too (implies device_assembly);
+        flags=FLOWS_STAY_ON_HOST: do not stage the flows in HBM (sharded batches gather their rows zero-copy)."""
         self.graph = graph
         h = C.c_void_p()
         co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
         if device_graph_stage is not None:
-            _check(lib().lfr_problem_build_hip(graph._h, int(device_graph_stage), int(max_nodes_in_component), _ptr(co), C.byref(h)))
+            _check(lib().lfr_problem_build_hip_ex(graph._h, int(device_graph_stage), int(max_nodes_in_component), _ptr(co),
+                                                  int(flags), C.byref(h)))
         else:
             fn = lib().lfr_problem_build_labels if device_assembly else lib().lfr_problem_build
             _check(fn(graph._h, int(max_nodes_in_component), _ptr(co), C.byref(h)))
@@ -356,6 +382,17 @@ class Batch:
             positions = np.zeros((n, 2), np.float64)
         _check(lib().lfr_batch_download(self._h, _ptr(positions)))
         return positions
+
+    def positions_view(self):
+        """Zero-copy [n, 2] float64 view of the batch's pinned staging buffer (valid until the next solve /
+        download / close of this batch; nodes outside the shard read 0)."""
+        n = self.problem.graph.n_nodes
+        p = C.c_void_p()
+        _check(lib().lfr_batch_positions_view(self._h, C.byref(p)))
+        if n == 0:
+            return np.zeros((0, 2), np.float64)
+        buf = (C.c_double * (2 * n)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.float64).reshape(n, 2)
 
     def component_info(self):
         n = lib().lfr_batch_component_info(self._h, None, None, None, None, None, None)

@@ -1,0 +1,141 @@
+"""GPU tests of the device pipeline around the solve kernels: device-resident graph and labels,
+sharded device assembly, zero-copy flow gather, pinned download view, slab caches.  Everything is
+compared bit for bit with the host-assembled path (itself checked against the oracle in
+test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from lfr_amd import capi, synthetic
+
+pytestmark = pytest.mark.gpu
+
+MIXED = dict(seed=99, n_images=64, n_tracks=3000, eps_out=0.001)
+BLOCKY = dict(seed=76, n_images=96, n_tracks=60, len_dist="uniform", len_lo=20, len_hi=80)
+GLOBAL = dict(seed=77, n_images=128, n_tracks=12, len_dist="uniform", len_lo=92, len_hi=120)
+
+
+def _info_tuple(b):
+    i = b.component_info()
+    return [i[k].copy() for k in ("component", "n_var_nodes", "n_edges", "iterations", "termination", "final_cost")]
+
+
+@pytest.mark.parametrize("kw", [MIXED, BLOCKY, GLOBAL])
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_device_assembly_equals_host_shards(lfr_lib, kw, world):
+    """lfr_batch_create(rank, world) of a labels-only problem (shard filtered on the GPU) == the shard cut
+    from the host-assembled batch: same components in the same order, bit-identical solutions; the shards
+    partition the solvable components and reassemble the unsharded solution."""
+    ma = synthetic.generate(**kw)
+    g = capi.Graph.from_arrays(ma)
+    ph = capi.Problem(g)
+    pd = capi.Problem(g, device_graph_stage=0, flags=capi.FLOWS_STAY_ON_HOST)
+    full, _ = ph.solve_hip(0)
+    merged = np.zeros_like(full)
+    seen = []
+    for r in range(world):
+        bh, bd = capi.Batch(ph, 0, r, world), capi.Batch(pd, 0, r, world)
+        sh, sd = bh.solve(), bd.solve()
+        for a, b in zip(_info_tuple(bh), _info_tuple(bd)):
+            assert (a == b).all()
+        for k in ("n_components", "n_edges", "n_nodes", "n_tracks", "ref_jacobian_passes_edges", "exec_passes_edges"):
+            assert sh[k] == sd[k], k
+        want = np.zeros_like(full)
+        got = np.zeros_like(full)
+        bh.download(want)
+        bd.download(got)
+        assert (want == got).all()
+        comps, _ = ph.shard_components(r, world)
+        assert (np.sort(comps) == np.sort(bd.component_info()["component"])).all()
+        seen.append(comps)
+        bd.download(merged)
+    allc = np.concatenate(seen)
+    assert len(np.unique(allc)) == len(allc) == ph.stats()["n_solved_components"]
+    assert (merged == full).all()
+
+
+def test_multi_device_entry_point_with_device_assembly(lfr_lib):
+    """lfr_solve_hip_multi on a labels-only problem: every shard is assembled on "its" GPU ([0, 0, 0] here)."""
+    ma = synthetic.generate(**MIXED)
+    g = capi.Graph.from_arrays(ma)
+    full, st1 = capi.Problem(g).solve_hip(0)
+    for flags in (0, capi.FLOWS_STAY_ON_HOST):
+        p = capi.Problem(g, device_graph_stage=0, flags=flags)
+        multi, stm = capi.solve_hip_multi(p, [0, 0, 0])
+        assert (full == multi).all()
+        for k in ("n_components", "n_edges", "n_tracks", "n_converged", "sum_iterations", "ref_jacobian_passes_edges"):
+            assert st1[k] == stm[k], k
+        g.evict_device()
+
+
+def test_resident_graph_and_eviction(lfr_lib):
+    """to_device / evict_device change where the pipeline starts from, never the result."""
+    ma = synthetic.generate(**MIXED)
+    g = capi.Graph.from_arrays(ma)
+    want, _ = capi.Problem(g).solve_hip(0)
+    g.to_device(0)                                   # ingest-time upload (streamed-ingest contract)
+    a, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+    g.evict_device()                                 # cold again: the pipeline uploads inside its own span
+    b, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+    p = capi.Problem(g, device_graph_stage=0)
+    g.evict_device()                                 # the problem keeps its own reference to the device copy
+    c, _ = p.solve_hip(0)
+    for x in (a, b, c):
+        assert (x == want).all()
+
+
+def test_positions_view_matches_download_and_waits_for_the_solve(lfr_lib):
+    import torch
+    ma = synthetic.generate(**MIXED)
+    g = capi.Graph.from_arrays(ma)
+    p = capi.Problem(g, device_graph_stage=0)
+    b = capi.Batch(p, 0)
+    side = torch.cuda.Stream()                       # a non-blocking stream: the download must order itself after it
+    for _ in range(3):
+        b.solve(side.cuda_stream, want_stats=False)
+    view = b.positions_view()
+    copy = b.download()
+    assert view.shape == copy.shape and (view == copy).all()
+    want, _ = capi.Problem(g).solve_hip(0)
+    assert (copy == want).all()
+
+
+def test_labels_are_fetched_lazily_and_match_the_host_stage(lfr_lib):
+    ma = synthetic.generate(**MIXED)
+    g = capi.Graph.from_arrays(ma)
+    pd = capi.Problem(g, device_graph_stage=0)
+    pos, _ = pd.solve_hip(0)                         # whole pipeline without the labels ever visiting the host
+    ph = capi.Problem(g)
+    for x, y in zip(ph.labels(), pd.labels()):
+        assert (x == y).all()
+    assert (pos == ph.solve_hip(0)[0]).all()
+
+
+def test_reserve_and_trim_do_not_change_results(lfr_lib):
+    ma = synthetic.generate(**BLOCKY)
+    g = capi.Graph.from_arrays(ma)
+    want, _ = capi.Problem(g).solve_hip(0)
+    assert lfr_lib.lfr_hip_reserve(0, g.n_nodes, g.n_edges // 2) == 0
+    a, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+    assert lfr_lib.lfr_hip_trim(0) == 0
+    g.evict_device()
+    b, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+    assert (a == want).all() and (b == want).all()
+
+
+def test_empty_and_trivial_graphs_through_the_device_pipeline(lfr_lib):
+    """No matches; a single match (one 2-node track)."""
+    from lfr_amd.synthetic import pairs_to_arrays
+    one = pairs_to_arrays([dict(image_name1="a.png", fact1=1.0, image_name2="b.png", fact2=1.0, matches=[
+        dict(feature_idx1=0, feature_idx2=0, similarity=0.9, disp1=[(-0.1, -0.1)] * 9, disp2=[(0.1, 0.1)] * 9)])])
+    g = capi.Graph.from_arrays(one)
+    want, _ = capi.Problem(g).solve_hip(0)
+    got, st = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+    assert (want == got).all() and st["n_components"] == 1
+    for world in (2, 5):                             # more shards than components: empty shards are fine
+        p = capi.Problem(g, device_graph_stage=0, flags=capi.FLOWS_STAY_ON_HOST)
+        acc = np.zeros_like(want)
+        for r in range(world):
+            b = capi.Batch(p, 0, r, world)
+            b.solve()
+            b.download(acc)
+        assert (acc == want).all()
