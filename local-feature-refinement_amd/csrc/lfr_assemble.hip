@@ -118,11 +118,11 @@ __global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, const uint32_
 }
 
 __global__ void k_node_keys(int64_t n_nodes, const int32_t *comp, const int32_t *di_of_comp, const uint8_t *is_var,
-                            uint32_t *keys, uint32_t *ids) {
+                            uint32_t dropped_key, uint32_t *keys, uint32_t *ids) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
     const int32_t di = di_of_comp[comp[n]];
-    keys[n] = di < 0 ? 0xffffffffu : (((uint32_t)di << 1) | (is_var[n] ? 0u : 1u));     // variables first, then constants
+    keys[n] = di < 0 ? dropped_key : (((uint32_t)di << 1) | (is_var[n] ? 0u : 1u));     // variables first, then constants
     ids[n] = (uint32_t)n;
 }
 
@@ -136,8 +136,8 @@ __global__ void k_node_locals(int64_t cap, const uint32_t *total_nodes, const ui
 }
 
 __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t *node2, const int32_t *comp,
-                            const int32_t *di_of_comp, const uint32_t *class_of_desc, const uint8_t *kept, uint64_t *keys,
-                            uint32_t *ids) {
+                            const int32_t *di_of_comp, const uint32_t *class_of_desc, const uint8_t *kept, int node_bits,
+                            uint64_t dropped_key, uint64_t *keys, uint32_t *ids) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= n_dir) return;
     uint32_t s, d;
@@ -147,9 +147,10 @@ __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t
     // (the sort is stable), so the two directions 2m, 2m+1 of a match become neighbouring records
     // (written with an early return + mask: the one-expression form `(di >= 0 && class < KC_BLOCK) ? 0 : s` was
     // miscompiled by hipcc 7.2 -O3 for gfx950 - the register holding s was reused before the select)
-    if (di < 0) { keys[e] = ~0ull; ids[e] = (uint32_t)e; return; }
+    // (keys are packed into node_bits + bits(C) bits so that the radix sort runs 5 passes instead of 8)
+    if (di < 0) { keys[e] = dropped_key; ids[e] = (uint32_t)e; return; }
     const uint32_t by_source = class_of_desc[di] >= (uint32_t)KC_BLOCK ? 0xffffffffu : 0u;
-    keys[e] = ((uint64_t)(uint32_t)di << 32) | (s & by_source);
+    keys[e] = ((uint64_t)(uint32_t)di << node_bits) | (s & by_source);
     ids[e] = (uint32_t)e;
 }
 
@@ -171,52 +172,67 @@ __global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const 
     if (q < 0 || q >= total_edges || edge_sorted[q] != (e ^ 1u)) *flag = 1u;
 }
 
-// one thread per (edge record, 16-byte chunk): writes EdgeRec, counts degrees, records run starts
+// one thread per (edge record, 16-byte chunk): writes the 80-byte EdgeRec of every kept edge whose match lies in
+// [row_lo, row_hi) - the flows arrive in chunks of matches on the copy stream and each chunk is gathered as soon
+// as it has landed
 __global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
-                             const int32_t *comp, const int32_t *di_of_comp, const uint32_t *edge_off, const uint32_t *node_off,
-                             const uint32_t *local_of, const uint32_t *flow_row, uint4 *records, NodeInc *inc, uint64_t *in_keys,
-                             uint32_t *in_vals) {
+                             const uint32_t *local_of, const uint32_t *flow_row, int64_t row_lo, int64_t row_hi, uint4 *records) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / 5;
     const int chunk = (int)(t - 5 * p);
-    if (p >= cap) return;
-    const int64_t total_edges = (int64_t)*total_edges_p;
-    if (p >= total_edges) {                                  // padding of the in-edge sort: sorts behind every real key
-        if (chunk == 4) { in_keys[p] = 0x0000ffffffffffffull; in_vals[p] = 0u; }
-        return;
-    }
+    if (p >= cap || p >= (int64_t)*total_edges_p) return;
     const uint32_t e = edge_sorted[p];
-    uint32_t s, d;
-    edge_ends(node1, node2, e, s, d);
-    const size_t frow = flow_row ? flow_row[e >> 1] : (size_t)(e >> 1);
+    const int64_t m = (int64_t)(e >> 1);
+    if (m < row_lo || m >= row_hi) return;
+    const size_t frow = flow_row ? flow_row[m] : (size_t)m;
     const float *fl = ((e & 1) ? disp1 : disp2) + 18 * frow;
     uint4 q;
     if (chunk < 4) {
         q.x = __float_as_uint(fl[4 * chunk]); q.y = __float_as_uint(fl[4 * chunk + 1]);
         q.z = __float_as_uint(fl[4 * chunk + 2]); q.w = __float_as_uint(fl[4 * chunk + 3]);
     } else {
+        uint32_t s, d;
+        edge_ends(node1, node2, e, s, d);
         const uint32_t ls = local_of[s], ld = local_of[d];
         const uint32_t kind = track[s] != track[d] ? 1u : 0u;
         q.x = __float_as_uint(fl[16]); q.y = __float_as_uint(fl[17]);
-        q.z = __float_as_uint(sim[e >> 1]);
+        q.z = __float_as_uint(sim[m]);
         q.w = ls | ((ld | (kind << 15)) << 16);
-        const uint32_t di = (uint32_t)di_of_comp[comp[s]];
-        const uint32_t eo = edge_off[di], no = node_off[di];
-        const uint32_t local_edge = (uint32_t)p - eo;
-        atomicAdd(&inc[no + ls].out_count, 1u);
-        atomicAdd(&inc[no + ld].in_count, 1u);
-        bool first = p == 0;
-        if (!first) {
-            uint32_t ps, pd;
-            edge_ends(node1, node2, edge_sorted[p - 1], ps, pd);
-            first = ps != s;
-        }
-        if (first) inc[no + ls].out_begin = local_edge;
-        in_keys[p] = ((uint64_t)di << 16) | ld;            // in-edge lists: by component, destination, edge index
-        in_vals[p] = local_edge;
     }
     records[5 * p + chunk] = q;
+}
+
+// Incidence lists of the workgroup-class components (the owner-computes assembly of solve_block_kernel walks a
+// node's out-edge run and its in-edge list; the packed kernels use neither): degrees, run starts, and the
+// (component, destination, edge index) keys of the in-edge sort.  Packed-class edges carry their key too (the sorted
+// position of a key is its position in the batch's edge array: solve_block_kernel indexes in_idx from the
+// component's edge offset); only the padding behind total_edges gets a key that sorts last.
+__global__ void k_incidence(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
+                            const int32_t *comp, const int32_t *di_of_comp, const uint32_t *class_of_desc, const uint32_t *edge_off,
+                            const uint32_t *node_off, const uint32_t *local_of, NodeInc *inc, uint64_t *in_keys, uint32_t *in_vals) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= cap) return;
+    in_keys[p] = 0x0000ffffffffffffull; in_vals[p] = 0u;
+    if (p >= (int64_t)*total_edges_p) return;
+    uint32_t s, d;
+    edge_ends(node1, node2, edge_sorted[p], s, d);
+    const uint32_t di = (uint32_t)di_of_comp[comp[s]];
+    const uint32_t ls = local_of[s], ld = local_of[d];
+    const uint32_t eo = edge_off[di], no = node_off[di];
+    const uint32_t local_edge = (uint32_t)p - eo;
+    in_keys[p] = ((uint64_t)di << 16) | ld;            // in-edge lists: by component, destination, edge index
+    in_vals[p] = local_edge;
+    if (class_of_desc[di] < (uint32_t)KC_BLOCK) return;
+    atomicAdd(&inc[no + ls].out_count, 1u);
+    atomicAdd(&inc[no + ld].in_count, 1u);
+    bool first = local_edge == 0;
+    if (!first) {
+        uint32_t ps, pd;
+        edge_ends(node1, node2, edge_sorted[p - 1], ps, pd);
+        first = ps != s;
+    }
+    if (first) inc[no + ls].out_begin = local_edge;
 }
 
 __global__ void k_in_begin(int64_t cap, const uint32_t *total_edges_p, const uint64_t *in_keys_sorted, const uint32_t *edge_off, const uint32_t *node_off,
@@ -224,6 +240,7 @@ __global__ void k_in_begin(int64_t cap, const uint32_t *total_edges_p, const uin
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= cap || p >= (int64_t)*total_edges_p) return;
     const uint64_t k = in_keys_sorted[p];
+    if (k == 0x0000ffffffffffffull) return;
     if (p == 0 || in_keys_sorted[p - 1] != k) {
         const uint32_t di = (uint32_t)(k >> 16), ld = (uint32_t)(k & 0xffffu);
         inc[node_off[di] + ld].in_begin = (uint32_t)p - edge_off[di];
@@ -252,23 +269,39 @@ __global__ void k_shard_class(int64_t n_comp, const uint32_t *class_sorted, int 
     out[i] = (c != 7u && snake_shard(i, shard_world) == shard_rank) ? c : 7u;
 }
 
-// class ranges, per-class edge totals, largest workgroup-class systems, per-edge scratch sizes
+// class ranges, solved tracks, largest workgroup-class systems, per-edge scratch sizes.  Sums and maxima are
+// reduced over the wave first: one atomic per wave instead of 147 k atomics on one address (1.7 ms -> 10 us).
 __global__ void k_summary(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
                           const uint32_t *c_edges, const uint32_t *c_tracks, AsmSummary *sum, unsigned long long *es_size) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > n_comp) return;
-    const int prev = i > 0 ? (int)class_sorted[i - 1] : -1;
-    const int cur = i < n_comp ? (int)class_sorted[i] : 7;
-    for (int kc = prev + 1; kc <= cur; ++kc) sum->class_begin[kc] = (uint32_t)i;     // first index with class >= kc
-    if (i == n_comp) return;
-    es_size[i] = 0ull;
-    if (cur == 7) return;
-    const uint32_t c = perm[i];
-    atomicAdd((unsigned long long *)&sum->class_edges[cur], (unsigned long long)c_edges[c]);
-    atomicAdd(&sum->n_tracks, c_tracks[c]);
-    if (cur == KC_BLOCK) atomicMax(&sum->block_max_rows, 2u * c_var[c]);
-    if (cur == KC_GLOBAL) atomicMax(&sum->global_max_rows, 2u * c_var[c]);
-    if (cur == KC_BLOCK || cur == KC_GLOBAL) es_size[i] = 8ull * c_edges[c];          // 64 B of Jacobian scratch per edge
+    uint32_t tracks = 0, rows_block = 0, rows_global = 0;
+    if (i <= n_comp) {
+        const int prev = i > 0 ? (int)class_sorted[i - 1] : -1;
+        const int cur = i < n_comp ? (int)class_sorted[i] : 7;
+        for (int kc = prev + 1; kc <= cur; ++kc) sum->class_begin[kc] = (uint32_t)i;     // first index with class >= kc
+        if (i < n_comp) {
+            unsigned long long es = 0ull;
+            if (cur != 7) {
+                const uint32_t c = perm[i];
+                tracks = c_tracks[c];
+                if (cur == KC_BLOCK) rows_block = 2u * c_var[c];
+                if (cur == KC_GLOBAL) rows_global = 2u * c_var[c];
+                if (cur == KC_BLOCK || cur == KC_GLOBAL) es = 8ull * c_edges[c];      // 64 B of Jacobian scratch per edge
+            }
+            es_size[i] = es;
+        }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        tracks += __shfl_xor(tracks, m, 64);
+        rows_block = max(rows_block, (uint32_t)__shfl_xor(rows_block, m, 64));
+        rows_global = max(rows_global, (uint32_t)__shfl_xor(rows_global, m, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (tracks) atomicAdd(&sum->n_tracks, tracks);
+        if (rows_block) atomicMax(&sum->block_max_rows, rows_block);
+        if (rows_global) atomicMax(&sum->global_max_rows, rows_global);
+    }
 }
 // global-matrix class: packed lower triangle + the vectors of the largest system of the class, per component
 __global__ void k_ws_sizes(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
@@ -291,6 +324,8 @@ __global__ void k_offsets(int64_t n_comp, const uint32_t *class_sorted, const un
         sum->es_doubles = es_scan[n_comp]; sum->ws_doubles = ws_scan[n_comp];
         sum->n_desc = sum->class_begin[7];
         sum->total_nodes = node_off[n_comp]; sum->total_edges = edge_off[n_comp];
+        for (int kc = 0; kc < KC_COUNT; ++kc)           // descs are sorted by class: a class is one range of the edge scan
+            sum->class_edges[kc] = (uint64_t)(edge_off[sum->class_begin[kc + 1]] - edge_off[sum->class_begin[kc]]);
         return;
     }
     es_off[i] = es_scan[i];
@@ -339,6 +374,8 @@ size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C) {
     return sizeof(CompDesc) * c + sizeof(EdgeRec) * E2 + 4 * n + sizeof(NodeInc) * n + 4 * E2 + 16 * c + 12 * c + 256 * 16;
 }
 
+static inline int nbits(uint64_t x) { int b = 1; while (x >>= 1) ++b; return b; }      // bits needed for values 0..x
+
 int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, int shard_world, DevArena &slab, DeviceAssembly &out) {
     const DevGraph &dg = *dp.graph;
     DevCtx *ctx = dp.ctx;
@@ -357,6 +394,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 
     const uint32_t *node1 = dg.n1, *node2 = dg.n2;
     const int32_t *track = dp.track, *comp = dp.comp;
+    const int node_bits = nbits((uint64_t)std::max<int64_t>(N - 1, 0)), comp_bits = nbits((uint64_t)C);
 
     // ---- outputs (capacities are upper bounds: every edge kept, every node in a solved component) ----
     TAKE_OUT(out.d_descs, CompDesc, C + 1); TAKE_OUT(out.d_edges, EdgeRec, E2);
@@ -365,15 +403,15 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE_OUT(out.d_desc_class, uint32_t, C + 1); TAKE_OUT(out.d_desc_tracks, uint32_t, C + 1); TAKE_OUT(out.d_desc_component, uint32_t, C + 1);
 
     // ---- which edges are kept, which nodes are variables, per-component sizes ----
+    // (everything that starts at zero sits in one block: one memset instead of a dozen)
+    const size_t zero_mark = arena.top;
     TAKE(sum, AsmSummary, 1);
-    TAKE(kept, uint8_t, E2); TAKE(opt, uint8_t, N); TAKE(is_var, uint8_t, N);
+    TAKE(opt, uint8_t, N);
     TAKE(cn, uint32_t, C + 1); TAKE(cv, uint32_t, C + 1); TAKE(ce, uint32_t, C + 1); TAKE(ct, uint32_t, C + 1);
-    TAKE(ts, uint32_t, T + 1); TAKE(tc, int32_t, T + 1);
-    LFR_HIP_TRY(hipMemsetAsync(sum, 0, sizeof(AsmSummary), st));
-    LFR_HIP_TRY(hipMemsetAsync(opt, 0, (size_t)N, st));
-    LFR_HIP_TRY(hipMemsetAsync(cn, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(cv, 0, 4 * (size_t)(C + 1), st));
-    LFR_HIP_TRY(hipMemsetAsync(ce, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(ct, 0, 4 * (size_t)(C + 1), st));
-    LFR_HIP_TRY(hipMemsetAsync(ts, 0, 4 * (size_t)(T + 1), st));
+    TAKE(ts, uint32_t, T + 1); TAKE(dn, uint32_t, C + 1); TAKE(de, uint32_t, C + 1);
+    TAKE(ws_size, unsigned long long, C + 1);
+    LFR_HIP_TRY(hipMemsetAsync(arena.base + zero_mark, 0, arena.top - zero_mark, st));
+    TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
     hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
     hipLaunchKernelGGL(k_count_edges, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, is_var, kept, ce);
@@ -398,17 +436,14 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         perm = id0; class_sorted = k1;     // (k1 is rewritten by the sort after k_shard_class has read it: stream ordered)
     }
 
-    TAKE(dn, uint32_t, C + 1); TAKE(de, uint32_t, C + 1); TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
-    LFR_HIP_TRY(hipMemsetAsync(dn, 0, 4 * (size_t)(C + 1), st)); LFR_HIP_TRY(hipMemsetAsync(de, 0, 4 * (size_t)(C + 1), st));
+    TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
     hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, cn, ce, dn, de, di);
     if ((rc = exclusive_sum(arena, dn, no, C + 1, st)) != LFR_OK) return rc;
     if ((rc = exclusive_sum(arena, de, eo, C + 1, st)) != LFR_OK) return rc;
     const uint32_t *total_nodes_p = no + C, *total_edges_p = eo + C;
 
     // ---- launch geometry + workspace offsets ----
-    TAKE(es_size, unsigned long long, C + 1); TAKE(ws_size, unsigned long long, C + 1);
-    TAKE(es_scan, unsigned long long, C + 1); TAKE(ws_scan, unsigned long long, C + 1);
-    LFR_HIP_TRY(hipMemsetAsync(ws_size, 0, 8 * (size_t)(C + 1), st));
+    TAKE(es_size, unsigned long long, C + 1); TAKE(es_scan, unsigned long long, C + 1); TAKE(ws_scan, unsigned long long, C + 1);
     hipLaunchKernelGGL(k_summary, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, perm, cv, ce, ct, sum, es_size);
     hipLaunchKernelGGL(k_ws_sizes, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, cv, sum, ws_size);
     if ((rc = exclusive_sum(arena, es_size, es_scan, C + 1, st)) != LFR_OK) return rc;
@@ -417,31 +452,46 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 
     // ---- local node numbering: nodes by (desc, variable first, node id) ----
     TAKE(nk0, uint32_t, N); TAKE(nk1, uint32_t, N); TAKE(ni0, uint32_t, N); TAKE(ni1, uint32_t, N); TAKE(local, uint32_t, N);
-    hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, di, is_var, nk0, ni0);
-    if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, 32, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, di, is_var, (uint32_t)(2 * C), nk0, ni0);
+    if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, std::min(32, nbits((uint64_t)2 * C)), st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_node_locals, grid_for(N), dim3(kThreads), 0, st, N, total_nodes_p, ni1, comp, di, no, out.d_node_ids, local);
 
     // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
     TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);
-    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, ek0, ei0);
-    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, 64, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
+                       (uint64_t)C << node_bits, ek0, ei0);
+    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_check_pairs, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted, eo, &sum->unpaired);
-
-    // ---- records, degrees, in-edge lists (the first consumer of the flows: wait for their upload) ----
-    if (dg.flows_staged && dg.ev_flows) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows, 0));
-    LFR_HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * (size_t)N, 16), st));
-    uint64_t *in_k0 = ek0, *in_k1 = ek1;   // reuse the key buffers
-    uint32_t *in_v0 = ei0;
-    hipLaunchKernelGGL(k_emit_edges, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                       dg.sim, dg.disp1, dg.disp2, track, comp, di, eo, no, local, dg.flow_row,
-                       reinterpret_cast<uint4 *>(out.d_edges), out.d_node_inc, in_k0, in_v0);
-    if ((rc = sort_pairs(arena, in_k0, in_k1, in_v0, out.d_in_idx, E2, 0, 48, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, in_k1, eo, no, out.d_node_inc);
 
     // ---- descriptors + the device copies behind the lazily fetched host mirrors ----
     hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks);
     LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_class, class_sorted, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
     LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_component, perm, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
+
+    // ---- incidence lists: workgroup classes only.  The graph stage's largest component tells whether such a class can
+    // exist (packed classes take up to 16 variable nodes); when it says no, the lists are skipped and the summary
+    // below has the last word (a small component with > 320 edges - duplicated matches - still lands there).
+    auto build_incidence = [&]() -> int {
+        LFR_HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * (size_t)N, 16), st));
+        hipLaunchKernelGGL(k_incidence, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted,
+                           eo, no, local, out.d_node_inc, ek0, ei0);                         // the key buffers are free again
+        const int r = sort_pairs(arena, ek0, ek1, ei0, out.d_in_idx, E2, 0, 48, st);
+        if (r != LFR_OK) return r;
+        hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, eo, no, out.d_node_inc);
+        return LFR_OK;
+    };
+    const bool expect_workgroup_classes = p.stats.max_component_size > 17;
+    if (expect_workgroup_classes && (rc = build_incidence()) != LFR_OK) return rc;
+
+    // ---- records: gather the flows (their first consumer); staged flows arrive in chunks on the copy stream ----
+    const int n_chunks = dg.flows_staged ? kFlowChunks : 1;
+    for (int c = 0; c < n_chunks; ++c) {
+        const int64_t lo = dg.flows_staged ? dg.chunk_row[c] : 0, hi = dg.flows_staged ? dg.chunk_row[c + 1] : M;
+        if (dg.flows_staged && dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
+        if (hi > lo || (c == 0 && n_chunks == 1))
+            hipLaunchKernelGGL(k_emit_edges, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
+                               dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges));
+    }
     LFR_HIP_TRY(hipGetLastError());
 
     // the one read-back of the stage
@@ -450,6 +500,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     out.summary = *h_sum;
     if (out.summary.too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
     if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
+    if (!expect_workgroup_classes && out.summary.class_begin[KC_BLOCK] < out.summary.n_desc) {
+        if ((rc = build_incidence()) != LFR_OK) return rc;
+        LFR_HIP_TRY(hipStreamSynchronize(st));         // the temporaries go back to the cache at return
+    }
     return LFR_OK;
 }
 

@@ -24,6 +24,7 @@ namespace lfr {
         }                                                                                     \
     } while (0)
 
+constexpr int kFlowChunks = 4;
 struct DevGraph {
     DevCtx *ctx = nullptr;
     int64_t N = 0, M = 0;
@@ -34,7 +35,10 @@ struct DevGraph {
     uint32_t *flow_row = nullptr;        // caller-owned device flows are indexed by their original row
     const float *disp1 = nullptr, *disp2 = nullptr;   // flows in match order: HBM (staged / caller-owned) or pinned host (zero copy)
     bool flows_staged = false, flows_zero_copy = false, flows_external = false;
-    hipEvent_t ev_flows = nullptr;       // recorded on s_copy after the staged upload
+    // staged flows travel in kFlowChunks chunks of matches [chunk_row[c], chunk_row[c+1]) on s_copy; ev_flows[c] fires
+    // when chunk c has landed, so the assembly gathers a chunk while the next one is still on the wire
+    hipEvent_t ev_flows[4] = {nullptr, nullptr, nullptr, nullptr};
+    int64_t chunk_row[5] = {0, 0, 0, 0, 0};
     ~DevGraph();
 };
 // The graph's device copy (created on first use, cached on the graph until lfr_graph_evict_device).

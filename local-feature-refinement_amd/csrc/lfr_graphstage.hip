@@ -74,13 +74,14 @@ __device__ __forceinline__ uint32_t sim_key(float s) {       // order-preserving
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
 
-// descending order of (sim, n1, n2) == ascending order of the complemented keys
-__global__ void k_match_keys(int64_t M, const uint32_t *n1, const uint32_t *n2, const float *sim, uint64_t *k_hi, uint32_t *k_lo,
-                             uint32_t *ids) {
+// descending order of (sim, n1, n2) == ascending order of the complemented keys; node ids are complemented inside
+// their node_bits bits (N-1-n) so that the radix sorts run over 32 + 2 x node_bits key bits instead of 96
+__global__ void k_match_keys(int64_t M, uint32_t n_minus_1, int node_bits, const uint32_t *n1, const uint32_t *n2, const float *sim,
+                             uint64_t *k_hi, uint32_t *k_lo, uint32_t *ids) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    k_hi[m] = ((uint64_t)(~sim_key(sim[m])) << 32) | (uint32_t)(~n1[m]);
-    k_lo[m] = ~n2[m];
+    k_hi[m] = ((uint64_t)(~sim_key(sim[m])) << node_bits) | (uint64_t)(n_minus_1 - n1[m]);
+    k_lo[m] = n_minus_1 - n2[m];
     ids[m] = (uint32_t)m;
 }
 __global__ void k_gather_u64(int64_t n, const uint32_t *idx, const uint64_t *src, uint64_t *dst) {
@@ -261,7 +262,7 @@ DevGraph::~DevGraph() {
         (void)hipStreamSynchronize(ctx->s_copy);
         (void)hipStreamSynchronize(ctx->s_main);
     }
-    if (ev_flows) (void)hipEventDestroy(ev_flows);
+    for (auto &e : ev_flows) if (e) (void)hipEventDestroy(e);
 }
 DevProblem::~DevProblem() {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->s_main); }
@@ -273,12 +274,16 @@ static int stage_flows_now(const Graph &g, DevGraph &dg) {
     const int64_t M = dg.M;
     float *d1 = dg.slab.take_n<float>((size_t)18 * M), *d2 = dg.slab.take_n<float>((size_t)18 * M);
     if (!d1 || !d2) { set_error("device graph: slab too small for the flows"); return LFR_ERR_NOMEM; }
-    if (M > 0) {
-        LFR_HIP_TRY(hipMemcpyAsync(d1, g.m_disp1.data(), (size_t)72 * M, hipMemcpyHostToDevice, ctx->s_copy));
-        LFR_HIP_TRY(hipMemcpyAsync(d2, g.m_disp2.data(), (size_t)72 * M, hipMemcpyHostToDevice, ctx->s_copy));
+    for (int c = 0; c < kFlowChunks; ++c) {
+        const int64_t lo = M * c / kFlowChunks, hi = M * (c + 1) / kFlowChunks;
+        dg.chunk_row[c] = lo; dg.chunk_row[c + 1] = hi;
+        if (hi > lo) {
+            LFR_HIP_TRY(hipMemcpyAsync(d1 + 18 * lo, g.m_disp1.data() + 18 * lo, (size_t)72 * (hi - lo), hipMemcpyHostToDevice, ctx->s_copy));
+            LFR_HIP_TRY(hipMemcpyAsync(d2 + 18 * lo, g.m_disp2.data() + 18 * lo, (size_t)72 * (hi - lo), hipMemcpyHostToDevice, ctx->s_copy));
+        }
+        if (!dg.ev_flows[c]) LFR_HIP_TRY(hipEventCreateWithFlags(&dg.ev_flows[c], hipEventDisableTiming));
+        LFR_HIP_TRY(hipEventRecord(dg.ev_flows[c], ctx->s_copy));
     }
-    if (!dg.ev_flows) LFR_HIP_TRY(hipEventCreateWithFlags(&dg.ev_flows, hipEventDisableTiming));
-    LFR_HIP_TRY(hipEventRecord(dg.ev_flows, ctx->s_copy));
     dg.disp1 = d1; dg.disp2 = d2;
     dg.flows_staged = true; dg.flows_zero_copy = false;
     return LFR_OK;
@@ -414,17 +419,26 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
 
     const uint32_t *n1 = dg->n1, *n2 = dg->n2;
     const float *sim = dg->sim;
+    int node_bits = 1;
+    while (((int64_t)1 << node_bits) < N) ++node_bits;
+    // everything that starts at zero sits in one block: one memset instead of a dozen
+    const size_t zero_mark = arena.top;
     TAKE(counts, uint32_t, CNT_WORDS);
-    LFR_HIP_TRY(hipMemsetAsync(counts, 0, 4 * CNT_WORDS, st));
+    TAKE(flags, uint32_t, M + 1); TAKE(rflag, uint32_t, N + 1); TAKE(tsize, uint32_t, N);
+    TAKE(score, double, N); TAKE(best, unsigned long long, N); TAKE(cflag, uint32_t, N + 1); TAKE(csize, uint32_t, N);
+    LFR_HIP_TRY(hipMemsetAsync(arena.base + zero_mark, 0, arena.top - zero_mark, st));
+    LFR_HIP_TRY(hipMemsetAsync(dp->is_root, 0, (size_t)N, st));
+    TAKE(bnode, int32_t, N);
+    LFR_HIP_TRY(hipMemsetAsync(bnode, 0xff, 4 * (size_t)N, st));          // -1
     LFR_HIP_TRY(hipEventRecord(ev[0], st));
 
     // 1. matches in the reference's order: descending (sim, n1, n2)
     TAKE(khi, uint64_t, M); TAKE(khi2, uint64_t, M); TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
     TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
-    hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, khi, klo, id0);
-    if ((rc = sort_pairs(arena, klo, klo2, id0, id1, M, 0, 32, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, (uint32_t)(N - 1), node_bits, n1, n2, sim, khi, klo, id0);
+    if ((rc = sort_pairs(arena, klo, klo2, id0, id1, M, 0, node_bits, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, id1, khi, khi2);
-    if ((rc = sort_pairs(arena, khi2, khi, id1, id0, M, 0, 64, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, khi2, khi, id1, id0, M, 0, 32 + node_bits, st)) != LFR_OK) return rc;
     uint32_t *order = id0;
 
     // 2. connected components of the match graph (conflicts ignored)
@@ -434,12 +448,11 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, cc);
 
     // 3. ordered matches grouped by connected component (stable)
-    TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(flags, uint32_t, M + 1); TAKE(segid, uint32_t, M + 1);
+    TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(segid, uint32_t, M + 1);
     TAKE(starts, uint32_t, std::min(N, M) + 2);
     hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, order, n1, cc, ck0);
-    if ((rc = sort_pairs(arena, ck0, ck1, order, id1, M, 0, 32, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, ck0, ck1, order, id1, M, 0, node_bits, st)) != LFR_OK) return rc;
     order = id1;
-    LFR_HIP_TRY(hipMemsetAsync(flags, 0, 4 * (size_t)(M + 1), st));
     hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
     if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc;
     const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
@@ -453,20 +466,13 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                        dg->node_image, par, next, tail, cnt);
 
     // 5. track ids (roots in ascending node index), sizes
-    TAKE(rflag, uint32_t, N + 1); TAKE(rrank, uint32_t, N + 1); TAKE(tsize, uint32_t, N);
-    LFR_HIP_TRY(hipMemsetAsync(rflag, 0, 4 * (size_t)(N + 1), st));
-    LFR_HIP_TRY(hipMemsetAsync(tsize, 0, 4 * (size_t)N, st));
+    TAKE(rrank, uint32_t, N + 1);
     hipLaunchKernelGGL(k_root_flags, grid_for(N), dim3(kThreads), 0, st, N, par, rflag);
     if ((rc = exclusive_sum(arena, rflag, rrank, N + 1, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_track_ids, grid_for(N), dim3(kThreads), 0, st, N, par, rrank, dp->track, tsize, counts);
     LFR_HIP_TRY(hipEventRecord(ev[1], st));
 
     // roots
-    TAKE(score, double, N); TAKE(best, unsigned long long, N); TAKE(bnode, int32_t, N);
-    LFR_HIP_TRY(hipMemsetAsync(score, 0, 8 * (size_t)N, st));
-    LFR_HIP_TRY(hipMemsetAsync(best, 0, 8 * (size_t)N, st));
-    LFR_HIP_TRY(hipMemsetAsync(bnode, 0xff, 4 * (size_t)N, st));          // -1
-    LFR_HIP_TRY(hipMemsetAsync(dp->is_root, 0, (size_t)N, st));
     hipLaunchKernelGGL(k_scores, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, score);
     hipLaunchKernelGGL(k_best_score, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best);
     hipLaunchKernelGGL(k_best_node, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best, bnode);
@@ -474,12 +480,10 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipEventRecord(ev[2], st));
 
     // components of the track meta-graph, numbered by their smallest track (solve.cc:292-300)
-    TAKE(mp, uint32_t, N); TAKE(cflag, uint32_t, N + 1); TAKE(crank, uint32_t, N + 1); TAKE(csize, uint32_t, N);
+    TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);
     hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp);
     hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, mp);
     hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, mp);
-    LFR_HIP_TRY(hipMemsetAsync(cflag, 0, 4 * (size_t)(N + 1), st));
-    LFR_HIP_TRY(hipMemsetAsync(csize, 0, 4 * (size_t)N, st));
     hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
     if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
