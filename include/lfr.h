@@ -149,6 +149,13 @@ int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_c
 int lfr_problem_build_hip_ex(const lfr_graph *g, int device, int64_t max_nodes_in_component,
                              const int64_t *component_override, int flags, lfr_problem **out);
 void lfr_problem_free(lfr_problem *p);
+/* The two-way cut this library substitutes for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
+ * (solve.cc:192; COLMAP wraps Graclus there, a third-party multilevel heuristic that cannot be restated: see
+ * DESIGN.md).  Exposed so that a checker can run the reference's recursion around the same primitive
+ * (tests/, oracle/).  edges (edge_a[k], edge_b[k]) with integer weights; writes the distinct node ids in
+ * ascending order and their side (0/1) - 2 * n_edges entries are always enough - and returns their count. */
+int64_t lfr_bisect_graph(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
+                         int32_t *nodes, int32_t *part);
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component);

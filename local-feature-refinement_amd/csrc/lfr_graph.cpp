@@ -76,7 +76,8 @@ static inline int32_t uf_root(std::vector<int32_t> &parent, int32_t i) {
 // third-party, heuristic and not reproducible, so results on inputs that need a cut are NOT
 // claimed to match the reference.  Method: maximum-adjacency region growing from
 // the smallest node id until half of the total edge-weight volume is absorbed, then one pass of
-// boundary refinement on the normalized-cut objective.
+// boundary refinement on the normalized-cut objective.  All sums are sums of integers held in doubles (exact),
+// so the result does not depend on the order of `edges`.
 // ----------------------------------------------------------------------------------------------
 void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
                   std::unordered_map<int, int> &part) {
@@ -102,15 +103,23 @@ void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vect
     std::vector<char> in(n, 0);
     double vol0 = 0.0;
     int n0 = 0;
-    // region growing (ties -> smallest id); restart from the smallest unvisited id if the
-    // frontier empties (disconnected input)
-    while (vol0 * 2 < volume && n0 < n - 1) {
-        int best = -1;
-        for (int i = 0; i < n; ++i)
-            if (!in[i] && (best < 0 || attach[i] > attach[best])) best = i;
-        if (best < 0) break;
+    // region growing: always absorb the outside node with the largest attachment to the region (ties ->
+    // smallest id; a node nobody is attached to yet has attachment 0, so an emptied frontier restarts from the
+    // smallest unvisited id).  Lazy-deletion max-heap keyed (attachment, -id): O(E log n) instead of the
+    // O(n^2) arg-max scan per absorbed node.
+    typedef std::pair<double, int> HeapKey;              // (attachment, -id)
+    std::priority_queue<HeapKey> heap;
+    for (int i = 0; i < n; ++i) heap.push(HeapKey(0.0, -i));
+    while (vol0 * 2 < volume && n0 < n - 1 && !heap.empty()) {
+        const HeapKey top = heap.top();
+        heap.pop();
+        const int best = -top.second;
+        if (in[best] || top.first != attach[best]) continue;      // stale entry
         in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
-        for (auto &nb : adj[best]) attach[nb.first] += nb.second;
+        for (auto &nb : adj[best]) {
+            attach[nb.first] += nb.second;
+            if (!in[nb.first]) heap.push(HeapKey(attach[nb.first], -nb.first));
+        }
     }
     // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
     double cut = 0.0;
@@ -544,6 +553,21 @@ int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component,
 }
 
 void lfr_problem_free(lfr_problem *p) { delete p; }
+
+int64_t lfr_bisect_graph(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights, int32_t *nodes,
+                         int32_t *part) {
+    if (n_edges < 0 || (n_edges > 0 && (!edge_a || !edge_b || !weights))) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::vector<std::pair<int, int>> e((size_t)n_edges);
+    std::vector<int> w((size_t)n_edges);
+    for (int64_t k = 0; k < n_edges; ++k) { e[k] = {edge_a[k], edge_b[k]}; w[k] = weights[k]; }
+    std::unordered_map<int, int> split;
+    bisect_graph(e, w, split);
+    std::vector<int> keys;
+    for (auto &it : split) keys.push_back(it.first);
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < keys.size(); ++k) { if (nodes) nodes[k] = keys[k]; if (part) part[k] = split[keys[k]]; }
+    return (int64_t)keys.size();
+}
 
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats) {
     if (!p || !stats) return LFR_ERR_ARG;

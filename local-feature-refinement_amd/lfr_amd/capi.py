@@ -83,6 +83,7 @@ def lib():
         "lfr_problem_build_hip": (C.c_int, [vp, C.c_int, i64, vp, pp]),
         "lfr_problem_build_hip_ex": (C.c_int, [vp, C.c_int, i64, vp, C.c_int, pp]),
         "lfr_problem_free": (None, [vp]),
+        "lfr_bisect_graph": (i64, [i64, vp, vp, vp, vp, vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
         "lfr_problem_shard_components": (i64, [vp, C.c_int, C.c_int, vp, vp]),
@@ -111,7 +112,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -266,6 +267,20 @@ def _contig(ma, flows=True):
             "sim": np.ascontiguousarray(ma.sim, np.float32),
             "d1": np.ascontiguousarray(ma.disp1, np.float32).reshape(M, 18),
             "d2": np.ascontiguousarray(ma.disp2, np.float32).reshape(M, 18)}
+
+
+def bisect_graph(edges, weights):
+    """The library's substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2) (solve.cc:192):
+    {node id: side}."""
+    e = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
+    a, b = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+    w = np.ascontiguousarray(weights, np.int32)
+    nodes = np.zeros(2 * len(w) + 1, np.int32)
+    part = np.zeros(2 * len(w) + 1, np.int32)
+    n = lib().lfr_bisect_graph(len(w), _ptr(a), _ptr(b), _ptr(w), _ptr(nodes), _ptr(part))
+    if n < 0:
+        _check(int(n))
+    return {int(nodes[i]): int(part[i]) for i in range(n)}
 
 
 def write_matching_file(path, ma):

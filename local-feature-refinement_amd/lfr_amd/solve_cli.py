@@ -6,11 +6,20 @@ prefixes; solve.cc:379-385), same stdout lines in the same order (solve.cc:484-4
 parse/write failures, solve.cc:433-436,674-677).  The work is done by liblfr_hip.so on a
 MI355X; there is no CPU fallback — a missing library or GPU is a loud error (exit 2).
 
+`--n_threads` (solve.cc:384,617: workers of the reference's CPU thread pool) has no GPU meaning; when it is given
+explicitly it sets the worker count of the host-side stages of this drop-in (MatchingFile scanner, host graph
+stage when it is used) exactly like LFR_HOST_THREADS; when it is left at its default the scanner uses
+min(cores, 32) threads.
+
 Environment (additions that default so the reference's scripts run unchanged):
-  LFR_DEVICE            HIP device ordinal (default 0)
+  LFR_DEVICE            HIP device ordinal (default 0; a single entry in LFR_GPUS means the same)
   LFR_GPUS              comma-separated device ordinals: shard the components over several GPUs of the
                         node from this one process (e.g. 0,1,2,3,4,5,6,7)
-  LFR_TUKEY_VARIANT     ceres1 (default; Ceres <= 1.14) | ceres2 (Ceres >= 2.0)
+  LFR_TUKEY_VARIANT     ceres1 (default; Ceres <= 1.14) | ceres2 (Ceres >= 2.0); the active flavour is printed
+                        once on stderr when the graph has inter-track edges to apply it to
+  LFR_UPLOAD_IN_TOTAL   1: keep the graph on the host until "Total time" starts (its PCIe upload is then inside that
+                        span); default: the graph is copied to HBM as the last step of ingest, as the reference builds
+                        its Graph object before its timer starts (solve.cc:405-487)
   LFR_COMPONENTS_FILE   raw little-endian int64[n_nodes] component ids replacing the size-cap
                         graph cut (side-car for exact parity with a reference run)
   LFR_HOST_GRAPH_STAGE  1: tracks/roots/components on the host (batch assembly stays on the GPU)
@@ -50,7 +59,7 @@ def parse_args(argv):
     """Boost.program_options-compatible parsing of solve.cc:379-396."""
     names = [o[0] for o in OPTIONS]
     takes = {o[0]: o[1] for o in OPTIONS}
-    out = {"help": False, "matches_file": None, "output_file": None, "n_threads": 8, "banned_images": []}
+    out = {"help": False, "matches_file": None, "output_file": None, "n_threads": 8, "n_threads_given": False, "banned_images": []}
     seen = set()
     i = 0
     while i < len(argv):
@@ -91,6 +100,7 @@ def parse_args(argv):
         if name == "n_threads":
             try:
                 out[name] = int(value)
+                out["n_threads_given"] = True
                 if out[name] < 0:
                     raise ValueError
             except ValueError:
@@ -125,8 +135,17 @@ def main(argv=None):
         sys.stderr.write("FATAL: %s\n" % e)
         return 2
 
-    device = int(os.environ.get("LFR_DEVICE", "0"))
-    warm = capi.hip_warmup_async(device)          # HIP context creation overlaps the parse
+    gpus = [int(x) for x in os.environ.get("LFR_GPUS", "").split(",") if x.strip() != ""]
+    device = gpus[0] if len(gpus) == 1 else int(os.environ.get("LFR_DEVICE", "0"))
+    if args["n_threads_given"] and "LFR_HOST_THREADS" not in os.environ:
+        os.environ["LFR_HOST_THREADS"] = str(max(1, args["n_threads"]))      # read by the scanner / host graph stage
+    # HIP context creation, kernel resolution and the slab caches overlap the parse (sizes guessed from the file
+    # size: ~230 B per match on the wire, ~2.8 matches per node)
+    try:
+        nbytes = os.path.getsize(args["matches_file"])
+    except OSError:
+        nbytes = 0
+    warm = capi.hip_warmup_async(device, n_nodes=int(nbytes / 230 / 2.8 * 1.1), n_matches=int(nbytes / 230 * 1.1))
     try:
         graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"])
     except capi.LfrError as e:
@@ -138,6 +157,14 @@ def main(argv=None):
     print("# graph nodes: %d" % graph.n_nodes)                            # solve.cc:484
     print("# graph edges: %d" % graph.n_edges)                            # solve.cc:485
     sys.stdout.flush()
+    device_pipeline = os.environ.get("LFR_HOST_ASSEMBLY") != "1" and os.environ.get("LFR_HOST_GRAPH_STAGE") != "1"
+    if device_pipeline and len(gpus) <= 1 and graph.n_nodes > 0 and os.environ.get("LFR_UPLOAD_IN_TOTAL") != "1":
+        warm.join()
+        try:
+            graph.to_device(device)               # last step of ingest: asynchronous, the pipeline continues from it
+        except capi.LfrError as e:
+            sys.stderr.write("FATAL: %s\n" % e)
+            return 2
 
     t_start = time.perf_counter()                                         # solve.cc:487
     override = None
@@ -153,14 +180,15 @@ def main(argv=None):
         try:
             # graph stage + batch assembly on the GPU (falls back to the host stage for the graph cut /
             # huge connected components); LFR_HOST_GRAPH_STAGE=1 / LFR_HOST_ASSEMBLY=1 force the host paths
-            gpus = [int(x) for x in os.environ.get("LFR_GPUS", "").split(",") if x.strip() != ""]
-            if len(gpus) > 1 or os.environ.get("LFR_HOST_ASSEMBLY") == "1":
-                problem = capi.Problem(graph, 0, override)          # multi-GPU shards are cut from the host batch
+            if os.environ.get("LFR_HOST_ASSEMBLY") == "1":
+                problem = capi.Problem(graph, 0, override)
             elif os.environ.get("LFR_HOST_GRAPH_STAGE") == "1":
                 problem = capi.Problem(graph, 0, override, device_assembly=True)
             else:
                 warm.join()
-                problem = capi.Problem(graph, 0, override, device_graph_stage=device)
+                # several GPUs: each assembles its own shard and gathers that shard's flows zero-copy
+                problem = capi.Problem(graph, 0, override, device_graph_stage=device,
+                                       flags=capi.FLOWS_STAY_ON_HOST if len(gpus) > 1 else 0)
         except capi.LfrError as e:
             sys.stderr.write("FATAL: %s\n" % e)
             return 2
@@ -178,6 +206,9 @@ def main(argv=None):
         t1 = time.perf_counter()                                          # solve.cc:615
         try:
             variant = os.environ.get("LFR_TUKEY_VARIANT", "ceres1")
+            if st["n_components"] < st["n_tracks"]:       # some component couples tracks through inter-track (Tukey) edges
+                sys.stderr.write("note: TukeyLoss flavour %s (%s; the reference pins no Ceres version - set "
+                                 "LFR_TUKEY_VARIANT to switch)\n" % (variant, "Ceres <= 1.14" if variant == "ceres1" else "Ceres >= 2.0"))
             if len(gpus) > 1:
                 positions, sst = capi.solve_hip_multi(problem, gpus, variant)
             else:

@@ -584,6 +584,54 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
     free(buf);
 }
 
+
+/* ------------------------------------------------------------------------------------------ */
+/* size cap: recursive_graph_cut (solve.cc:185-250) around a caller-supplied two-way cut          */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's primitive is colmap::ComputeNormalizedMinGraphCut(edges, weights, 2) = Graclus (solve.cc:192),
+ * which cannot be restated.  A checker may install a substitute (tests install the product's own
+ * lfr_bisect_graph): writes the distinct node ids of `edges` and their side (0/1), returns their count.
+ * Everything around the primitive - meta edges, integer weights, recursion, orphans, dropping cut edges,
+ * BFS re-labelling (solve.cc:311-364) - is restated here independently of the product. */
+typedef int64_t (*lfro_bisect_fn)(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
+                                  int32_t *nodes, int32_t *part);
+static lfro_bisect_fn g_bisect = NULL;
+void lfro_set_bisect(lfro_bisect_fn fn) { g_bisect = fn; }
+
+/* final_subset[node] (indexed by meta node = track id) receives base + the subset index local to this call;
+ * returns the number of subset indices used.  Mirrors the reference's control flow; its unordered_map
+ * iteration orders only permute subset NUMBERS, never the partition (the caller re-labels by BFS). */
+static int64_t recursive_graph_cut(int64_t ne, const int32_t *ea, const int32_t *eb, const int32_t *w, const int64_t *node_weights,
+                                   int64_t max_subset_weight, int64_t base, int64_t *final_subset) {
+    int32_t *nodes = (int32_t *)malloc(sizeof(int32_t) * (2 * ne + 1)), *part = (int32_t *)malloc(sizeof(int32_t) * (2 * ne + 1));
+    const int64_t nn = g_bisect(ne, ea, eb, w, nodes, part);            /* solve.cc:192 (substitute) */
+    int64_t subset_weights[2] = {0, 0};
+    for (int64_t k = 0; k < nn; ++k) { subset_weights[part[k]] += node_weights[nodes[k]]; final_subset[nodes[k]] = -1; }
+    int64_t max_subset_idx = 0;
+    for (int subset_idx = 0; subset_idx < 2; ++subset_idx) {
+        if (subset_weights[subset_idx] <= max_subset_weight) {                          /* solve.cc:205-211 */
+            for (int64_t k = 0; k < nn; ++k) if (part[k] == subset_idx) final_subset[nodes[k]] = base + max_subset_idx;
+            ++max_subset_idx;
+            continue;
+        }
+        int64_t nsub = 0;
+        int32_t *sa = (int32_t *)malloc(sizeof(int32_t) * (ne + 1)), *sb = (int32_t *)malloc(sizeof(int32_t) * (ne + 1)), *sw = (int32_t *)malloc(sizeof(int32_t) * (ne + 1));
+        for (int64_t k = 0; k < ne; ++k) {                                              /* solve.cc:213-227 */
+            int64_t ia = 0, ib = 0, hi;
+            hi = nn - 1; while (ia < hi) { const int64_t m = (ia + hi) / 2; if (nodes[m] < ea[k]) ia = m + 1; else hi = m; }
+            hi = nn - 1; while (ib < hi) { const int64_t m = (ib + hi) / 2; if (nodes[m] < eb[k]) ib = m + 1; else hi = m; }
+            if (part[ia] == subset_idx && part[ib] == subset_idx) { sa[nsub] = ea[k]; sb[nsub] = eb[k]; sw[nsub] = w[k]; ++nsub; }
+        }
+        if (nsub > 0)                                                                   /* solve.cc:229-238 */
+            max_subset_idx += recursive_graph_cut(nsub, sa, sb, sw, node_weights, max_subset_weight, base + max_subset_idx, final_subset);
+        free(sa); free(sb); free(sw);
+        for (int64_t k = 0; k < nn; ++k)                                                /* solve.cc:240-246: orphans -> singletons */
+            if (part[k] == subset_idx && final_subset[nodes[k]] < 0) final_subset[nodes[k]] = base + max_subset_idx++;
+    }
+    free(nodes); free(part);
+    return max_subset_idx;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* graph stage                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
@@ -847,10 +895,77 @@ int lfro_build(int n_images_seen, int64_t n_matches, const int32_t *match_img1, 
         for (int64_t t = 0; t < n_tracks; ++t) { const int64_t r = uf_root(mp, t); if (label[r] < 0) label[r] = nc++; label[t] = label[r]; }
         int64_t *csize = (int64_t *)calloc(nc + 1, sizeof(int64_t));
         for (int64_t t = 0; t < n_tracks; ++t) csize[label[t]] += tsize[t];
-        for (int64_t c = 0; c < nc; ++c) if (csize[c] > n_images_seen) o->n_oversized++;
-        if (o->n_oversized > 0) rc = ERR_NEEDS_CUT;
-        for (int64_t i = 0; i < n_nodes; ++i) o->comp[i] = label[o->track[i]];
-        o->n_components = nc;
+        for (int64_t c = 0; c < nc; ++c) if (csize[c] > n_images_seen) o->n_oversized++;      /* solve.cc:314 */
+        if (o->n_oversized > 0 && !g_bisect) rc = ERR_NEEDS_CUT;
+        int64_t *final_label = label, n_final = nc;
+        if (o->n_oversized > 0 && g_bisect) {
+            /* meta edges of the oversized components (solve.cc:268-289): per ordered track pair, sum of similarities in
+             * node order / out-edge order; collected as (ta, tb, sim) triples, sorted by (ta, tb) with a stable sort */
+            typedef struct { int64_t ta, tb; double sim; int64_t seq; } MEdge;
+            int64_t nme = 0, cap_me = 1024;
+            MEdge *me = (MEdge *)malloc(sizeof(MEdge) * cap_me);
+            for (int64_t i = 0; i < n_nodes; ++i) {
+                const int64_t ta = o->track[i];
+                if (csize[label[ta]] <= n_images_seen) continue;
+                for (int64_t e = o->out_off[i]; e < o->out_off[i + 1]; ++e) {
+                    const int64_t tb = o->track[o->out[e].dst];
+                    if (ta == tb) continue;
+                    if (nme == cap_me) { cap_me *= 2; me = (MEdge *)realloc(me, sizeof(MEdge) * cap_me); }
+                    me[nme].ta = ta; me[nme].tb = tb; me[nme].sim = (double)o->out[e].sim; me[nme].seq = nme; ++nme;
+                }
+            }
+            /* sort by (ta, tb, seq): the sums below then run in insertion order, as meta_edges[ta][tb] += sim does */
+            for (int64_t gap = nme / 2; gap > 0; gap /= 2)            /* shell sort: no comparator context needed, sizes are small */
+                for (int64_t i = gap; i < nme; ++i) {
+                    MEdge t = me[i]; int64_t j = i;
+                    while (j >= gap && (me[j - gap].ta > t.ta || (me[j - gap].ta == t.ta && (me[j - gap].tb > t.tb || (me[j - gap].tb == t.tb && me[j - gap].seq > t.seq))))) { me[j] = me[j - gap]; j -= gap; }
+                    me[j] = t;
+                }
+            /* unique (ta, tb) with summed weight */
+            int64_t nu = 0;
+            for (int64_t k = 0; k < nme;) {
+                int64_t j = k; double sum = 0.;
+                while (j < nme && me[j].ta == me[k].ta && me[j].tb == me[k].tb) { sum += me[j].sim; ++j; }
+                me[nu].ta = me[k].ta; me[nu].tb = me[k].tb; me[nu].sim = sum; ++nu;
+                k = j;
+            }
+            int64_t *gc = (int64_t *)calloc(n_tracks + 1, sizeof(int64_t)), ngc = 0;
+            int64_t *fs = (int64_t *)malloc(sizeof(int64_t) * (n_tracks + 1));
+            for (int64_t c = 0; c < nc; ++c) {
+                if (csize[c] <= n_images_seen) { for (int64_t t = 0; t < n_tracks; ++t) if (label[t] == c) gc[t] = ngc; ++ngc; continue; }
+                int64_t ne = 0;
+                for (int64_t k = 0; k < nu; ++k) if (label[me[k].ta] == c && me[k].ta < me[k].tb) ++ne;
+                int32_t *ea = (int32_t *)malloc(sizeof(int32_t) * (ne + 1)), *eb = (int32_t *)malloc(sizeof(int32_t) * (ne + 1)), *ew = (int32_t *)malloc(sizeof(int32_t) * (ne + 1));
+                ne = 0;
+                for (int64_t k = 0; k < nu; ++k) if (label[me[k].ta] == c && me[k].ta < me[k].tb) {     /* solve.cc:325-331 */
+                    ea[ne] = (int32_t)me[k].ta; eb[ne] = (int32_t)me[k].tb; ew[ne] = (int)(100 * me[k].sim); ++ne;
+                }
+                for (int64_t t = 0; t < n_tracks; ++t) if (label[t] == c) fs[t] = -1;
+                const int64_t used = recursive_graph_cut(ne, ea, eb, ew, tsize, n_images_seen, 0, fs);
+                for (int64_t t = 0; t < n_tracks; ++t) if (label[t] == c) gc[t] = ngc + fs[t];          /* solve.cc:337-341 */
+                ngc += used;
+                free(ea); free(eb); free(ew);
+            }
+            /* drop cut meta edges, re-split (solve.cc:345-364): union-find over the kept meta edges, labelled in order of
+             * first meta node (== BFS labelling) */
+            int64_t *mp2 = (int64_t *)malloc(sizeof(int64_t) * (n_tracks + 1));
+            for (int64_t t = 0; t < n_tracks; ++t) mp2[t] = -1;
+            for (int64_t i = 0; i < n_nodes; ++i)
+                for (int64_t e = o->out_off[i]; e < o->out_off[i + 1]; ++e) {
+                    const int64_t ta = o->track[i], tb = o->track[o->out[e].dst];
+                    if (ta == tb || gc[ta] != gc[tb]) continue;
+                    const int64_t ra = uf_root(mp2, ta), rb = uf_root(mp2, tb);
+                    if (ra != rb) mp2[ra > rb ? ra : rb] = ra > rb ? rb : ra;
+                }
+            final_label = (int64_t *)malloc(sizeof(int64_t) * (n_tracks + 1));
+            for (int64_t t = 0; t < n_tracks; ++t) final_label[t] = -1;
+            n_final = 0;
+            for (int64_t t = 0; t < n_tracks; ++t) { const int64_t r = uf_root(mp2, t); if (final_label[r] < 0) final_label[r] = n_final++; final_label[t] = final_label[r]; }
+            free(me); free(gc); free(fs); free(mp2);
+        }
+        for (int64_t i = 0; i < n_nodes; ++i) o->comp[i] = final_label[o->track[i]];
+        o->n_components = n_final;
+        if (final_label != label) free(final_label);
         free(mp); free(label); free(csize);
     }
     free(tsize);

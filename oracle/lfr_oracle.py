@@ -50,6 +50,8 @@ def lib():
             getattr(L, "lfro_" + n).restype = C.c_void_p
             getattr(L, "lfro_" + n).argtypes = [C.c_void_p]
         L.lfro_free.argtypes = [C.c_void_p]
+        L.lfro_set_bisect.argtypes = [C.c_void_p]
+        L.lfro_set_bisect.restype = None
         L.lfro_eval_edge.restype = C.c_double
         L.lfro_minimize_poly.restype = C.c_double
         assert L.lfro_info_size() == INFO_DTYPE.itemsize
@@ -88,10 +90,18 @@ def flatten(ma, banned=()):
     return (remap[i1].astype(np.int32), remap[i2].astype(np.int32), keep, names)
 
 
+BISECT_FN = C.CFUNCTYPE(C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                        C.POINTER(C.c_int32), C.POINTER(C.c_int32))
+
+
 def run(ma, banned=(), n_threads=1, tukey_variant="ceres1", comp_override=None, trace_comp=None,
-        solve=True):
-    """Run graph stage (+ solve) of the C oracle on a MatchArrays.  Returns a dict."""
+        solve=True, bisect=None):
+    """Run graph stage (+ solve) of the C oracle on a MatchArrays.  Returns a dict.
+    bisect: address (int / ctypes function pointer) of a two-way cut with the signature of lfr_bisect_graph, standing
+    in for colmap::ComputeNormalizedMinGraphCut (solve.cc:192) when a component exceeds the size cap; without it such
+    inputs return rc != 0 (the Graclus cut cannot be restated)."""
     L = lib()
+    L.lfro_set_bisect(None if bisect is None else C.c_void_p(bisect) if isinstance(bisect, int) else C.cast(bisect, C.c_void_p))
     i1, i2, keep, names = flatten(ma, banned)
     f1 = np.ascontiguousarray(ma.feat1[keep], np.uint32)
     f2 = np.ascontiguousarray(ma.feat2[keep], np.uint32)

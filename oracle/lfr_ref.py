@@ -573,11 +573,53 @@ def _bfs_components(n, adj):
     return comp, nc
 
 
-def split_components(g, track, n_tracks, max_nodes, cut_fn=None):
-    """solve.cc:252-373 (separate_meta_graph).  Components above ``max_nodes`` need the
-    Graclus normalized cut, which cannot be restated; ``cut_fn(meta_nodes, edges,
-    weights, node_weights, max_nodes) -> {meta_node: part}`` supplies a substitute
-    (tests only use it with the product's own deterministic bisection).  Returns
+def recursive_graph_cut(edges, weights, node_weights, max_subset_weight, bisect_fn):
+    """solve.cc:185-250, literally, around ``bisect_fn(edges, weights) -> {node: 0/1}`` standing in for
+    colmap::ComputeNormalizedMinGraphCut(edges, weights, 2) (solve.cc:192).  Returns {node: subset}.  The
+    reference iterates std::unordered_maps here; their order only permutes the subset NUMBERS (labels), never the
+    partition, and the caller re-labels by BFS (solve.cc:356-364)."""
+    n_subsets = 2
+    nodes_to_subsets = bisect_fn(edges, weights)
+    subset_weights = [0] * n_subsets
+    nodes_in_subset = [[] for _ in range(n_subsets)]
+    for node in sorted(nodes_to_subsets):
+        sub = nodes_to_subsets[node]
+        subset_weights[sub] += node_weights[node]
+        nodes_in_subset[sub].append(node)
+    max_subset_idx = 0
+    final = {}
+    for subset_idx in range(n_subsets):
+        if subset_weights[subset_idx] <= max_subset_weight:                       # solve.cc:205-211
+            for node in nodes_in_subset[subset_idx]:
+                final.setdefault(node, max_subset_idx)
+            max_subset_idx += 1
+            continue
+        sub_e, sub_w = [], []
+        for (a, b), w in zip(edges, weights):                                      # solve.cc:213-227
+            if nodes_to_subsets[a] == subset_idx and nodes_to_subsets[b] == subset_idx:
+                sub_e.append((a, b))
+                sub_w.append(w)
+        if sub_e:                                                                  # solve.cc:229-238
+            sub = recursive_graph_cut(sub_e, sub_w, node_weights, max_subset_weight, bisect_fn)
+            new_max = max_subset_idx
+            for node, part in sub.items():
+                final.setdefault(node, max_subset_idx + part)
+                new_max = max(new_max, max_subset_idx + part)
+            max_subset_idx = new_max + 1
+        for node in nodes_in_subset[subset_idx]:                                   # solve.cc:240-246: orphans -> singletons
+            if node in final:
+                continue
+            final[node] = max_subset_idx
+            max_subset_idx += 1
+    return final
+
+
+def split_components(g, track, n_tracks, max_nodes, bisect_fn=None):
+    """solve.cc:252-373 (separate_meta_graph).  Components above ``max_nodes`` go through recursive_graph_cut
+    (solve.cc:311-343); its two-way cut is Graclus in the reference, which cannot be restated, so
+    ``bisect_fn(edges, weights) -> {meta_node: 0/1}`` supplies the primitive (tests pass the product's own
+    deterministic bisection, lfr_bisect_graph: everything AROUND the primitive - meta edges, integer weights,
+    recursion, orphans, dropping cut edges, re-labelling - is then checked independently).  Returns
     (component per node, n_components, n_oversized)."""
     size = [0] * n_tracks
     for i in range(g.n_nodes):
@@ -597,21 +639,24 @@ def split_components(g, track, n_tracks, max_nodes, cut_fn=None):
     ngc = 0
     n_over = 0
     for c in range(nc):
-        if csize[c] <= max_nodes:
+        if csize[c] <= max_nodes:                                                  # solve.cc:314 (== cap is not cut)
             for t in members[c]:
                 gc[t] = ngc
             ngc += 1
             continue
         n_over += 1
-        if cut_fn is None:
+        if bisect_fn is None:
             raise NotImplementedError("component above the size cap needs a graph cut")
         e, w = [], []
         for t in members[c]:
             for (u, s) in meta[t].items():
-                if t < u:
+                if t < u:                                                          # solve.cc:325-331
                     e.append((t, u))
                     w.append(int(100 * s))
-        split = cut_fn(members[c], e, w, size, max_nodes)
+        split = recursive_graph_cut(e, w, size, max_nodes, bisect_fn)
+        # solve.cc:335 asserts split.size() == #meta nodes: true whenever the cap is #images (a lone track never exceeds
+        # it, and every track of a multi-track component has a meta edge)
+        assert len(split) == len(members[c]) or not e
         top = 0
         for t, part in split.items():
             gc[t] = ngc + part
@@ -620,7 +665,7 @@ def split_components(g, track, n_tracks, max_nodes, cut_fn=None):
     post = [dict() for _ in range(n_tracks)]
     for t in range(n_tracks):
         for (u, s) in meta[t].items():
-            if gc[t] == gc[u]:
+            if gc[t] == gc[u]:                                                     # solve.cc:346-353
                 post[t][u] = s
     fcomp, nfc = _bfs_components(n_tracks, post)
     return [fcomp[track[i]] for i in range(g.n_nodes)], nfc, n_over
@@ -648,7 +693,7 @@ def assemble_component(g, track, is_root, comp, nodes):
     return var_nodes, edges
 
 
-def solve_pairs(pairs, banned=(), tukey_variant="ceres1", cut_fn=None, want_trace=False):
+def solve_pairs(pairs, banned=(), tukey_variant="ceres1", bisect_fn=None, want_trace=False):
     """The whole of solve.cc main() between parsing and serialisation.
     Returns dict with positions (n_nodes x 2), node keys, stats and per-component infos."""
     g = MatchGraph(pairs, banned)
@@ -661,7 +706,7 @@ def solve_pairs(pairs, banned=(), tukey_variant="ceres1", cut_fn=None, want_trac
         return out
     track, n_tracks = build_tracks(g)
     is_root = select_roots(g, track, n_tracks)
-    comp, n_comp, n_over = split_components(g, track, n_tracks, len(g.images_set), cut_fn)
+    comp, n_comp, n_over = split_components(g, track, n_tracks, len(g.images_set), bisect_fn)
     nodes_in = [[] for _ in range(n_comp)]
     for i in range(g.n_nodes):
         nodes_in[comp[i]].append(i)

@@ -23,15 +23,21 @@ CASES = {
 }
 
 
+def bisect_ptr():
+    import ctypes
+    return ctypes.cast(capi.lib().lfr_bisect_graph, ctypes.c_void_p).value
+
+
 def solve_both(ma, variant="ceres1", banned=()):
     g = capi.Graph.from_arrays(ma, banned)
     p = capi.Problem(g)
     b = capi.Batch(p, 0, tukey_variant=variant)
     st = b.solve()
     pos = b.download()
-    ref = O.run(ma, banned=banned, n_threads=8, tukey_variant=variant)
-    if ref["rc"] != 0:       # oversized components: Graclus is not restatable -> share the product's cut
-        ref = O.run(ma, banned=banned, n_threads=8, tukey_variant=variant, comp_override=p.labels()[2])
+    # oversized components: Graclus is not restatable -> the oracle runs the reference's recursion (solve.cc:185-250,
+    # 311-364) around the product's two-way primitive and must arrive at the product's components by itself
+    ref = O.run(ma, banned=banned, n_threads=8, tukey_variant=variant, bisect=bisect_ptr())
+    assert ref["rc"] == 0 and (ref["comp"] == p.labels()[2]).all()
     return g, p, b, st, pos, ref
 
 
@@ -204,9 +210,8 @@ def test_fuzz_small_irregular_graphs(lfr_lib):
         g = capi.Graph.from_arrays(ma)
         p = capi.Problem(g)
         pos, st = p.solve_hip(0)
-        ref = O.run(ma, n_threads=1)
-        if ref["rc"] != 0:
-            ref = O.run(ma, n_threads=1, comp_override=p.labels()[2])
+        ref = O.run(ma, n_threads=1, bisect=bisect_ptr())
+        assert ref["rc"] == 0 and (ref["comp"] == p.labels()[2]).all(), seed
         assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS, seed
         assert st["n_failed"] == int((ref["infos"]["termination"][ref["comp_nvar"] > 0] == 2).sum())
         checked += 1

@@ -10,6 +10,12 @@ import lfr_ref as R
 from lfr_amd import capi, synthetic
 
 
+def bisect_ptr():
+    """address of the product's two-way cut (include/lfr.h: lfr_bisect_graph) for the C oracle's recursion"""
+    import ctypes
+    return ctypes.cast(capi.lib().lfr_bisect_graph, ctypes.c_void_p).value
+
+
 def fuzz_pairs(seed):
     rng = np.random.default_rng(seed)
     n_images = int(rng.integers(3, 7))
@@ -48,19 +54,20 @@ def test_tracks_and_roots_fuzz(lfr_lib, seed):
     for t in range(n_tracks):
         imgs = [g.node_key[i][0] for i in range(g.n_nodes) if track[i] == t]
         assert len(imgs) == len(set(imgs))
-    # components: identical when nothing exceeds the cap; otherwise the product must respect the cap
+    # components (solve.cc:252-373).  Above the cap the reference calls Graclus, which cannot be restated: the
+    # literal restatement runs the reference's recursion / orphan rule / re-labelling around the product's own
+    # two-way cut (lfr_bisect_graph), so everything but that primitive is checked independently
     cap = len(g.images_set)
     st = prob.stats()
-    try:
-        comp, n_comp, _ = R.split_components(g, track, n_tracks, cap)
-        assert (c2 == np.asarray(comp)).all() and st["n_components"] == n_comp and st["n_cut_components"] == 0
-        assert o["rc"] == 0 and (o["comp"] == np.asarray(comp)).all()
-    except NotImplementedError:
-        assert st["n_cut_components"] >= 1 and o["rc"] != 0
-        # a component may exceed the cap only if it is a single track (tracks are never split)
-        for c in np.unique(c2):
-            members = np.nonzero(c2 == c)[0]
-            assert len(members) <= cap or len(set(t2[members])) == 1
+    comp, n_comp, n_over = R.split_components(g, track, n_tracks, cap, bisect_fn=capi.bisect_graph)
+    assert (c2 == np.asarray(comp)).all() and st["n_components"] == n_comp and st["n_cut_components"] == n_over
+    assert o["rc"] == (0 if n_over == 0 else -2)
+    o2 = O.run(ma, solve=False, bisect=bisect_ptr())
+    assert o2["rc"] == 0 and (o2["comp"] == np.asarray(comp)).all() and o2["n_oversized"] == n_over
+    # a component may exceed the cap only if it is a single track (tracks are never split)
+    for c in np.unique(c2):
+        members = np.nonzero(c2 == c)[0]
+        assert len(members) <= cap or len(set(t2[members])) == 1
 
 
 def test_component_equal_to_cap_is_not_cut(lfr_lib):
@@ -94,6 +101,63 @@ def test_synthetic_graphs_match_oracle_at_scale(lfr_lib):
     for k in ("n_tracks", "max_track_size", "n_components", "max_component_size"):
         assert st[k] == o[k]
     assert st["n_solved_edges"] <= g.n_edges and st["n_solved_components"] <= st["n_components"]
+
+
+@pytest.mark.parametrize("seed,cap", [(s, c) for s in range(8) for c in (14, 17, 25)])
+def test_size_cap_recursion_against_literal_restatement(lfr_lib, seed, cap):
+    """Oversized components on purpose (small caps): the product's recursive cut + re-split (lfr_graph.cpp) vs the
+    literal restatements of solve.cc:185-250,311-364 in oracle/lfr_ref.py and oracle/lfr_oracle.c, all three around
+    the same two-way primitive.  Checks the recursion, the orphan rule, the integer weights and the re-labelling."""
+    ma = synthetic.generate(seed=600 + seed, n_images=14, n_tracks=60, eps_out=0.03)
+    pairs = ma.to_pairs()
+    g = R.MatchGraph(pairs)
+    track, n_tracks = R.build_tracks(g)
+    comp, n_comp, n_over = R.split_components(g, track, n_tracks, cap, bisect_fn=capi.bisect_graph)
+    p = capi.Problem(capi.Graph.from_arrays(ma), cap)
+    t2, _, c2 = p.labels()
+    assert (t2 == np.asarray(track)).all()
+    assert n_over >= 1 and p.stats()["n_cut_components"] == n_over
+    assert (c2 == np.asarray(comp)).all() and p.stats()["n_components"] == n_comp
+    sizes = np.bincount(c2)
+    for c in np.nonzero(sizes > cap)[0]:                       # only a single (uncuttable) track may stay above the cap
+        assert len(set(t2[c2 == c])) == 1
+
+
+def test_graph_cut_of_a_huge_component_is_fast_and_respects_the_cap(lfr_lib):
+    """the region growing scanned all nodes per absorbed node (O(n^2) per bisection: 357 ms at 40 k tracks,
+    minutes at 10^6).  One meta-component of ~10^5 two-node tracks chained by rejected matches, cap 8."""
+    import time
+    n_img, n_tr = 8, 100_000
+    rng = np.random.default_rng(5)
+    # track t = nodes (image a_t, feature t) - (image b_t, feature t); chain: a rejected match between track t and
+    # t+1 on a shared image pair (same images => the image-conflict rule keeps the tracks apart)
+    a = rng.integers(0, n_img - 1, n_tr)
+    b = a + 1
+    p1 = np.concatenate([a, a[:-1]]).astype(np.int32)
+    p2 = np.concatenate([b, b[1:]]).astype(np.int32)
+    keep = np.ones(len(p1), bool)
+    keep[n_tr:] = a[:-1] == a[1:]                              # chain link only where both tracks use the same image pair
+    f1 = np.concatenate([np.arange(n_tr), np.arange(n_tr - 1)]).astype(np.uint32)
+    f2 = np.concatenate([np.arange(n_tr), np.arange(1, n_tr)]).astype(np.uint32)
+    sim = np.concatenate([np.full(n_tr, 0.9, np.float32), np.full(n_tr - 1, 0.5, np.float32)])
+    p1, p2, f1, f2, sim = p1[keep], p2[keep], f1[keep], f2[keep], sim[keep]
+    order = np.lexsort((p2, p1))                               # one ImagePair per (image1, image2)
+    p1, p2, f1, f2, sim = p1[order], p2[order], f1[order], f2[order], sim[order]
+    change = np.r_[True, (p1[1:] != p1[:-1]) | (p2[1:] != p2[:-1])]
+    starts = np.nonzero(change)[0]
+    off = np.r_[starts, len(p1)].astype(np.int64)
+    M = len(p1)
+    ma = synthetic.MatchArrays(["%d.png" % i for i in range(n_img)], np.ones(n_img, np.float32), p1[starts], p2[starts], off,
+                               f1, f2, sim, np.zeros((M, 9, 2), np.float32), np.zeros((M, 9, 2), np.float32))
+    g = capi.Graph.from_arrays(ma)
+    t0 = time.perf_counter()
+    p = capi.Problem(g, device_assembly=True)                  # labels only: this test is about the cut
+    dt = time.perf_counter() - t0
+    st = p.stats()
+    assert st["n_tracks"] == n_tr and st["n_cut_components"] >= 1
+    _, _, comp = p.labels()
+    assert np.bincount(comp).max() <= n_img
+    assert st["graph_cut_ms"] < 20_000 and dt < 40, (st["graph_cut_ms"], dt)
 
 
 def test_component_override_sidecar(lfr_lib):
