@@ -225,6 +225,14 @@ int lfr_batch_positions_view(lfr_batch *b, const double **positions);
 int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
                                  double *final_cost, int32_t *n_var_nodes, int32_t *n_edges);
 
+/* Unit-level probe of the device arithmetic (cost.cc:13-48,78-90 + the loss / corrector of solve.cc:111,120): for
+ * each of n edges (flows n x 18 float32, sim, kind 0 = intra-track/Cauchy 1 = inter-track/Tukey, x1 = source and
+ * x2 = destination position) the kernels' eval_edge on the GPU: out8[8i..] = 0.5*rho, corrected residual r0 r1,
+ * corrected d r / d x1 (j00 j01 j10 j11), sqrt(rho') (= d r / d x2 diagonal); cost_only[i] = 0.5*rho from the
+ * cost-only variant the line search uses.  Test infrastructure for parity at 1e-12, not part of the solve path. */
+int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float *sim, const int32_t *kind, const double *x1,
+                         const double *x2, int tukey_variant, double *out8, double *cost_only);
+
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
                   lfr_solve_stats *stats);

@@ -1386,6 +1386,50 @@ int lfr_hip_reserve(int device, int64_t n_nodes, int64_t n_matches) {
     return LFR_OK;
 }
 
+namespace {
+__global__ void eval_edges_kernel(int64_t n, const float *flows, const float *sim, const int32_t *kind, const double *x1,
+                                  const double *x2, int tukey_variant, double *out8, double *cost_only) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float fl[18];
+    for (int k = 0; k < 18; ++k) fl[k] = flows[18 * i + k];
+    EdgeOut o;
+    eval_edge<true>(fl, sim[i], kind[i], tukey_variant, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1], o);
+    double *r = out8 + 8 * i;
+    r[0] = o.cost; r[1] = o.r0; r[2] = o.r1; r[3] = o.j00; r[4] = o.j01; r[5] = o.j10; r[6] = o.j11; r[7] = o.sq;
+    EdgeOut c;
+    eval_edge<false>(fl, sim[i], kind[i], tukey_variant, x1[2 * i], x1[2 * i + 1], x2[2 * i], x2[2 * i + 1], c);
+    cost_only[i] = c.cost;
+}
+}  // namespace
+
+int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float *sim, const int32_t *kind, const double *x1,
+                         const double *x2, int tukey_variant, double *out8, double *cost_only) {
+    if (n < 0 || (n > 0 && (!flows || !sim || !kind || !x1 || !x2 || !out8 || !cost_only))) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    if (n == 0) return LFR_OK;
+    HIP_TRY(hipSetDevice(device));
+    lfr::DevArena ar;
+    if (!ar.init(ctx, (size_t)n * (72 + 4 + 4 + 16 + 16 + 64 + 8) + 4096)) return LFR_ERR_NOMEM;
+    float *d_fl = ar.take_n<float>(18 * n), *d_sim = ar.take_n<float>(n);
+    int32_t *d_kind = ar.take_n<int32_t>(n);
+    double *d_x1 = ar.take_n<double>(2 * n), *d_x2 = ar.take_n<double>(2 * n), *d_out = ar.take_n<double>(8 * n), *d_c = ar.take_n<double>(n);
+    if (!d_c) { lfr::set_error("arena exhausted"); return LFR_ERR_NOMEM; }
+    hipStream_t st = ctx->s_main;
+    HIP_TRY(hipMemcpyAsync(d_fl, flows, 72 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_sim, sim, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_kind, kind, 4 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_x1, x1, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_x2, x2, 16 * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(eval_edges_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, d_fl, d_sim, d_kind, d_x1, d_x2, tukey_variant, d_out, d_c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out8, d_out, 64 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(cost_only, d_c, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return LFR_OK;
+}
+
 int lfr_hip_trim(int device) {
     lfr::DevCtx *ctx = lfr::dev_ctx(device);
     if (!ctx) return LFR_ERR_HIP;

@@ -97,6 +97,7 @@ def lib():
         "lfr_batch_positions_view": (C.c_int, [vp, pp]),
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
+        "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
@@ -112,7 +113,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -267,6 +268,21 @@ def _contig(ma, flows=True):
             "sim": np.ascontiguousarray(ma.sim, np.float32),
             "d1": np.ascontiguousarray(ma.disp1, np.float32).reshape(M, 18),
             "d2": np.ascontiguousarray(ma.disp2, np.float32).reshape(M, 18)}
+
+
+def eval_edges_hip(flows, sim, kind, x1, x2, tukey_variant="ceres1", device=0):
+    """The kernels' per-edge arithmetic on the GPU (lfr_debug_eval_edges): returns (out[n, 8], cost_only[n])."""
+    flows = np.ascontiguousarray(flows, np.float32).reshape(-1, 18)
+    n = flows.shape[0]
+    sim = np.ascontiguousarray(sim, np.float32)
+    kind = np.ascontiguousarray(kind, np.int32)
+    x1 = np.ascontiguousarray(x1, np.float64).reshape(n, 2)
+    x2 = np.ascontiguousarray(x2, np.float64).reshape(n, 2)
+    out = np.zeros((n, 8), np.float64)
+    cost = np.zeros(n, np.float64)
+    _check(lib().lfr_debug_eval_edges(device, n, _ptr(flows), _ptr(sim), _ptr(kind), _ptr(x1), _ptr(x2), TUKEY[tukey_variant],
+                                      _ptr(out), _ptr(cost)))
+    return out, cost
 
 
 def bisect_graph(edges, weights):

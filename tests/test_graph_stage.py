@@ -127,37 +127,28 @@ def test_graph_cut_of_a_huge_component_is_fast_and_respects_the_cap(lfr_lib):
     """the region growing scanned all nodes per absorbed node (O(n^2) per bisection: 357 ms at 40 k tracks,
     minutes at 10^6).  One meta-component of ~10^5 two-node tracks chained by rejected matches, cap 8."""
     import time
-    n_img, n_tr = 8, 100_000
-    rng = np.random.default_rng(5)
-    # track t = nodes (image a_t, feature t) - (image b_t, feature t); chain: a rejected match between track t and
-    # t+1 on a shared image pair (same images => the image-conflict rule keeps the tracks apart)
-    a = rng.integers(0, n_img - 1, n_tr)
-    b = a + 1
-    p1 = np.concatenate([a, a[:-1]]).astype(np.int32)
-    p2 = np.concatenate([b, b[1:]]).astype(np.int32)
-    keep = np.ones(len(p1), bool)
-    keep[n_tr:] = a[:-1] == a[1:]                              # chain link only where both tracks use the same image pair
+    n_tr, cap = 100_000, 8
+    # track t = (image 0, feature t) - (image 1, feature t), similarity 0.9; the match (image 0, feature t) -
+    # (image 1, feature t+1), similarity 0.5, is rejected (both tracks already hold both images) and stays as an
+    # inter-track edge: ONE meta-component, a chain of 10^5 tracks / 2*10^5 nodes
     f1 = np.concatenate([np.arange(n_tr), np.arange(n_tr - 1)]).astype(np.uint32)
     f2 = np.concatenate([np.arange(n_tr), np.arange(1, n_tr)]).astype(np.uint32)
     sim = np.concatenate([np.full(n_tr, 0.9, np.float32), np.full(n_tr - 1, 0.5, np.float32)])
-    p1, p2, f1, f2, sim = p1[keep], p2[keep], f1[keep], f2[keep], sim[keep]
-    order = np.lexsort((p2, p1))                               # one ImagePair per (image1, image2)
-    p1, p2, f1, f2, sim = p1[order], p2[order], f1[order], f2[order], sim[order]
-    change = np.r_[True, (p1[1:] != p1[:-1]) | (p2[1:] != p2[:-1])]
-    starts = np.nonzero(change)[0]
-    off = np.r_[starts, len(p1)].astype(np.int64)
-    M = len(p1)
-    ma = synthetic.MatchArrays(["%d.png" % i for i in range(n_img)], np.ones(n_img, np.float32), p1[starts], p2[starts], off,
-                               f1, f2, sim, np.zeros((M, 9, 2), np.float32), np.zeros((M, 9, 2), np.float32))
+    M = len(f1)
+    ma = synthetic.MatchArrays(["0.png", "1.png"], np.ones(2, np.float32), np.zeros(1, np.int32), np.ones(1, np.int32),
+                               np.array([0, M], np.int64), f1, f2, sim, np.zeros((M, 9, 2), np.float32), np.zeros((M, 9, 2), np.float32))
     g = capi.Graph.from_arrays(ma)
     t0 = time.perf_counter()
-    p = capi.Problem(g, device_assembly=True)                  # labels only: this test is about the cut
+    p = capi.Problem(g, cap, device_assembly=True)             # labels only: this test is about the cut
     dt = time.perf_counter() - t0
     st = p.stats()
-    assert st["n_tracks"] == n_tr and st["n_cut_components"] >= 1
-    _, _, comp = p.labels()
-    assert np.bincount(comp).max() <= n_img
+    assert st["n_tracks"] == n_tr and st["n_cut_components"] == 1
+    track, _, comp = p.labels()
+    sizes = np.bincount(comp)
+    assert sizes.max() <= cap and sizes.min() >= 2             # tracks are never split
+    assert (np.diff(comp[np.argsort(track, kind="stable")].reshape(n_tr, 2), axis=1) == 0).all()
     assert st["graph_cut_ms"] < 20_000 and dt < 40, (st["graph_cut_ms"], dt)
+    print("graph cut of a %d-track chain: %.0f ms" % (n_tr, st["graph_cut_ms"]))
 
 
 def test_component_override_sidecar(lfr_lib):
