@@ -121,6 +121,7 @@ typedef struct lfr_problem_stats {
     int64_t n_solved_edges;        /* directed edges = residual blocks of the reduced programs */
     int64_t n_solved_nodes;        /* nodes (variable + constant) inside solved components */
     double tracks_ms, roots_ms, graph_cut_ms, assemble_ms;
+    double kruskal_rounds;         /* device graph stage: parallel rounds spent on large connected components (0: none) */
 } lfr_problem_stats;
 
 /* max_nodes_in_component <= 0: use the number of seen images (solve.cc:586).

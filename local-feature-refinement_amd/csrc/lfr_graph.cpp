@@ -175,6 +175,103 @@ static std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<in
     return final_map;
 }
 
+
+// out-edge CSR of the match graph: out_eid[out_off[n] .. out_off[n+1]) = directed edge ids of node n, ascending =
+// the reference's insertion order (graph.cc:17-23)
+void build_out_csr(const Graph &g, std::vector<int64_t> &out_off, std::vector<int64_t> &out_eid) {
+    const int64_t N = g.n_nodes(), M = g.n_matches();
+    out_off.assign(N + 1, 0);
+    for (int64_t m = 0; m < M; ++m) { ++out_off[g.m_node1[m] + 1]; ++out_off[g.m_node2[m] + 1]; }
+    for (int64_t i = 0; i < N; ++i) out_off[i + 1] += out_off[i];
+    out_eid.resize(2 * M);
+    std::vector<int64_t> cur(out_off.begin(), out_off.end() - 1);
+    for (int64_t m = 0; m < M; ++m) { out_eid[cur[g.m_node1[m]]++] = 2 * m; out_eid[cur[g.m_node2[m]]++] = 2 * m + 1; }
+}
+
+// separate_meta_graph (solve.cc:252-373) given the tracks: meta graph, connected components numbered by their
+// smallest track (= the BFS order of solve.cc:292-300), size cap by recursive cut, cut edges dropped, re-split.
+// Also the continuation of the DEVICE graph stage when a component exceeds the cap: the priority-queue region
+// growing of bisect_graph is sequential, the meta graph is small, so the cut stays on the host.
+void components_from_tracks(const Graph &g, const std::vector<int64_t> &track, int64_t n_tracks, const std::vector<int64_t> &tsize,
+                            int64_t max_nodes, const std::vector<int64_t> *out_off_in, const std::vector<int64_t> *out_eid_in,
+                            std::vector<int64_t> &comp, int64_t &n_components, int64_t &n_cut) {
+    const int64_t N = g.n_nodes(), M = g.n_matches();
+    comp.assign(N, -1);
+    n_cut = 0;
+    auto edge_dst = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node1[e >> 1] : g.m_node2[e >> 1]; };
+    std::vector<int32_t> mp(n_tracks, -1);
+    for (int64_t m = 0; m < M; ++m) {
+        const int64_t ta = track[g.m_node1[m]], tb = track[g.m_node2[m]];
+        if (ta == tb) continue;
+        const int32_t ra = uf_root(mp, (int32_t)ta), rb = uf_root(mp, (int32_t)tb);
+        if (ra != rb) mp[std::max(ra, rb)] = std::min(ra, rb);
+    }
+    std::vector<int64_t> label(n_tracks, -1);
+    int64_t nc = 0;
+    for (int64_t t = 0; t < n_tracks; ++t) {      // BFS labelling order of solve.cc:292-300
+        const int32_t r = uf_root(mp, (int32_t)t);
+        if (label[r] < 0) label[r] = nc++;
+        label[t] = label[r];
+    }
+    std::vector<int64_t> csize(nc, 0);
+    for (int64_t t = 0; t < n_tracks; ++t) csize[label[t]] += tsize[t];
+    bool any_over = false;
+    for (int64_t c = 0; c < nc; ++c) if (csize[c] > max_nodes) { any_over = true; ++n_cut; }
+    std::vector<int64_t> final_label = label;
+    int64_t n_final = nc;
+    if (any_over) {
+        std::vector<int64_t> off_local, eid_local;
+        if (!out_off_in || !out_eid_in) build_out_csr(g, off_local, eid_local);
+        const std::vector<int64_t> &out_off = out_off_in ? *out_off_in : off_local, &out_eid = out_eid_in ? *out_eid_in : eid_local;
+        // meta edges of the oversized components (solve.cc:268-289, 322-332)
+        std::vector<std::unordered_map<int64_t, double>> meta(n_tracks);
+        for (int64_t i = 0; i < N; ++i) {
+            const int64_t ts = track[i];
+            if (csize[label[ts]] <= max_nodes) continue;
+            for (int64_t k = out_off[i]; k < out_off[i + 1]; ++k) {
+                const int64_t e = out_eid[k], tt = track[edge_dst(e)];
+                if (tt != ts) meta[ts][tt] += (double)g.m_sim[e >> 1];
+            }
+        }
+        std::vector<std::vector<int64_t>> members(nc);
+        for (int64_t t = 0; t < n_tracks; ++t) if (csize[label[t]] > max_nodes) members[label[t]].push_back(t);
+        std::vector<int64_t> gc(n_tracks, 0);
+        int64_t ngc = 0;
+        for (int64_t c = 0; c < nc; ++c) {
+            if (csize[c] <= max_nodes) { ++ngc; continue; }      // ids only need to differ between components
+            std::vector<std::pair<int, int>> e; std::vector<int> w;
+            for (int64_t t : members[c]) {
+                std::vector<std::pair<int64_t, double>> nb(meta[t].begin(), meta[t].end());
+                std::sort(nb.begin(), nb.end());
+                for (auto &it : nb) if (t < it.first) { e.push_back({(int)t, (int)it.first}); w.push_back(static_cast<int>(100 * it.second)); }
+            }
+            auto split = recursive_cut(e, w, tsize, max_nodes);
+            int64_t top = 0;
+            for (auto &it : split) { gc[it.first] = ngc + it.second; top = std::max(top, gc[it.first]); }
+            ngc = top + 1;
+        }
+        // drop cut meta edges, re-split (solve.cc:345-364): union-find restricted to kept edges
+        std::vector<int32_t> mp2(n_tracks, -1);
+        for (int64_t m = 0; m < M; ++m) {
+            const int64_t ta = track[g.m_node1[m]], tb = track[g.m_node2[m]];
+            if (ta == tb) continue;
+            const bool over = csize[label[ta]] > max_nodes;
+            if (over && gc[ta] != gc[tb]) continue;
+            const int32_t ra = uf_root(mp2, (int32_t)ta), rb = uf_root(mp2, (int32_t)tb);
+            if (ra != rb) mp2[std::max(ra, rb)] = std::min(ra, rb);
+        }
+        std::fill(final_label.begin(), final_label.end(), -1);
+        n_final = 0;
+        for (int64_t t = 0; t < n_tracks; ++t) {
+            const int32_t r = uf_root(mp2, (int32_t)t);
+            if (final_label[r] < 0) final_label[r] = n_final++;
+            final_label[t] = final_label[r];
+        }
+    }
+    for (int64_t i = 0; i < N; ++i) comp[i] = final_label[track[i]];
+    n_components = n_final;
+}
+
 static int classify(int rows, int64_t n_edges) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
     if (rows <= 16 && n_edges <= 96) return KC_G16;
@@ -248,14 +345,8 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     p.stats.roots_ms = ms_since(t0);
 
     // out-edge CSR: directed edge ids ascending per source node == insertion order
-    std::vector<int64_t> out_off(N + 1, 0);
-    for (int64_t m = 0; m < M; ++m) { ++out_off[g.m_node1[m] + 1]; ++out_off[g.m_node2[m] + 1]; }
-    for (int64_t i = 0; i < N; ++i) out_off[i + 1] += out_off[i];
-    std::vector<int64_t> out_eid(2 * M);
-    {
-        std::vector<int64_t> cur(out_off.begin(), out_off.end() - 1);
-        for (int64_t m = 0; m < M; ++m) { out_eid[cur[g.m_node1[m]]++] = 2 * m; out_eid[cur[g.m_node2[m]]++] = 2 * m + 1; }
-    }
+    std::vector<int64_t> out_off, out_eid;
+    if (host_batch) build_out_csr(g, out_off, out_eid);        // (labels only: built on demand by the size cap)
     auto edge_dst = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node1[e >> 1] : g.m_node2[e >> 1]; };
     auto edge_src = [&](int64_t e) -> uint32_t { return (e & 1) ? g.m_node2[e >> 1] : g.m_node1[e >> 1]; };
 
@@ -269,74 +360,8 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
             n_components = std::max(n_components, p.comp[i] + 1);
         }
     } else {
-        std::vector<int32_t> mp(n_tracks, -1);
-        for (int64_t m = 0; m < M; ++m) {
-            const int64_t ta = p.track[g.m_node1[m]], tb = p.track[g.m_node2[m]];
-            if (ta == tb) continue;
-            const int32_t ra = uf_root(mp, (int32_t)ta), rb = uf_root(mp, (int32_t)tb);
-            if (ra != rb) mp[std::max(ra, rb)] = std::min(ra, rb);
-        }
-        std::vector<int64_t> label(n_tracks, -1);
-        int64_t nc = 0;
-        for (int64_t t = 0; t < n_tracks; ++t) {      // BFS labelling order of solve.cc:292-300
-            const int32_t r = uf_root(mp, (int32_t)t);
-            if (label[r] < 0) label[r] = nc++;
-            label[t] = label[r];
-        }
-        std::vector<int64_t> csize(nc, 0);
-        for (int64_t t = 0; t < n_tracks; ++t) csize[label[t]] += tsize[t];
-        bool any_over = false;
-        for (int64_t c = 0; c < nc; ++c) if (csize[c] > max_nodes) { any_over = true; ++p.stats.n_cut_components; }
-        std::vector<int64_t> final_label = label;
-        int64_t n_final = nc;
-        if (any_over) {
-            // meta edges of the oversized components (solve.cc:268-289, 322-332)
-            std::vector<std::unordered_map<int64_t, double>> meta(n_tracks);
-            for (int64_t i = 0; i < N; ++i) {
-                const int64_t ts = p.track[i];
-                if (csize[label[ts]] <= max_nodes) continue;
-                for (int64_t k = out_off[i]; k < out_off[i + 1]; ++k) {
-                    const int64_t e = out_eid[k], tt = p.track[edge_dst(e)];
-                    if (tt != ts) meta[ts][tt] += (double)g.m_sim[e >> 1];
-                }
-            }
-            std::vector<std::vector<int64_t>> members(nc);
-            for (int64_t t = 0; t < n_tracks; ++t) if (csize[label[t]] > max_nodes) members[label[t]].push_back(t);
-            std::vector<int64_t> gc(n_tracks, 0);
-            int64_t ngc = 0;
-            for (int64_t c = 0; c < nc; ++c) {
-                if (csize[c] <= max_nodes) { ++ngc; continue; }      // ids only need to differ between components
-                std::vector<std::pair<int, int>> e; std::vector<int> w;
-                for (int64_t t : members[c]) {
-                    std::vector<std::pair<int64_t, double>> nb(meta[t].begin(), meta[t].end());
-                    std::sort(nb.begin(), nb.end());
-                    for (auto &it : nb) if (t < it.first) { e.push_back({(int)t, (int)it.first}); w.push_back(static_cast<int>(100 * it.second)); }
-                }
-                auto split = recursive_cut(e, w, tsize, max_nodes);
-                int64_t top = 0;
-                for (auto &it : split) { gc[it.first] = ngc + it.second; top = std::max(top, gc[it.first]); }
-                ngc = top + 1;
-            }
-            // drop cut meta edges, re-split (solve.cc:345-364): union-find restricted to kept edges
-            std::vector<int32_t> mp2(n_tracks, -1);
-            for (int64_t m = 0; m < M; ++m) {
-                const int64_t ta = p.track[g.m_node1[m]], tb = p.track[g.m_node2[m]];
-                if (ta == tb) continue;
-                const bool over = csize[label[ta]] > max_nodes;
-                if (over && gc[ta] != gc[tb]) continue;
-                const int32_t ra = uf_root(mp2, (int32_t)ta), rb = uf_root(mp2, (int32_t)tb);
-                if (ra != rb) mp2[std::max(ra, rb)] = std::min(ra, rb);
-            }
-            std::fill(final_label.begin(), final_label.end(), -1);
-            n_final = 0;
-            for (int64_t t = 0; t < n_tracks; ++t) {
-                const int32_t r = uf_root(mp2, (int32_t)t);
-                if (final_label[r] < 0) final_label[r] = n_final++;
-                final_label[t] = final_label[r];
-            }
-        }
-        for (int64_t i = 0; i < N; ++i) p.comp[i] = final_label[p.track[i]];
-        n_components = n_final;
+        components_from_tracks(g, p.track, n_tracks, tsize, max_nodes, host_batch ? &out_off : nullptr, host_batch ? &out_eid : nullptr,
+                               p.comp, n_components, p.stats.n_cut_components);
     }
     p.stats.n_components = n_components;
     p.stats.graph_cut_ms = ms_since(t0);

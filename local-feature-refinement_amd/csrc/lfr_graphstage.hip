@@ -8,15 +8,22 @@
 //   1. radix-sort the matches by (similarity, n1, n2) descending            (hipCUB)
 //   2. plain connected components of the match graph, ignoring image conflicts (lock-free union-find)
 //   3. stable-sort the ordered matches by connected component
-//   4. one thread per connected component runs the reference's sequential union-find with the
-//      image-conflict test over its own matches, in order
+//   4. small connected components: one thread each replays the reference's sequential union-find with the
+//      image-conflict test over its own matches, in order.  Large ones (real match graphs are typically ONE
+//      giant connected component: wrong matches link the tracks) run the same greedy rule in parallel ROUNDS:
+//      a match whose two roots are equal or share an image can be retired at once (sets only grow, so the verdict
+//      can never change); of the others, a match is accepted in this round iff no earlier pending match touches
+//      either of its roots - such matches have pairwise disjoint roots and commute with everything before them,
+//      so every union happens with exactly the operands it has in the sequential order (same roots, same sizes,
+//      same tie rule).  Image sets are per-root bitsets (#images bits).
 //   5. track ids = rank of the root nodes; roots = arg-max (score, node) per track; components =
 //      connected components of the track meta-graph, numbered by their smallest track.
 // The whole chain is enqueued on ONE stream without host round trips: counts that size later steps
 // (segments, tracks, components) stay on the device and bound the kernels there; every array is sized
 // by its upper bound (N or M).  One 64-byte read-back at the end delivers the counts for the stdout lines
-// and the two conditions under which the caller must use the host stage instead (a component above the
-// size cap needs the graph cut; a very large connected component would serialise step 4 on one thread).
+// (a second one, mid-way, only tells whether large connected components exist).  A component above the size cap
+// needs the graph cut: the sequential priority-queue bisection stays on the host, fed with the device's tracks
+// (lfr_graph.cpp: components_from_tracks), and the labels go back to HBM.
 // Integer work throughout; the only floating-point accumulation (root scores, sums of float32
 // similarities in fp64) is exact for any realistic input, hence order independent.
 #include <hip/hip_runtime.h>
@@ -24,7 +31,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "lfr_assemble.hpp"
@@ -34,7 +44,10 @@ namespace lfr {
 namespace {
 
 constexpr int kThreads = kPipeThreads;
-constexpr int64_t kMaxSegmentEdges = 1 << 16;     // larger connected components: host stage
+constexpr int64_t kSerialSegmentEdges = 2048;     // connected components up to this many matches: one thread each
+                                                   // (LFR_SERIAL_SEGMENT_EDGES overrides it: tests push everything through the rounds)
+constexpr int kMaxRounds = 100000;                 // larger ones: parallel rounds (a path-shaped dependency chain this long: host stage)
+constexpr size_t kMaxBitsetBytes = (size_t)24 << 30;
 inline dim3 grid_for(int64_t n) { return pipe_grid(n); }
 
 struct ArenaMark {                                 // temporaries: released at scope end (reuse is stream ordered)
@@ -122,9 +135,16 @@ __global__ void k_cc_union(int64_t M, const uint32_t *n1, const uint32_t *n2, ui
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m < M) uf_union(parent, n1[m], n2[m]);
 }
-__global__ void k_cc_flatten(int64_t n, uint32_t *parent) {
+// Labels = roots, written to a SEPARATE array by a read-only walk.  (Flattening in place - parent[i] = find(i) with
+// path halving - is wrong under concurrency: another thread's halving store, computed from an older read of
+// parent[i], can land after the flattened value and leave an intermediate ancestor there; a giant connected
+// component then appears split into two labels.)
+__global__ void k_cc_labels(int64_t n, const uint32_t *parent, uint32_t *label) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) parent[i] = uf_find(parent, (uint32_t)i);
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i, p = uf_load(parent, x);
+    while (p != x) { x = p; p = uf_load(parent, x); }
+    label[i] = x;
 }
 __global__ void k_cc_keys(int64_t M, const uint32_t *order, const uint32_t *n1, const uint32_t *cc, uint32_t *keys) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -156,13 +176,13 @@ __device__ __forceinline__ int32_t seq_root(int32_t *parent, int32_t i) {
     while (parent[i] >= 0) { const int32_t nx = parent[i]; parent[i] = r; i = nx; }
     return r;
 }
-__global__ void k_kruskal(int64_t cap, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
+__global__ void k_kruskal(int64_t cap, int64_t serial_limit, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
                           const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
                           int32_t *count) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
     const int64_t lo = starts[s], hi = starts[s + 1];
-    if (hi - lo > kMaxSegmentEdges) return;                  // the host stage takes this input (CNT_MAX_SEG tells the caller)
+    if (hi - lo > serial_limit) return;                      // large connected component: parallel rounds (k_round_*)
     for (int64_t k = lo; k < hi; ++k) {
         const uint32_t m = order[k];
         const int32_t r1 = seq_root(parent, (int32_t)n1[m]), r2 = seq_root(parent, (int32_t)n2[m]);
@@ -178,6 +198,96 @@ __global__ void k_kruskal(int64_t cap, const uint32_t *counts, const uint32_t *s
         parent[small] = big;
         next[tail[big]] = small; tail[big] = tail[small]; count[big] += count[small];
     }
+}
+
+// ---- the same greedy rule in parallel rounds (large connected components) ----
+// parent[] is shared with k_kruskal (-1 = root).  Finds compress by halving; within the evaluation kernel no union
+// happens, so a stale pointer is still an ancestor.
+__device__ __forceinline__ int32_t par_load(const int32_t *parent, int32_t x) {
+    return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int32_t par_find(int32_t *parent, int32_t x) {
+    for (;;) {
+        const int32_t p = par_load(parent, x);
+        if (p < 0) return x;
+        const int32_t gp = par_load(parent, p);
+        if (gp >= 0) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        x = p;
+    }
+}
+// append to a list with one atomic per wave
+__device__ __forceinline__ uint32_t wave_append(bool keep, uint32_t *counter) {
+    const unsigned long long mask = __ballot(keep);
+    const int lane = (int)(threadIdx.x & 63);
+    uint32_t base = 0;
+    if (mask) {
+        const int leader = __ffsll((long long)mask) - 1;
+        if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+        base = __shfl(base, leader, 64);
+    }
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+struct Pending { uint32_t k; int32_t ra, rb; };     // position in the ordered match list, roots of n1 / n2
+// matches of large connected components -> the first pending list; bit of the own image for their nodes
+__global__ void k_large_pending(int64_t M, int64_t serial_limit, const uint32_t *flags, const uint32_t *seg_id, const uint32_t *starts, const uint32_t *order,
+                                const uint32_t *n1, const uint32_t *n2, const int32_t *node_image, int W, unsigned long long *bits,
+                                Pending *pend, uint32_t *n_pend) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool large = false;
+    uint32_t m = 0;
+    if (k < M) {
+        const uint32_t s = seg_id[k] + flags[k] - 1u;           // segment of position k
+        large = (int64_t)(starts[s + 1] - starts[s]) > serial_limit;
+        m = order[k];
+    }
+    const uint32_t at = wave_append(large, n_pend);
+    if (!large) return;
+    const uint32_t a = n1[m], b = n2[m];
+    pend[at] = Pending{(uint32_t)k, (int32_t)a, (int32_t)b};
+    if (bits) {                                                  // (idempotent: several matches set the same bit)
+        atomicOr(&bits[(size_t)a * W + (node_image[a] >> 6)], 1ull << (node_image[a] & 63));
+        atomicOr(&bits[(size_t)b * W + (node_image[b] >> 6)], 1ull << (node_image[b] & 63));
+    }
+}
+// retire what can never be accepted (same root / shared image: monotone), bid for the roots with the rest
+__global__ void k_round_eval(uint32_t n_in, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
+                             unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    Pending q{0, 0, 0};
+    if (i < n_in) {
+        q = in[i];
+        q.ra = par_find(parent, q.ra); q.rb = par_find(parent, q.rb);
+        if (q.ra != q.rb) {
+            const unsigned long long *A = bits + (size_t)q.ra * W, *B = bits + (size_t)q.rb * W;
+            unsigned long long any = 0ull;
+            for (int w = 0; w < W; ++w) any |= A[w] & B[w];       // solve.cc:506-511
+            keep = any == 0ull;
+        }
+    }
+    const uint32_t at = wave_append(keep, n_out);
+    if (!keep) return;
+    out[at] = q;
+    const unsigned long long key = round_hi | q.k;                // a later round's bid beats every stale entry
+    atomicMin(&minpos[q.ra], key);
+    atomicMin(&minpos[q.rb], key);
+}
+// a bidder that holds both of its roots is the earliest pending match touching either: accept (solve.cc:513-521)
+__global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigned long long round_hi, const unsigned long long *minpos,
+                               int32_t *parent, int32_t *count, unsigned long long *bits, int W, uint32_t *n_accepted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_p) return;
+    const Pending q = pend[i];
+    const unsigned long long key = round_hi | q.k;
+    if (minpos[q.ra] != key || minpos[q.rb] != key) return;
+    int32_t big = q.ra, small = q.rb;                              // r1 = root of n1, r2 = root of n2
+    if (count[q.ra] < count[q.rb]) { big = q.rb; small = q.ra; }   // ties: root2 under root1
+    __hip_atomic_store(&parent[small], big, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    count[big] += count[small];
+    unsigned long long *A = bits + (size_t)big * W;
+    const unsigned long long *B = bits + (size_t)small * W;
+    for (int w = 0; w < W; ++w) A[w] |= B[w];
+    atomicAdd(n_accepted, 1u);
 }
 __global__ void k_init_nodes(int64_t n, int32_t *parent, int32_t *next, int32_t *tail, int32_t *count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,10 +552,10 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     uint32_t *order = id0;
 
     // 2. connected components of the match graph (conflicts ignored)
-    TAKE(cc, uint32_t, N);
-    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, cc);
-    hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, cc);
-    hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, cc);
+    TAKE(cc_parent, uint32_t, N); TAKE(cc, uint32_t, N);
+    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, cc_parent);
+    hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, cc_parent);
+    hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, cc_parent, cc);
 
     // 3. ordered matches grouped by connected component (stable)
     TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(segid, uint32_t, M + 1);
@@ -459,11 +569,50 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
     hipLaunchKernelGGL(k_seg_maxlen, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
 
-    // 4. greedy constrained union-find per connected component
+    // 4. greedy constrained union-find per connected component: small ones one thread each ...
     TAKE(par, int32_t, N); TAKE(next, int32_t, N); TAKE(tail, int32_t, N); TAKE(cnt, int32_t, N);
     hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, par, next, tail, cnt);
-    hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, counts, starts, order, n1, n2,
+    int64_t serial_limit = kSerialSegmentEdges;
+    if (const char *e = getenv("LFR_SERIAL_SEGMENT_EDGES")) serial_limit = std::max<int64_t>(0, atoll(e));
+    hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
                        dg->node_image, par, next, tail, cnt);
+    // ... large ones in parallel rounds (first read-back: is there any?)
+    LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
+    LFR_HIP_TRY(hipStreamSynchronize(st));
+    DevArena rounds_arena;
+    if ((int64_t)h_counts[CNT_MAX_SEG] > serial_limit) {
+        const int W = (int)((g.image_names.size() + 63) / 64);
+        const size_t bits_bytes = (size_t)N * W * 8;
+        if (bits_bytes > kMaxBitsetBytes) return LFR_GRAPHSTAGE_USE_HOST;
+        if (!rounds_arena.init(ctx, bits_bytes + 2 * (size_t)M * sizeof(Pending) + 8 * (size_t)N + 65536)) return LFR_ERR_NOMEM;
+        unsigned long long *bits = rounds_arena.take_n<unsigned long long>((size_t)N * W);
+        unsigned long long *minpos = rounds_arena.take_n<unsigned long long>(N);
+        Pending *pa = rounds_arena.take_n<Pending>(M), *pb = rounds_arena.take_n<Pending>(M);
+        uint32_t *ctr = rounds_arena.take_n<uint32_t>(64);
+        if (!bits || !minpos || !pa || !pb || !ctr) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
+        LFR_HIP_TRY(hipMemsetAsync(bits, 0, bits_bytes, st));
+        LFR_HIP_TRY(hipMemsetAsync(minpos, 0xff, 8 * (size_t)N, st));
+        LFR_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * 64, st));
+        hipLaunchKernelGGL(k_large_pending, grid_for(M), dim3(kThreads), 0, st, M, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, bits, pa, ctr);
+        uint32_t *h_ctr = h_counts + 8;                 // (the pinned block has 16 words; the counts proper use 6)
+        LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 4, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(hipStreamSynchronize(st));
+        uint32_t n_in = h_ctr[0];
+        int64_t rounds = 0;
+        for (; n_in > 0; ++rounds) {
+            if (rounds >= kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;       // a path-shaped dependency chain: sequential anyway
+            const unsigned long long round_hi = (unsigned long long)(kMaxRounds - rounds) << 32;
+            uint32_t *n_out = ctr + 1 + (rounds & 1);
+            LFR_HIP_TRY(hipMemsetAsync(n_out, 0, 4, st));
+            hipLaunchKernelGGL(k_round_eval, grid_for(n_in), dim3(kThreads), 0, st, n_in, pa, par, bits, W, round_hi, minpos, pb, n_out);
+            hipLaunchKernelGGL(k_round_accept, grid_for(n_in), dim3(kThreads), 0, st, n_out, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
+            LFR_HIP_TRY(hipMemcpyAsync(h_ctr, n_out, 4, hipMemcpyDeviceToHost, st));
+            LFR_HIP_TRY(hipStreamSynchronize(st));
+            n_in = h_ctr[0];
+            std::swap(pa, pb);
+        }
+        p.stats.kruskal_rounds = (double)rounds;
+    }
 
     // 5. track ids (roots in ascending node index), sizes
     TAKE(rrank, uint32_t, N + 1);
@@ -480,10 +629,10 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipEventRecord(ev[2], st));
 
     // components of the track meta-graph, numbered by their smallest track (solve.cc:292-300)
-    TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);
-    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp);
-    hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, mp);
-    hipLaunchKernelGGL(k_cc_flatten, grid_for(N), dim3(kThreads), 0, st, N, mp);
+    TAKE(mp_parent, uint32_t, N); TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);
+    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp_parent);
+    hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, mp_parent);
+    hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, mp_parent, mp);
     hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
     if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
@@ -495,8 +644,18 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     // the one read-back of the stage
     LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
     LFR_HIP_TRY(hipStreamSynchronize(st));
-    if ((int64_t)h_counts[CNT_MAX_SEG] > kMaxSegmentEdges) return LFR_GRAPHSTAGE_USE_HOST;   // step 4 skipped that component
-    if ((int64_t)h_counts[CNT_MAX_COMP] > max_nodes) return LFR_GRAPHSTAGE_USE_HOST;          // needs the graph cut (solve.cc:311-343)
+    const bool needs_cut = (int64_t)h_counts[CNT_MAX_COMP] > max_nodes;      // solve.cc:311-343
+    if (const char *dd = getenv("LFR_DEBUG_DUMP")) {      // intermediates of the stage as raw files (debugging aid)
+        auto dump = [&](const char *name, const void *dptr, size_t bytes) {
+            std::vector<char> h(bytes);
+            (void)hipMemcpy(h.data(), dptr, bytes, hipMemcpyDeviceToHost);
+            const std::string path = std::string(dd) + "/" + name + ".bin";
+            if (FILE *f = fopen(path.c_str(), "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+        };
+        dump("order", order, 4 * (size_t)M); dump("cc", cc, 4 * (size_t)N); dump("starts", starts, 4 * (size_t)(std::min(N, M) + 2));
+        dump("par", par, 4 * (size_t)N); dump("track", dp->track, 4 * (size_t)N); dump("counts", counts, 64);
+        dump("segid", segid, 4 * (size_t)(M + 1)); dump("cnt", cnt, 4 * (size_t)N);
+    }
     float ms = 0.f;
     LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[0], ev[1])); p.stats.tracks_ms = ms;
     LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[1], ev[2])); p.stats.roots_ms = ms;
@@ -509,6 +668,25 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         p.host_labels_valid = false;                  // fetched from HBM on demand
         p.devs.assign((size_t)device + 1, nullptr);
         p.devs[device] = dp;
+    }
+    if (needs_cut) {
+        // The size cap: the deterministic bisection grows a region with a priority queue - sequential, and the meta
+        // graph is small - so it runs on the host (lfr_graph.cpp), fed with the tracks computed here; the component
+        // labels go back to HBM and the pipeline continues on the device.
+        const auto tc = std::chrono::steady_clock::now();
+        if ((rc = p.ensure_host_labels()) != LFR_OK) return rc;
+        std::vector<int64_t> tsz((size_t)p.stats.n_tracks, 0);
+        for (int64_t i = 0; i < N; ++i) ++tsz[p.track[i]];
+        int64_t n_components = 0, n_cut = 0;
+        components_from_tracks(g, p.track, p.stats.n_tracks, tsz, max_nodes, nullptr, nullptr, p.comp, n_components, n_cut);
+        std::vector<int32_t> c32(N);
+        std::vector<int64_t> csz((size_t)n_components, 0);
+        for (int64_t i = 0; i < N; ++i) { c32[i] = (int32_t)p.comp[i]; ++csz[p.comp[i]]; }
+        LFR_HIP_TRY(hipMemcpyAsync(dp->comp, c32.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+        LFR_HIP_TRY(hipStreamSynchronize(st));
+        p.stats.n_components = n_components; p.stats.n_cut_components = n_cut;
+        p.stats.max_component_size = *std::max_element(csz.begin(), csz.end());
+        p.stats.graph_cut_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
     }
     return LFR_OK;
 }

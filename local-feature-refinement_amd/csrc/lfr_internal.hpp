@@ -142,6 +142,11 @@ struct Problem {
 std::vector<int32_t> assign_shards(const Problem &p, int world);
 
 int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_override, Problem &p, bool host_batch = true);
+void build_out_csr(const Graph &g, std::vector<int64_t> &out_off, std::vector<int64_t> &out_eid);
+// separate_meta_graph (solve.cc:252-373) given the tracks (lfr_graph.cpp); out_off/out_eid: optional out-edge CSR
+void components_from_tracks(const Graph &g, const std::vector<int64_t> &track, int64_t n_tracks, const std::vector<int64_t> &tsize,
+                            int64_t max_nodes, const std::vector<int64_t> *out_off, const std::vector<int64_t> *out_eid,
+                            std::vector<int64_t> &comp, int64_t &n_components, int64_t &n_cut);
 
 // deterministic substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
 // (solve.cc:192): returns part (0/1) per node id appearing in `edges`.

@@ -4,6 +4,7 @@ compared bit for bit with the host-assembled path (itself checked against the or
 test_gpu_parity.py)."""
 import numpy as np
 import pytest
+import torch  # noqa: F401  (before liblfr_hip.so is loaded: one HIP runtime for both, INTEGRATION.md §5)
 
 from lfr_amd import capi, synthetic
 
@@ -84,7 +85,6 @@ def test_resident_graph_and_eviction(lfr_lib):
 
 
 def test_positions_view_matches_download_and_waits_for_the_solve(lfr_lib):
-    import torch
     ma = synthetic.generate(**MIXED)
     g = capi.Graph.from_arrays(ma)
     p = capi.Problem(g, device_graph_stage=0)
@@ -139,3 +139,56 @@ def test_empty_and_trivial_graphs_through_the_device_pipeline(lfr_lib):
             b.solve()
             b.download(acc)
         assert (acc == want).all()
+
+
+# ---- device graph stage on "real" graph shapes: giant connected components, components above the size cap ----
+def _labels_equal(ma, **kw):
+    g = capi.Graph.from_arrays(ma)
+    ph, pd = capi.Problem(g), capi.Problem(g, device_graph_stage=0)
+    for x, y in zip(ph.labels(), pd.labels()):
+        assert (x == y).all()
+    for k in ("n_tracks", "max_track_size", "n_components", "max_component_size", "n_cut_components"):
+        assert ph.stats()[k] == pd.stats()[k], k
+    return ph, pd
+
+
+@pytest.mark.parametrize("kw", [
+    dict(seed=201, n_images=40, n_tracks=3000, eps_out=0.05),                 # wrong matches link almost every track
+    dict(seed=202, n_images=200, n_tracks=6000, eps_out=0.03, sim_lo=0.3),
+    dict(seed=203, n_images=96, n_tracks=80, len_dist="uniform", len_lo=40, len_hi=96, eps_out=0.02),   # long tracks, dense
+])
+def test_giant_connected_component_runs_in_parallel_rounds(lfr_lib, kw):
+    """One connected component holds most matches (what real match graphs look like): the device stage runs the
+    constrained union-find in rounds (solve.cc:499-523 semantics, union for union) - labels bit-identical to the
+    host stage, also where components exceed the cap (host bisection fed with the device's tracks)."""
+    ma = synthetic.generate(**kw)
+    ph, pd = _labels_equal(ma)
+    assert pd.stats()["kruskal_rounds"] > 0
+    a, _ = ph.solve_hip(0)
+    b, _ = pd.solve_hip(0)
+    assert (a == b).all()
+
+
+@pytest.mark.parametrize("maker", ["config1_standin", "config3_standin", "config5"])
+def test_real_shaped_configs_stay_on_the_device_stage(lfr_lib, maker):
+    ma = getattr(synthetic, maker)()
+    ph, pd = _labels_equal(ma)
+    assert pd.stats()["tracks_ms"] > 0 and pd.stats()["assemble_ms"] == 0    # device stage ran (the host stage fills assemble_ms only when it assembles)
+
+
+def test_round_based_union_find_fuzz(lfr_lib, monkeypatch):
+    """Every connected component through the rounds (LFR_SERIAL_SEGMENT_EDGES=0): ties, duplicated matches,
+    image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523."""
+    from test_graph_stage import fuzz_pairs
+    monkeypatch.setenv("LFR_SERIAL_SEGMENT_EDGES", "0")
+    n_ok = 0
+    for seed in range(3000, 3150):
+        ma = synthetic.pairs_to_arrays(fuzz_pairs(seed))
+        if ma.n_matches == 0:
+            continue
+        _, pd = _labels_equal(ma)
+        assert pd.stats()["kruskal_rounds"] > 0
+        n_ok += 1
+    for seed in (71, 72):
+        _labels_equal(synthetic.generate(seed=seed, n_images=64, n_tracks=3000, eps_out=0.004 * (seed - 71)))
+    assert n_ok >= 120
