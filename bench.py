@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=147_000, help="tracks of the synthetic graph (147000 -> ~5.0M edges)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--span-reps", type=int, default=7)
+    ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: the local rank); with LFR_DIST_BACKEND=gloo "
+                                                  "several ranks may share one GPU (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
@@ -93,9 +95,11 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the solver path has no CPU fallback)")
-    rank, world, local = dist.init()
+    rank, world, local = dist.init(backend=os.environ.get("LFR_DIST_BACKEND") or None)
     if args.gpus != world:
         raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if args.devices:
+        local = [int(x) for x in args.devices.split(",")][rank]
     if local >= torch.cuda.device_count():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (rank, torch.cuda.device_count()))
     torch.cuda.set_device(local)

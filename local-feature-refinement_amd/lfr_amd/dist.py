@@ -43,7 +43,7 @@ def barrier():
 def _tensor(values):
     import torch
     import torch.distributed as td
-    dev = "cuda" if (td.is_initialized() and td.get_backend() == "nccl") else "cpu"
+    dev = "cuda" if (td.is_initialized() and td.get_backend() == "nccl") else "cpu"   # "nccl" is RCCL on ROCm
     return torch.tensor(values, dtype=torch.float64, device=dev)
 
 

@@ -192,3 +192,32 @@ def test_round_based_union_find_fuzz(lfr_lib, monkeypatch):
     for seed in (71, 72):
         _labels_equal(synthetic.generate(seed=seed, n_images=64, n_tracks=3000, eps_out=0.004 * (seed - 71)))
     assert n_ok >= 120
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_on_one_gpu(lfr_lib, scaling):
+    """bench.py's N>1 path end to end: two ranks (gloo, both on GPU 0) started by bench.py itself; weak = one graph per
+    rank, strong = one graph sharded on the device; the weak line carries the strong-scaling object as well."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFR_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--devices", "0,0", "--steps", "2", "--warmup", "1",
+                        "--tracks", "20000", "--span-reps", "2", "--no-cpu-baseline", "--scaling", scaling],
+                       capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    one_graph = out["config"]["edges_per_gpu"] if scaling == "weak" else None
+    if scaling == "weak":
+        assert "strong_scaling" in out and out["strong_scaling"]["edges"] > 0
+        assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 2 * one_graph) / (2 * one_graph) < 0.02      # two graphs
+    else:
+        total = out["value"] * out["ms_per_step"] * 1e-3
+        assert abs(out["config"]["edges_per_gpu"] * 2 - total) / total < 0.05                                # one graph, two shards
+    for k in ("solver_span", "total_span", "total_span_resident_graph"):
+        assert out[k]["ms"] > 0
