@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--devices", default="", help="comma-separated HIP device per rank (default: the local rank); with LFR_DIST_BACKEND=gloo "
                                                   "several ranks may share one GPU (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-long-tracks", action="store_true", help="skip the second, workgroup-kernel dominated workload (config 5 stand-in)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -300,6 +301,49 @@ def main():
             }
             res["speedup_vs_cpu_baseline"] = {"solver_span": ref["solver_ms"] / res["solver_span"]["ms"],
                                               "total_span": (ref["solver_ms"] + ref["graph_ms"]) / res["total_span"]["ms"]}
+        if not args.no_long_tracks and world == 1:
+            # config 4 holds only components of <= 32 rows (packed kernel).  Real long-track data (BASELINE
+            # configs[4], ETH3D) runs in the workgroup-per-component kernels: a second, clearly labelled workload.
+            t0 = time.perf_counter()
+            ma5 = synthetic.config5()
+            g5 = capi.Graph.from_arrays(ma5)
+            t_prep5 = time.perf_counter() - t0
+            L.lfr_hip_reserve(local, g5.n_nodes, g5.n_edges // 2)
+
+            def pipe5(keep=None):
+                p5 = capi.Problem(g5, device_graph_stage=local)
+                b5 = capi.Batch(p5, local)
+                b5.solve(stream, want_stats=False)
+                b5.positions_view()
+                if keep is not None:
+                    keep.extend([p5, b5])
+            k5 = []
+            pipe5(k5)
+            p5, b5 = k5
+            g5.to_device(local)
+            sp5 = spans(lambda: pipe5(), max(1, min(3, reps)), sync)
+            n5 = 5
+            for _ in range(2):
+                b5.solve(stream, want_stats=False)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(n5):
+                b5.solve(stream, want_stats=False)
+            sync()
+            ms5 = (time.perf_counter() - t0) / n5 * 1e3
+            st5 = b5.solve(stream, want_stats=True)
+            _, c5, e5 = b5.timing(0)
+            res["long_tracks_workload"] = {
+                "workload": "config5 stand-in: synthetic match graph, 96 images, 2000 tracks of 48-96 nodes, 2 %% wrong matches (components above the "
+                            "size cap are cut), %d directed edges, %d components" % (st5["n_edges"], st5["n_components"]),
+                "ms_per_step": ms5, "edges_per_s": st5["n_edges"] / (ms5 * 1e-3), "tracks_per_s": st5["n_tracks"] / (ms5 * 1e-3), "steps": n5,
+                "kernel_ms": {kernel_names[i]: round(float(c5[i]), 3) for i in range(7) if e5[i] > 0},
+                "kernel_edges": {kernel_names[i]: int(e5[i]) for i in range(7) if e5[i] > 0},
+                "total_span_resident_graph_ms": sp5["ms"], "graph_stage": {k: p5.stats()[k] for k in ("tracks_ms", "roots_ms", "graph_cut_ms", "kruskal_rounds", "n_cut_components")},
+                "mean_iterations": st5["sum_iterations"] / max(1, st5["n_components"]), "failed": st5["n_failed"], "no_convergence": st5["n_no_convergence"],
+                "setup_s": t_prep5,
+            }
+            del b5, p5, g5, ma5
         ref_bin = os.environ.get("LFR_REFERENCE_SOLVE")
         if ref_bin and world == 1:
             # a reference-built `solve`, if someone supplies one, on the same graph as a .pb

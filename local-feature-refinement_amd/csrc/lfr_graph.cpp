@@ -139,7 +139,7 @@ void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vect
 }
 
 // recursive_graph_cut of solve.cc:185-250 with bisect_graph in place of Graclus
-static std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
+std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
                                                   const std::vector<int> &weights,
                                                   const std::vector<int64_t> &node_weights, int64_t max_weight) {
     std::unordered_map<int, int> split;

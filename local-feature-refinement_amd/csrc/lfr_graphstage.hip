@@ -289,6 +289,35 @@ __global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigne
     for (int w = 0; w < W; ++w) A[w] |= B[w];
     atomicAdd(n_accepted, 1u);
 }
+
+// ---- size cap (solve.cc:311-364): the cut itself runs on the host, on the handful of inter-track matches it needs ----
+struct CutEdge { int32_t ta, tb; float sim; };
+// component (pre-cut) of every track, and the inter-track matches of components above the cap, compacted
+__global__ void k_track_comp(int64_t cap, const uint32_t *counts, const uint32_t *mlabel, const uint32_t *rank, int32_t *tcomp) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < cap && t < (int64_t)counts[CNT_TRACKS]) tcomp[t] = (int32_t)rank[mlabel[t]];
+}
+__global__ void k_cut_edges(int64_t M, const uint32_t *n1, const uint32_t *n2, const float *sim, const int32_t *track, const int32_t *tcomp,
+                            const uint32_t *csize, uint32_t max_nodes, CutEdge *list, uint32_t *n_list) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool keep = false;
+    int32_t ta = 0, tb = 0;
+    if (m < M) {
+        ta = track[n1[m]]; tb = track[n2[m]];
+        keep = ta != tb && csize[tcomp[ta]] > max_nodes;
+    }
+    const uint32_t at = wave_append(keep, n_list);
+    if (keep) list[at] = CutEdge{ta, tb, sim[m]};
+}
+// meta union without the cut edges (solve.cc:346-353): gc[t] = subset of track t inside its oversized component, -1 elsewhere
+__global__ void k_meta_union_cut(int64_t M, const uint32_t *n1, const uint32_t *n2, const int32_t *track, const int32_t *gc, uint32_t *parent) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int32_t ta = track[n1[m]], tb = track[n2[m]];
+    if (ta == tb) return;
+    if (gc[ta] >= 0 && gc[ta] != gc[tb]) return;        // both tracks are in the same oversized component: the edge was cut
+    uf_union(parent, (uint32_t)ta, (uint32_t)tb);
+}
 __global__ void k_init_nodes(int64_t n, int32_t *parent, int32_t *next, int32_t *tail, int32_t *count) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { parent[i] = -1; next[i] = -1; tail[i] = (int32_t)i; count[i] = 1; }
@@ -670,23 +699,91 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         p.devs[device] = dp;
     }
     if (needs_cut) {
-        // The size cap: the deterministic bisection grows a region with a priority queue - sequential, and the meta
-        // graph is small - so it runs on the host (lfr_graph.cpp), fed with the tracks computed here; the component
-        // labels go back to HBM and the pipeline continues on the device.
-        const auto tc = std::chrono::steady_clock::now();
-        if ((rc = p.ensure_host_labels()) != LFR_OK) return rc;
-        std::vector<int64_t> tsz((size_t)p.stats.n_tracks, 0);
-        for (int64_t i = 0; i < N; ++i) ++tsz[p.track[i]];
-        int64_t n_components = 0, n_cut = 0;
-        components_from_tracks(g, p.track, p.stats.n_tracks, tsz, max_nodes, nullptr, nullptr, p.comp, n_components, n_cut);
-        std::vector<int32_t> c32(N);
-        std::vector<int64_t> csz((size_t)n_components, 0);
-        for (int64_t i = 0; i < N; ++i) { c32[i] = (int32_t)p.comp[i]; ++csz[p.comp[i]]; }
-        LFR_HIP_TRY(hipMemcpyAsync(dp->comp, c32.data(), 4 * (size_t)N, hipMemcpyHostToDevice, st));
+        // The size cap.  The deterministic bisection grows a region with a priority queue - sequential, and the meta
+        // graph is tiny next to the match graph - so it runs on the host (lfr_graph.cpp: recursive_cut), but only on what
+        // it needs: the device compacts the inter-track matches of the oversized components (a few per cent of a per cent
+        // of the matches), the host cuts, the subset of every affected track goes back, and the device re-labels.
+        hipEvent_t c0 = nullptr, c1 = nullptr;
+        struct EvPair { hipEvent_t &a, &b; ~EvPair() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } evp{c0, c1};
+        LFR_HIP_TRY(hipEventCreate(&c0)); LFR_HIP_TRY(hipEventCreate(&c1));
+        LFR_HIP_TRY(hipEventRecord(c0, st));
+        const int64_t T = h_counts[CNT_TRACKS];
+        TAKE(tcomp, int32_t, T + 1); TAKE(cut_list, CutEdge, M); TAKE(cut_n, uint32_t, 16); TAKE(gc_dev, int32_t, T + 1);
+        LFR_HIP_TRY(hipMemsetAsync(cut_n, 0, 64, st));
+        hipLaunchKernelGGL(k_track_comp, grid_for(T), dim3(kThreads), 0, st, T, counts, mp, crank, tcomp);
+        hipLaunchKernelGGL(k_cut_edges, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, cut_list, cut_n);
+        uint32_t *h_n = h_counts + 8;
+        LFR_HIP_TRY(hipMemcpyAsync(h_n, cut_n, 4, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(hipStreamSynchronize(st));
-        p.stats.n_components = n_components; p.stats.n_cut_components = n_cut;
-        p.stats.max_component_size = *std::max_element(csz.begin(), csz.end());
-        p.stats.graph_cut_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc).count();
+        const size_t n_cut_edges = h_n[0];
+        std::vector<CutEdge> h_list(n_cut_edges);
+        std::vector<int32_t> h_tcomp((size_t)T), h_gc((size_t)T, -1);
+        std::vector<uint32_t> h_tsize((size_t)T);
+        if (n_cut_edges) LFR_HIP_TRY(hipMemcpyAsync(h_list.data(), cut_list, sizeof(CutEdge) * n_cut_edges, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(hipMemcpyAsync(h_tcomp.data(), tcomp, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(hipMemcpyAsync(h_tsize.data(), tsize, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(hipStreamSynchronize(st));
+        {
+            // meta edges (solve.cc:268-289,322-332): per unordered track pair the sum of the similarities (sums of float32
+            // values in fp64: exact, hence independent of the order) -> int weight 100 * sum
+            struct Key { int32_t comp, t, u; double w; };
+            std::vector<Key> keys(n_cut_edges);
+            for (size_t k = 0; k < n_cut_edges; ++k) {
+                const CutEdge &e = h_list[k];
+                keys[k] = Key{h_tcomp[e.ta], std::min(e.ta, e.tb), std::max(e.ta, e.tb), (double)e.sim};
+            }
+            std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
+                if (a.comp != b.comp) return a.comp < b.comp;
+                if (a.t != b.t) return a.t < b.t;
+                return a.u < b.u;
+            });
+            std::vector<int64_t> tsize64((size_t)T);
+            for (int64_t t = 0; t < T; ++t) tsize64[t] = h_tsize[t];
+            for (size_t lo = 0; lo < keys.size();) {
+                size_t hi = lo;
+                std::vector<std::pair<int, int>> e;
+                std::vector<int> w;
+                while (hi < keys.size() && keys[hi].comp == keys[lo].comp) {
+                    size_t k = hi;
+                    double sum = 0.0;
+                    while (k < keys.size() && keys[k].comp == keys[hi].comp && keys[k].t == keys[hi].t && keys[k].u == keys[hi].u) sum += keys[k++].w;
+                    e.push_back({keys[hi].t, keys[hi].u});
+                    w.push_back(static_cast<int>(100 * sum));                    // solve.cc:329
+                    hi = k;
+                }
+                const auto split = recursive_cut(e, w, tsize64, max_nodes);
+                for (auto &it : split) h_gc[it.first] = it.second;
+                lo = hi;
+            }
+            // (an oversized component without any meta edge is a single track: nothing to cut, it stays whole)
+            p.stats.n_cut_components = 0;
+            {   // count the components above the cap the way the host stage does (with or without meta edges)
+                std::vector<int64_t> csz;
+                for (int64_t t = 0; t < T; ++t) { if ((size_t)h_tcomp[t] >= csz.size()) csz.resize(h_tcomp[t] + 1, 0); csz[h_tcomp[t]] += h_tsize[t]; }
+                for (int64_t c : csz) if (c > max_nodes) ++p.stats.n_cut_components;
+            }
+        }
+        LFR_HIP_TRY(hipMemcpyAsync(gc_dev, h_gc.data(), 4 * (size_t)T, hipMemcpyHostToDevice, st));
+        // drop the cut edges and re-label (solve.cc:345-372), same kernels as the first labelling
+        hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp_parent);
+        hipLaunchKernelGGL(k_meta_union_cut, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, gc_dev, mp_parent);
+        hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, mp_parent, mp);
+        LFR_HIP_TRY(hipMemsetAsync(cflag, 0, 4 * (size_t)(N + 1), st));
+        LFR_HIP_TRY(hipMemsetAsync(csize, 0, 4 * (size_t)N, st));
+        LFR_HIP_TRY(hipMemsetAsync(counts + CNT_MAX_COMP, 0, 4, st));
+        hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
+        if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
+        hipLaunchKernelGGL(k_max_csize, grid_for(N), dim3(kThreads), 0, st, N, counts, csize);
+        hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, dp->track, mp, crank, dp->comp);
+        LFR_HIP_TRY(hipGetLastError());
+        LFR_HIP_TRY(hipEventRecord(c1, st));
+        LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(hipStreamSynchronize(st));          // (the staging vectors above die at scope end)
+        p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
+        float cms = 0.f;
+        LFR_HIP_TRY(hipEventElapsedTime(&cms, c0, c1));
+        p.stats.graph_cut_ms += cms;
     }
     return LFR_OK;
 }

@@ -148,6 +148,10 @@ void components_from_tracks(const Graph &g, const std::vector<int64_t> &track, i
                             int64_t max_nodes, const std::vector<int64_t> *out_off, const std::vector<int64_t> *out_eid,
                             std::vector<int64_t> &comp, int64_t &n_components, int64_t &n_cut);
 
+// recursive_graph_cut (solve.cc:185-250) around bisect_graph: {meta node: subset index} (lfr_graph.cpp)
+std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
+                                           const std::vector<int64_t> &node_weights, int64_t max_weight);
+
 // deterministic substitute for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
 // (solve.cc:192): returns part (0/1) per node id appearing in `edges`.
 void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
