@@ -197,6 +197,9 @@ int lfr_hip_warmup(int device);
  * n_nodes / n_matches will ask for, so that a one-shot caller's timed span pays no allocation; lfr_hip_trim
  * returns every cached slab to the driver. */
 int lfr_hip_reserve(int device, int64_t n_nodes, int64_t n_matches);
+/* Wait for everything the library has in flight on its own streams of `device` (e.g. the upload started by
+ * lfr_graph_to_device). */
+int lfr_hip_synchronize(int device);
 int lfr_hip_trim(int device);
 
 /* Shard `shard_rank` of `shard_world` (see lfr_problem_shard_components) resident on HIP device `device`:

@@ -496,13 +496,13 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 
     // the one read-back of the stage
     LFR_HIP_TRY(hipMemcpyAsync(h_sum, sum, sizeof(AsmSummary), hipMemcpyDeviceToHost, st));
-    LFR_HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(stream_wait(st));
     out.summary = *h_sum;
     if (out.summary.too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
     if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
     if (!expect_workgroup_classes && out.summary.class_begin[KC_BLOCK] < out.summary.n_desc) {
         if ((rc = build_incidence()) != LFR_OK) return rc;
-        LFR_HIP_TRY(hipStreamSynchronize(st));         // the temporaries go back to the cache at return
+        LFR_HIP_TRY(stream_wait(st));         // the temporaries go back to the cache at return
     }
     return LFR_OK;
 }

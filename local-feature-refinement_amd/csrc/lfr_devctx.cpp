@@ -1,6 +1,7 @@
 // Per-device streams + slab caches, pinned host arrays (see lfr_devctx.hpp).
 #include "lfr_devctx.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -29,6 +30,20 @@ size_t env_mb(const char *name, size_t dflt_bytes) {
 }
 
 }  // namespace
+
+hipError_t stream_wait(hipStream_t st) {
+    static const bool spin = [] { const char *e = getenv("LFR_BLOCKING_SYNC"); return !(e && e[0] == '1'); }();
+    if (spin) {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int it = 0;; ++it) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) return hipSuccess;
+            if (q != hipErrorNotReady) return q;
+            if ((it & 63) == 63 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        }
+    }
+    return hipStreamSynchronize(st);
+}
 
 void *host_alloc(size_t bytes, bool *pinned) {
     *pinned = false;

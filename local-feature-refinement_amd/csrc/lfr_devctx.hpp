@@ -76,6 +76,11 @@ struct DevCtx {
     void pinned_release(void *p, size_t bytes);
     void trim();                       // hipFree / hipHostFree everything cached
 };
+// Wait for a stream the way a latency-bound pipeline wants it: poll hipStreamQuery for up to ~200 ms (the blocking
+// hipStreamSynchronize was measured returning 20-30 ms after the GPU had finished when the process had just run many
+// host threads - an interrupt-driven wake-up), then fall back to the blocking call.
+hipError_t stream_wait(hipStream_t st);
+
 // context of HIP device `device` (created on first use: hipSetDevice + two non-blocking streams);
 // nullptr + set_error() when the device does not exist
 DevCtx *dev_ctx(int device);

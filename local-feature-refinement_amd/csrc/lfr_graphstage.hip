@@ -527,6 +527,12 @@ int Problem::ensure_host_labels() const {
 // =================================================================================================
 int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p) {
     const int64_t N = g.n_nodes(), M = g.n_matches();
+    const char *vb = getenv("LFR_VERBOSE");
+    const bool trace = vb && vb[0] == '2';
+    const auto tr0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (trace) fprintf(stderr, "lfr graph stage: %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), what);
+    };
     p.g = &g;
     p.stats = lfr_problem_stats{};
     p.host_batch = false;
@@ -540,6 +546,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     DevCtx *ctx = dg->ctx;
     LFR_HIP_TRY(hipSetDevice(device));
     hipStream_t st = ctx->s_main;
+    lap("device graph ready");
 
     std::shared_ptr<DevProblem> dp(new DevProblem());
     dp->ctx = ctx; dp->graph = dg; dp->N = N;
@@ -555,11 +562,14 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     struct EvGuard { hipEvent_t *e; ~EvGuard() { for (int i = 0; i < 4; ++i) if (e[i]) (void)hipEventDestroy(e[i]); } } ev_guard{ev};
     for (auto &e : ev) LFR_HIP_TRY(hipEventCreate(&e));
+    lap("slabs, pinned block, events");
 
     const uint32_t *n1 = dg->n1, *n2 = dg->n2;
     const float *sim = dg->sim;
     int node_bits = 1;
     while (((int64_t)1 << node_bits) < N) ++node_bits;
+    hipEvent_t ev_begin = nullptr;
+    if (trace) { LFR_HIP_TRY(hipEventCreate(&ev_begin)); LFR_HIP_TRY(hipEventRecord(ev_begin, st)); }
     // everything that starts at zero sits in one block: one memset instead of a dozen
     const size_t zero_mark = arena.top;
     TAKE(counts, uint32_t, CNT_WORDS);
@@ -606,8 +616,16 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
                        dg->node_image, par, next, tail, cnt);
     // ... large ones in parallel rounds (first read-back: is there any?)
+    lap("sorts / connected components / small-component union-find enqueued");
     LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
-    LFR_HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(stream_wait(st));
+    lap("first read-back");
+    if (trace && ev_begin) {
+        float a = 0.f;
+        (void)hipEventElapsedTime(&a, ev_begin, ev[0]);
+        fprintf(stderr, "lfr graph stage: device time of the memsets before the first kernel: %.3f ms (zero block %zu bytes)\n", a, arena.top - zero_mark);
+        (void)hipEventDestroy(ev_begin);
+    }
     DevArena rounds_arena;
     if ((int64_t)h_counts[CNT_MAX_SEG] > serial_limit) {
         const int W = (int)((g.image_names.size() + 63) / 64);
@@ -625,7 +643,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         hipLaunchKernelGGL(k_large_pending, grid_for(M), dim3(kThreads), 0, st, M, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, bits, pa, ctr);
         uint32_t *h_ctr = h_counts + 8;                 // (the pinned block has 16 words; the counts proper use 6)
         LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 4, hipMemcpyDeviceToHost, st));
-        LFR_HIP_TRY(hipStreamSynchronize(st));
+        LFR_HIP_TRY(stream_wait(st));
         uint32_t n_in = h_ctr[0];
         int64_t rounds = 0;
         for (; n_in > 0; ++rounds) {
@@ -636,7 +654,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
             hipLaunchKernelGGL(k_round_eval, grid_for(n_in), dim3(kThreads), 0, st, n_in, pa, par, bits, W, round_hi, minpos, pb, n_out);
             hipLaunchKernelGGL(k_round_accept, grid_for(n_in), dim3(kThreads), 0, st, n_out, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
             LFR_HIP_TRY(hipMemcpyAsync(h_ctr, n_out, 4, hipMemcpyDeviceToHost, st));
-            LFR_HIP_TRY(hipStreamSynchronize(st));
+            LFR_HIP_TRY(stream_wait(st));
             n_in = h_ctr[0];
             std::swap(pa, pb);
         }
@@ -671,8 +689,10 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipEventRecord(ev[3], st));
 
     // the one read-back of the stage
+    lap("tracks / roots / components enqueued");
     LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
-    LFR_HIP_TRY(hipStreamSynchronize(st));
+    LFR_HIP_TRY(stream_wait(st));
+    lap("final read-back");
     const bool needs_cut = (int64_t)h_counts[CNT_MAX_COMP] > max_nodes;      // solve.cc:311-343
     if (const char *dd = getenv("LFR_DEBUG_DUMP")) {      // intermediates of the stage as raw files (debugging aid)
         auto dump = [&](const char *name, const void *dptr, size_t bytes) {
@@ -714,7 +734,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         hipLaunchKernelGGL(k_cut_edges, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, cut_list, cut_n);
         uint32_t *h_n = h_counts + 8;
         LFR_HIP_TRY(hipMemcpyAsync(h_n, cut_n, 4, hipMemcpyDeviceToHost, st));
-        LFR_HIP_TRY(hipStreamSynchronize(st));
+        LFR_HIP_TRY(stream_wait(st));
         const size_t n_cut_edges = h_n[0];
         std::vector<CutEdge> h_list(n_cut_edges);
         std::vector<int32_t> h_tcomp((size_t)T), h_gc((size_t)T, -1);
@@ -722,7 +742,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         if (n_cut_edges) LFR_HIP_TRY(hipMemcpyAsync(h_list.data(), cut_list, sizeof(CutEdge) * n_cut_edges, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(hipMemcpyAsync(h_tcomp.data(), tcomp, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(hipMemcpyAsync(h_tsize.data(), tsize, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
-        LFR_HIP_TRY(hipStreamSynchronize(st));
+        LFR_HIP_TRY(stream_wait(st));
         {
             // meta edges (solve.cc:268-289,322-332): per unordered track pair the sum of the similarities (sums of float32
             // values in fp64: exact, hence independent of the order) -> int weight 100 * sum
@@ -779,7 +799,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(hipGetLastError());
         LFR_HIP_TRY(hipEventRecord(c1, st));
         LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
-        LFR_HIP_TRY(hipStreamSynchronize(st));          // (the staging vectors above die at scope end)
+        LFR_HIP_TRY(stream_wait(st));          // (the staging vectors above die at scope end)
         p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
         float cms = 0.f;
         LFR_HIP_TRY(hipEventElapsedTime(&cms, c0, c1));

@@ -49,6 +49,9 @@ struct Graph {
     std::vector<int64_t> img_off;
     std::vector<uint32_t> img_nodes;
 
+    // ingest temporaries kept mapped until the graph dies (lfr_wire.cpp: large unmaps right before GPU work stall the queues)
+    std::vector<std::shared_ptr<void>> ingest_keepalive;
+
     // the graph's copy in HBM (lfr_assemble.hpp), created on first use by the device pipeline or by
     // lfr_graph_to_device, dropped by lfr_graph_evict_device
     mutable std::vector<std::shared_ptr<DevGraph>> devgs;      // indexed by HIP device ordinal

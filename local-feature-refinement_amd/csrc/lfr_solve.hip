@@ -1141,7 +1141,7 @@ int ensure_mirrors(lfr_batch *b) {
         HIP_TRY(hipMemcpyAsync(trk.data(), b->d_desc_tracks, 4 * nd, hipMemcpyDeviceToHost, st));
     }
     if (nn) HIP_TRY(hipMemcpyAsync(b->node_ids.data(), b->d_node_ids, 4 * nn, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(lfr::stream_wait(st));
     for (size_t i = 0; i < nd; ++i) { b->desc_component[i] = comp[i]; b->desc_class[i] = (int32_t)cls[i]; b->desc_tracks[i] = (int32_t)trk[i]; }
     b->mirrors_valid = true;
     return LFR_OK;
@@ -1322,6 +1322,9 @@ int lfr_hip_warmup(int device) {
     hipLaunchKernelGGL(lfr_warmup_kernel, dim3(1), dim3(64), 0, nullptr, (int *)nullptr);   // loads this unit's code object
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
+    int level = 2;                                   // LFR_WARMUP_LEVEL: 0 = context only, 1 = + toy graph, 2 = + a million matches
+    if (const char *e = getenv("LFR_WARMUP_LEVEL")) level = atoi(e);
+    if (level < 1) return LFR_OK;
     // HIP also resolves every kernel on its first launch (~1 ms each; the graph stage and the assembly launch
     // about forty different ones, rocPRIM's included): push a toy graph - one 18-node track (workgroup kernel)
     // and one 3-node track (packed kernel) - through the whole device pipeline once.  Best effort.
@@ -1350,6 +1353,46 @@ int lfr_hip_warmup(int device) {
             lfr_batch_create(pr, device, 0, 1, LFR_TUKEY_CERES1, &bt) == LFR_OK) {
             lfr_solve_stats st;
             (void)lfr_batch_solve(bt, nullptr, &st);
+            const double *view = nullptr;
+            (void)lfr_batch_positions_view(bt, &view);
+        }
+        lfr_batch_free(bt); lfr_problem_free(pr); lfr_graph_free(g);
+    }
+    if (level < 2) return LFR_OK;
+    // rocPRIM picks other kernels (one-sweep radix sort, look-back scans) once the inputs are large: a second pass with a
+    // million matches (170 k four-node tracks, zero flows) resolves those as well, so that a one-shot caller's
+    // "Total time" is not spent loading code.  Best effort, ~30 ms beside the caller's parse.
+    {
+        constexpr int kImg = 64, kLen = 4;
+        constexpr int64_t kTracks = 170000;
+        std::vector<std::string> names(kImg);
+        std::vector<const char *> name_ptrs(kImg);
+        std::vector<float> facts(kImg, 1.0f);
+        for (int i = 0; i < kImg; ++i) { names[i] = "warmup" + std::to_string(i); name_ptrs[i] = names[i].c_str(); }
+        // one ImagePair per (image a, image b = a + d): its matches are the tracks whose window covers both
+        std::vector<int32_t> p1, p2;
+        std::vector<int64_t> off{0};
+        std::vector<uint32_t> f1, f2;
+        for (int a = 0; a < kImg; ++a)
+            for (int d = 1; d < kLen; ++d) {
+                const int b = a + d;
+                if (b >= kImg) continue;
+                p1.push_back(a); p2.push_back(b);
+                for (int64_t t = 0; t < kTracks; ++t) {              // track t sits on images s .. s + kLen - 1, s = t % (kImg - kLen + 1)
+                    const int s0 = (int)(t % (kImg - kLen + 1));
+                    if (a >= s0 && b < s0 + kLen) { f1.push_back((uint32_t)t); f2.push_back((uint32_t)t); }
+                }
+                off.push_back((int64_t)f1.size());
+            }
+        const size_t M = f1.size();
+        std::vector<float> sim(M), flows(18 * M, 0.0f);
+        for (size_t m = 0; m < M; ++m) sim[m] = 0.5f + 0.4f * (float)((m * 2654435761u) & 0xffff) / 65536.0f;
+        lfr_graph *g = nullptr; lfr_problem *pr = nullptr; lfr_batch *bt = nullptr;
+        if (lfr_graph_from_arrays(kImg, name_ptrs.data(), facts.data(), (int64_t)p1.size(), p1.data(), p2.data(), off.data(),
+                                  f1.data(), f2.data(), sim.data(), flows.data(), flows.data(), nullptr, 0, &g) == LFR_OK &&
+            lfr_problem_build_hip(g, device, 0, nullptr, &pr) == LFR_OK &&
+            lfr_batch_create(pr, device, 0, 1, LFR_TUKEY_CERES1, &bt) == LFR_OK) {
+            (void)lfr_batch_solve(bt, ctx->s_main, nullptr);
             const double *view = nullptr;
             (void)lfr_batch_positions_view(bt, &view);
         }
@@ -1426,7 +1469,16 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out8, d_out, 64 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(cost_only, d_c, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(lfr::stream_wait(st));
+    return LFR_OK;
+}
+
+int lfr_hip_synchronize(int device) {
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipStreamSynchronize(ctx->s_copy));
+    HIP_TRY(hipStreamSynchronize(ctx->s_main));
     return LFR_OK;
 }
 
@@ -1588,7 +1640,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     b->infos_valid = false;
     if (!stats) return LFR_OK;
 
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(lfr::stream_wait(st));
 #ifdef LFR_PROFILE_PHASES
     {
         unsigned long long h[8 * lfr::KC_COUNT];
@@ -1609,7 +1661,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     b->infos.resize(b->descs.size());
     if (!b->descs.empty()) {
         HIP_TRY(hipMemcpyAsync(b->infos.data(), b->d_infos, b->descs.size() * sizeof(CompInfoDev), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(lfr::stream_wait(st));
     }
     b->infos_valid = true;
     stats->n_components = (int64_t)b->descs.size();
@@ -1689,7 +1741,7 @@ int lfr_batch_positions_view(lfr_batch *b, const double **positions) {
     hipStream_t st = b->ctx->s_main;
     if (b->n_solves > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev[1], 0));        // end of the latest solve, whatever stream it ran on
     HIP_TRY(hipMemcpyAsync(b->h_positions, b->d_positions, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(lfr::stream_wait(st));
     *positions = b->h_positions;
     return LFR_OK;
 }

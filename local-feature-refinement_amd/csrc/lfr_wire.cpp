@@ -7,6 +7,9 @@
 #include <fcntl.h>
 #include <unistd.h>
 
+#include <chrono>
+#include <atomic>
+#include <memory>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -218,7 +221,11 @@ static int scan_threads() {
     return (int)std::max(1u, std::min(h ? h : 1u, 32u));
 }
 
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, const std::set<std::string> &banned) {
+    const bool verbose = getenv("LFR_VERBOSE") != nullptr;
+    const double t_a = wall_ms();
     // pass A
     std::vector<Cursor> pairs;
     {
@@ -237,6 +244,7 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
     }
     const int64_t P = (int64_t)pairs.size();
     if (P == 0) return LFR_OK;
+    const double t_b = wall_ms();
     // pass B
     int T = (int)std::max<int64_t>(1, std::min<int64_t>(scan_threads(), (int64_t)(size >> 22) + 1));
     std::vector<int64_t> cuts(T + 1, P);
@@ -268,6 +276,7 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
             set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
         return b.rc;
     }
+    const double t_c = wall_ms();
     // pass C
     struct Job { int32_t buf; int64_t src, dst, n; };
     std::vector<Job> jobs;
@@ -295,8 +304,10 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
             M += r.count;
         }
     }
+    const double t_d = wall_ms();
     // pass D
     g.m_sim.resize(M); g.m_disp1.resize(18 * M); g.m_disp2.resize(18 * M);
+    const double t_d2 = wall_ms();
     {
         const int TJ = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, jobs.size()));
         auto work = [&](int t) {
@@ -313,6 +324,412 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
         work(0);
         for (auto &x : th) x.join();
     }
+    if (verbose)
+        fprintf(stderr, "lfr scanner: %zu bytes, %lld pairs, %d threads: split %.1f ms, decode %.1f ms, intern+number %.1f ms, alloc %.1f ms, move %.1f ms\n",
+                size, (long long)P, T, t_b - t_a, t_c - t_b, t_d - t_c, t_d2 - t_d, wall_ms() - t_d2);
+    return LFR_OK;
+}
+
+
+// ---- whole-input parallel scanner (all files of a matches set at once) ------------------------------------
+// Every order-dependent rule of solve.cc:438-478 is a "first appearance" rule (image list, first fact wins, node
+// ids: node1 before node2, match by match, file by file), and first appearance = minimum position, which is
+// order-free to compute:
+//   0  mmap all files, fault the pages in from T threads (the page-cache walk is the slowest sequential step otherwise)
+//   A  per file: split the top level into ImagePair cursors            (sequential per file, files in parallel)
+//   B  chunks of pairs (balanced by bytes): decode into thread-local SoA buffers, distinct image names per chunk in
+//      order of local first appearance
+//   C  merge the chunk name lists in chunk order -> global image ids, first facts, banned filter (a few thousand names)
+//   D  per pair: global match offset (prefix sum over the kept pairs)
+//   E  nodes: a concurrent hash map (image, feature) -> smallest position (2 * match + side), filled from all threads
+//      with CAS / atomic-min; occupied slots sorted by position = node ids in order of first appearance; one more
+//      parallel pass writes the endpoints of every match.  Meanwhile another thread allocates the (pinned) arrays
+//      of similarities and flows and moves the decoded values in.
+namespace {
+
+struct NodeSlot { std::atomic<uint64_t> key; std::atomic<uint64_t> val; };      // key = (image << 32 | feature) + 1, 0 = empty
+
+struct MappedFile {
+    const uint8_t *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    ~MappedFile() {
+        if (data && size) munmap((void *)data, size);
+        if (fd >= 0) close(fd);
+    }
+};
+
+template <class F>
+void run_threads(int T, F f) {
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; ++t) th.emplace_back(f, t);
+    f(0);
+    for (auto &x : th) x.join();
+}
+
+}  // namespace
+
+static int parse_all(const std::vector<std::string> &paths, Graph &g, const std::set<std::string> &banned) {
+    const bool verbose = getenv("LFR_VERBOSE") != nullptr;
+    const double t0 = wall_ms();
+    const int T = scan_threads();
+    // ---- 0: map + prefault
+    std::vector<MappedFile> files(paths.size());
+    size_t total_bytes = 0;
+    for (size_t i = 0; i < paths.size(); ++i) {
+        MappedFile &mf = files[i];
+        mf.fd = open(paths[i].c_str(), O_RDONLY);
+        if (mf.fd < 0) { set_error("cannot open %s", paths[i].c_str()); return LFR_ERR_IO; }
+        struct stat st;
+        if (fstat(mf.fd, &st) != 0) { set_error("cannot stat %s", paths[i].c_str()); return LFR_ERR_IO; }
+        mf.size = (size_t)st.st_size;
+        if (mf.size) {
+            void *m = mmap(nullptr, mf.size, PROT_READ, MAP_PRIVATE, mf.fd, 0);
+            if (m == MAP_FAILED) { mf.size = 0; set_error("cannot mmap %s", paths[i].c_str()); return LFR_ERR_IO; }
+            mf.data = (const uint8_t *)m;
+        }
+        total_bytes += mf.size;
+    }
+    {
+        std::atomic<size_t> cursor{0};
+        const size_t kStep = (size_t)8 << 20;
+        std::vector<std::pair<const uint8_t *, size_t>> spans;
+        for (auto &mf : files) for (size_t o = 0; o < mf.size; o += kStep) spans.push_back({mf.data + o, std::min(kStep, mf.size - o)});
+        volatile uint64_t sink = 0;
+        run_threads((int)std::max<size_t>(1, std::min<size_t>((size_t)T, spans.size())), [&](int) {
+            uint64_t acc = 0;
+            for (;;) {
+                const size_t k = cursor.fetch_add(1);
+                if (k >= spans.size()) break;
+                for (size_t o = 0; o < spans[k].second; o += 4096) acc += spans[k].first[o];
+            }
+            sink = sink + acc;
+        });
+    }
+    const double t_a = wall_ms();
+    // ---- A: pair cursors.  The top level is a chain of (tag 0x0A, length, ImagePair) records: finding record k needs
+    // record k-1's length, one dependent cache miss per pair (846 k of them in a 605 MB file = 0.2 s).  So a big file is
+    // cut into segments; each segment's thread GUESSES a record start at/after its cut (a position from which several
+    // records in a row parse as ImagePairs whose first field is a string), walks on from there, and the walks are
+    // then chained: a segment's walk must end exactly where the next one began, otherwise (a wrong guess, or a file
+    // that is not a clean chain) that stretch is re-walked sequentially.  The result is the sequential split, always.
+    std::vector<std::vector<Cursor>> file_pairs(files.size());
+    std::vector<int> file_rc(files.size(), LFR_OK);
+    auto walk = [](const uint8_t *base, const uint8_t *from, const uint8_t *until, const uint8_t *end, std::vector<Cursor> &out,
+                   const uint8_t *&stopped_at) -> int {
+        // records that START before `until`; stopped_at = start of the first record not taken
+        Cursor c{from, end};
+        (void)base;
+        while (!c.done() && c.p < until) {
+            const uint64_t key = c.varint();
+            const int field = (int)(key >> 3), wt = (int)(key & 7);
+            if (!c.ok || field == 0) return LFR_ERR_PARSE;
+            if (field == 1 && wt == 2) {
+                Cursor pc = c.sub();
+                if (!c.ok) return LFR_ERR_PARSE;
+                out.push_back(pc);
+            } else { c.skip(wt); if (!c.ok) return LFR_ERR_PARSE; }
+        }
+        stopped_at = c.p;
+        return LFR_OK;
+    };
+    auto plausible_start = [](const uint8_t *p, const uint8_t *end) -> bool {
+        // kCheck records in a row: tag 0x0A, a length that fits, and inside: tag 0x0A + a short string (image_name1)
+        constexpr int kCheck = 6;
+        Cursor c{p, end};
+        for (int k = 0; k < kCheck; ++k) {
+            if (c.done()) return k > 0;
+            if (*c.p != 0x0A) return false;
+            ++c.p;
+            Cursor pc = c.sub();
+            if (!c.ok) return false;
+            if (pc.p < pc.end) {
+                if (*pc.p != 0x0A) return false;
+                ++pc.p;
+                const uint64_t len = pc.varint();
+                if (!pc.ok || len > 4096 || (uint64_t)(pc.end - pc.p) < len) return false;
+            }
+        }
+        return true;
+    };
+    for (size_t i = 0; i < files.size(); ++i) {
+        const MappedFile &mf = files[i];
+        const uint8_t *b = mf.data, *e = mf.data + mf.size;
+        size_t seg_bytes = (size_t)8 << 20;                                                         // >= 8 MB per segment
+        if (const char *sb = getenv("LFR_SCANNER_SEGMENT_BYTES")) seg_bytes = (size_t)std::max(64ll, atoll(sb));   // (tests: tiny segments)
+        const int S = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, mf.size / seg_bytes));
+        auto &out = file_pairs[i];
+        if (S <= 1) {
+            const uint8_t *stop = b;
+            out.reserve(mf.size / 600 + 16);
+            file_rc[i] = mf.size ? walk(b, b, e, e, out, stop) : LFR_OK;
+            continue;
+        }
+        std::vector<const uint8_t *> start(S, nullptr), stop(S, nullptr);
+        std::vector<std::vector<Cursor>> seg(S);
+        std::vector<int> rcs(S, LFR_OK);
+        run_threads(S, [&](int t) {
+            const uint8_t *cut = b + mf.size / S * t, *next_cut = t + 1 < S ? b + mf.size / S * (t + 1) : e;
+            const uint8_t *p = cut;
+            if (t > 0) {
+                const uint8_t *limit = std::min(next_cut, cut + ((size_t)4 << 20));
+                while (p < limit && !plausible_start(p, e)) ++p;
+                if (p >= limit) { start[t] = nullptr; return; }          // no guess: the chain step re-walks this stretch
+            }
+            start[t] = p;
+            seg[t].reserve((size_t)(next_cut - cut) / 600 + 16);
+            rcs[t] = walk(b, p, next_cut, e, seg[t], stop[t]);
+        });
+        // chain
+        const uint8_t *pos = b;
+        int rc = LFR_OK;
+        for (int t = 0; t < S && rc == LFR_OK; ++t) {
+            const uint8_t *next_cut = t + 1 < S ? b + mf.size / S * (t + 1) : e;
+            if (start[t] == pos && rcs[t] == LFR_OK) {
+                out.insert(out.end(), seg[t].begin(), seg[t].end());
+                pos = stop[t];
+            } else if (pos < next_cut) {                               // wrong / missing guess: the sequential truth for this stretch
+                rc = walk(b, pos, next_cut, e, out, pos);
+            }                                                          // (else: the previous walk already ran past this segment)
+        }
+        if (rc == LFR_OK && pos != e) rc = pos < e ? walk(b, pos, e, e, out, pos) : LFR_ERR_PARSE;
+        file_rc[i] = rc;
+    }
+    for (int rc : file_rc) if (rc != LFR_OK) return rc;
+    std::vector<Cursor> pairs;
+    {
+        size_t n = 0;
+        for (auto &v : file_pairs) n += v.size();
+        pairs.reserve(n);
+        for (auto &v : file_pairs) { pairs.insert(pairs.end(), v.begin(), v.end()); std::vector<Cursor>().swap(v); }
+    }
+    const int64_t P = (int64_t)pairs.size();
+    if (P == 0) return LFR_OK;
+    const double t_b = wall_ms();
+    // ---- B: decode (chunks balanced by bytes) + per-chunk distinct names
+    const int TB = (int)std::max<int64_t>(1, std::min<int64_t>(T, (int64_t)(total_bytes >> 22) + 1));
+    std::vector<int64_t> cuts(TB + 1, P);
+    cuts[0] = 0;
+    {
+        std::vector<size_t> pre(P + 1, 0);
+        for (int64_t i = 0; i < P; ++i) pre[i + 1] = pre[i] + (size_t)(pairs[i].end - pairs[i].p);
+        for (int t = 1; t < TB; ++t) {
+            const size_t target = pre[P] / TB * t;
+            cuts[t] = std::max<int64_t>(cuts[t - 1], (int64_t)(std::lower_bound(pre.begin(), pre.end(), target) - pre.begin()));
+            cuts[t] = std::min<int64_t>(cuts[t], P);
+        }
+    }
+    struct ChunkNames {
+        std::vector<std::string> names;          // distinct, in order of local first appearance
+        std::vector<float> facts;                // fact at that first appearance
+        std::unordered_map<std::string, int32_t> index;
+    };
+    std::vector<MatchBuf> bufs(TB);
+    std::vector<PairRec> recs(P);
+    std::vector<ChunkNames> cnames(TB);
+    std::vector<int32_t> loc1(P), loc2(P);       // chunk-local image ids of the pair
+    run_threads(TB, [&](int t) {
+        MatchBuf &b = bufs[t];
+        ChunkNames &cn = cnames[t];
+        const char *last1 = nullptr; uint32_t last1_len = 0; int32_t last1_id = -1;
+        for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+            recs[i].buf = t;
+            const int rc = parse_pair(pairs[i], recs[i], b);
+            if (rc != LFR_OK) { b.rc = rc; return; }
+            const PairRec &r = recs[i];
+            auto intern = [&](const char *nm, uint32_t len, float fact) -> int32_t {
+                std::string key(nm ? nm : "", len);
+                auto it = cn.index.find(key);
+                if (it != cn.index.end()) return it->second;
+                const int32_t id = (int32_t)cn.names.size();
+                cn.index.emplace(key, id); cn.names.push_back(std::move(key)); cn.facts.push_back(fact);
+                return id;
+            };
+            // (pairs usually come grouped by their first image: one string hash per pair instead of two)
+            if (last1_id >= 0 && r.len1 == last1_len && (r.len1 == 0 || memcmp(r.name1, last1, r.len1) == 0)) loc1[i] = last1_id;
+            else { loc1[i] = intern(r.name1, r.len1, r.fact1); last1 = r.name1; last1_len = r.len1; last1_id = loc1[i]; }
+            loc2[i] = intern(r.name2, r.len2, r.fact2);
+        }
+    });
+    for (auto &b : bufs) if (b.rc != LFR_OK) {
+        if (b.rc == LFR_ERR_UNSUPPORTED)
+            set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
+        return b.rc;
+    }
+    const double t_c = wall_ms();
+    // ---- C: global image ids in order of first appearance over the KEPT pairs (solve.cc:444-451)
+    // A name first seen in a banned pair must not enter the list there, and "first appearance" inside a chunk must skip
+    // banned pairs too: mark banned names per chunk, then walk every chunk's kept pairs for names not yet interned.
+    std::vector<std::vector<uint8_t>> cbanned(TB);
+    for (int t = 0; t < TB; ++t) {
+        cbanned[t].resize(cnames[t].names.size());
+        for (size_t k = 0; k < cnames[t].names.size(); ++k) cbanned[t][k] = banned.count(cnames[t].names[k]) ? 1 : 0;
+    }
+    std::vector<std::vector<int32_t>> cglobal(TB);
+    const size_t images_before = g.image_names.size();
+    (void)images_before;
+    for (int t = 0; t < TB; ++t) {
+        cglobal[t].assign(cnames[t].names.size(), -1);
+        size_t pending = cnames[t].names.size();
+        for (int64_t i = cuts[t]; i < cuts[t + 1] && pending > 0; ++i) {
+            const int32_t a = loc1[i], b = loc2[i];
+            if (cbanned[t][a] || cbanned[t][b]) continue;
+            // first fact wins = the fact carried by the first KEPT pair that names the image (solve.cc:449,451)
+            if (cglobal[t][a] < 0) { cglobal[t][a] = g.intern_image(cnames[t].names[a], recs[i].fact1); --pending; }
+            if (cglobal[t][b] < 0) { cglobal[t][b] = g.intern_image(cnames[t].names[b], recs[i].fact2); --pending; }
+        }
+    }
+    // ---- D: global match offsets of the kept pairs
+    std::vector<int64_t> moff(P + 1, 0);
+    const int64_t M0 = g.n_matches();
+    {
+        int64_t acc = M0;
+        for (int t = 0; t < TB; ++t)
+            for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+                moff[i] = acc;
+                if (!(cbanned[t][loc1[i]] || cbanned[t][loc2[i]])) acc += recs[i].count;
+                else recs[i].count = -recs[i].count - 1;            // banned: remember it (count < 0)
+            }
+        moff[P] = acc;
+    }
+    const int64_t M = moff[P];
+    const double t_d = wall_ms();
+    // ---- E: node numbering (concurrent first-position map) beside the allocation + move of similarities and flows
+    std::thread mover([&] {
+        g.m_sim.resize((size_t)M); g.m_disp1.resize((size_t)18 * M); g.m_disp2.resize((size_t)18 * M);
+        std::atomic<int64_t> next{0};
+        run_threads(TB, [&](int) {
+            for (;;) {
+                const int64_t lo = next.fetch_add(4096);
+                if (lo >= P) break;
+                const int64_t hi = std::min<int64_t>(P, lo + 4096);
+                for (int64_t i = lo; i < hi; ++i) {
+                    const PairRec &r = recs[i];
+                    if (r.count <= 0) continue;
+                    const MatchBuf &b = bufs[r.buf];
+                    memcpy(&g.m_sim[moff[i]], &b.sim[r.first], sizeof(float) * r.count);
+                    memcpy(&g.m_disp1[18 * moff[i]], &b.d1[18 * r.first], sizeof(float) * 18 * r.count);
+                    memcpy(&g.m_disp2[18 * moff[i]], &b.d2[18 * r.first], sizeof(float) * 18 * r.count);
+                }
+            }
+        });
+    });
+    const int64_t n_new = M - M0;
+    // existing nodes of the graph (an earlier call on the same handle): seed the map with their ids
+    uint64_t cap = 1024;
+    while (cap < (uint64_t)(2 * n_new + g.n_nodes()) * 3 / 2 + 16) cap <<= 1;        // load <= 2/3 even if every endpoint is a new node
+    std::unique_ptr<NodeSlot[]> slots(new NodeSlot[cap]);
+    const uint64_t mask = cap - 1;
+    run_threads(TB, [&](int t) {
+        const uint64_t lo = cap / TB * t, hi = t == TB - 1 ? cap : cap / TB * (t + 1);
+        for (uint64_t k = lo; k < hi; ++k) { slots[k].key.store(0, std::memory_order_relaxed); slots[k].val.store(~0ull, std::memory_order_relaxed); }
+    });
+    const int64_t N0 = g.n_nodes();
+    auto touch = [&](uint64_t key, uint64_t pos) {
+        uint64_t h = mix64(key) & mask;
+        for (;;) {
+            uint64_t cur = slots[h].key.load(std::memory_order_acquire);
+            if (cur == 0) {
+                uint64_t expected = 0;
+                if (slots[h].key.compare_exchange_strong(expected, key + 1, std::memory_order_acq_rel)) cur = key + 1;
+                else cur = expected;
+            }
+            if (cur == key + 1) {
+                uint64_t v = slots[h].val.load(std::memory_order_relaxed);
+                while (pos < v && !slots[h].val.compare_exchange_weak(v, pos, std::memory_order_relaxed)) {}
+                return;
+            }
+            h = (h + 1) & mask;
+        }
+    };
+    for (int64_t n = 0; n < N0; ++n) touch(((uint64_t)(uint32_t)g.node_image[n] << 32) | g.node_feat[n], (uint64_t)n);   // positions below every new one
+    const uint64_t pos_base = (uint64_t)N0;
+    run_threads(TB, [&](int t) {
+        for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+            const PairRec &r = recs[i];
+            if (r.count <= 0) continue;
+            const uint64_t i1 = (uint64_t)(uint32_t)cglobal[t][loc1[i]] << 32, i2 = (uint64_t)(uint32_t)cglobal[t][loc2[i]] << 32;
+            const MatchBuf &b = bufs[r.buf];
+            for (int64_t k = 0; k < r.count; ++k) {
+                const uint64_t pos = pos_base + 2 * (uint64_t)(moff[i] - M0 + k);
+                touch(i1 | b.f1[r.first + k], pos);                      // node1 before node2 (solve.cc:474-475)
+                touch(i2 | b.f2[r.first + k], pos + 1);
+            }
+        }
+    });
+    // occupied slots in order of first position = node ids.  Positions are distinct integers below N0 + 2 * n_new: every
+    // slot drops its index at its position, a prefix count over the positions ranks them - no sort.
+    const uint64_t n_pos = (uint64_t)N0 + 2 * (uint64_t)n_new;
+    std::vector<uint32_t> slot_at(n_pos, 0);                   // slot index + 1 (the table has < 2^32 slots: checked below)
+    if (cap >= ((uint64_t)1 << 32)) { mover.join(); set_error("matches file too large for the node table"); return LFR_ERR_UNSUPPORTED; }
+    run_threads(TB, [&](int t) {
+        const uint64_t lo = cap / TB * t, hi = t == TB - 1 ? cap : cap / TB * (t + 1);
+        for (uint64_t k = lo; k < hi; ++k)
+            if (slots[k].key.load(std::memory_order_relaxed)) slot_at[slots[k].val.load(std::memory_order_relaxed)] = (uint32_t)k + 1;
+    });
+    std::vector<int64_t> chunk_count(TB + 1, 0);
+    run_threads(TB, [&](int t) {
+        int64_t c = 0;
+        for (uint64_t q = n_pos * t / TB; q < n_pos * (t + 1) / TB; ++q) c += slot_at[q] != 0;
+        chunk_count[t + 1] = c;
+    });
+    for (int t = 0; t < TB; ++t) chunk_count[t + 1] += chunk_count[t];
+    const int64_t N = chunk_count[TB];
+    if (N >= ((int64_t)1 << 32)) { mover.join(); set_error("more than 2^32 nodes"); return LFR_ERR_UNSUPPORTED; }
+    g.node_image.resize(N); g.node_feat.resize(N);
+    run_threads(TB, [&](int t) {
+        int64_t n = chunk_count[t];
+        for (uint64_t q = n_pos * t / TB; q < n_pos * (t + 1) / TB; ++q) {
+            if (!slot_at[q]) continue;
+            NodeSlot &sl = slots[slot_at[q] - 1];
+            const uint64_t key = sl.key.load(std::memory_order_relaxed) - 1;
+            sl.val.store((uint64_t)n, std::memory_order_relaxed);                        // position -> node id
+            if (n >= N0) { g.node_image[n] = (int32_t)(key >> 32); g.node_feat[n] = (uint32_t)key; }
+            ++n;
+        }
+    });
+    auto lookup = [&](uint64_t key) -> uint32_t {
+        uint64_t h = mix64(key) & mask;
+        while (slots[h].key.load(std::memory_order_relaxed) != key + 1) h = (h + 1) & mask;
+        return (uint32_t)slots[h].val.load(std::memory_order_relaxed);
+    };
+    g.m_node1.resize((size_t)M); g.m_node2.resize((size_t)M);
+    run_threads(TB, [&](int t) {
+        for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+            const PairRec &r = recs[i];
+            if (r.count <= 0) continue;
+            const uint64_t i1 = (uint64_t)(uint32_t)cglobal[t][loc1[i]] << 32, i2 = (uint64_t)(uint32_t)cglobal[t][loc2[i]] << 32;
+            const MatchBuf &b = bufs[r.buf];
+            for (int64_t k = 0; k < r.count; ++k) {
+                g.m_node1[moff[i] + k] = lookup(i1 | b.f1[r.first + k]);
+                g.m_node2[moff[i] + k] = lookup(i2 | b.f2[r.first + k]);
+            }
+        }
+    });
+    const double t_e = wall_ms();
+    mover.join();
+    // Do NOT give ~1.3 GB of mappings back to the OS now: unmapping large ranges right before GPU work stalls the device's
+    // queues (measured on this stack: the first kernels after the parse started 25-40 ms late - the whole "Total time" of a
+    // one-shot run - and on time when the ranges stay mapped; the address-space notifier of the GPU driver is the likely
+    // cause).  The decode buffers, the node table and the file mappings ride along with the graph and go when it goes
+    // (lfr_graph_free; a one-shot caller simply exits).  LFR_FREE_INGEST_EARLY=1 restores the immediate release.
+    {
+        const char *early = getenv("LFR_FREE_INGEST_EARLY");
+        if (!(early && early[0] == '1')) {
+            struct Keep {
+                std::vector<MatchBuf> bufs; std::vector<PairRec> recs; std::vector<uint32_t> slot_at;
+                std::unique_ptr<NodeSlot[]> slots; std::vector<MappedFile> files;
+            };
+            auto keep = std::make_shared<Keep>();
+            keep->bufs = std::move(bufs); keep->recs = std::move(recs); keep->slot_at = std::move(slot_at);
+            keep->slots = std::move(slots); keep->files = std::move(files);
+            g.ingest_keepalive.push_back(keep);
+        }
+    }
+    if (verbose)
+        fprintf(stderr, "lfr scanner: %zu bytes in %zu file(s), %lld pairs, %d threads: map+prefault %.1f ms, split %.1f ms, decode %.1f ms, "
+                        "images+offsets %.1f ms, nodes %.1f ms (+%.1f ms waiting for the flow arrays)\n",
+                total_bytes, files.size(), (long long)P, TB, t_a - t0, t_b - t_a, t_c - t_b, t_d - t_c, t_e - t_d, wall_ms() - t_e);
     return LFR_OK;
 }
 
@@ -375,8 +792,17 @@ int lfr_graph_from_files(const char *const *paths, int n_paths, const char *cons
     std::set<std::string> ban;
     for (int i = 0; i < n_banned; ++i) ban.insert(banned[i]);
     lfr_graph *h = new lfr_graph();
-    for (int i = 0; i < n_paths; ++i) {
-        const int rc = parse_matching_path(paths[i], h->g, ban);
+    const char *seq = getenv("LFR_SCANNER_SEQUENTIAL");
+    if (seq && seq[0] == '1') {                        // the file-by-file scanner with the sequential numbering pass (cross-check)
+        for (int i = 0; i < n_paths; ++i) {
+            const int rc = parse_matching_path(paths[i], h->g, ban);
+            if (rc != LFR_OK) { delete h; *out = nullptr; return rc; }
+        }
+    } else {
+        std::vector<std::string> all;
+        for (int i = 0; i < n_paths; ++i) all.push_back(paths[i]);
+        const int rc = parse_all(all, h->g, ban);
+        if (rc == LFR_ERR_PARSE) set_error("Failed to parse proto object.");
         if (rc != LFR_OK) { delete h; *out = nullptr; return rc; }
     }
     h->g.finish();

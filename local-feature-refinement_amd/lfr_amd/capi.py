@@ -90,6 +90,7 @@ def lib():
         "lfr_hip_warmup": (C.c_int, [C.c_int]),
         "lfr_hip_reserve": (C.c_int, [C.c_int, i64, i64]),
         "lfr_hip_trim": (C.c_int, [C.c_int]),
+        "lfr_hip_synchronize": (C.c_int, [C.c_int]),
         "lfr_batch_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, pp]),
         "lfr_batch_free": (None, [vp]),
         "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
@@ -113,7 +114,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",

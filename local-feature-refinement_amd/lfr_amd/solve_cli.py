@@ -116,6 +116,7 @@ def parse_args(argv):
 
 
 def main(argv=None):
+    t_main = time.perf_counter()
     argv = sys.argv[1:] if argv is None else argv
     try:
         args = parse_args(argv)
@@ -127,25 +128,53 @@ def main(argv=None):
         sys.stdout.write("Patch Match graph problem solver\n\n" + usage())
         return 0
 
+    # First thing: load the library and start creating the HIP context on a side thread (a few hundred ms, the longest
+    # fixed cost of a run) - before numpy is even imported; kernel resolution and the slab caches follow on that thread
+    # while this one parses (sizes guessed from the file size: ~230 B per match on the wire, ~2.8 matches per node).
+    import ctypes
+    import threading
+    gpus = [int(x) for x in os.environ.get("LFR_GPUS", "").split(",") if x.strip() != ""]
+    device = gpus[0] if len(gpus) == 1 else int(os.environ.get("LFR_DEVICE", "0"))
+    if args["n_threads_given"] and "LFR_HOST_THREADS" not in os.environ:
+        os.environ["LFR_HOST_THREADS"] = str(max(1, args["n_threads"]))      # read by the scanner / host graph stage
+    try:
+        nbytes = os.path.getsize(args["matches_file"])
+    except OSError:
+        nbytes = 0
+    warm_ms = [0.0]
+    lib_path = os.environ.get("LFR_LIB_OVERRIDE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblfr_hip.so")
+    try:
+        raw = ctypes.CDLL(lib_path)
+    except OSError as e:
+        sys.stderr.write("FATAL: %s (build it with `python __graft_entry__.py`; there is no CPU fallback)\n" % e)
+        return 2
+
+    ctx_ready = threading.Event()
+
+    def _warm():
+        t0 = time.perf_counter()
+        if nbytes > 0:      # creates the context (~0.2 s) and the slab caches; everything after it is optional
+            raw.lfr_hip_reserve(ctypes.c_int(device), ctypes.c_int64(int(nbytes / 230 / 2.8 * 1.1)), ctypes.c_int64(int(nbytes / 230 * 1.1)))
+        ctx_ready.set()
+        # kernel resolution with a toy graph and a million-match graph (~0.35 s): whatever is done when the parse ends is
+        # time the pipeline does not spend loading code; the rest simply runs beside it (LFR_WAIT_WARMUP=1: wait for all of it,
+        # the steadiest "Total time"; LFR_WARMUP_LEVEL=0: context only)
+        raw.lfr_hip_warmup(ctypes.c_int(device))
+        warm_ms[0] = (time.perf_counter() - t0) * 1e3
+    warm = threading.Thread(target=_warm, daemon=True)
+    warm.start()
+    wait_all = os.environ.get("LFR_WAIT_WARMUP") == "1"
+
+    def warm_join():
+        (warm.join if wait_all else ctx_ready.wait)()
     import numpy as np
+    t_imp = time.perf_counter()
     try:
         from . import capi
         capi.lib()
     except (ImportError, OSError) as e:
         sys.stderr.write("FATAL: %s\n" % e)
         return 2
-
-    gpus = [int(x) for x in os.environ.get("LFR_GPUS", "").split(",") if x.strip() != ""]
-    device = gpus[0] if len(gpus) == 1 else int(os.environ.get("LFR_DEVICE", "0"))
-    if args["n_threads_given"] and "LFR_HOST_THREADS" not in os.environ:
-        os.environ["LFR_HOST_THREADS"] = str(max(1, args["n_threads"]))      # read by the scanner / host graph stage
-    # HIP context creation, kernel resolution and the slab caches overlap the parse (sizes guessed from the file
-    # size: ~230 B per match on the wire, ~2.8 matches per node)
-    try:
-        nbytes = os.path.getsize(args["matches_file"])
-    except OSError:
-        nbytes = 0
-    warm = capi.hip_warmup_async(device, n_nodes=int(nbytes / 230 / 2.8 * 1.1), n_matches=int(nbytes / 230 * 1.1))
     try:
         graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"])
     except capi.LfrError as e:
@@ -154,14 +183,20 @@ def main(argv=None):
             return 255
         sys.stderr.write("%s\n" % e)
         return 255
+    t_parsed = time.perf_counter()
     print("# graph nodes: %d" % graph.n_nodes)                            # solve.cc:484
     print("# graph edges: %d" % graph.n_edges)                            # solve.cc:485
     sys.stdout.flush()
     device_pipeline = os.environ.get("LFR_HOST_ASSEMBLY") != "1" and os.environ.get("LFR_HOST_GRAPH_STAGE") != "1"
     if device_pipeline and len(gpus) <= 1 and graph.n_nodes > 0 and os.environ.get("LFR_UPLOAD_IN_TOTAL") != "1":
-        warm.join()
+        warm_join()
         try:
+            t_up = time.perf_counter()
             graph.to_device(device)               # last step of ingest: asynchronous, the pipeline continues from it
+            if os.environ.get("LFR_VERBOSE") == "2":            # diagnostics: how long does the upload itself take here?
+                capi.lib().lfr_hip_synchronize(device)
+                sys.stderr.write("lfr: upload of the graph %.1f ms (waited for; normally it overlaps the graph stage)\n"
+                                 % ((time.perf_counter() - t_up) * 1e3))
         except capi.LfrError as e:
             sys.stderr.write("FATAL: %s\n" % e)
             return 2
@@ -185,7 +220,7 @@ def main(argv=None):
             elif os.environ.get("LFR_HOST_GRAPH_STAGE") == "1":
                 problem = capi.Problem(graph, 0, override, device_assembly=True)
             else:
-                warm.join()
+                warm_join()
                 # several GPUs: each assembles its own shard and gathers that shard's flows zero-copy
                 problem = capi.Problem(graph, 0, override, device_graph_stage=device,
                                        flags=capi.FLOWS_STAY_ON_HOST if len(gpus) > 1 else 0)
@@ -193,6 +228,7 @@ def main(argv=None):
             sys.stderr.write("FATAL: %s\n" % e)
             return 2
         st = problem.stats()
+        t_graph = time.perf_counter()
         print("# tracks: %d" % st["n_tracks"])                            # solve.cc:534
         print("max track size: %d" % st["max_track_size"])                # solve.cc:549
         print("Graph-cut time: %dms" % int(st["graph_cut_ms"]))           # solve.cc:589
@@ -202,7 +238,7 @@ def main(argv=None):
             sys.stderr.write("note: %d component(s) above the size cap were split by the built-in bisection, "
                              "not by Graclus (see DESIGN.md)\n" % st["n_cut_components"])
         sys.stdout.flush()
-        warm.join()
+        warm_join()
         t1 = time.perf_counter()                                          # solve.cc:615
         try:
             variant = os.environ.get("LFR_TUKEY_VARIANT", "ceres1")
@@ -220,9 +256,11 @@ def main(argv=None):
         print("Solver time: %dms" % int((t2 - t1) * 1e3))                 # solve.cc:638
         print("Total time: %dms" % int((t2 - t_start) * 1e3))             # solve.cc:641
         if os.environ.get("LFR_VERBOSE"):
-            sys.stderr.write("lfr: kernels %.3f ms, h2d %.3f ms, d2h %.3f ms, %d components (%d failed, %d not converged)\n"
-                             % (sst["kernel_ms"], sst["h2d_ms"], sst["d2h_ms"], sst["n_components"], sst["n_failed"],
-                                sst["n_no_convergence"]))
+            sys.stderr.write("lfr: graph stage wall %.3f ms (device: tracks %.3f roots %.3f components %.3f ms, %d union-find rounds), "
+                             "solve kernels %.3f ms, assembly %.3f ms, d2h %.3f ms, %d components (%d failed, %d not converged)\n"
+                             % ((t_graph - t_start) * 1e3, st["tracks_ms"], st["roots_ms"], st["graph_cut_ms"], int(st.get("kruskal_rounds", 0)),
+                                sst["kernel_ms"], sst["h2d_ms"], sst["d2h_ms"], sst["n_components"], sst["n_failed"], sst["n_no_convergence"]))
+    t_solved = time.perf_counter()
     try:
         n_outside = graph.write_solution(positions, args["output_file"])
     except capi.LfrError:
@@ -230,6 +268,11 @@ def main(argv=None):
         sys.stderr.write("Failed to write proto object.\n")               # solve.cc:674-677
         return 255
     print("# points with at least one coordinate > 0.5: %d" % n_outside)  # solve.cc:670
+    if os.environ.get("LFR_VERBOSE"):
+        t_end = time.perf_counter()
+        sys.stderr.write("lfr: wall inside main %.3f s = imports %.3f + parse %.3f + upload/graph stage/solve %.3f + write %.3f "
+                         "(HIP context + kernel warm-up on the side thread: %.0f ms)\n"
+                         % (t_end - t_main, t_imp - t_main, t_parsed - t_imp, t_solved - t_parsed, t_end - t_solved, warm_ms[0]))
     return 0
 
 

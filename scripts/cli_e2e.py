@@ -9,5 +9,5 @@ t = time.time(); capi.write_matching_file(pb, ma); print("write .pb %.2f s (%.0f
 for rep in range(2):
     t = time.time()
     r = subprocess.run([os.path.join(ROOT, "multi-view-refinement/build/solve"), "--matches_file", pb, "--output_file", "/tmp/sol.pb"],
-                       capture_output=True, text=True, env=dict(os.environ, LFR_VERBOSE="1"))
+                       capture_output=True, text=True, env=dict(os.environ, LFR_VERBOSE=os.environ.get("LFR_VERBOSE", "1")))
     print("solve CLI wall %.2f s rc=%d" % (time.time() - t, r.returncode)); print(r.stdout.strip()); print(r.stderr.strip())

@@ -176,3 +176,86 @@ def test_apply_displacements_matches_the_consumer_arithmetic(lfr_lib):
         assert (got == want).all()
     with pytest.raises(capi.LfrError):
         g.apply_displacements(pos, names[0], np.zeros((1, 2), np.float32))       # feature_idx out of range
+
+
+def _graph_signature(g):
+    import numpy as np
+    from lfr_amd import capi
+    img, feat = g.nodes()
+    p = capi.Problem(g, device_assembly=True)              # labels only (host stage): a fingerprint of endpoints + similarities
+    t, r, c = p.labels()
+    return (g.n_nodes, g.n_edges, g.image_names(), [float(x) for x in g.image_facts()], img.tolist(), feat.tolist(),
+            t.tolist(), r.tolist(), c.tolist())
+
+
+@pytest.mark.parametrize("n_parts", [1, 3])
+@pytest.mark.parametrize("banned", [(), ("000003.png", "000011.png")])
+def test_parallel_scanner_equals_the_sequential_one(lfr_lib, tmp_path, monkeypatch, n_parts, banned):
+    """the whole-input parallel scanner (first-appearance = minimum position: images, first facts,
+    node ids) against the file-by-file scanner with the sequential numbering pass, on `.part.N` files (solve.cc:416-424),
+    with banned images (solve.cc:444-446), differing facts for one image (first wins, solve.cc:449-451) and
+    duplicated matches - same nodes, same labels, same solution bytes."""
+    import numpy as np
+    from lfr_amd import capi, synthetic
+    ma = synthetic.generate(seed=31, n_images=16, n_tracks=400, eps_out=0.02)
+    pairs = ma.to_pairs()
+    pairs[5]["fact1"] = 0.5                                   # a later, different fact for an image seen before: ignored
+    pairs[7]["matches"] = pairs[7]["matches"] + pairs[7]["matches"][:2]      # duplicates are kept (solve.cc:476-478)
+    base = tmp_path / "m.pb"
+    cut = [len(pairs) * k // n_parts for k in range(n_parts + 1)]
+    for k in range(n_parts):
+        path = base if n_parts == 1 else tmp_path / ("m.pb.part.%d" % k)
+        path.write_bytes(wire.encode_matching_file(pairs[cut[k]:cut[k + 1]]))
+    monkeypatch.setenv("LFR_HOST_THREADS", "5")
+    monkeypatch.setenv("LFR_SCANNER_SEGMENT_BYTES", "3000")        # several speculative segments per (small) file
+    monkeypatch.delenv("LFR_SCANNER_SEQUENTIAL", raising=False)
+    g_par = capi.Graph.from_matches_file(str(base), banned)
+    monkeypatch.setenv("LFR_SCANNER_SEQUENTIAL", "1")
+    g_seq = capi.Graph.from_matches_file(str(base), banned)
+    assert _graph_signature(g_par) == _graph_signature(g_seq)
+    pos = np.random.default_rng(1).uniform(-0.4, 0.4, (g_par.n_nodes, 2))
+    g_par.write_solution(pos, str(tmp_path / "a.sol"))
+    g_seq.write_solution(pos, str(tmp_path / "b.sol"))
+    assert (tmp_path / "a.sol").read_bytes() == (tmp_path / "b.sol").read_bytes()
+    for b in banned:
+        assert b not in g_par.image_names()
+
+
+def test_parallel_scanner_rejects_what_the_sequential_one_rejects(lfr_lib, tmp_path):
+    from lfr_amd import capi
+    bad = tmp_path / "bad.pb"
+    bad.write_bytes(b"\x0a\xff\xff\xff\xff\x0f" + b"\x00" * 10)       # a length that runs past the end of the file
+    with pytest.raises(capi.LfrError) as e:
+        capi.Graph.from_matches_file(str(bad))
+    assert e.value.code == -3
+    empty = tmp_path / "empty.pb"
+    empty.write_bytes(b"")
+    g = capi.Graph.from_matches_file(str(empty))
+    assert g.n_nodes == 0 and g.n_edges == 0
+
+
+def test_speculative_split_survives_misleading_bytes(lfr_lib, tmp_path, monkeypatch):
+    """The parallel top-level split guesses record starts inside each segment; image names and flow values that look like
+    record headers (0x0A, small lengths) must at worst cost a sequential re-walk of that stretch, never a different graph."""
+    import numpy as np
+    from lfr_amd import capi, synthetic
+    ma = synthetic.generate(seed=33, n_images=9, n_tracks=300, eps_out=0.05)
+    pairs = ma.to_pairs()
+    for k, p in enumerate(pairs):                               # names full of record-start look-alikes
+        p["image_name1"] = "\n\x02\n\x00" + p["image_name1"] + "\n\x03\n\x01a"
+        p["image_name2"] = "\n\x04\n\x02ab" + p["image_name2"]
+    tricky = np.frombuffer(b"\n\x02\n\x00", dtype=np.float32)[0]       # a float32 whose bytes spell a tiny record
+    for p in pairs[::3]:
+        for m in p["matches"]:
+            m["disp1"] = [(float(tricky), float(tricky))] * 9
+    path = tmp_path / "t.pb"
+    path.write_bytes(wire.encode_matching_file(pairs))
+    sigs = []
+    for seg in ("64", "257", "5000", "100000000"):
+        monkeypatch.setenv("LFR_SCANNER_SEGMENT_BYTES", seg)
+        monkeypatch.setenv("LFR_HOST_THREADS", "7")
+        sigs.append(_graph_signature(capi.Graph.from_matches_file(str(path))))
+    monkeypatch.setenv("LFR_SCANNER_SEQUENTIAL", "1")
+    ref = _graph_signature(capi.Graph.from_matches_file(str(path)))
+    for sg in sigs:
+        assert sg == ref
