@@ -398,6 +398,7 @@ int build_problem(const Graph &g, int64_t max_nodes, const int64_t *component_ov
     std::vector<int64_t> ccuts;                       // component ranges balanced by node count
     {
         int chunks = (int)std::max<int64_t>(1, std::min<int64_t>(T, N / 20000));
+        if (component_override) chunks = 1;       // a side-car may split a track over components: seen_track[] would be shared between threads
         ccuts.push_back(0);
         for (int c = 1; c < chunks; ++c) {
             const int64_t target = N * c / chunks;

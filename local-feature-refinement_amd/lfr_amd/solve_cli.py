@@ -235,8 +235,10 @@ def main(argv=None):
         print("# components: %d" % st["n_components"])                    # solve.cc:591
         print("max component size: %d" % st["max_component_size"])        # solve.cc:606
         if st["n_cut_components"]:
-            sys.stderr.write("note: %d component(s) above the size cap were split by the built-in bisection, "
-                             "not by Graclus (see DESIGN.md)\n" % st["n_cut_components"])
+            sys.stderr.write("note: %d component(s) above the size cap (#images nodes) were split by the built-in deterministic "
+                             "bisection, not by COLMAP/Graclus as the reference does (solve.cc:192): the refined positions of this input are "
+                             "NOT reference-equivalent; supply the reference's components through LFR_COMPONENTS_FILE for that "
+                             "(DESIGN.md, section 3)\n" % st["n_cut_components"])
         sys.stdout.flush()
         warm_join()
         t1 = time.perf_counter()                                          # solve.cc:615
