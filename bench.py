@@ -219,8 +219,8 @@ def main():
     if rank == 0:
         serial = os.environ.get("LFR_SERIAL_CLASSES") == "1"
         kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,6>", "(retired)",
-                        "solve_group_kernel<32,1,6>", "solve_group_kernel<32,2,5>", "solve_block_kernel<lds>",
-                        "solve_block_kernel<hbm>"]
+                        "solve_group_kernel<32,1,6>", "solve_group_kernel<32,2,5>", "solve_block_kernel<lds,rows<=88>",
+                        "solve_block_kernel<lds,rows<=130>", "solve_block_kernel<lds,rows<=192>", "solve_block_kernel<hbm>"]
         if not serial:      # one launch for all packed classes; its events sit in the slot of the largest class
             kernel_names[dom if dom < 5 else 0] = "solve_packed_kernel"
         dur_s = cls_ms[dom] * 1e-3
@@ -250,7 +250,7 @@ def main():
                                         "the kernel does not move these bytes, so this is not a roofline fraction"},
         }
         res["all_kernels_ms"] = tot_ms
-        keep = range(7) if serial else [dom if dom < 5 else 0, 5, 6]
+        keep = range(9) if serial else [dom if dom < 5 else 0, 5, 6, 7, 8]
         res["class_ms"] = {kernel_names[i]: round(float(cls_ms[i]), 4) for i in keep if cls_edges[i] > 0}
         res["class_edges"] = {kernel_names[i]: int(cls_edges[i]) for i in keep if cls_edges[i] > 0}
         res["setup_ms"] = {"generate": t_gen * 1e3, "ingest_arrays": t_ingest * 1e3,
@@ -337,8 +337,8 @@ def main():
                 "workload": "config5 stand-in: synthetic match graph, 96 images, 2000 tracks of 48-96 nodes, 2 %% wrong matches (components above the "
                             "size cap are cut), %d directed edges, %d components" % (st5["n_edges"], st5["n_components"]),
                 "ms_per_step": ms5, "edges_per_s": st5["n_edges"] / (ms5 * 1e-3), "tracks_per_s": st5["n_tracks"] / (ms5 * 1e-3), "steps": n5,
-                "kernel_ms": {kernel_names[i]: round(float(c5[i]), 3) for i in range(7) if e5[i] > 0},
-                "kernel_edges": {kernel_names[i]: int(e5[i]) for i in range(7) if e5[i] > 0},
+                "kernel_ms": {kernel_names[i]: round(float(c5[i]), 3) for i in range(9) if e5[i] > 0},
+                "kernel_edges": {kernel_names[i]: int(e5[i]) for i in range(9) if e5[i] > 0},
                 "total_span_resident_graph_ms": sp5["ms"], "graph_stage": {k: p5.stats()[k] for k in ("tracks_ms", "roots_ms", "graph_cut_ms", "kruskal_rounds", "n_cut_components")},
                 "mean_iterations": st5["sum_iterations"] / max(1, st5["n_components"]), "failed": st5["n_failed"], "no_convergence": st5["n_no_convergence"],
                 "setup_s": t_prep5,

@@ -215,8 +215,9 @@ void lfr_batch_free(lfr_batch *b);
 int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
 /* HIP-event timings of one of the last 64 lfr_batch_solve calls (solves_back = 0: the latest);
  * waits for that solve to finish.  class_ms / class_edges: LFR_NUM_KERNEL_CLASSES entries, one
- * per kernel launch (packed <8,1,3>, <16,1,6>, a retired slot, <32,1,6>, <32,2,5>, block, global-matrix). */
-#define LFR_NUM_KERNEL_CLASSES 7
+ * per kernel launch (packed <8,1,3>, <16,1,6>, a retired slot, <32,1,6>, <32,2,5>; workgroup per component with the matrix
+ * in LDS: <= 88 rows, <= 130 rows, <= 192 rows; workgroup per component with the matrix in HBM). */
+#define LFR_NUM_KERNEL_CLASSES 9
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written.  Waits for the
  * latest lfr_batch_solve of this batch, whatever stream it was issued on. */

@@ -78,25 +78,27 @@ __global__ void k_count_tracks(int64_t n_tracks, const uint32_t *t_size, const i
     if (t_size[t] >= 2) atomicAdd(&c_tracks[t_comp[t]], 1u);
 }
 
-__device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges) {
+__device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uint32_t block_max) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
     if (rows <= 16 && n_edges <= 96) return KC_G16;
     if (rows <= 24 && n_edges <= 192) return KC_G64_2;
     if (rows <= 32 && n_edges <= 320) return KC_G64_4;
-    if (rows <= (uint32_t)kBlockMaxRows) return KC_BLOCK;
+    if (rows <= min((uint32_t)kBlockRowsS, block_max)) return KC_BLOCK;
+    if (rows <= min((uint32_t)kBlockRowsM, block_max)) return KC_BLOCK_M;
+    if (rows <= block_max) return KC_BLOCK_L;
     return KC_GLOBAL;
 }
 
 // per component: solvable? class; the three sort keys of the batch order
 __global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges,
-                            uint32_t *key_var, uint32_t *key_edges, uint32_t *key_class, uint32_t *ids, uint32_t *too_big) {
+                            uint32_t *key_var, uint32_t *key_edges, uint32_t *key_class, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
     if (solvable && c_nodes[c] > 32767) *too_big = 1u;
     key_var[c] = 0xffffu - min(c_var[c], 0xffffu);             // descending
     key_edges[c] = 0xffffffffu - c_edges[c];                   // descending
-    key_class[c] = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c]) : 7u;
+    key_class[c] = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c], block_max) : kNoClass;
     ids[c] = (uint32_t)c;
 }
 
@@ -111,7 +113,7 @@ __global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, const uint32_
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_comp) return;
     const uint32_t c = perm[i];
-    const bool solvable = key_class_sorted[i] != 7u;
+    const bool solvable = key_class_sorted[i] != kNoClass;
     d_nodes[i] = solvable ? c_nodes[c] : 0u;
     d_edges[i] = solvable ? c_edges[c] : 0u;
     di_of_comp[c] = solvable ? (int32_t)i : -1;
@@ -251,7 +253,7 @@ __global__ void k_fill_descs(int64_t cap, const uint32_t *class_sorted, const ui
                              const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges, const uint32_t *c_tracks,
                              CompDesc *descs, uint32_t *desc_tracks) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap || class_sorted[i] == 7u) return;
+    if (i >= cap || class_sorted[i] == kNoClass) return;
     const uint32_t c = perm[i];
     CompDesc d;
     d.edge_off = edge_off[i]; d.n_edges = c_edges[c]; d.node_off = node_off[i];
@@ -266,7 +268,7 @@ __global__ void k_shard_class(int64_t n_comp, const uint32_t *class_sorted, int 
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_comp) return;
     const uint32_t c = class_sorted[i];
-    out[i] = (c != 7u && snake_shard(i, shard_world) == shard_rank) ? c : 7u;
+    out[i] = (c != kNoClass && snake_shard(i, shard_world) == shard_rank) ? c : kNoClass;
 }
 
 // class ranges, solved tracks, largest workgroup-class systems, per-edge scratch sizes.  Sums and maxima are
@@ -274,34 +276,28 @@ __global__ void k_shard_class(int64_t n_comp, const uint32_t *class_sorted, int 
 __global__ void k_summary(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
                           const uint32_t *c_edges, const uint32_t *c_tracks, AsmSummary *sum, unsigned long long *es_size) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t tracks = 0, rows_block = 0, rows_global = 0;
+    uint32_t tracks = 0, rows_wg = 0;
+    int my_class = KC_COUNT;
     if (i <= n_comp) {
-        const int prev = i > 0 ? (int)class_sorted[i - 1] : -1;
-        const int cur = i < n_comp ? (int)class_sorted[i] : 7;
+        const int prev = i > 0 ? min((int)class_sorted[i - 1], (int)KC_COUNT) : -1;
+        const int cur = min(i < n_comp ? (int)class_sorted[i] : KC_COUNT, (int)KC_COUNT);   // (unsolved components: behind every class)
         for (int kc = prev + 1; kc <= cur; ++kc) sum->class_begin[kc] = (uint32_t)i;     // first index with class >= kc
         if (i < n_comp) {
             unsigned long long es = 0ull;
-            if (cur != 7) {
+            if (cur != KC_COUNT) {
                 const uint32_t c = perm[i];
                 tracks = c_tracks[c];
-                if (cur == KC_BLOCK) rows_block = 2u * c_var[c];
-                if (cur == KC_GLOBAL) rows_global = 2u * c_var[c];
-                if (cur == KC_BLOCK || cur == KC_GLOBAL) es = 8ull * c_edges[c];      // 64 B of Jacobian scratch per edge
+                if (cur >= KC_BLOCK) { rows_wg = 2u * c_var[c]; es = 8ull * c_edges[c]; }   // 64 B of Jacobian scratch per edge
             }
             es_size[i] = es;
+            my_class = cur;
         }
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        tracks += __shfl_xor(tracks, m, 64);
-        rows_block = max(rows_block, (uint32_t)__shfl_xor(rows_block, m, 64));
-        rows_global = max(rows_global, (uint32_t)__shfl_xor(rows_global, m, 64));
-    }
-    if ((threadIdx.x & 63) == 0) {
-        if (tracks) atomicAdd(&sum->n_tracks, tracks);
-        if (rows_block) atomicMax(&sum->block_max_rows, rows_block);
-        if (rows_global) atomicMax(&sum->global_max_rows, rows_global);
-    }
+    for (int m = 32; m >= 1; m >>= 1) tracks += __shfl_xor(tracks, m, 64);
+    if ((threadIdx.x & 63) == 0 && tracks) atomicAdd(&sum->n_tracks, tracks);
+    // largest system per workgroup class (sizes the launch's LDS): few such components, one atomic each
+    if (rows_wg) atomicMax(&sum->class_max_rows[my_class], rows_wg);
 }
 // global-matrix class: packed lower triangle + the vectors of the largest system of the class, per component
 __global__ void k_ws_sizes(int64_t n_comp, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *c_var,
@@ -311,7 +307,7 @@ __global__ void k_ws_sizes(int64_t n_comp, const uint32_t *class_sorted, const u
     unsigned long long v = 0ull;
     if (class_sorted[i] == (uint32_t)KC_GLOBAL) {
         const unsigned long long rows = 2ull * c_var[perm[i]], mat = rows * (rows + 1) / 2;
-        v = mat + (mat & 1ull) + (10ull * sum->global_max_rows + 4ull);              // block_vector_doubles(global_max_rows)
+        v = mat + (mat & 1ull) + (10ull * sum->class_max_rows[KC_GLOBAL] + 4ull);    // block_vector_doubles(largest global system)
     }
     ws_size[i] = v;
 }
@@ -322,7 +318,7 @@ __global__ void k_offsets(int64_t n_comp, const uint32_t *class_sorted, const un
     if (i > n_comp) return;
     if (i == n_comp) {
         sum->es_doubles = es_scan[n_comp]; sum->ws_doubles = ws_scan[n_comp];
-        sum->n_desc = sum->class_begin[7];
+        sum->n_desc = sum->class_begin[KC_COUNT];
         sum->total_nodes = node_off[n_comp]; sum->total_edges = edge_off[n_comp];
         for (int kc = 0; kc < KC_COUNT; ++kc)           // descs are sorted by class: a class is one range of the edge scan
             sum->class_edges[kc] = (uint64_t)(edge_off[sum->class_begin[kc + 1]] - edge_off[sum->class_begin[kc]]);
@@ -420,19 +416,19 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
     TAKE(kv, uint32_t, C + 1); TAKE(ke, uint32_t, C + 1); TAKE(kc, uint32_t, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, kv, ke, kc, id0, &sum->too_big);
+    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, kv, ke, kc, id0, &sum->too_big, (uint32_t)block_max_rows());
     int rc;
     // LSD over the three keys (each pass stable): variables, edges, class
     if ((rc = sort_pairs(arena, kv, k0, id0, id1, C, 0, 16, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id1, ke, k0);
     if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, 32, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id0, kc, k0);
-    if ((rc = sort_pairs(arena, k0, k1, id0, id1, C, 0, 3, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, k0, k1, id0, id1, C, 0, kClassBits, st)) != LFR_OK) return rc;
     uint32_t *perm = id1;                  // perm[i] = component of desc i
     uint32_t *class_sorted = k1;
     if (shard_world > 1) {                 // keep this shard's components (same relative order), the rest becomes class 7
         hipLaunchKernelGGL(k_shard_class, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, shard_rank, shard_world, k0);
-        if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, 3, st)) != LFR_OK) return rc;
+        if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, kClassBits, st)) != LFR_OK) return rc;
         perm = id0; class_sorted = k1;     // (k1 is rewritten by the sort after k_shard_class has read it: stream ordered)
     }
 

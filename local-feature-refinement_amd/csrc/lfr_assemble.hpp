@@ -68,8 +68,8 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
 struct AsmSummary {
     uint32_t n_desc, total_nodes, total_edges, n_tracks;
     uint32_t class_begin[KC_COUNT + 1];
-    uint32_t block_max_rows, global_max_rows;
-    uint32_t too_big, unpaired;
+    uint32_t class_max_rows[KC_COUNT];   // largest system (rows) of every workgroup class
+    uint32_t too_big, unpaired, pad_;
     uint64_t class_edges[KC_COUNT];
     uint64_t es_doubles, ws_doubles;     // per-edge scratch, + HBM matrices of the global class
 };

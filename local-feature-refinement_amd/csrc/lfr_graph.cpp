@@ -272,12 +272,23 @@ void components_from_tracks(const Graph &g, const std::vector<int64_t> &track, i
     n_components = n_final;
 }
 
+int block_max_rows() {
+    static const int v = [] {
+        if (const char *e = getenv("LFR_BLOCK_MAX_ROWS")) { const int x = atoi(e); if (x >= 0 && x <= kBlockMaxRows) return x; }
+        return kBlockMaxRows;
+    }();
+    return v;
+}
+
 static int classify(int rows, int64_t n_edges) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
     if (rows <= 16 && n_edges <= 96) return KC_G16;
     if (rows <= 24 && n_edges <= 192) return KC_G64_2;
     if (rows <= 32 && n_edges <= 320) return KC_G64_4;
-    if (rows <= kBlockMaxRows) return KC_BLOCK;
+    const int lds_max = block_max_rows();
+    if (rows <= std::min(kBlockRowsS, lds_max)) return KC_BLOCK;
+    if (rows <= std::min(kBlockRowsM, lds_max)) return KC_BLOCK_M;
+    if (rows <= lds_max) return KC_BLOCK_L;
     return KC_GLOBAL;
 }
 

@@ -101,11 +101,20 @@ enum KernelClass : int {
     KC_G32,         // retired (was <16,2,3>: 2 comps/wave); kept so that the class indices of the C ABI stay put
     KC_G64_2,       // packed <32,1,6>: 2 comps/wave, <=24 rows, <=192 edges (2 slots resident, 4 re-read per sweep)
     KC_G64_4,       // packed <32,2,5>: 1 comp/wave,  <=32 rows, <=320 edges (2 slots resident, 3 re-read per sweep)
-    KC_BLOCK,       // workgroup per component, normal matrix in LDS
+    // workgroup per component, normal matrix in LDS - three classes by LDS footprint so that small systems share a CU:
+    KC_BLOCK,       //   <= 88 rows : <= 39.6 KB of LDS, 128 threads -> 4 workgroups per CU
+    KC_BLOCK_M,     //   <= 130 rows: <= 79 KB, 256 threads        -> 2 workgroups per CU
+    KC_BLOCK_L,     //   <= 192 rows: <= 160 KB, 256 threads       -> 1 workgroup per CU
     KC_GLOBAL,      // workgroup per component, normal matrix in HBM workspace
     KC_COUNT
 };
+constexpr uint32_t kNoClass = 15;            // sort key of components that are not solved (by this shard)
+constexpr int kClassBits = 4;
+constexpr int kBlockRowsS = 88, kBlockRowsM = 130;
+inline bool is_lds_class(int cls) { return cls >= KC_BLOCK && cls <= KC_BLOCK_L; }
 constexpr int kBlockMaxRows = 192;   // packed lower triangle 192*193/2*8 B = 148.2 KB + 15.4 KB of vectors <= 160 KiB of LDS
+// rows above which a component's matrix lives in the HBM workspace instead of LDS: kBlockMaxRows, or LFR_BLOCK_MAX_ROWS (0..192)
+int block_max_rows();
 
 struct Problem {
     const Graph *g = nullptr;

@@ -565,20 +565,22 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
 // =============================================================================================
 // workgroup-per-component kernel (packed lower-triangular normal matrix in LDS or HBM)
 // =============================================================================================
-#ifndef LFR_BLOCK_THREADS
-#define LFR_BLOCK_THREADS 512
-#endif
-constexpr int kBlockThreads = LFR_BLOCK_THREADS;   // one workgroup per component
-constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
+// One workgroup per component; its size is a template parameter.  The launch is wait-bound (72 % of the wave cycles on config
+// 5), so what counts is how many components share a CU, and that is set by LDS and by the 8 waves of 256 VGPRs a CU
+// holds: 128 threads x 4 workgroups (<= 88 rows), 256 x 2 (<= 130 rows), 256 x 1 (<= 192 rows, measured: 22.0 ms against 23.1 ms
+// with 512 threads - most phases keep fewer than 200 threads busy), 256 for the HBM-matrix variant (29.1 ms against 34.3 ms).
 
 __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // j <= i
 
 struct BlockShared {
-    double red[kBlockThreads / 64];
+    double red[8];
     double bcast[4];
     int flag;
 };
 
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+
+template <int kBlockThreads>
 __device__ __forceinline__ double block_sum(double v, BlockShared &sh) {
     v = wave_sum(v);
     __syncthreads();
@@ -589,6 +591,7 @@ __device__ __forceinline__ double block_sum(double v, BlockShared &sh) {
     for (int w = 0; w < kBlockThreads / 64; ++w) s += sh.red[w];
     return s;
 }
+template <int kBlockThreads>
 __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
     v = wave_max(v);
     __syncthreads();
@@ -601,8 +604,9 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 }
 
 // vectors live in LDS for both variants: 8 vectors of n doubles
-template <bool GLOBAL_MATRIX>
+template <bool GLOBAL_MATRIX, int kBlockThreads>
 __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const KernelArgs a, int max_rows) {
+    constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
     extern __shared__ double dyn[];
     __shared__ BlockShared sh;
     const int tid = threadIdx.x;
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
             w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
         }
-        const double total = block_sum(cost, sh);          // (barriers inside: scratch is complete)
+        const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch is complete)
         for (int row = tid; row < n; row += kBlockThreads) {
             const int v = row >> 1, c = row & 1;
             const lfr::NodeInc ni = inc[v];
@@ -752,7 +756,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     auto grad_max = [&](const double *xv, const double *gv) {
         double m = 0.0;
         for (int i = tid; i < n; i += kBlockThreads) m = fmax(m, fabs(xv[i] - clampb(xv[i] - gv[i])));
-        return block_max(m, sh);
+        return block_max<kBlockThreads>(m, sh);
     };
     double gmax = grad_max(vx, vg);
     double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
@@ -844,6 +848,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 }
             }
             __syncthreads();
+            PROF_MARK(3);                             // 3: diagonal blocks of the factorization (one thread)
             if (sh.flag) break;                                           // uniform
             if (ke < n) {
                 double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
@@ -864,45 +869,48 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 }
             }
             __syncthreads();
-            const int mt = (n - ke + 3) / 4, n_tiles = mt * (mt + 1) / 2;
-            for (int t = tid; t < n_tiles; t += kBlockThreads) {
-                int I = (int)((sqrtf(8.f * (float)t + 1.f) - 1.f) * 0.5f);
-                while (I * (I + 1) / 2 > t) --I;
-                while ((I + 1) * (I + 2) / 2 <= t) ++I;
-                const int J = t - I * (I + 1) / 2;
-                const int i0 = ke + 4 * I, j0 = ke + 4 * J;
-                double acc[4][4];
+            PROF_MARK(4);                             // (profile builds: row panels land in slot 4)
+            {   // trailing matrix -= (panel columns) (panel columns / d)^T: a rank-nb update of the lower triangle, one 16x16
+                // tile per wave and step on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4] and
+                // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
+                // of the kernel: 0.75 LDS accesses per multiply-add with 4-8-way bank conflicts on the packed rows; a tile step
+                // here is 14 LDS accesses for 2048 multiply-adds, the tile's rows are contiguous in LDS.
+                const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+                const bool k0 = kq < nb, k1 = 4 + kq < nb;
+                const double ninv0 = k0 ? -vinv[kb + kq] : 0.0, ninv1 = k1 ? -vinv[kb + 4 + kq] : 0.0;
+                const int mt = (n - ke + 15) >> 4;
+                int t = 0;
+                for (int I = 0; I < mt; ++I) {
+                    const int ia = ke + 16 * I + r16;
+                    for (int J = 0; J <= I; ++J, ++t) {
+                        if ((t & (kBlockThreads / 64 - 1)) != wave) continue;            // wave-uniform
+                        const int jb = ke + 16 * J + r16, row0 = ke + 16 * I + kq;
+                        const double a0 = (ia < n && k0) ? Mat[tri(ia, kb + kq)] : 0.0;
+                        const double b0 = (jb < n && k0) ? Mat[tri(jb, kb + kq)] * ninv0 : 0.0;
+                        f64x4 c;
+                        bool ok[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = row0 + 4 * r;
+                            ok[r] = row < n && jb <= row;
+                            c[r] = ok[r] ? Mat[tri(row, jb)] : 0.0;
+                        }
+                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
+                        if (nb > 4) {
+                            const double a1 = (ia < n && k1) ? Mat[tri(ia, kb + 4 + kq)] : 0.0;
+                            const double b1 = (jb < n && k1) ? Mat[tri(jb, kb + 4 + kq)] * ninv1 : 0.0;
+                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
+                        }
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
-#pragma unroll
-                for (int k = 0; k < kPanel; ++k) {
-                    if (k < nb) {
-                        const double inv = vinv[kb + k];
-                        double ai[4], wj[4];
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) ai[u] = (i0 + u < n) ? Mat[tri(i0 + u, kb + k)] : 0.0;
-#pragma unroll
-                        for (int v = 0; v < 4; ++v) wj[v] = (j0 + v < n) ? Mat[tri(j0 + v, kb + k)] * inv : 0.0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-#pragma unroll
-                            for (int v = 0; v < 4; ++v) acc[u][v] = fma(ai[u], wj[v], acc[u][v]);
+                        for (int r = 0; r < 4; ++r) if (ok[r]) Mat[tri(row0 + 4 * r, jb)] = c[r];
                     }
                 }
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int i = i0 + u, j = j0 + v;
-                        if (i < n && j <= i) Mat[tri(i, j)] -= acc[u][v];
-                    }
             }
             __syncthreads();
+            PROF_MARK(1);                             // 1: trailing updates of the factorization
         }
         __syncthreads();
-        PROF_MARK(1);                                 // 1: factorization
+        PROF_MARK(1);
         bool valid = sh.flag == 0;
         if (valid) {
             // triangular solves, one column per step (a step is one barrier + one LDS round trip, ~200 cycles:
@@ -930,8 +938,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 if (!isfinite(st)) bad = 1.0;
                 part += -rhs0 * st + vD[i] * vD[i] * st * st;
             }
-            model_cost_change = 0.5 * block_sum(part, sh);
-            bad = block_max(bad, sh);
+            model_cost_change = 0.5 * block_sum<kBlockThreads>(part, sh);
+            bad = block_max<kBlockThreads>(bad, sh);
             valid = bad == 0.0 && model_cost_change > 0.0;
         }
         if (!valid) {
@@ -948,8 +956,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             gd_part += vg[i] * dl;
             dm_part = fmax(dm_part, fabs(dl));
         }
-        const double g_dot_delta = block_sum(gd_part, sh);
-        const double dir_max = block_max(dm_part, sh);
+        const double g_dot_delta = block_sum<kBlockThreads>(gd_part, sh);
+        const double dir_max = block_max<kBlockThreads>(dm_part, sh);
 
         // ---- projected Armijo line search ----
         double alpha = 1.0, cost_c = 0.0;
@@ -970,7 +978,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 if (current.value_valid) {
                     double p = 0.0;
                     for (int i = tid; i < n; i += kBlockThreads) p += vdelta[i] * vgn[i];
-                    current.gradient = block_sum(p, sh);
+                    current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
                 const double nstep = ls_next_step(initial, previous, current, dir_max, n_iter);
@@ -989,7 +997,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
         double sn = 0.0;
         for (int i = tid; i < n; i += kBlockThreads) sn += (vx[i] - vxc[i]) * (vx[i] - vxc[i]);
-        const double step_norm = sqrt(block_sum(sn, sh));
+        const double step_norm = sqrt(block_sum<kBlockThreads>(sn, sh));
         if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
         const double cost_change = cost - cost_cand;
         if (fabs(cost_change) <= kFunctionTol * cost) break;
@@ -998,7 +1006,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             double xn = 0.0;
             __syncthreads();
             for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; }
-            x_norm = sqrt(block_sum(xn, sh));
+            x_norm = sqrt(block_sum<kBlockThreads>(xn, sh));
             // the accepted candidate is the last evaluated point: its cost, gradient and J^T J (in Mat,
             // the factorization was no longer needed) are already there - no extra sweep
             for (int i = tid; i < n; i += kBlockThreads) vg[i] = vgn[i];
@@ -1031,6 +1039,20 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     }
 }
 
+#ifndef LFR_THREADS_S
+#define LFR_THREADS_S 128
+#endif
+#ifndef LFR_THREADS_M
+#define LFR_THREADS_M 256
+#endif
+#ifndef LFR_THREADS_L
+#define LFR_THREADS_L 256
+#endif
+#ifndef LFR_THREADS_G
+#define LFR_THREADS_G 256
+#endif
+constexpr int kThreadsS = LFR_THREADS_S, kThreadsM = LFR_THREADS_M, kThreadsL = LFR_THREADS_L, kThreadsG = LFR_THREADS_G;
+
 size_t block_vector_doubles(int max_rows) { return 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows; }
 size_t block_lds_bytes(int max_rows, bool global_matrix) {
     if (global_matrix) return 0;                       // matrix and vectors live in the HBM workspace
@@ -1061,7 +1083,7 @@ struct lfr_batch {
     int n_desc = 0;
     int class_begin[lfr::KC_COUNT + 1] = {0};
     int64_t class_edges[lfr::KC_COUNT] = {0};
-    int block_max_rows = 0, global_max_rows = 0;
+    int class_max_rows[lfr::KC_COUNT] = {0};          // largest system of every workgroup class (sizes its launch's LDS)
     int64_t n_edges = 0, n_nodes = 0, n_tracks = 0;
     // device: everything lives in `slab` (+ the workgroup kernels' workspace in `ws_slab`)
     lfr::DevArena slab, ws_slab;
@@ -1094,7 +1116,8 @@ struct lfr_batch {
     int64_t n_solves = 0;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
-    hipStream_t side_stream = nullptr, side_stream2 = nullptr;   // workgroup-per-component kernels run beside the packed launch
+    hipStream_t side_stream = nullptr;                 // the packed launch runs beside the workgroup-per-component kernels
+    hipStream_t wg_stream[lfr::KC_COUNT] = {nullptr};  // one stream per further workgroup class
     hipStream_t last_stream = nullptr;                 // stream of the latest solve (downloads wait for it)
     int packed_slot = 0;                               // class slot that carries the packed launch's events
     double h2d_ms = 0.0;             // upload (host-assembled) or device assembly incl. waiting for the flows
@@ -1107,14 +1130,14 @@ struct lfr_batch {
             (void)hipSetDevice(device);
             if (n_solves > 0) (void)hipStreamSynchronize(last_stream);      // nothing may still use the slab
             if (side_stream) (void)hipStreamSynchronize(side_stream);
-            if (side_stream2) (void)hipStreamSynchronize(side_stream2);
+            for (auto &w : wg_stream) if (w) (void)hipStreamSynchronize(w);
             (void)hipStreamSynchronize(ctx->s_main);
             if (h_positions) ctx->pinned_release(h_positions, h_positions_bytes);
         }
         for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (side_stream) (void)hipStreamDestroy(side_stream);
-        if (side_stream2) (void)hipStreamDestroy(side_stream2);
+        for (auto &w : wg_stream) if (w) (void)hipStreamDestroy(w);
         // slab / ws_slab return to the context's cache in their destructors
     }
 };
@@ -1186,7 +1209,7 @@ int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     b->n_desc = (int)s.n_desc; b->n_edges = s.total_edges; b->n_nodes = s.total_nodes; b->n_tracks = s.n_tracks;
     for (int c = 0; c <= lfr::KC_COUNT; ++c) b->class_begin[c] = (int)s.class_begin[c];
     for (int c = 0; c < lfr::KC_COUNT; ++c) b->class_edges[c] = (int64_t)s.class_edges[c];
-    b->block_max_rows = (int)s.block_max_rows; b->global_max_rows = (int)s.global_max_rows;
+    for (int c = 0; c < lfr::KC_COUNT; ++c) b->class_max_rows[c] = (int)s.class_max_rows[c];
     const uint64_t ws = s.es_doubles + s.ws_doubles;
     if (ws) {
         if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
@@ -1223,9 +1246,10 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
         b->desc_class.push_back(p.desc_class[i]); b->desc_tracks.push_back(p.desc_tracks[i]);
         const int cls = p.desc_class[i], rows = 2 * d.n_var;
         es_off.push_back(ws); ws_off.push_back(0);
-        if (cls == lfr::KC_BLOCK || cls == lfr::KC_GLOBAL) ws += 8 * (uint64_t)d.n_edges;      // per-edge scratch
-        if (cls == lfr::KC_BLOCK) b->block_max_rows = std::max(b->block_max_rows, rows);
-        if (cls == lfr::KC_GLOBAL) b->global_max_rows = std::max(b->global_max_rows, rows);
+        if (cls >= lfr::KC_BLOCK) {
+            ws += 8 * (uint64_t)d.n_edges;                                                     // per-edge scratch
+            b->class_max_rows[cls] = std::max(b->class_max_rows[cls], rows);
+        }
         b->class_edges[cls] += d.n_edges;
         b->n_edges += d.n_edges; b->n_nodes += d.n_nodes; b->n_tracks += p.desc_tracks[i];
     }
@@ -1238,7 +1262,7 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
             const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;
             ws += ws & 1;
             ws_off[i] = ws;
-            ws += mat + (mat & 1) + block_vector_doubles(b->global_max_rows);
+            ws += mat + (mat & 1) + block_vector_doubles(b->class_max_rows[lfr::KC_GLOBAL]);
         }
     b->n_desc = (int)b->descs.size();
     {   // class ranges (descs are sorted by class)
@@ -1511,11 +1535,15 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
         HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
-        HIP_TRY(hipStreamCreateWithFlags(&b->side_stream2, hipStreamNonBlocking));
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)block_lds_bytes(std::max(b->block_max_rows, 2), false)));
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)block_lds_bytes(std::max(b->global_max_rows, 2), true)));
+        for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls)
+            if (b->class_begin[cls + 1] > b->class_begin[cls]) HIP_TRY(hipStreamCreateWithFlags(&b->wg_stream[cls], hipStreamNonBlocking));
+        const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
+        const int lds_m = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_M], 2), false);
+        const int lds_l = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_L], 2), false);
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    std::max(lds_l, std::max(kThreadsL == kThreadsM ? lds_m : 0, kThreadsL == kThreadsS ? lds_s : 0))));
     }
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
@@ -1544,16 +1572,20 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
     static const int kPackedOrder[5] = {lfr::KC_G64_4, lfr::KC_G64_2, lfr::KC_G32, lfr::KC_G16, lfr::KC_G8};
-    static const int kCompsPerBlock[lfr::KC_COUNT] = {8 * kPackedWaves, 4 * kPackedWaves, 2 * kPackedWaves, 2 * kPackedWaves, kPackedWaves, 1, 1};
+    static const int kCompsPerBlock[lfr::KC_COUNT] = {8 * kPackedWaves, 4 * kPackedWaves, 2 * kPackedWaves, 2 * kPackedWaves, kPackedWaves, 1, 1, 1, 1};
     const dim3 blk(64 * kPackedWaves);
     auto launch_block = [&](int cls, hipStream_t cs) -> int {
         a.desc_begin = b->class_begin[cls]; a.desc_end = b->class_begin[cls + 1]; a.cls = cls;
         const int n = a.desc_end - a.desc_begin;
         if (n <= 0) return LFR_OK;
-        if (cls == lfr::KC_BLOCK)
-            hipLaunchKernelGGL((solve_block_kernel<false>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->block_max_rows, false), cs, a, b->block_max_rows);
-        else
-            hipLaunchKernelGGL((solve_block_kernel<true>), dim3(n), dim3(kBlockThreads), block_lds_bytes(b->global_max_rows, true), cs, a, b->global_max_rows);
+        const int rows = b->class_max_rows[cls];
+        const size_t lds = block_lds_bytes(rows, cls == lfr::KC_GLOBAL);
+        switch (cls) {
+            case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<false, kThreadsS>), dim3(n), dim3(kThreadsS), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsM>), dim3(n), dim3(kThreadsM), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(n), dim3(kThreadsL), lds, cs, a, rows); break;
+            default:              hipLaunchKernelGGL((solve_block_kernel<true, kThreadsG>), dim3(n), dim3(kThreadsG), lds, cs, a, rows); break;
+        }
         HIP_TRY(hipGetLastError());
         return LFR_OK;
     };
@@ -1613,18 +1645,20 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             recorded |= 1u << cls;
             return LFR_OK;
         };
-        const bool have_block = b->class_begin[lfr::KC_BLOCK + 1] > b->class_begin[lfr::KC_BLOCK];
-        const bool have_global = b->class_begin[lfr::KC_GLOBAL + 1] > b->class_begin[lfr::KC_GLOBAL];
         if (!have_side) {
             if (nb > 0) { const int rc = launch_packed(st); if (rc != LFR_OK) return rc; }
         } else {
-            const int first = have_global ? lfr::KC_GLOBAL : lfr::KC_BLOCK;        // longest-running class on the caller's stream
-            const bool second = have_global && have_block;
-            if (second || nb > 0) HIP_TRY(hipEventRecord(b->ev_fork, st));
+            // longest-running class first, on the caller's stream; every further workgroup class on its own stream
+            static const int kBigOrder[4] = {lfr::KC_GLOBAL, lfr::KC_BLOCK_L, lfr::KC_BLOCK_M, lfr::KC_BLOCK};
+            int first = -1, n_big = 0;
+            for (int i = 0; i < 4; ++i) if (b->class_begin[kBigOrder[i] + 1] > b->class_begin[kBigOrder[i]]) { if (first < 0) first = kBigOrder[i]; ++n_big; }
+            if (n_big > 1 || nb > 0) HIP_TRY(hipEventRecord(b->ev_fork, st));
             { const int rc = launch_big(first, st); if (rc != LFR_OK) return rc; }
-            if (second) {
-                HIP_TRY(hipStreamWaitEvent(b->side_stream2, b->ev_fork, 0));
-                const int rc = launch_big(lfr::KC_BLOCK, b->side_stream2);
+            for (int i = 0; i < 4; ++i) {
+                const int cls = kBigOrder[i];
+                if (cls == first || b->class_begin[cls + 1] <= b->class_begin[cls]) continue;
+                HIP_TRY(hipStreamWaitEvent(b->wg_stream[cls], b->ev_fork, 0));
+                const int rc = launch_big(cls, b->wg_stream[cls]);
                 if (rc != LFR_OK) return rc;
             }
             if (nb > 0) {
@@ -1633,7 +1667,11 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                 if (rc != LFR_OK) return rc;
                 HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * b->packed_slot], 0));
             }
-            if (second) HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * lfr::KC_BLOCK], 0));
+            for (int i = 0; i < 4; ++i) {
+                const int cls = kBigOrder[i];
+                if (cls == first || b->class_begin[cls + 1] <= b->class_begin[cls]) continue;
+                HIP_TRY(hipStreamWaitEvent(st, b->ev[3 + 2 * cls], 0));
+            }
         }
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));

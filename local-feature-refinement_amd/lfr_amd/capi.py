@@ -22,6 +22,9 @@ class LfrError(RuntimeError):
         self.code = code
 
 
+NUM_KERNEL_CLASSES = 9          # LFR_NUM_KERNEL_CLASSES
+
+
 class ProblemStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_tracks", "max_track_size", "n_components", "max_component_size", "n_cut_components",
@@ -403,8 +406,8 @@ class Batch:
     def timing(self, solves_back=0):
         """HIP-event times of one of the last 64 solves: (total_ms, per-kernel-class ms, per-class edges)."""
         tot = C.c_double(0.0)
-        cls = np.zeros(7, np.float64)
-        edges = np.zeros(7, np.int64)
+        cls = np.zeros(NUM_KERNEL_CLASSES, np.float64)
+        edges = np.zeros(NUM_KERNEL_CLASSES, np.int64)
         _check(lib().lfr_batch_timing(self._h, solves_back, C.byref(tot), _ptr(cls), _ptr(edges)))
         return tot.value, cls, edges
 

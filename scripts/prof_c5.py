@@ -13,3 +13,7 @@ for i in range(3):
     print("config5: edges %d comps %d kernel %.3f ms dominant %.3f ms  noconv %d fail %d" % (st["n_edges"], st["n_components"], st["kernel_ms"], st["dominant_kernel_ms"], st["n_no_convergence"], st["n_failed"]), flush=True)
 info = b.component_info()
 print("rows: min %d max %d mean %.1f; iterations mean %.2f max %d" % (2 * info["n_var_nodes"].min(), 2 * info["n_var_nodes"].max(), 2 * info["n_var_nodes"].mean(), info["iterations"].mean(), info["iterations"].max()))
+tot, cms, ced = b.timing()
+print("per launch ms:", {i: round(float(cms[i]), 3) for i in range(len(cms)) if ced[i] > 0}, "edges:", {i: int(ced[i]) for i in range(len(cms)) if ced[i] > 0})
+cb = np.bincount(np.minimum(2 * info["n_var_nodes"], 400) // 10)
+print("rows histogram (bins of 10):", cb.tolist())

@@ -179,8 +179,8 @@ def test_small_image_count_standins(lfr_lib, maker, tmp_path):
 
 
 def test_every_kernel_class_is_exercised(lfr_lib):
-    """One graph with track lengths 2..17 plus long tracks: all five packed classes and both
-    workgroup kernels run, and each agrees with the oracle."""
+    """One graph with track lengths 2..17 plus long tracks: all five packed classes and all four
+    workgroup launches (three LDS footprints, HBM matrix) run, and each agrees with the oracle."""
     parts = [synthetic.generate(seed=95, n_images=400, n_tracks=3000),                                   # packed classes
              synthetic.generate(seed=96, n_images=400, n_tracks=40, len_dist="uniform", len_lo=18, len_hi=90),   # LDS matrix
              synthetic.generate(seed=97, n_images=400, n_tracks=3, len_dist="uniform", len_lo=100, len_hi=130)]  # HBM matrix
@@ -192,9 +192,9 @@ def test_every_kernel_class_is_exercised(lfr_lib):
         rows, edges = 2 * info["n_var_nodes"], info["n_edges"]
         for r, e in zip(rows, edges):
             cls = ("G8" if r <= 8 and e <= 24 else "G16" if r <= 16 and e <= 48 else "G16_streamed" if r <= 16 and e <= 96 else
-                   "G64_2" if r <= 24 and e <= 192 else "G64_4" if r <= 32 and e <= 320 else "BLOCK" if r <= 192 else "GLOBAL")
+                   "G64_2" if r <= 24 and e <= 192 else "G64_4" if r <= 32 and e <= 320 else "BLOCK_S" if r <= 88 else "BLOCK_M" if r <= 130 else "BLOCK_L" if r <= 192 else "GLOBAL")
             seen.add(cls)
-    assert seen == {"G8", "G16", "G16_streamed", "G64_2", "G64_4", "BLOCK", "GLOBAL"}, seen   # every kernel path, resident and re-read slots
+    assert seen == {"G8", "G16", "G16_streamed", "G64_2", "G64_4", "BLOCK_S", "BLOCK_M", "BLOCK_L", "GLOBAL"}, seen   # every kernel path, resident and re-read slots
 
 
 def test_fuzz_small_irregular_graphs(lfr_lib):
