@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <memory>
 #include <string>
@@ -79,6 +80,15 @@ struct KernelArgs {
 #define PROF_DECL
 #define PROF_MARK(i)
 #define PROF_FLUSH()
+#endif
+// -DLFR_PROFILE_SWEEP (with LFR_PROFILE_PHASES): slot 3 = edge evaluation of the workgroup kernel's sweeps, slots 0/2 keep their
+// assembly walks, the factorization reports as one number in slot 1
+#if defined(LFR_PROFILE_PHASES) && defined(LFR_PROFILE_SWEEP)
+#define PROF_SWEEP_MARK(i) PROF_MARK(i)
+#define PROF_FACTOR_MARK(i) PROF_MARK(1)
+#else
+#define PROF_SWEEP_MARK(i)
+#define PROF_FACTOR_MARK(i) PROF_MARK(i)
 #endif
 enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
 
@@ -570,6 +580,13 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
 // holds: 128 threads x 4 workgroups (<= 88 rows), 256 x 2 (<= 130 rows), 256 x 1 (<= 192 rows, measured: 22.0 ms against 23.1 ms
 // with 512 threads - most phases keep fewer than 200 threads busy), 256 for the HBM-matrix variant (29.1 ms against 34.3 ms).
 
+// Accumulate into a matrix entry its row's thread owns.  A read-modify-write in program order made every edge of the walk wait
+// for an LDS round trip (a row may hit the same entry twice, so the compiler cannot overlap them); the no-return atomic is
+// fire-and-forget, and the adds of one thread to one address still apply in issue order: the sum stays bitwise reproducible.
+__device__ __forceinline__ void mat_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ double readlane_f64(double v, int uniform_lane) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), uniform_lane), __builtin_amdgcn_readlane(__double2loint(v), uniform_lane));
+}
 __device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // j <= i
 
 struct BlockShared {
@@ -642,13 +659,24 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
     const lfr::NodeInc *inc = a.node_inc + d.node_off;
     const uint32_t *in_idx = a.in_idx + d.edge_off;
     double *es = a.workspace + a.es_off[ci];
+    const int lane = tid;     // PROF_FLUSH uses `lane == 0`
+    (void)lane;
+    PROF_DECL
     auto sweep = [&](const double *xv, double *gout, bool want_matrix) -> double {
         double cost = 0.0;
-        for (int e = tid; e < E; e += kBlockThreads) {
-            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
-            uint4 q[5];
+        PROF_SWEEP_MARK(4);
+        uint4 q[5], qn[5];                           // the next record is in flight while this one is evaluated
+        if (tid < E) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + tid);
 #pragma unroll
             for (int i = 0; i < 5; ++i) q[i] = rp[i];
+        }
+        for (int e = tid; e < E; e += kBlockThreads) {
+            if (e + kBlockThreads < E) {
+                const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e + kBlockThreads);
+#pragma unroll
+                for (int i = 0; i < 5; ++i) qn[i] = rp[i];
+            }
             float flow[18];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -666,8 +694,11 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
             double2 *w = reinterpret_cast<double2 *>(es + 8 * (size_t)e);
             w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
             w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = qn[i];
         }
         const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch is complete)
+        PROF_SWEEP_MARK(3);
         for (int row = tid; row < n; row += kBlockThreads) {
             const int v = row >> 1, c = row & 1;
             const lfr::NodeInc ni = inc[v];
@@ -700,8 +731,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                         if (c) dlow += a0.y * a0.x + a1.y * a1.x;
                         const int wn = wn_[u];
                         if (wn < v) {                           // block (v, w) += J1^T * sq
-                            Mat[tri(row, 2 * wn)] += jc0 * a2.x;
-                            Mat[tri(row, 2 * wn + 1)] += jc1 * a2.x;
+                            mat_add(&Mat[tri(row, 2 * wn)], jc0 * a2.x);
+                            mat_add(&Mat[tri(row, 2 * wn + 1)], jc1 * a2.x);
                         }
                     }
                 }
@@ -728,8 +759,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                         dsame += sq * sq;
                         const int wn = wn_[u];
                         if (wn < v) {                           // block (v, w) += sq * J1'
-                            Mat[tri(row, 2 * wn)] += sq * (c ? a1.x : a0.x);
-                            Mat[tri(row, 2 * wn + 1)] += sq * (c ? a1.y : a0.y);
+                            mat_add(&Mat[tri(row, 2 * wn)], sq * (c ? a1.x : a0.x));
+                            mat_add(&Mat[tri(row, 2 * wn + 1)], sq * (c ? a1.y : a0.y));
                         }
                     }
                 }
@@ -745,9 +776,6 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         return total;
     };
 
-    const int lane = tid;     // PROF_FLUSH uses `lane == 0`
-    (void)lane;
-    PROF_DECL
     int exec_passes = 1;
     double cost = sweep(vx, vg, true);
     PROF_MARK(0);                                     // 0: sweeps (evaluate + owner-computes assembly)
@@ -848,7 +876,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 }
             }
             __syncthreads();
-            PROF_MARK(3);                             // 3: diagonal blocks of the factorization (one thread)
+            PROF_FACTOR_MARK(3);                      // 3: diagonal blocks of the factorization (one thread)
             if (sh.flag) break;                                           // uniform
             if (ke < n) {
                 double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
@@ -869,7 +897,7 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 }
             }
             __syncthreads();
-            PROF_MARK(4);                             // (profile builds: row panels land in slot 4)
+            PROF_FACTOR_MARK(4);                      // (profile builds: row panels land in slot 4)
             {   // trailing matrix -= (panel columns) (panel columns / d)^T: a rank-nb update of the lower triangle, one 16x16
                 // tile per wave and step on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4] and
                 // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
@@ -913,19 +941,80 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
         PROF_MARK(1);
         bool valid = sh.flag == 0;
         if (valid) {
-            // triangular solves, one column per step (a step is one barrier + one LDS round trip, ~200 cycles:
-            // cheaper than panel steps with a single-thread block solve, which were measured at 2.7k each)
-            for (int k = 0; k < n; ++k) {                                 // forward: L z = rhs
-                const double t = vstep[k] * vinv[k];
-                for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * t;
+            if constexpr (!GLOBAL_MATRIX) {
+                // Triangular solves by ONE wave with the vector in registers (n <= 192: three values per lane): a step is a
+                // v_readlane broadcast and one multiply-add per register - ~50 cycles against the ~270 of a step that crosses a
+                // workgroup barrier and an LDS round trip, and there are 2 n steps per solve.  The matrix entries do not depend
+                // on the running vector, so four steps' worth is loaded ahead of the dependent chain.  Same operations per element
+                // as the barrier version below: the results are bitwise the same.
+                if (tid < 64) {
+                    constexpr int kR = 3;
+                    double x[kR], inv[kR];
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) {
+                        const int i = tid + 64 * r;
+                        x[r] = i < n ? vstep[i] : 0.0;
+                        inv[r] = i < n ? vinv[i] : 0.0;
+                    }
+#pragma unroll
+                    for (int r0 = 0; r0 < kR; ++r0) {                                 // forward: L z = rhs
+                        for (int k4 = 64 * r0; k4 < min(n, 64 * r0 + 64); k4 += 4) {
+                            double l[4][kR];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int r = r0; r < kR; ++r) {
+                                    const int i = tid + 64 * r, k = k4 + u;
+                                    l[u][r] = (i > k && i < n) ? Mat[tri(i, k)] : 0.0;
+                                }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double t = readlane_f64(x[r0] * inv[r0], (k4 + u) & 63);
+#pragma unroll
+                                for (int r = r0; r < kR; ++r) x[r] -= l[u][r] * t;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) x[r] *= inv[r];
+#pragma unroll
+                    for (int r0 = kR - 1; r0 >= 0; --r0) {                            // backward: L^T y = w
+                        if (64 * r0 >= n) continue;
+                        for (int k4 = min(n - 1, 64 * r0 + 63) | 3; k4 >= 64 * r0; k4 -= 4) {
+                            double w[4][kR];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                                for (int r = 0; r <= r0; ++r) {
+                                    const int j = tid + 64 * r, k = k4 - u;
+                                    w[u][r] = (j < k && k < n) ? Mat[tri(k, j)] * inv[r] : 0.0;
+                                }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double yk = readlane_f64(x[r0], (k4 - u) & 63);
+#pragma unroll
+                                for (int r = 0; r <= r0; ++r) x[r] -= w[u][r] * yk;
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < kR; ++r) if (tid + 64 * r < n) vstep[tid + 64 * r] = x[r];
+                }
                 __syncthreads();
-            }
-            for (int i = tid; i < n; i += kBlockThreads) vstep[i] *= vinv[i];
-            __syncthreads();
-            for (int k = n - 1; k > 0; --k) {                             // backward: L^T y = w
-                const double yk = vstep[k];
-                for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * vinv[j] * yk;
+            } else {
+                // one column per step (a step is one barrier + one memory round trip)
+                for (int k = 0; k < n; ++k) {                                 // forward: L z = rhs
+                    const double t = vstep[k] * vinv[k];
+                    for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * t;
+                    __syncthreads();
+                }
+                for (int i = tid; i < n; i += kBlockThreads) vstep[i] *= vinv[i];
                 __syncthreads();
+                for (int k = n - 1; k > 0; --k) {                             // backward: L^T y = w
+                    const double yk = vstep[k];
+                    for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * vinv[j] * yk;
+                    __syncthreads();
+                }
             }
         }
         PROF_MARK(6);                                 // 6: triangular solves
@@ -1648,8 +1737,23 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         if (!have_side) {
             if (nb > 0) { const int rc = launch_packed(st); if (rc != LFR_OK) return rc; }
         } else {
-            // longest-running class first, on the caller's stream; every further workgroup class on its own stream
-            static const int kBigOrder[4] = {lfr::KC_GLOBAL, lfr::KC_BLOCK_L, lfr::KC_BLOCK_M, lfr::KC_BLOCK};
+            // Every workgroup class on its own stream (the first on the caller's).  Dispatch order = issue order: the HBM-matrix
+            // class first (its components run longest), then the LDS classes from the smallest footprint up.  A 160 KB
+            // workgroup only starts on an empty CU, so issued first it keeps the smaller classes out until its queue drains,
+            // and a slow component among THEM (iteration counts vary 8x) then starts late and ends the solve alone:
+            // config 5 measured 17.0 ms with the largest class first, LFR_WG_ORDER overrides for experiments.
+            static const std::array<int, 4> kBigOrder = [] {
+                std::array<int, 4> o = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_BLOCK_M, lfr::KC_BLOCK_L};
+                if (const char *e = getenv("LFR_WG_ORDER")) {
+                    int v[4];
+                    if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {
+                        unsigned seen = 0;
+                        for (int i = 0; i < 4; ++i) if (v[i] >= lfr::KC_BLOCK && v[i] < lfr::KC_COUNT) seen |= 1u << v[i];
+                        if (seen == (0xfu << lfr::KC_BLOCK)) for (int i = 0; i < 4; ++i) o[i] = v[i];
+                    }
+                }
+                return o;
+            }();
             int first = -1, n_big = 0;
             for (int i = 0; i < 4; ++i) if (b->class_begin[kBigOrder[i] + 1] > b->class_begin[kBigOrder[i]]) { if (first < 0) first = kBigOrder[i]; ++n_big; }
             if (n_big > 1 || nb > 0) HIP_TRY(hipEventRecord(b->ev_fork, st));

@@ -17,3 +17,9 @@ tot, cms, ced = b.timing()
 print("per launch ms:", {i: round(float(cms[i]), 3) for i in range(len(cms)) if ced[i] > 0}, "edges:", {i: int(ced[i]) for i in range(len(cms)) if ced[i] > 0})
 cb = np.bincount(np.minimum(2 * info["n_var_nodes"], 400) // 10)
 print("rows histogram (bins of 10):", cb.tolist())
+rows = 2 * info["n_var_nodes"]; it = info["iterations"]
+top = np.argsort(-it)[:8]
+print("most iterations:", [(int(it[i]), int(rows[i]), int(info["n_edges"][i])) for i in top])
+for lo, hi in ((33, 88), (89, 130), (131, 192)):
+    m = (rows >= lo) & (rows <= hi)
+    if m.any(): print("rows %d-%d: comps %d iterations mean %.2f max %d, sum(iter*rows^2) %.3g" % (lo, hi, m.sum(), it[m].mean(), it[m].max(), float((it[m] * rows[m].astype(float) ** 2).sum())))
