@@ -621,8 +621,10 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 }
 
 // vectors live in LDS for both variants: 8 vectors of n doubles
+// (two waves per SIMD = 256 registers each, VGPRs + the MFMA accumulators: what the 4 / 2 workgroups per CU of the two smaller
+// LDS classes need; without the attribute the allocator takes 264)
 template <bool GLOBAL_MATRIX, int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const KernelArgs a, int max_rows) {
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
     constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
     extern __shared__ double dyn[];
     __shared__ BlockShared sh;
@@ -903,35 +905,53 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
                 // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
                 // of the kernel: 0.75 LDS accesses per multiply-add with 4-8-way bank conflicts on the packed rows; a tile step
                 // here is 14 LDS accesses for 2048 multiply-adds, the tile's rows are contiguous in LDS.
+                // A wave works on two tiles at a time and every load is unconditional (clamped index, value selected
+                // afterwards): the 20 LDS reads of a pair are in flight together and the four MFMAs of the two independent
+                // accumulators alternate, instead of one load -> multiply -> MFMA -> store chain per tile.
                 const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+                constexpr int kWaves = kBlockThreads / 64;
                 const bool k0 = kq < nb, k1 = 4 + kq < nb;
-                const double ninv0 = k0 ? -vinv[kb + kq] : 0.0, ninv1 = k1 ? -vinv[kb + 4 + kq] : 0.0;
+                const int kc0 = kb + min(kq, nb - 1), kc1 = kb + min(4 + kq, nb - 1);
+                const double ninv0 = -vinv[kc0], ninv1 = -vinv[kc1];
                 const int mt = (n - ke + 15) >> 4;
-                int t = 0;
-                for (int I = 0; I < mt; ++I) {
-                    const int ia = ke + 16 * I + r16;
-                    for (int J = 0; J <= I; ++J, ++t) {
-                        if ((t & (kBlockThreads / 64 - 1)) != wave) continue;            // wave-uniform
-                        const int jb = ke + 16 * J + r16, row0 = ke + 16 * I + kq;
-                        const double a0 = (ia < n && k0) ? Mat[tri(ia, kb + kq)] : 0.0;
-                        const double b0 = (jb < n && k0) ? Mat[tri(jb, kb + kq)] * ninv0 : 0.0;
-                        f64x4 c;
-                        bool ok[4];
+                struct Tile { double a0, a1, b0, b1; f64x4 c; bool ok[4]; int row0, jb; };
+                auto load_tile = [&](int I, int J, Tile &T) {
+                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n - 1), jbc = min(jb, n - 1);
+                    T.row0 = ke + 16 * I + kq; T.jb = jb;
+                    const double a0 = Mat[tri(iac, kc0)], a1 = Mat[tri(iac, kc1)], b0 = Mat[tri(jbc, kc0)], b1 = Mat[tri(jbc, kc1)];
+                    double cv[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = row0 + 4 * r;
-                            ok[r] = row < n && jb <= row;
-                            c[r] = ok[r] ? Mat[tri(row, jb)] : 0.0;
-                        }
-                        c = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, c, 0, 0, 0);
-                        if (nb > 4) {
-                            const double a1 = (ia < n && k1) ? Mat[tri(ia, kb + 4 + kq)] : 0.0;
-                            const double b1 = (jb < n && k1) ? Mat[tri(jb, kb + 4 + kq)] * ninv1 : 0.0;
-                            c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, c, 0, 0, 0);
-                        }
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) if (ok[r]) Mat[tri(row0 + 4 * r, jb)] = c[r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = T.row0 + 4 * r, rc = min(row, n - 1);
+                        T.ok[r] = row < n && jb <= row;
+                        cv[r] = Mat[tri(rc, min(jbc, rc))];
                     }
+                    T.a0 = (ia < n && k0) ? a0 : 0.0; T.a1 = (ia < n && k1) ? a1 : 0.0;
+                    T.b0 = (jb < n && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n && k1) ? b1 * ninv1 : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
+                };
+                auto store_tile = [&](const Tile &T) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
+                };
+                int I = 0, J = wave;                                     // tile t = wave, wave + kWaves, ... of the row-major lower triangle
+                while (J > I) { J -= I + 1; ++I; }
+                while (I < mt) {                                         // wave-uniform
+                    const int I0 = I, J0 = J;
+                    J += kWaves; while (J > I) { J -= I + 1; ++I; }
+                    const bool two = I < mt;
+                    const int I1 = I, J1 = J;
+                    J += kWaves; while (J > I) { J -= I + 1; ++I; }
+                    Tile t0, t1;
+                    load_tile(I0, J0, t0);
+                    load_tile(I1, J1, t1);                               // (past the end: clamped loads, nothing stored)
+                    t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a0, t0.b0, t0.c, 0, 0, 0);
+                    t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a0, t1.b0, t1.c, 0, 0, 0);
+                    t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a1, t0.b1, t0.c, 0, 0, 0);
+                    t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a1, t1.b1, t1.c, 0, 0, 0);
+                    store_tile(t0);
+                    if (two) store_tile(t1);
                 }
             }
             __syncthreads();
@@ -965,7 +985,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
 #pragma unroll
                                 for (int r = r0; r < kR; ++r) {
                                     const int i = tid + 64 * r, k = k4 + u;
-                                    l[u][r] = (i > k && i < n) ? Mat[tri(i, k)] : 0.0;
+                                    const double m = Mat[tri(min(i, n - 1), min(k, n - 1))];     // unconditional: the loads overlap
+                                    l[u][r] = (i > k && i < n) ? m : 0.0;
                                 }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
@@ -987,7 +1008,8 @@ __global__ __launch_bounds__(kBlockThreads) void solve_block_kernel(const Kernel
 #pragma unroll
                                 for (int r = 0; r <= r0; ++r) {
                                     const int j = tid + 64 * r, k = k4 - u;
-                                    w[u][r] = (j < k && k < n) ? Mat[tri(k, j)] * inv[r] : 0.0;
+                                    const double m = Mat[tri(min(k, n - 1), min(j, n - 1))];
+                                    w[u][r] = (j < k && k < n) ? m * inv[r] : 0.0;
                                 }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
