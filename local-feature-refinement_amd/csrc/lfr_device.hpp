@@ -156,25 +156,104 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
 // ------------------------------------------------------------------------------------------
 struct LsSample { double x, value, gradient; bool value_valid, gradient_valid; };
 
-__device__ inline double ipow(double x, int n) {       // x^n, n >= 0 (Ceres uses pow())
-    double v = 1.0;
-    for (int i = 0; i < n; ++i) v *= x;
-    return v;
-}
-
-__device__ inline double polyval(const double *p, int n, double x) {
+// The interpolation runs in REGISTERS: every loop below has compile-time bounds (the number of constraints N = 3..6 is a
+// template parameter) and every array index is static after unrolling.  The first version indexed small local arrays with
+// run-time values (pivot rows, constraint counts, root counts); the compiler put them in scratch memory and one call cost
+// ~4e5 cycles (measured: a component that contracted its step 40 times lived 12 ms and set the duration of the whole
+// config-5 launch).
+template <int N>
+__device__ __forceinline__ double polyval_n(const double (&p)[N], double x) {
     double v = 0.0;
-    for (int i = 0; i < n; ++i) v = v * x + p[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) v = v * x + p[i];
     return v;
 }
 
-__device__ inline int poly_root_real_parts(const double *pin, int n, double *out) {
-    while (n > 0 && pin[0] == 0.0) { ++pin; --n; }
-    const int deg = n - 1;
+// ---- real roots of a cubic / quartic inside [lo, hi] ----
+// Ceres takes the real parts of ALL roots of the interpolant's derivative (companion-matrix eigenvalues) and keeps those inside
+// the interval as candidates for the minimum.  Only real roots can win there (a polynomial without a real critical point
+// between two candidates is monotone between them), so the kernels isolate the real roots directly: the critical points of q
+// cut [lo, hi] into monotone pieces, a sign change brackets exactly one root, a safeguarded Newton iteration polishes it.
+// Unlike a simultaneous complex iteration started on a circle of radius 1 + max |a_i / a_0| (the first version: Aberth), this
+// stays accurate when the leading coefficient is tiny (a nearly cubic function fitted by a quartic puts one root near
+// infinity), and it is a few hundred dependent multiply-adds instead of up to 200 complex iterations.
+// Every level returns exactly M ascending values inside [lo, hi]: a piece without a root contributes its left end
+// (x_min or an inflection point of the interpolant - a harmless extra candidate).
+template <int M>
+__device__ __forceinline__ double horner(const double (&q)[M + 1], double x) {
+    double v = q[0];
+#pragma unroll
+    for (int i = 1; i <= M; ++i) v = v * x + q[i];
+    return v;
+}
+template <int M>
+__device__ __forceinline__ double bracketed_root(const double (&q)[M + 1], const double (&dq)[M], double a, double b, double fa) {
+    double x = 0.5 * (a + b);
+    for (int it = 0; it < 200; ++it) {
+        const double fx = horner<M>(q, x);
+        if (fx == 0.0) break;
+        if ((fx < 0.0) == (fa < 0.0)) a = x; else b = x;
+        const double d = horner<M - 1>(dq, x);
+        double xn = x - fx / d;
+        if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+        if (!(xn > a && xn < b)) break;                          // the bracket is down to neighbouring numbers
+        if (fabs(xn - x) <= 2.220446049250313e-16 * fabs(xn)) { x = xn; break; }
+        x = xn;
+    }
+    return x;
+}
+template <int M>
+__device__ __forceinline__ void real_roots_in(const double (&q)[M + 1], double lo, double hi, double (&out)[M]) {
+    static_assert(M >= 2 && M <= 4, "quadratic, cubic or quartic");
+    if constexpr (M == 2) {
+        const double A = q[0], B = q[1], C = q[2];
+        const double D = B * B - 4 * A * C;
+        double r0 = lo, r1 = lo;
+        if (D >= 0) {
+            const double sD = sqrt(D), t = B >= 0 ? -B - sD : -B + sD;          // t = -(B + sign(B) sqrt(D)): no cancellation
+            const double u = t / (2.0 * A), v = t != 0.0 ? (2.0 * C) / t : u;
+            r0 = fmin(u, v); r1 = fmax(u, v);
+            if (!(r0 == r0)) r0 = lo;                                            // (A == 0 or overflow: no usable breakpoint)
+            if (!(r1 == r1)) r1 = lo;
+        }
+        out[0] = fmin(fmax(r0, lo), hi); out[1] = fmin(fmax(r1, lo), hi);
+    } else {
+        double dq[M], bp[M - 1];
+#pragma unroll
+        for (int i = 0; i < M; ++i) dq[i] = q[i] * (M - i);
+        real_roots_in<M - 1>(dq, lo, hi, bp);
+#pragma unroll
+        for (int i = 0; i < M; ++i) {
+            const double a = i == 0 ? lo : bp[i - 1], b = i == M - 1 ? hi : bp[i];
+            const double fa = horner<M>(q, a), fb = horner<M>(q, b);
+            double r = a;
+            if (fa != 0.0 && fb == 0.0) r = b;
+            else if ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0)) r = bracketed_root<M>(q, dq, a, b, fa);
+            out[i] = r;
+        }
+    }
+}
+
+// candidate abscissae for the minimum of the interpolant: real parts of the roots of its derivative d[0] x^(M-1) + ... + d[M-1]
+// (leading zeros skipped); returns their count (<= 4).  Degree <= 2 in closed form exactly as Ceres' FindPolynomialRoots
+// (a complex pair contributes its real part), degree 3 and 4: the real roots inside [lo, hi].
+template <int M>
+__device__ __forceinline__ int poly_root_real_parts_n(const double (&d)[M], double lo, double hi, double (&out)[4]) {
+    static_assert(M >= 2 && M <= 5, "derivative of a polynomial with 3..6 coefficients");
+    int lead = 0;
+    bool counting = true;
+#pragma unroll
+    for (int i = 0; i < M; ++i) { counting = counting && d[i] == 0.0; lead += counting ? 1 : 0; }
+    double e[5] = {0.0, 0.0, 0.0, 0.0, 0.0};                 // e[i] = d[i + lead]
+#pragma unroll
+    for (int i = 0; i < M; ++i)
+#pragma unroll
+        for (int l = 0; l + i < M; ++l) e[i] = (lead == l) ? d[i + l] : e[i];
+    const int deg = M - lead - 1;
     if (deg <= 0) return 0;
-    if (deg == 1) { out[0] = -pin[1] / pin[0]; return 1; }
+    if (deg == 1) { out[0] = -e[1] / e[0]; return 1; }
     if (deg == 2) {
-        const double a = pin[0], b = pin[1], c = pin[2];
+        const double a = e[0], b = e[1], c = e[2];
         const double D = b * b - 4 * a * c, sD = sqrt(fabs(D));
         if (D >= 0) {
             if (b >= 0) { out[0] = (-b - sD) / (2.0 * a); out[1] = (2.0 * c) / (-b - sD); }
@@ -182,106 +261,97 @@ __device__ inline int poly_root_real_parts(const double *pin, int n, double *out
         } else { out[0] = -b / (2.0 * a); out[1] = -b / (2.0 * a); }
         return 2;
     }
-    double a[5], zr[4], zi[4];
-    double R = 0.0;
-    for (int i = 0; i <= deg; ++i) a[i] = pin[i] / pin[0];
-    for (int i = 1; i <= deg; ++i) R = fmax(R, fabs(a[i]));
-    R = 1.0 + R;
-    // Durand-Kerner style start points R * (0.4 + 0.9i)^k
-    const double sr0[4] = {1.0, 0.4, -0.65, -0.908}, si0[4] = {0.0, 0.9, 0.72, -0.297};
-    for (int k = 0; k < deg; ++k) { zr[k] = R * sr0[k]; zi[k] = R * si0[k]; }
-    for (int it = 0; it < 200; ++it) {          // Aberth-Ehrlich
-        double maxw = 0.0;
-        for (int k = 0; k < deg; ++k) {
-            double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;
-            for (int i = 1; i <= deg; ++i) {
-                const double ndr = dr * zr[k] - di * zi[k] + pr, ndi = dr * zi[k] + di * zr[k] + pi;
-                const double npr = pr * zr[k] - pi * zi[k] + a[i], npi = pr * zi[k] + pi * zr[k];
-                dr = ndr; di = ndi; pr = npr; pi = npi;
-            }
-            double den = dr * dr + di * di;
-            if (den == 0.0) continue;
-            const double wr = (pr * dr + pi * di) / den, wi = (pi * dr - pr * di) / den;
-            double sr = 0.0, si = 0.0;
-            for (int j = 0; j < deg; ++j) {
-                if (j == k) continue;
-                const double er = zr[k] - zr[j], ei = zi[k] - zi[j], d2 = er * er + ei * ei;
-                if (d2 == 0.0) continue;
-                sr += er / d2; si += -ei / d2;
-            }
-            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
-            den = qr * qr + qi * qi;
-            if (den == 0.0) continue;
-            const double cr = (wr * qr + wi * qi) / den, ci = (wi * qr - wr * qi) / den;
-            zr[k] -= cr; zi[k] -= ci;
-            maxw = fmax(maxw, fabs(cr) + fabs(ci));
-        }
-        if (maxw < 1e-15 * R) break;
+    if constexpr (M >= 5) {
+        if (deg == 4) { const double q[5] = {e[0], e[1], e[2], e[3], e[4]}; real_roots_in<4>(q, lo, hi, out); return 4; }
     }
-    for (int k = 0; k < deg; ++k) out[k] = zr[k];
-    return deg;
-}
-
-__device__ inline int solve_dense(double *A, double *b, int n) {
-    for (int k = 0; k < n; ++k) {
-        int piv = k;
-        for (int i = k + 1; i < n; ++i) if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
-        if (A[piv * n + k] == 0.0) return -1;
-        if (piv != k) {
-            for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
-            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
-        }
-        for (int i = k + 1; i < n; ++i) {
-            const double f = A[i * n + k] / A[k * n + k];
-            for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
-            b[i] -= f * b[k];
-        }
-    }
-    for (int k = n - 1; k >= 0; --k) {
-        double s = b[k];
-        for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * b[j];
-        b[k] = s / A[k * n + k];
+    if constexpr (M >= 4) {
+        const double q[4] = {e[0], e[1], e[2], e[3]};
+        double r[3];
+        real_roots_in<3>(q, lo, hi, r);
+        out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
+        return 3;
     }
     return 0;
 }
 
-// Ceres MinimizeInterpolatingPolynomial over [x_min, x_max]
-__device__ inline double minimize_interpolating_polynomial(const LsSample *s, int ns, double x_min, double x_max) {
-    int ncons = 0;
-    for (int i = 0; i < ns; ++i) ncons += (int)s[i].value_valid + (int)s[i].gradient_valid;
-    const int deg = ncons - 1;
-    double lhs[36], poly[6];
-    for (int i = 0; i < 36; ++i) lhs[i] = 0.0;
-    int row = 0;
-    for (int i = 0; i < ns; ++i) {
-        if (s[i].value_valid) {
-            for (int j = 0; j <= deg; ++j) lhs[row * ncons + j] = ipow(s[i].x, deg - j);
-            poly[row++] = s[i].value;
+// Gaussian elimination with partial pivoting on registers: the pivot row is exchanged by selects
+template <int N>
+__device__ __forceinline__ bool solve_dense_n(double (&A)[N][N], double (&b)[N]) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        int piv = k;
+        double pv = A[k][k];
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) if (fabs(A[i][k]) > fabs(pv)) { piv = i; pv = A[i][k]; }
+        if (pv == 0.0) return false;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const bool sw = piv == i;
+#pragma unroll
+            for (int j = 0; j < N; ++j) { const double t = A[k][j], u = A[i][j]; A[k][j] = sw ? u : t; A[i][j] = sw ? t : u; }
+            const double t = b[k], u = b[i]; b[k] = sw ? u : t; b[i] = sw ? t : u;
         }
-        if (s[i].gradient_valid) {
-            for (int j = 0; j < deg; ++j) lhs[row * ncons + j] = (deg - j) * ipow(s[i].x, deg - j - 1);
-            poly[row++] = s[i].gradient;
+#pragma unroll
+        for (int i = k + 1; i < N; ++i) {
+            const double f = A[i][k] / A[k][k];
+#pragma unroll
+            for (int j = k; j < N; ++j) A[i][j] -= f * A[k][j];
+            b[i] -= f * b[k];
         }
     }
+#pragma unroll
+    for (int k = N - 1; k >= 0; --k) {
+        double s = b[k];
+#pragma unroll
+        for (int j = k + 1; j < N; ++j) s -= A[k][j] * b[j];
+        b[k] = s / A[k][k];
+    }
+    return true;
+}
+
+// Ceres MinimizeInterpolatingPolynomial over [x_min, x_max] with N constraints: cx/cv/cg = abscissa, right-hand side and
+// "is a gradient constraint" of constraint r, in the order value, gradient per sample; sx = the ns sample abscissae
+template <int N>
+__device__ __forceinline__ double minimize_interpolating_polynomial_n(const double (&cx)[6], const double (&cv)[6], const bool (&cg)[6],
+                                                                      const double (&sx)[3], int ns, double x_min, double x_max) {
+    constexpr int deg = N - 1;
+    double A[N][N], poly[N];
+#pragma unroll
+    for (int r = 0; r < N; ++r) {
+        double pw[N];                                            // pw[j] = x^j by repeated multiplication from 1 (Ceres: pow())
+        pw[0] = 1.0;
+#pragma unroll
+        for (int j = 1; j < N; ++j) pw[j] = pw[j - 1] * cx[r];
+#pragma unroll
+        for (int j = 0; j <= deg; ++j) {
+            const double value_row = pw[deg - j];
+            const double gradient_row = j < deg ? (deg - j) * pw[j < deg ? deg - j - 1 : 0] : 0.0;
+            A[r][j] = cg[r] ? gradient_row : value_row;
+        }
+        poly[r] = cv[r];
+    }
     double best_x = (x_min + x_max) / 2.0;
-    if (solve_dense(lhs, poly, ncons) != 0) return best_x;
-    double best_v = polyval(poly, ncons, best_x), v;
-    v = polyval(poly, ncons, x_min); if (v < best_v) { best_v = v; best_x = x_min; }
-    v = polyval(poly, ncons, x_max); if (v < best_v) { best_v = v; best_x = x_max; }
-    if (ncons > 2) {
-        double deriv[5], roots[4];
+    if (!solve_dense_n<N>(A, poly)) return best_x;
+    double best_v = polyval_n<N>(poly, best_x), v;
+    v = polyval_n<N>(poly, x_min); if (v < best_v) { best_v = v; best_x = x_min; }
+    v = polyval_n<N>(poly, x_max); if (v < best_v) { best_v = v; best_x = x_max; }
+    {
+        double deriv[N - 1], roots[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
         for (int i = 0; i < deg; ++i) deriv[i] = poly[i] * (deg - i);
-        const int nr = poly_root_real_parts(deriv, deg, roots);
-        for (int i = 0; i < nr; ++i) {
-            if (roots[i] < x_min || roots[i] > x_max) continue;
-            v = polyval(poly, ncons, roots[i]);
+        const int nr = poly_root_real_parts_n<N - 1>(deriv, x_min, x_max, roots);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i >= nr || roots[i] < x_min || roots[i] > x_max) continue;
+            v = polyval_n<N>(poly, roots[i]);
             if (v < best_v) { best_v = v; best_x = roots[i]; }
         }
     }
-    for (int i = 0; i < ns; ++i) {
-        if (s[i].x < x_min || s[i].x > x_max) continue;
-        v = polyval(poly, ncons, s[i].x);
-        if (v < best_v) { best_v = v; best_x = s[i].x; }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i >= ns || sx[i] < x_min || sx[i] > x_max) continue;
+        v = polyval_n<N>(poly, sx[i]);
+        if (v < best_v) { best_v = v; best_x = sx[i]; }
     }
     return best_x;
 }
@@ -289,16 +359,40 @@ __device__ inline double minimize_interpolating_polynomial(const LsSample *s, in
 // One contraction of ArmijoLineSearch::DoSearch: given the failed `current` sample, returns the
 // next step size, or a negative value when the search gives up.  `n_iter` is incremented.
 __device__ __noinline__ double ls_next_step(const LsSample &initial, const LsSample &previous, const LsSample &current,
-                                      double dir_max, int &n_iter) {
+                                            double dir_max, int &n_iter) {
     if (++n_iter >= kLsMaxIterations) return -1.0;
     const double lo = kLsMaxContraction * current.x, hi = kLsMinContraction * current.x;
     double step;
     if (!current.value_valid) step = fmin(fmax(current.x * 0.5, lo), hi);
     else {
-        LsSample s[3]; int ns = 0;
-        s[ns++] = initial; s[ns++] = current;
-        if (previous.value_valid) s[ns++] = previous;
-        step = minimize_interpolating_polynomial(s, ns, lo, hi);
+        // candidate constraints in Ceres' order (value, gradient per sample: initial, current, previous), compacted to the valid ones
+        const bool with_prev = previous.value_valid;
+        const int ns = with_prev ? 3 : 2;
+        const double sx[3] = {initial.x, current.x, previous.x};
+        const double px[6] = {initial.x, initial.x, current.x, current.x, previous.x, previous.x};
+        const double pv[6] = {initial.value, initial.gradient, current.value, current.gradient, previous.value, previous.gradient};
+        const bool ok[6] = {initial.value_valid, initial.gradient_valid, current.value_valid, current.gradient_valid,
+                            with_prev && previous.value_valid, with_prev && previous.gradient_valid};
+        double cx[6], cv[6]; bool cg[6];
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) { cx[r] = 0.0; cv[r] = 0.0; cg[r] = false; }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+#pragma unroll
+            for (int r = 0; r <= c; ++r) {
+                const bool here = ok[c] && n == r;
+                cx[r] = here ? px[c] : cx[r]; cv[r] = here ? pv[c] : cv[r]; cg[r] = here ? (c & 1) != 0 : cg[r];
+            }
+            n += ok[c] ? 1 : 0;
+        }
+        switch (n) {
+            case 3: step = minimize_interpolating_polynomial_n<3>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 4: step = minimize_interpolating_polynomial_n<4>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 5: step = minimize_interpolating_polynomial_n<5>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 6: step = minimize_interpolating_polynomial_n<6>(cx, cv, cg, sx, ns, lo, hi); break;
+            default: step = fmin(fmax(current.x * 0.5, lo), hi); break;      // < 3 constraints: not reachable (the initial sample always has both)
+        }
     }
     if (step * dir_max < kLsMinStep) return -1.0;
     return step;

@@ -577,17 +577,17 @@ __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_pack
 // =============================================================================================
 // One workgroup per component; its size is a template parameter.  The launch is wait-bound (72 % of the wave cycles on config
 // 5), so what counts is how many components share a CU, and that is set by LDS and by the 8 waves of 256 VGPRs a CU
-// holds: 128 threads x 4 workgroups (<= 88 rows), 256 x 2 (<= 130 rows), 256 x 1 (<= 192 rows, measured: 22.0 ms against 23.1 ms
-// with 512 threads - most phases keep fewer than 200 threads busy), 256 for the HBM-matrix variant (29.1 ms against 34.3 ms).
+// holds: 128 threads x 4 workgroups (<= 88 rows), 256 x 2 (<= 130 rows), 512 x 1 (<= 192 rows: the whole CU; with the
+// barrier-per-column phases gone the second wave per SIMD pays - 10.15 ms against 10.8 ms with 256), 256 for the HBM-matrix variant.
 
 // Accumulate into a matrix entry its row's thread owns.  A read-modify-write in program order made every edge of the walk wait
 // for an LDS round trip (a row may hit the same entry twice, so the compiler cannot overlap them); the no-return atomic is
 // fire-and-forget, and the adds of one thread to one address still apply in issue order: the sum stays bitwise reproducible.
 __device__ __forceinline__ void mat_add(double *p, double v) { __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ double readlane_f64(double v, int uniform_lane) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), uniform_lane), __builtin_amdgcn_readlane(__double2loint(v), uniform_lane));
-}
-__device__ __forceinline__ size_t tri(int i, int j) { return (size_t)i * (i + 1) / 2 + j; }   // j <= i
+// Packed lower triangle: element (i, j), j <= i.  Rows are < 2^16 (32767 nodes per component), so i (i + 1) fits 32 bits and the
+// product is a full-rate 24-bit multiply (v_mul_u32_u24) instead of the quarter-rate v_mul_lo_u32: the index arithmetic of the
+// factorization's tile loop was costing more issue cycles than its MFMAs.
+__device__ __forceinline__ uint32_t tri(int i, int j) { return (__umul24((unsigned)i, (unsigned)i + 1u) >> 1) + (unsigned)j; }
 
 struct BlockShared {
     double red[8];
@@ -626,6 +626,10 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 template <bool GLOBAL_MATRIX, int kBlockThreads>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
     constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
+#ifdef LFR_PROFILE_WGTIME
+    const unsigned long long wg_t0_ = __builtin_amdgcn_s_memtime();
+    const unsigned long long wg_r0_ = wall_clock64();          // 100 MHz, the same counter on every XCD
+#endif
     extern __shared__ double dyn[];
     __shared__ BlockShared sh;
     const int tid = threadIdx.x;
@@ -935,6 +939,15 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
 #pragma unroll
                     for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
                 };
+                // interior tiles of a full panel (every row < n, strictly below the diagonal): no clamps, no selects
+                auto load_full = [&](int I, int J, Tile &T) {
+                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16;
+                    T.row0 = ke + 16 * I + kq; T.jb = jb;
+                    const uint32_t oa = tri(ia, kb + kq), ob = tri(jb, kb + kq);
+                    T.a0 = Mat[oa]; T.a1 = Mat[oa + 4]; T.b0 = Mat[ob] * ninv0; T.b1 = Mat[ob + 4] * ninv1;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { T.ok[r] = true; T.c[r] = Mat[tri(T.row0 + 4 * r, jb)]; }
+                };
                 int I = 0, J = wave;                                     // tile t = wave, wave + kWaves, ... of the row-major lower triangle
                 while (J > I) { J -= I + 1; ++I; }
                 while (I < mt) {                                         // wave-uniform
@@ -944,8 +957,13 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
                     const int I1 = I, J1 = J;
                     J += kWaves; while (J > I) { J -= I + 1; ++I; }
                     Tile t0, t1;
-                    load_tile(I0, J0, t0);
-                    load_tile(I1, J1, t1);                               // (past the end: clamped loads, nothing stored)
+                    if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n) {       // (I0 <= I1)
+                        load_full(I0, J0, t0);
+                        load_full(I1, J1, t1);
+                    } else {
+                        load_tile(I0, J0, t0);
+                        load_tile(I1, J1, t1);                           // (past the end: clamped loads, nothing stored)
+                    }
                     t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a0, t0.b0, t0.c, 0, 0, 0);
                     t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a0, t1.b0, t1.c, 0, 0, 0);
                     t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a1, t0.b1, t0.c, 0, 0, 0);
@@ -1138,6 +1156,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
     }
     __syncthreads();
     PROF_MARK(4);
+#ifdef LFR_PROFILE_ONLY_ITER       // diagnostic builds: phase profile of the slow components only
+    if (iteration >= LFR_PROFILE_ONLY_ITER)
+#endif
     PROF_FLUSH();
     for (int i = tid; i < n; i += kBlockThreads)
         a.positions[2 * (size_t)a.node_ids[d.node_off + (i >> 1)] + (i & 1)] = term != LFR_TERM_FAILURE ? vx[i] : 0.0;
@@ -1146,6 +1167,17 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
         inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
         inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
         inf.final_cost = cost;
+#ifdef LFR_PROFILE_WGTIME          // diagnostic builds: the workgroup's lifetime in s_memtime ticks instead of the cost
+        inf.final_cost = (double)(__builtin_amdgcn_s_memtime() - wg_t0_);
+        if (LFR_PROFILE_WGTIME == 2) inf.final_cost = exec_passes + 1e3 * n_ls_evals + 1e6 * n_cand + 1e9 * n_successful + 1e12 * n_invalid;
+        if (LFR_PROFILE_WGTIME == 3) {           // start time, lifetime in kiloticks, hardware id (XCC, SE, CU)
+            inf.final_cost = (double)wg_r0_;
+            inf.iterations = (int)(wall_clock64() - wg_r0_);
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));          // HW_ID: cu [11:8], sh [12], se [15:13]
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));         // XCC_ID [3:0]
+            inf.termination = (int)(((hw >> 8) & 0xffu) | ((xcc & 0xfu) << 8));
+        }
+#endif
         a.infos[ci] = inf;
     }
 }
@@ -1157,7 +1189,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
 #define LFR_THREADS_M 256
 #endif
 #ifndef LFR_THREADS_L
-#define LFR_THREADS_L 256
+#define LFR_THREADS_L 512
 #endif
 #ifndef LFR_THREADS_G
 #define LFR_THREADS_G 256
@@ -1604,6 +1636,41 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out8, d_out, 64 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(cost_only, d_c, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
+    HIP_TRY(lfr::stream_wait(st));
+    return LFR_OK;
+}
+
+namespace {
+// samples: 15 doubles per case = (x, value, gradient, value_valid, gradient_valid) of the initial, previous and current sample
+__global__ void ls_next_step_kernel(int64_t n, const double *samples, const double *dir_max, double *step) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    LsSample s[3];
+    for (int k = 0; k < 3; ++k) {
+        const double *q = samples + 15 * i + 5 * k;
+        s[k].x = q[0]; s[k].value = q[1]; s[k].gradient = q[2]; s[k].value_valid = q[3] != 0.0; s[k].gradient_valid = q[4] != 0.0;
+    }
+    int it0 = 0;
+    step[i] = ls_next_step(s[0], s[1], s[2], dir_max[i], it0);
+}
+}  // namespace
+
+int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, double *step) {
+    if (n < 0 || (n > 0 && (!samples || !dir_max || !step))) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    if (n == 0) return LFR_OK;
+    HIP_TRY(hipSetDevice(device));
+    lfr::DevArena ar;
+    if (!ar.init(ctx, (size_t)n * 8 * 18 + 4096)) return LFR_ERR_NOMEM;
+    double *d_s = ar.take_n<double>(15 * n), *d_d = ar.take_n<double>(n), *d_a = ar.take_n<double>(n);
+    if (!d_a) { lfr::set_error("arena exhausted"); return LFR_ERR_NOMEM; }
+    hipStream_t st = ctx->s_main;
+    HIP_TRY(hipMemcpyAsync(d_s, samples, 120 * (size_t)n, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_d, dir_max, 8 * (size_t)n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ls_next_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, d_s, d_d, d_a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(step, d_a, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(lfr::stream_wait(st));
     return LFR_OK;
 }

@@ -102,6 +102,7 @@ def lib():
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
+        "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
@@ -117,7 +118,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -287,6 +288,17 @@ def eval_edges_hip(flows, sim, kind, x1, x2, tukey_variant="ceres1", device=0):
     _check(lib().lfr_debug_eval_edges(device, n, _ptr(flows), _ptr(sim), _ptr(kind), _ptr(x1), _ptr(x2), TUKEY[tukey_variant],
                                       _ptr(out), _ptr(cost)))
     return out, cost
+
+
+def ls_next_step_hip(samples, dir_max, device=0):
+    """The kernels' line-search contraction on the GPU (lfr_debug_ls_next_step): samples[n, 3, 5] = (x, value, gradient,
+    value_valid, gradient_valid) of the initial / previous / current sample.  Returns the next step sizes (negative: give up)."""
+    samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 15)
+    n = samples.shape[0]
+    dir_max = np.ascontiguousarray(dir_max, np.float64)
+    a = np.zeros(n, np.float64)
+    _check(lib().lfr_debug_ls_next_step(device, n, _ptr(samples), _ptr(dir_max), _ptr(a)))
+    return a
 
 
 def bisect_graph(edges, weights):

@@ -200,10 +200,63 @@ static double polyval(const double *p, int n, double x) {
     return v;
 }
 
-/* real parts of all roots of a polynomial of degree <= 4 (coefficients highest first).
- * degree <= 2 closed form exactly as Ceres FindQuadraticPolynomialRoots; higher degree by
- * Aberth-Ehrlich iteration (Ceres uses companion-matrix eigenvalues: same roots to rounding). */
-static int poly_root_real_parts(const double *pin, int n, double *out) {
+/* Real roots of q (degree m = 2..4, coefficients highest first, q[0] != 0) inside [lo, hi]: the critical points of q
+ * cut the interval into monotone pieces, a sign change brackets one root, a safeguarded Newton iteration polishes it.
+ * Writes exactly m ascending values inside [lo, hi]; a piece without a root contributes its left end (x_min or an
+ * inflection point of the interpolant: a harmless extra candidate for the minimum). */
+static double horner(const double *q, int m, double x) {
+    double v = q[0];
+    for (int i = 1; i <= m; ++i) v = v * x + q[i];
+    return v;
+}
+static void real_roots_in(const double *q, int m, double lo, double hi, double *out) {
+    if (m == 2) {
+        const double A = q[0], B = q[1], C = q[2], D = B * B - 4 * A * C;
+        double r0 = lo, r1 = lo;
+        if (D >= 0) {
+            const double sD = sqrt(D), t = B >= 0 ? -B - sD : -B + sD;
+            const double u = t / (2.0 * A), v = t != 0.0 ? (2.0 * C) / t : u;
+            r0 = fmin(u, v); r1 = fmax(u, v);
+            if (!(r0 == r0)) r0 = lo;
+            if (!(r1 == r1)) r1 = lo;
+        }
+        out[0] = fmin(fmax(r0, lo), hi); out[1] = fmin(fmax(r1, lo), hi);
+        return;
+    }
+    double dq[4], bp[3];
+    for (int i = 0; i < m; ++i) dq[i] = q[i] * (m - i);
+    real_roots_in(dq, m - 1, lo, hi, bp);
+    for (int i = 0; i < m; ++i) {
+        double a = i == 0 ? lo : bp[i - 1], b = i == m - 1 ? hi : bp[i];
+        const double fa = horner(q, m, a), fb = horner(q, m, b);
+        double r = a;
+        if (fa != 0.0 && fb == 0.0) r = b;
+        else if ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0)) {
+            double x = 0.5 * (a + b);
+            for (int it = 0; it < 200; ++it) {
+                const double fx = horner(q, m, x);
+                if (fx == 0.0) break;
+                if ((fx < 0.0) == (fa < 0.0)) a = x; else b = x;
+                double xn = x - fx / horner(dq, m - 1, x);
+                if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+                if (!(xn > a && xn < b)) break;
+                if (fabs(xn - x) <= 2.220446049250313e-16 * fabs(xn)) { x = xn; break; }
+                x = xn;
+            }
+            r = x;
+        }
+        out[i] = r;
+    }
+}
+
+/* Candidate abscissae for the minimum of the interpolant over [lo, hi]: Ceres takes the real parts of all roots of the
+ * derivative (FindPolynomialRoots: companion-matrix eigenvalues) and keeps those inside the interval.  Degree <= 2 in
+ * closed form exactly as Ceres' FindLinear/FindQuadraticPolynomialRoots (a complex pair contributes its real part);
+ * degree 3 and 4: the real roots inside the interval - only a real critical point can be the minimum, and unlike a
+ * simultaneous complex iteration (the first version of this oracle: Aberth-Ehrlich from a circle of radius
+ * 1 + max |a_i / a_0|) the bracketing stays accurate when the leading coefficient is tiny.  Pinned against
+ * numpy.roots in tests/test_oracle_kat.py. */
+static int poly_root_real_parts(const double *pin, int n, double lo, double hi, double *out) {
     while (n > 0 && pin[0] == 0.0) { ++pin; --n; }
     const int deg = n - 1;
     if (deg <= 0) return 0;
@@ -217,43 +270,7 @@ static int poly_root_real_parts(const double *pin, int n, double *out) {
         } else { out[0] = -b / (2.0 * a); out[1] = -b / (2.0 * a); }
         return 2;
     }
-    double a[5], zr[4], zi[4];
-    double R = 0.0;
-    for (int i = 0; i <= deg; ++i) a[i] = pin[i] / pin[0];
-    for (int i = 1; i <= deg; ++i) R = fmax(R, fabs(a[i]));
-    R = 1.0 + R;
-    /* Durand-Kerner style start points R * (0.4 + 0.9i)^k */
-    const double sr0[4] = {1.0, 0.4, -0.65, -0.908}, si0[4] = {0.0, 0.9, 0.72, -0.297};
-    for (int k = 0; k < deg; ++k) { zr[k] = R * sr0[k]; zi[k] = R * si0[k]; }
-    for (int it = 0; it < 200; ++it) {
-        double maxw = 0.0;
-        for (int k = 0; k < deg; ++k) {
-            double pr = 1.0, pi = 0.0, dr = 0.0, di = 0.0;     /* p(z) and p'(z) by Horner */
-            for (int i = 1; i <= deg; ++i) {
-                const double ndr = dr * zr[k] - di * zi[k] + pr, ndi = dr * zi[k] + di * zr[k] + pi;
-                const double npr = pr * zr[k] - pi * zi[k] + a[i], npi = pr * zi[k] + pi * zr[k];
-                dr = ndr; di = ndi; pr = npr; pi = npi;
-            }
-            double den = dr * dr + di * di;
-            if (den == 0.0) continue;
-            const double wr = (pr * dr + pi * di) / den, wi = (pi * dr - pr * di) / den;   /* p/p' */
-            double sr = 0.0, si = 0.0;
-            for (int j = 0; j < deg; ++j) {
-                if (j == k) continue;
-                const double er = zr[k] - zr[j], ei = zi[k] - zi[j], d2 = er * er + ei * ei;
-                if (d2 == 0.0) continue;
-                sr += er / d2; si += -ei / d2;
-            }
-            const double qr = 1.0 - (wr * sr - wi * si), qi = -(wr * si + wi * sr);
-            den = qr * qr + qi * qi;
-            if (den == 0.0) continue;
-            const double cr = (wr * qr + wi * qi) / den, ci = (wi * qr - wr * qi) / den;
-            zr[k] -= cr; zi[k] -= ci;
-            maxw = fmax(maxw, fabs(cr) + fabs(ci));
-        }
-        if (maxw < 1e-15 * R) break;
-    }
-    for (int k = 0; k < deg; ++k) out[k] = zr[k];
+    real_roots_in(pin, deg, lo, hi, out);
     return deg;
 }
 
@@ -308,7 +325,7 @@ static double minimize_interpolating_polynomial(const Sample *s, int ns, double 
     if (ncons > 2) {
         double deriv[5], roots[4];
         for (int i = 0; i < deg; ++i) deriv[i] = poly[i] * (deg - i);
-        const int nr = poly_root_real_parts(deriv, deg, roots);
+        const int nr = poly_root_real_parts(deriv, deg, x_min, x_max, roots);
         for (int i = 0; i < nr; ++i) {
             if (roots[i] < x_min || roots[i] > x_max) continue;
             v = polyval(poly, ncons, roots[i]);

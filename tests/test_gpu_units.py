@@ -95,3 +95,22 @@ def test_baseline_configs_at_full_size(lfr_lib, name):
     solved = ref["comp_nvar"] > 0
     assert (np.sort(info["component"]) == np.nonzero(solved)[0]).all()
     assert (info["iterations"] == ref["infos"]["iterations"][info["component"]]).all()
+
+
+def test_line_search_contraction_matches_numpy_roots(lfr_lib):
+    """ArmijoLineSearch::DoSearch's step contraction (MinimizeInterpolatingPolynomial over 3..6 value / gradient constraints)
+    as the kernels compute it, against the numpy restatement (np.roots), including interpolants whose leading coefficients vanish."""
+    import ls_cases
+    S, dir_max, want = ls_cases.make(4000)
+    got = capi.ls_next_step_hip(S, dir_max)
+    gave_up = want < 0
+    assert ((got < 0) == gave_up).all()
+    ok = ~gave_up
+    rel = np.abs(got[ok] - want[ok]) / np.abs(want[ok])
+    # where the abscissae differ the two candidates must be a tie in VALUE (a flat interpolant): compare the interpolant there
+    for k in np.flatnonzero(ok)[rel > 1e-8]:
+        v = ls_cases.interpolant_values(S[k], np.array([got[k], want[k]]))
+        assert v[0] <= v[1] + 1e-9 * max(1.0, abs(v[1])), (k, got[k], want[k], v)
+    assert (rel > 1e-8).sum() <= 0.05 * rel.size, (rel > 1e-8).sum()
+    ncons = 2 + S[:, 2, 3] + S[:, 2, 4] + S[:, 1, 3] + S[:, 1, 4]
+    assert set(np.unique(ncons[S[:, 2, 3] > 0]).astype(int)) == {3, 4, 5, 6}

@@ -159,6 +159,27 @@ def test_polynomial_minimisation_matches_numpy_roots():
     assert O.minimize_poly([[0, 1, -1, 1, 1], [1, 1, 1, 1, 1]], 1e-3, 0.6) == pytest.approx(0.5, abs=1e-12)
 
 
+def test_polynomial_minimisation_with_vanishing_leading_coefficients():
+    """Samples of exact quadratics / cubics / quartics: the degree-5 interpolant's derivative has roots near infinity
+    (the first version of the oracle, a simultaneous complex iteration from a coefficient bound, lost the small roots there)."""
+    import ls_cases
+    S, dir_max, want = ls_cases.make(1500, seed=12)
+    n_diff = 0
+    for k in range(S.shape[0]):
+        if not S[k, 2, 3]:
+            continue
+        xc = S[k, 2, 0]
+        lo, hi = R.LS_MAX_STEP_CONTRACTION * xc, R.LS_MIN_STEP_CONTRACTION * xc
+        rows = [S[k, 0], S[k, 2]] + ([S[k, 1]] if S[k, 1, 3] else [])
+        got = O.minimize_poly(rows, lo, hi)
+        ref = R.minimize_interpolating_polynomial(ls_cases.reference_samples(S[k]), lo, hi)
+        if abs(got - ref) > 1e-8 * abs(ref):                      # must be a tie in value (or np.roots lost accuracy: better)
+            v = ls_cases.interpolant_values(S[k], np.array([got, ref]))
+            assert v[0] <= v[1] + 1e-9 * max(1.0, abs(v[1])), (k, got, ref, v)
+            n_diff += 1
+    assert n_diff <= 0.05 * S.shape[0], n_diff
+
+
 CASES = {
     "clean": dict(seed=41, n_images=30, n_tracks=60),
     "outliers": dict(seed=42, n_images=200, n_tracks=60, eps_out=0.03),
