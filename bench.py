@@ -176,7 +176,7 @@ def main():
 
     # ---- per-kernel durations of the timed steps (HIP events recorded on the launch stream) ----
     n_ev = min(args.steps, 64)
-    cls_ms = np.zeros(7)
+    cls_ms = np.zeros(capi.NUM_KERNEL_CLASSES)
     tot_ms = 0.0
     for back in range(n_ev):
         t, c, cls_edges = batch.timing(back)

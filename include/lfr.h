@@ -241,8 +241,9 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
 /* Unit-level probe of the Armijo line search's step contraction (Ceres line_search.cc ArmijoLineSearch::DoSearch +
  * polynomial.cc MinimizeInterpolatingPolynomial): for each of n cases, samples holds 15 doubles = (x, value, gradient,
  * value_valid, gradient_valid) of the initial, the previous and the current sample; step[i] = the next step size the kernels
- * compute (negative: the search gives up).  Test infrastructure, not part of the solve path. */
-int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, double *step);
+ * compute (negative: the search gives up); register_version 0 = the loop version the packed kernel calls, 1 = the unrolled
+ * version of the workgroup-per-component kernel.  Test infrastructure, not part of the solve path. */
+int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, int register_version, double *step);
 
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,

@@ -156,11 +156,188 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
 // ------------------------------------------------------------------------------------------
 struct LsSample { double x, value, gradient; bool value_valid, gradient_valid; };
 
-// The interpolation runs in REGISTERS: every loop below has compile-time bounds (the number of constraints N = 3..6 is a
-// template parameter) and every array index is static after unrolling.  The first version indexed small local arrays with
-// run-time values (pivot rows, constraint counts, root counts); the compiler put them in scratch memory and one call cost
-// ~4e5 cycles (measured: a component that contracted its step 40 times lived 12 ms and set the duration of the whole
-// config-5 launch).
+__device__ inline double ipow(double x, int n) {       // x^n, n >= 0 (Ceres uses pow())
+    double v = 1.0;
+    for (int i = 0; i < n; ++i) v *= x;
+    return v;
+}
+
+__device__ inline double polyval(const double *p, int n, double x) {
+    double v = 0.0;
+    for (int i = 0; i < n; ++i) v = v * x + p[i];
+    return v;
+}
+
+// Real roots of q (degree m = 2..4, coefficients highest first, q[0] != 0) inside [lo, hi]: the critical points of q cut
+// the interval into monotone pieces, a sign change brackets one root, a safeguarded Newton iteration polishes it.  Writes
+// exactly m ascending values inside [lo, hi]; a piece without a root contributes its left end (x_min or an inflection point of
+// the interpolant: a harmless extra candidate for the minimum).
+__device__ inline double horner(const double *q, int m, double x) {
+    double v = q[0];
+    for (int i = 1; i <= m; ++i) v = v * x + q[i];
+    return v;
+}
+__device__ inline void real_roots_in(const double *q, int m, double lo, double hi, double *out) {
+    double c[3][5];                                           // q and its derivatives down to the quadratic
+    const int nlev = m - 2;
+    for (int i = 0; i <= m; ++i) c[0][i] = q[i];
+    for (int l = 1; l <= nlev; ++l)
+        for (int i = 0; i <= m - l; ++i) c[l][i] = c[l - 1][i] * (m - l + 1 - i);
+    double r[4], bp[4];
+    {
+        const double A = c[nlev][0], B = c[nlev][1], C = c[nlev][2], D = B * B - 4 * A * C;
+        double r0 = lo, r1 = lo;
+        if (D >= 0) {
+            const double sD = sqrt(D), t = B >= 0 ? -B - sD : -B + sD;      // -(B + sign(B) sqrt(D)): no cancellation
+            const double u = t / (2.0 * A), v = t != 0.0 ? (2.0 * C) / t : u;
+            r0 = fmin(u, v); r1 = fmax(u, v);
+            if (!(r0 == r0)) r0 = lo;
+            if (!(r1 == r1)) r1 = lo;
+        }
+        r[0] = fmin(fmax(r0, lo), hi); r[1] = fmin(fmax(r1, lo), hi);
+    }
+    for (int l = nlev - 1; l >= 0; --l) {
+        const int dl = m - l;                                 // degree of c[l]; c[l + 1] is its derivative
+        for (int i = 0; i < dl - 1; ++i) bp[i] = r[i];
+        for (int i = 0; i < dl; ++i) {
+            double a = i == 0 ? lo : bp[i - 1], b = i == dl - 1 ? hi : bp[i];
+            const double fa = horner(c[l], dl, a), fb = horner(c[l], dl, b);
+            double x = a;
+            if (fa != 0.0 && fb == 0.0) x = b;
+            else if ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0)) {
+                x = 0.5 * (a + b);
+                for (int it = 0; it < 200; ++it) {
+                    const double fx = horner(c[l], dl, x);
+                    if (fx == 0.0) break;
+                    if ((fx < 0.0) == (fa < 0.0)) a = x; else b = x;
+                    double xn = x - fx / horner(c[l + 1], dl - 1, x);
+                    if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
+                    if (!(xn > a && xn < b)) break;           // the bracket is down to neighbouring numbers
+                    if (fabs(xn - x) <= 2.220446049250313e-16 * fabs(xn)) { x = xn; break; }
+                    x = xn;
+                }
+            }
+            r[i] = x;
+        }
+    }
+    for (int i = 0; i < m; ++i) out[i] = r[i];
+}
+
+// Candidate abscissae for the minimum of the interpolant over [lo, hi]: Ceres takes the real parts of ALL roots of the
+// derivative (FindPolynomialRoots: companion-matrix eigenvalues) and keeps those inside the interval.  Degree <= 2 in closed
+// form exactly as Ceres (a complex pair contributes its real part); degree 3 and 4: the real roots inside the interval - only a
+// real critical point can be the minimum (a polynomial without one between two candidates is monotone there).  The first version
+// ran a simultaneous complex iteration (Aberth) from a circle of radius 1 + max |a_i / a_0|: up to 200 complex steps on
+// scratch arrays (~4e5 cycles per call: one component that contracted its step 40 times set the duration of the whole config-5
+// launch), and it lost the small roots when the leading coefficient is tiny (a nearly cubic function fitted by a quartic).
+// Loop bounds are run-time values on purpose: the arrays live in scratch and the function keeps a small register footprint, which
+// is what the packed kernel needs around its (rare) call - a fully unrolled register version cost it 42 spilled VGPRs and 14 %.
+__device__ inline int poly_root_real_parts(const double *pin, int n, double lo, double hi, double *out) {
+    while (n > 0 && pin[0] == 0.0) { ++pin; --n; }
+    const int deg = n - 1;
+    if (deg <= 0) return 0;
+    if (deg == 1) { out[0] = -pin[1] / pin[0]; return 1; }
+    if (deg == 2) {
+        const double a = pin[0], b = pin[1], c = pin[2];
+        const double D = b * b - 4 * a * c, sD = sqrt(fabs(D));
+        if (D >= 0) {
+            if (b >= 0) { out[0] = (-b - sD) / (2.0 * a); out[1] = (2.0 * c) / (-b - sD); }
+            else        { out[0] = (2.0 * c) / (-b + sD); out[1] = (-b + sD) / (2.0 * a); }
+        } else { out[0] = -b / (2.0 * a); out[1] = -b / (2.0 * a); }
+        return 2;
+    }
+    real_roots_in(pin, deg, lo, hi, out);
+    return deg;
+}
+
+__device__ inline int solve_dense(double *A, double *b, int n) {
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < n; ++i) if (fabs(A[i * n + k]) > fabs(A[piv * n + k])) piv = i;
+        if (A[piv * n + k] == 0.0) return -1;
+        if (piv != k) {
+            for (int j = 0; j < n; ++j) { const double t = A[k * n + j]; A[k * n + j] = A[piv * n + j]; A[piv * n + j] = t; }
+            const double t = b[k]; b[k] = b[piv]; b[piv] = t;
+        }
+        for (int i = k + 1; i < n; ++i) {
+            const double f = A[i * n + k] / A[k * n + k];
+            for (int j = k; j < n; ++j) A[i * n + j] -= f * A[k * n + j];
+            b[i] -= f * b[k];
+        }
+    }
+    for (int k = n - 1; k >= 0; --k) {
+        double s = b[k];
+        for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * b[j];
+        b[k] = s / A[k * n + k];
+    }
+    return 0;
+}
+
+// Ceres MinimizeInterpolatingPolynomial over [x_min, x_max]
+__device__ inline double minimize_interpolating_polynomial(const LsSample *s, int ns, double x_min, double x_max) {
+    int ncons = 0;
+    for (int i = 0; i < ns; ++i) ncons += (int)s[i].value_valid + (int)s[i].gradient_valid;
+    const int deg = ncons - 1;
+    double lhs[36], poly[6];
+    for (int i = 0; i < 36; ++i) lhs[i] = 0.0;
+    int row = 0;
+    for (int i = 0; i < ns; ++i) {
+        if (s[i].value_valid) {
+            for (int j = 0; j <= deg; ++j) lhs[row * ncons + j] = ipow(s[i].x, deg - j);
+            poly[row++] = s[i].value;
+        }
+        if (s[i].gradient_valid) {
+            for (int j = 0; j < deg; ++j) lhs[row * ncons + j] = (deg - j) * ipow(s[i].x, deg - j - 1);
+            poly[row++] = s[i].gradient;
+        }
+    }
+    double best_x = (x_min + x_max) / 2.0;
+    if (solve_dense(lhs, poly, ncons) != 0) return best_x;
+    double best_v = polyval(poly, ncons, best_x), v;
+    v = polyval(poly, ncons, x_min); if (v < best_v) { best_v = v; best_x = x_min; }
+    v = polyval(poly, ncons, x_max); if (v < best_v) { best_v = v; best_x = x_max; }
+    if (ncons > 2) {
+        double deriv[5], roots[4];
+        for (int i = 0; i < deg; ++i) deriv[i] = poly[i] * (deg - i);
+        const int nr = poly_root_real_parts(deriv, deg, x_min, x_max, roots);
+        for (int i = 0; i < nr; ++i) {
+            if (roots[i] < x_min || roots[i] > x_max) continue;
+            v = polyval(poly, ncons, roots[i]);
+            if (v < best_v) { best_v = v; best_x = roots[i]; }
+        }
+    }
+    for (int i = 0; i < ns; ++i) {
+        if (s[i].x < x_min || s[i].x > x_max) continue;
+        v = polyval(poly, ncons, s[i].x);
+        if (v < best_v) { best_v = v; best_x = s[i].x; }
+    }
+    return best_x;
+}
+
+// One contraction of ArmijoLineSearch::DoSearch: given the failed `current` sample, returns the
+// next step size, or a negative value when the search gives up.  `n_iter` is incremented.
+__device__ __noinline__ double ls_next_step(const LsSample &initial, const LsSample &previous, const LsSample &current,
+                                      double dir_max, int &n_iter) {
+    if (++n_iter >= kLsMaxIterations) return -1.0;
+    const double lo = kLsMaxContraction * current.x, hi = kLsMinContraction * current.x;
+    double step;
+    if (!current.value_valid) step = fmin(fmax(current.x * 0.5, lo), hi);
+    else {
+        LsSample s[3]; int ns = 0;
+        s[ns++] = initial; s[ns++] = current;
+        if (previous.value_valid) s[ns++] = previous;
+        step = minimize_interpolating_polynomial(s, ns, lo, hi);
+    }
+    if (step * dir_max < kLsMinStep) return -1.0;
+    return step;
+}
+
+// ---- the same contraction in REGISTERS, for the workgroup-per-component kernel ----
+// Every loop below has compile-time bounds (the number of constraints N = 3..6 is a template parameter) and every array index is
+// static after unrolling.  The loop version above keeps its small arrays in scratch memory and costs ~4e5 cycles per call
+// whatever the root finder (measured: a component that contracted its step 40 times lived 10-12 ms and set the duration of the
+// whole config-5 launch; 6.4 ms with this version).  The packed kernel keeps the loop version: this one's register footprint
+// cost it 42 spilled VGPRs around the call and 14 % of its run time.  Both are pinned against numpy.roots (test_gpu_units.py).
 template <int N>
 __device__ __forceinline__ double polyval_n(const double (&p)[N], double x) {
     double v = 0.0;
@@ -169,16 +346,7 @@ __device__ __forceinline__ double polyval_n(const double (&p)[N], double x) {
     return v;
 }
 
-// ---- real roots of a cubic / quartic inside [lo, hi] ----
-// Ceres takes the real parts of ALL roots of the interpolant's derivative (companion-matrix eigenvalues) and keeps those inside
-// the interval as candidates for the minimum.  Only real roots can win there (a polynomial without a real critical point
-// between two candidates is monotone between them), so the kernels isolate the real roots directly: the critical points of q
-// cut [lo, hi] into monotone pieces, a sign change brackets exactly one root, a safeguarded Newton iteration polishes it.
-// Unlike a simultaneous complex iteration started on a circle of radius 1 + max |a_i / a_0| (the first version: Aberth), this
-// stays accurate when the leading coefficient is tiny (a nearly cubic function fitted by a quartic puts one root near
-// infinity), and it is a few hundred dependent multiply-adds instead of up to 200 complex iterations.
-// Every level returns exactly M ascending values inside [lo, hi]: a piece without a root contributes its left end
-// (x_min or an inflection point of the interpolant - a harmless extra candidate).
+// real roots of a cubic / quartic inside [lo, hi] (see real_roots_in above): every level returns exactly M ascending values
 template <int M>
 __device__ __forceinline__ double horner(const double (&q)[M + 1], double x) {
     double v = q[0];
@@ -234,9 +402,7 @@ __device__ __forceinline__ void real_roots_in(const double (&q)[M + 1], double l
     }
 }
 
-// candidate abscissae for the minimum of the interpolant: real parts of the roots of its derivative d[0] x^(M-1) + ... + d[M-1]
-// (leading zeros skipped); returns their count (<= 4).  Degree <= 2 in closed form exactly as Ceres' FindPolynomialRoots
-// (a complex pair contributes its real part), degree 3 and 4: the real roots inside [lo, hi].
+// poly_root_real_parts for d[0] x^(M-1) + ... + d[M-1]
 template <int M>
 __device__ __forceinline__ int poly_root_real_parts_n(const double (&d)[M], double lo, double hi, double (&out)[4]) {
     static_assert(M >= 2 && M <= 5, "derivative of a polynomial with 3..6 coefficients");
@@ -356,9 +522,7 @@ __device__ __forceinline__ double minimize_interpolating_polynomial_n(const doub
     return best_x;
 }
 
-// One contraction of ArmijoLineSearch::DoSearch: given the failed `current` sample, returns the
-// next step size, or a negative value when the search gives up.  `n_iter` is incremented.
-__device__ __noinline__ double ls_next_step(const LsSample &initial, const LsSample &previous, const LsSample &current,
+__device__ __noinline__ double ls_next_step_regs(const LsSample &initial, const LsSample &previous, const LsSample &current,
                                             double dir_max, int &n_iter) {
     if (++n_iter >= kLsMaxIterations) return -1.0;
     const double lo = kLsMaxContraction * current.x, hi = kLsMinContraction * current.x;

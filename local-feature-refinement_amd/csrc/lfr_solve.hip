@@ -1110,7 +1110,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
                     current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
-                const double nstep = ls_next_step(initial, previous, current, dir_max, n_iter);
+                const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;
@@ -1642,7 +1642,7 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
 
 namespace {
 // samples: 15 doubles per case = (x, value, gradient, value_valid, gradient_valid) of the initial, previous and current sample
-__global__ void ls_next_step_kernel(int64_t n, const double *samples, const double *dir_max, double *step) {
+__global__ void ls_next_step_kernel(int64_t n, const double *samples, const double *dir_max, int register_version, double *step) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     LsSample s[3];
@@ -1651,11 +1651,11 @@ __global__ void ls_next_step_kernel(int64_t n, const double *samples, const doub
         s[k].x = q[0]; s[k].value = q[1]; s[k].gradient = q[2]; s[k].value_valid = q[3] != 0.0; s[k].gradient_valid = q[4] != 0.0;
     }
     int it0 = 0;
-    step[i] = ls_next_step(s[0], s[1], s[2], dir_max[i], it0);
+    step[i] = register_version ? ls_next_step_regs(s[0], s[1], s[2], dir_max[i], it0) : ls_next_step(s[0], s[1], s[2], dir_max[i], it0);
 }
 }  // namespace
 
-int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, double *step) {
+int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, int register_version, double *step) {
     if (n < 0 || (n > 0 && (!samples || !dir_max || !step))) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     lfr::DevCtx *ctx = lfr::dev_ctx(device);
     if (!ctx) return LFR_ERR_HIP;
@@ -1668,7 +1668,7 @@ int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const d
     hipStream_t st = ctx->s_main;
     HIP_TRY(hipMemcpyAsync(d_s, samples, 120 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_d, dir_max, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ls_next_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, d_s, d_d, d_a);
+    hipLaunchKernelGGL(ls_next_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, d_s, d_d, register_version, d_a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(step, d_a, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(lfr::stream_wait(st));

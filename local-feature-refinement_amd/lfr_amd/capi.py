@@ -102,7 +102,7 @@ def lib():
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
-        "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, vp]),
+        "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, C.c_int, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
@@ -290,14 +290,14 @@ def eval_edges_hip(flows, sim, kind, x1, x2, tukey_variant="ceres1", device=0):
     return out, cost
 
 
-def ls_next_step_hip(samples, dir_max, device=0):
+def ls_next_step_hip(samples, dir_max, register_version=False, device=0):
     """The kernels' line-search contraction on the GPU (lfr_debug_ls_next_step): samples[n, 3, 5] = (x, value, gradient,
     value_valid, gradient_valid) of the initial / previous / current sample.  Returns the next step sizes (negative: give up)."""
     samples = np.ascontiguousarray(samples, np.float64).reshape(-1, 15)
     n = samples.shape[0]
     dir_max = np.ascontiguousarray(dir_max, np.float64)
     a = np.zeros(n, np.float64)
-    _check(lib().lfr_debug_ls_next_step(device, n, _ptr(samples), _ptr(dir_max), _ptr(a)))
+    _check(lib().lfr_debug_ls_next_step(device, n, _ptr(samples), _ptr(dir_max), int(bool(register_version)), _ptr(a)))
     return a
 
 
