@@ -6,6 +6,7 @@
 // Image names are interned to integers at ingest: every use in the reference is an equality
 // test (std::set<std::string> intersection/union, solve.cc:493-519).
 #include <algorithm>
+#include <future>
 #include <atomic>
 #include <chrono>
 #include <cstring>
@@ -139,6 +140,10 @@ void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vect
 }
 
 // recursive_graph_cut of solve.cc:185-250 with bisect_graph in place of Graclus
+// The two halves of a bisection are independent sub-problems: the second one runs on another thread while this one
+// handles the first (big halves only, a bounded number of tasks); the results are merged in the reference's order
+// (solve.cc:210-246: subset 0 first), so the numbering does not depend on the schedule.
+static std::atomic<int> g_cut_tasks{0};
 std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
                                                   const std::vector<int> &weights,
                                                   const std::vector<int64_t> &node_weights, int64_t max_weight) {
@@ -152,6 +157,25 @@ std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>
         std::sort(keys.begin(), keys.end());
         for (int k : keys) { subset_w[split[k]] += node_weights[k]; members[split[k]].push_back(k); }
     }
+    struct Side { bool recurse = false; std::vector<std::pair<int, int>> e; std::vector<int> w; std::unordered_map<int, int> sub; } side[2];
+    if (subset_w[0] > max_weight || subset_w[1] > max_weight) {
+        for (size_t k = 0; k < edges.size(); ++k) {
+            const int sa = split.find(edges[k].first)->second, sb = split.find(edges[k].second)->second;
+            if (sa == sb && subset_w[sa] > max_weight) { side[sa].e.push_back(edges[k]); side[sa].w.push_back(weights[k]); }
+        }
+        for (int s = 0; s < 2; ++s) side[s].recurse = !side[s].e.empty();
+    }
+    std::future<std::unordered_map<int, int>> second;
+    bool spawned = false;
+    if (side[0].recurse && side[1].recurse && side[1].e.size() >= 2048) {
+        if (g_cut_tasks.fetch_add(1) < 64) {
+            second = std::async(std::launch::async, [&] { return recursive_cut(side[1].e, side[1].w, node_weights, max_weight); });
+            spawned = true;
+        } else g_cut_tasks.fetch_sub(1);
+    }
+    if (side[0].recurse) side[0].sub = recursive_cut(side[0].e, side[0].w, node_weights, max_weight);
+    if (side[1].recurse) side[1].sub = spawned ? second.get() : recursive_cut(side[1].e, side[1].w, node_weights, max_weight);
+    if (spawned) g_cut_tasks.fetch_sub(1);
     int max_idx = 0;
     std::unordered_map<int, int> final_map;
     for (int s = 0; s < 2; ++s) {
@@ -160,14 +184,9 @@ std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>
             ++max_idx;
             continue;
         }
-        std::vector<std::pair<int, int>> sub_e;
-        std::vector<int> sub_w;
-        for (size_t k = 0; k < edges.size(); ++k)
-            if (split[edges[k].first] == s && split[edges[k].second] == s) { sub_e.push_back(edges[k]); sub_w.push_back(weights[k]); }
-        if (!sub_e.empty()) {
-            auto sub = recursive_cut(sub_e, sub_w, node_weights, max_weight);
+        if (side[s].recurse) {
             int new_max = max_idx;
-            for (auto &it : sub) { final_map.emplace(it.first, max_idx + it.second); new_max = std::max(new_max, max_idx + it.second); }
+            for (auto &it : side[s].sub) { final_map.emplace(it.first, max_idx + it.second); new_max = std::max(new_max, max_idx + it.second); }
             max_idx = new_max + 1;
         }
         for (int k : members[s]) if (!final_map.count(k)) { final_map.emplace(k, max_idx); ++max_idx; }

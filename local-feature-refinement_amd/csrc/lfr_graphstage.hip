@@ -70,6 +70,17 @@ int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, in
     LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
     return LFR_OK;
 }
+// sums of the values of equal adjacent keys (hipCUB ReduceByKey); *n_runs (device) = number of distinct runs
+int sum_by_key(DevArena &arena, const unsigned long long *keys, unsigned long long *unique, const double *vals, double *sums, uint32_t *n_runs,
+               int64_t n, hipStream_t st) {
+    size_t bytes = 0;
+    LFR_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, bytes, keys, unique, vals, sums, n_runs, hipcub::Sum(), (int)n, st));
+    void *tmp = arena.take(bytes);
+    if (!tmp) { set_error("graph stage: device arena exhausted (reduce-by-key)"); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(tmp, bytes, keys, unique, vals, sums, n_runs, hipcub::Sum(), (int)n, st));
+    return LFR_OK;
+}
+
 int exclusive_sum(DevArena &arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
@@ -291,14 +302,14 @@ __global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigne
 }
 
 // ---- size cap (solve.cc:311-364): the cut itself runs on the host, on the handful of inter-track matches it needs ----
-struct CutEdge { int32_t ta, tb; float sim; };
-// component (pre-cut) of every track, and the inter-track matches of components above the cap, compacted
+// component (pre-cut) of every track, and the inter-track matches of components above the cap, compacted as
+// (unordered track pair, similarity): key = min << 32 | max
 __global__ void k_track_comp(int64_t cap, const uint32_t *counts, const uint32_t *mlabel, const uint32_t *rank, int32_t *tcomp) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t < cap && t < (int64_t)counts[CNT_TRACKS]) tcomp[t] = (int32_t)rank[mlabel[t]];
 }
 __global__ void k_cut_edges(int64_t M, const uint32_t *n1, const uint32_t *n2, const float *sim, const int32_t *track, const int32_t *tcomp,
-                            const uint32_t *csize, uint32_t max_nodes, CutEdge *list, uint32_t *n_list) {
+                            const uint32_t *csize, uint32_t max_nodes, unsigned long long *pair_key, double *pair_sim, uint32_t *n_list) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool keep = false;
     int32_t ta = 0, tb = 0;
@@ -307,7 +318,10 @@ __global__ void k_cut_edges(int64_t M, const uint32_t *n1, const uint32_t *n2, c
         keep = ta != tb && csize[tcomp[ta]] > max_nodes;
     }
     const uint32_t at = wave_append(keep, n_list);
-    if (keep) list[at] = CutEdge{ta, tb, sim[m]};
+    if (keep) {
+        pair_key[at] = ((unsigned long long)(uint32_t)min(ta, tb) << 32) | (uint32_t)max(ta, tb);
+        pair_sim[at] = (double)sim[m];
+    }
 }
 // meta union without the cut edges (solve.cc:346-353): gc[t] = subset of track t inside its oversized component, -1 elsewhere
 __global__ void k_meta_union_cut(int64_t M, const uint32_t *n1, const uint32_t *n2, const int32_t *track, const int32_t *gc, uint32_t *parent) {
@@ -728,53 +742,71 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(hipEventCreate(&c0)); LFR_HIP_TRY(hipEventCreate(&c1));
         LFR_HIP_TRY(hipEventRecord(c0, st));
         const int64_t T = h_counts[CNT_TRACKS];
-        TAKE(tcomp, int32_t, T + 1); TAKE(cut_list, CutEdge, M); TAKE(cut_n, uint32_t, 16); TAKE(gc_dev, int32_t, T + 1);
+        TAKE(tcomp, int32_t, T + 1); TAKE(cut_n, uint32_t, 16); TAKE(gc_dev, int32_t, T + 1);
+        DevArena cut_arena;                               // (pair, similarity) of every inter-track match of an oversized component
+        if (!cut_arena.init(ctx, 16 * (size_t)M + 65536)) return LFR_ERR_NOMEM;
+        unsigned long long *pair_key = cut_arena.take_n<unsigned long long>(M);
+        double *pair_sim = cut_arena.take_n<double>(M);
+        if (!pair_key || !pair_sim) { set_error("graph stage: cut arena exhausted"); return LFR_ERR_NOMEM; }
         LFR_HIP_TRY(hipMemsetAsync(cut_n, 0, 64, st));
         hipLaunchKernelGGL(k_track_comp, grid_for(T), dim3(kThreads), 0, st, T, counts, mp, crank, tcomp);
-        hipLaunchKernelGGL(k_cut_edges, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, cut_list, cut_n);
+        hipLaunchKernelGGL(k_cut_edges, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, pair_key, pair_sim, cut_n);
         uint32_t *h_n = h_counts + 8;
         LFR_HIP_TRY(hipMemcpyAsync(h_n, cut_n, 4, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(stream_wait(st));
         const size_t n_cut_edges = h_n[0];
-        std::vector<CutEdge> h_list(n_cut_edges);
+        // Meta edges (solve.cc:268-289,322-332): per unordered track pair the sum of the similarities -> int weight 100 * sum.
+        // Sorted and summed on the device (radix sort + reduce-by-key: 0.7 M matches of config 5 took a host std::sort 60 ms);
+        // sums of float32 values in fp64 are exact here, hence independent of the order of the additions.
+        DevArena sum_arena;
+        size_t n_pairs = 0;
+        std::vector<unsigned long long> h_pair;
+        std::vector<double> h_sum;
         std::vector<int32_t> h_tcomp((size_t)T), h_gc((size_t)T, -1);
         std::vector<uint32_t> h_tsize((size_t)T);
-        if (n_cut_edges) LFR_HIP_TRY(hipMemcpyAsync(h_list.data(), cut_list, sizeof(CutEdge) * n_cut_edges, hipMemcpyDeviceToHost, st));
+        if (n_cut_edges) {
+            if (!sum_arena.init(ctx, 64 * n_cut_edges + ((size_t)16 << 20))) return LFR_ERR_NOMEM;
+            unsigned long long *key_s = sum_arena.take_n<unsigned long long>(n_cut_edges), *key_u = sum_arena.take_n<unsigned long long>(n_cut_edges);
+            double *sim_s = sum_arena.take_n<double>(n_cut_edges), *sim_u = sum_arena.take_n<double>(n_cut_edges);
+            if (!key_s || !key_u || !sim_s || !sim_u) { set_error("graph stage: cut arena exhausted"); return LFR_ERR_NOMEM; }
+            int tbits = 1;
+            while (((int64_t)1 << tbits) < T) ++tbits;
+            if ((rc = sort_pairs(sum_arena, pair_key, key_s, pair_sim, sim_s, (int64_t)n_cut_edges, 0, 32 + tbits, st)) != LFR_OK) return rc;
+            if ((rc = sum_by_key(sum_arena, key_s, key_u, sim_s, sim_u, cut_n + 1, (int64_t)n_cut_edges, st)) != LFR_OK) return rc;
+            LFR_HIP_TRY(hipMemcpyAsync(h_n + 1, cut_n + 1, 4, hipMemcpyDeviceToHost, st));
+            LFR_HIP_TRY(stream_wait(st));
+            n_pairs = h_n[1];
+            h_pair.resize(n_pairs); h_sum.resize(n_pairs);
+            LFR_HIP_TRY(hipMemcpyAsync(h_pair.data(), key_u, 8 * n_pairs, hipMemcpyDeviceToHost, st));
+            LFR_HIP_TRY(hipMemcpyAsync(h_sum.data(), sim_u, 8 * n_pairs, hipMemcpyDeviceToHost, st));
+        }
         LFR_HIP_TRY(hipMemcpyAsync(h_tcomp.data(), tcomp, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(hipMemcpyAsync(h_tsize.data(), tsize, 4 * (size_t)T, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(stream_wait(st));
+        lap("cut: meta edges of the oversized components on the host");
         {
-            // meta edges (solve.cc:268-289,322-332): per unordered track pair the sum of the similarities (sums of float32
-            // values in fp64: exact, hence independent of the order) -> int weight 100 * sum
-            struct Key { int32_t comp, t, u; double w; };
-            std::vector<Key> keys(n_cut_edges);
-            for (size_t k = 0; k < n_cut_edges; ++k) {
-                const CutEdge &e = h_list[k];
-                keys[k] = Key{h_tcomp[e.ta], std::min(e.ta, e.tb), std::max(e.ta, e.tb), (double)e.sim};
-            }
-            std::sort(keys.begin(), keys.end(), [](const Key &a, const Key &b) {
-                if (a.comp != b.comp) return a.comp < b.comp;
-                if (a.t != b.t) return a.t < b.t;
-                return a.u < b.u;
-            });
+            // the pairs arrive sorted by (t, u); group them by component, keeping that order (what the host stage feeds the cut)
+            std::vector<uint32_t> order(n_pairs);
+            for (size_t k = 0; k < n_pairs; ++k) order[k] = (uint32_t)k;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return h_tcomp[h_pair[a] >> 32] < h_tcomp[h_pair[b] >> 32]; });
             std::vector<int64_t> tsize64((size_t)T);
             for (int64_t t = 0; t < T; ++t) tsize64[t] = h_tsize[t];
-            for (size_t lo = 0; lo < keys.size();) {
+            for (size_t lo = 0; lo < n_pairs;) {
                 size_t hi = lo;
+                const int32_t comp = h_tcomp[h_pair[order[lo]] >> 32];
                 std::vector<std::pair<int, int>> e;
                 std::vector<int> w;
-                while (hi < keys.size() && keys[hi].comp == keys[lo].comp) {
-                    size_t k = hi;
-                    double sum = 0.0;
-                    while (k < keys.size() && keys[k].comp == keys[hi].comp && keys[k].t == keys[hi].t && keys[k].u == keys[hi].u) sum += keys[k++].w;
-                    e.push_back({keys[hi].t, keys[hi].u});
-                    w.push_back(static_cast<int>(100 * sum));                    // solve.cc:329
-                    hi = k;
+                while (hi < n_pairs && h_tcomp[h_pair[order[hi]] >> 32] == comp) {
+                    const unsigned long long key = h_pair[order[hi]];
+                    e.push_back({(int)(key >> 32), (int)(key & 0xffffffffull)});
+                    w.push_back(static_cast<int>(100 * h_sum[order[hi]]));          // solve.cc:329
+                    ++hi;
                 }
                 const auto split = recursive_cut(e, w, tsize64, max_nodes);
                 for (auto &it : split) h_gc[it.first] = it.second;
                 lo = hi;
             }
+            lap("cut: recursive bisection");
             // (an oversized component without any meta edge is a single track: nothing to cut, it stays whole)
             p.stats.n_cut_components = 0;
             {   // count the components above the cap the way the host stage does (with or without meta edges)
@@ -800,6 +832,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(hipEventRecord(c1, st));
         LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(stream_wait(st));          // (the staging vectors above die at scope end)
+        lap("cut: re-labelled");
         p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
         float cms = 0.f;
         LFR_HIP_TRY(hipEventElapsedTime(&cms, c0, c1));
