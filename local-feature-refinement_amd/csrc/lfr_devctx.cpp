@@ -145,6 +145,19 @@ void DevCtx::pinned_release(void *p, size_t bytes) {
     for (auto &s : drop) (void)hipHostFree(s.p);
 }
 
+hipStream_t DevCtx::side_stream(int i) {
+    if (i < 0 || i >= kSideStreams) { set_error("side stream %d out of range", i); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!s_side[i]) {
+        (void)hipSetDevice(device);
+        if (hipStreamCreateWithFlags(&s_side[i], hipStreamNonBlocking) != hipSuccess) {
+            set_error("hipStreamCreate failed on device %d: %s", device, hipGetErrorString(hipGetLastError()));
+            s_side[i] = nullptr;
+        }
+    }
+    return s_side[i];
+}
+
 void DevCtx::trim() {
     std::vector<Slab> d, h;
     {

@@ -63,6 +63,11 @@ struct DevCtx {
     int device = -1;
     hipStream_t s_main = nullptr;     // graph stage, assembly
     hipStream_t s_copy = nullptr;     // bulk H2D of the flows, beside s_main
+    // streams the solve forks its concurrent kernel launches onto (hipStreamCreate costs milliseconds: a batch that created its
+    // own five spent 18 ms of a 23 ms batch creation there); created on first use, shared by the batches of this device
+    static constexpr int kSideStreams = 12;
+    hipStream_t s_side[kSideStreams] = {nullptr};
+    hipStream_t side_stream(int i);    // nullptr + set_error() on failure
     std::mutex mu;
     struct Slab { void *p; size_t bytes; };
     std::vector<Slab> free_dev, free_pinned;

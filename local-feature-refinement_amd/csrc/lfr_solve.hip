@@ -1260,7 +1260,7 @@ struct lfr_batch {
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
     hipStream_t side_stream = nullptr;                 // the packed launch runs beside the workgroup-per-component kernels
-    hipStream_t wg_stream[lfr::KC_COUNT] = {nullptr};  // one stream per further workgroup class
+    hipStream_t wg_stream[lfr::KC_COUNT] = {nullptr};  // one stream per further workgroup class (all owned by the device context)
     hipStream_t last_stream = nullptr;                 // stream of the latest solve (downloads wait for it)
     int packed_slot = 0;                               // class slot that carries the packed launch's events
     double h2d_ms = 0.0;             // upload (host-assembled) or device assembly incl. waiting for the flows
@@ -1279,8 +1279,6 @@ struct lfr_batch {
         }
         for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (side_stream) (void)hipStreamDestroy(side_stream);
-        for (auto &w : wg_stream) if (w) (void)hipStreamDestroy(w);
         // slab / ws_slab return to the context's cache in their destructors
     }
 };
@@ -1492,6 +1490,7 @@ int lfr_hip_warmup(int device) {
     int level = 2;                                   // LFR_WARMUP_LEVEL: 0 = context only, 1 = + toy graph, 2 = + a million matches
     if (const char *e = getenv("LFR_WARMUP_LEVEL")) level = atoi(e);
     if (level < 1) return LFR_OK;
+    for (int i = 0; i <= lfr::KC_COUNT; ++i) (void)ctx->side_stream(i);     // a few ms each; the toy graph below only needs two
     // HIP also resolves every kernel on its first launch (~1 ms each; the graph stage and the assembly launch
     // about forty different ones, rocPRIM's included): push a toy graph - one 18-node track (workgroup kernel)
     // and one 3-node track (packed kernel) - through the whole device pipeline once.  Best effort.
@@ -1712,9 +1711,9 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     if (rc != LFR_OK) return rc;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
-        HIP_TRY(hipStreamCreateWithFlags(&b->side_stream, hipStreamNonBlocking));
+        if (!(b->side_stream = ctx->side_stream(0))) return LFR_ERR_HIP;
         for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls)
-            if (b->class_begin[cls + 1] > b->class_begin[cls]) HIP_TRY(hipStreamCreateWithFlags(&b->wg_stream[cls], hipStreamNonBlocking));
+            if (b->class_begin[cls + 1] > b->class_begin[cls] && !(b->wg_stream[cls] = ctx->side_stream(1 + cls))) return LFR_ERR_HIP;
         const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
         const int lds_m = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_M], 2), false);
         const int lds_l = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_L], 2), false);
