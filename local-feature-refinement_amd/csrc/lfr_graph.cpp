@@ -80,26 +80,37 @@ static inline int32_t uf_root(std::vector<int32_t> &parent, int32_t i) {
 // boundary refinement on the normalized-cut objective.  All sums are sums of integers held in doubles (exact),
 // so the result does not depend on the order of `edges`.
 // ----------------------------------------------------------------------------------------------
-void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
-                  std::unordered_map<int, int> &part) {
-    part.clear();
+namespace {
+// A (sub)graph of the cut recursion in compact form: node i is ids[i] (ascending), edges join local indices.
+// Hash maps keyed by track id and per-edge binary searches were most of the host time of a cut (config 5: 0.6 M meta
+// edges, twelve levels): the recursion hands local indices down instead.
+struct SubGraph {
     std::vector<int> ids;
-    for (auto &e : edges) { ids.push_back(e.first); ids.push_back(e.second); }
-    std::sort(ids.begin(), ids.end());
-    ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
-    const int n = (int)ids.size();
+    std::vector<int> ea, eb, w;
+};
+
+void bisect_core(const SubGraph &g, std::vector<char> &side) {
+    const int n = (int)g.ids.size();
+    side.assign(n, 1);
     if (n == 0) return;
-    auto local = [&](int id) { return (int)(std::lower_bound(ids.begin(), ids.end(), id) - ids.begin()); };
-    std::vector<std::vector<std::pair<int, double>>> adj(n);
+    const size_t E = g.ea.size();
+    std::vector<uint32_t> off(n + 1, 0);                          // CSR adjacency, neighbours in edge order
+    for (size_t k = 0; k < E; ++k) { ++off[g.ea[k] + 1]; ++off[g.eb[k] + 1]; }
+    for (int i = 0; i < n; ++i) off[i + 1] += off[i];
+    std::vector<int> nb(2 * E);
+    std::vector<double> nw(2 * E);
     std::vector<double> deg(n, 0.0);
     double volume = 0.0;
-    for (size_t k = 0; k < edges.size(); ++k) {
-        const int a = local(edges[k].first), b = local(edges[k].second);
-        const double w = (double)std::max(weights[k], 1);
-        adj[a].push_back({b, w}); adj[b].push_back({a, w});
-        deg[a] += w; deg[b] += w; volume += 2 * w;
+    {
+        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        for (size_t k = 0; k < E; ++k) {
+            const int a = g.ea[k], b = g.eb[k];
+            const double w = (double)std::max(g.w[k], 1);
+            nb[fill[a]] = b; nw[fill[a]++] = w;
+            nb[fill[b]] = a; nw[fill[b]++] = w;
+            deg[a] += w; deg[b] += w; volume += 2 * w;
+        }
     }
-    std::vector<int> side(n, 1);
     std::vector<double> attach(n, 0.0);
     std::vector<char> in(n, 0);
     double vol0 = 0.0;
@@ -117,18 +128,18 @@ void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vect
         const int best = -top.second;
         if (in[best] || top.first != attach[best]) continue;      // stale entry
         in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
-        for (auto &nb : adj[best]) {
-            attach[nb.first] += nb.second;
-            if (!in[nb.first]) heap.push(HeapKey(attach[nb.first], -nb.first));
+        for (uint32_t q = off[best]; q < off[best + 1]; ++q) {
+            attach[nb[q]] += nw[q];
+            if (!in[nb[q]]) heap.push(HeapKey(attach[nb[q]], -nb[q]));
         }
     }
     // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
     double cut = 0.0;
-    for (int i = 0; i < n; ++i) for (auto &nb : adj[i]) if (side[i] == 0 && side[nb.first] == 1) cut += nb.second;
+    for (int i = 0; i < n; ++i) if (side[i] == 0) for (uint32_t q = off[i]; q < off[i + 1]; ++q) if (side[nb[q]] == 1) cut += nw[q];
     auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
     for (int i = 0; i < n; ++i) {
         double to_same = 0.0, to_other = 0.0;
-        for (auto &nb : adj[i]) (side[nb.first] == side[i] ? to_same : to_other) += nb.second;
+        for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nb[q]] == side[i] ? to_same : to_other) += nw[q];
         const double ncut_now = ncut(cut, vol0);
         const double c2 = cut + to_same - to_other;
         const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
@@ -136,61 +147,92 @@ void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vect
         if (cnt0 <= 0 || cnt0 >= n) continue;
         if (ncut(c2, v2) < ncut_now) { side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; }
     }
-    for (int i = 0; i < n; ++i) part[ids[i]] = side[i];
 }
 
-// recursive_graph_cut of solve.cc:185-250 with bisect_graph in place of Graclus
+// nodes = endpoints of the edges, ascending; edges in local indices
+SubGraph compact(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights) {
+    SubGraph g;
+    g.ids.reserve(2 * edges.size());
+    for (auto &e : edges) { g.ids.push_back(e.first); g.ids.push_back(e.second); }
+    std::sort(g.ids.begin(), g.ids.end());
+    g.ids.erase(std::unique(g.ids.begin(), g.ids.end()), g.ids.end());
+    auto local = [&](int id) { return (int)(std::lower_bound(g.ids.begin(), g.ids.end(), id) - g.ids.begin()); };
+    g.ea.resize(edges.size()); g.eb.resize(edges.size()); g.w = weights;
+    for (size_t k = 0; k < edges.size(); ++k) { g.ea[k] = local(edges[k].first); g.eb[k] = local(edges[k].second); }
+    return g;
+}
+
+// recursive_graph_cut of solve.cc:185-250 with bisect_core in place of Graclus: out[i] = subset of node i.
 // The two halves of a bisection are independent sub-problems: the second one runs on another thread while this one
 // handles the first (big halves only, a bounded number of tasks); the results are merged in the reference's order
 // (solve.cc:210-246: subset 0 first), so the numbering does not depend on the schedule.
-static std::atomic<int> g_cut_tasks{0};
-std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
-                                                  const std::vector<int> &weights,
-                                                  const std::vector<int64_t> &node_weights, int64_t max_weight) {
-    std::unordered_map<int, int> split;
-    bisect_graph(edges, weights, split);
+std::atomic<int> g_cut_tasks{0};
+void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_t max_weight, std::vector<int> &out) {
+    const int n = (int)g.ids.size();
+    std::vector<char> side;
+    bisect_core(g, side);
     int64_t subset_w[2] = {0, 0};
-    std::vector<int> members[2];
-    {
-        std::vector<int> keys;
-        for (auto &it : split) keys.push_back(it.first);
-        std::sort(keys.begin(), keys.end());
-        for (int k : keys) { subset_w[split[k]] += node_weights[k]; members[split[k]].push_back(k); }
+    for (int i = 0; i < n; ++i) subset_w[(int)side[i]] += node_weights[g.ids[i]];
+    // the half of an oversized side that still has edges: nodes with an internal edge, in ascending order
+    SubGraph child[2];
+    std::vector<int> up[2];                                        // child index -> index here
+    for (int s = 0; s < 2; ++s) {
+        if (subset_w[s] <= max_weight) continue;
+        std::vector<int> down(n, -1);
+        for (size_t k = 0; k < g.ea.size(); ++k)
+            if (side[g.ea[k]] == s && side[g.eb[k]] == s) { down[g.ea[k]] = 0; down[g.eb[k]] = 0; }
+        for (int i = 0; i < n; ++i) if (down[i] == 0) { down[i] = (int)up[s].size(); up[s].push_back(i); child[s].ids.push_back(g.ids[i]); }
+        for (size_t k = 0; k < g.ea.size(); ++k)
+            if (side[g.ea[k]] == s && side[g.eb[k]] == s) { child[s].ea.push_back(down[g.ea[k]]); child[s].eb.push_back(down[g.eb[k]]); child[s].w.push_back(g.w[k]); }
     }
-    struct Side { bool recurse = false; std::vector<std::pair<int, int>> e; std::vector<int> w; std::unordered_map<int, int> sub; } side[2];
-    if (subset_w[0] > max_weight || subset_w[1] > max_weight) {
-        for (size_t k = 0; k < edges.size(); ++k) {
-            const int sa = split.find(edges[k].first)->second, sb = split.find(edges[k].second)->second;
-            if (sa == sb && subset_w[sa] > max_weight) { side[sa].e.push_back(edges[k]); side[sa].w.push_back(weights[k]); }
-        }
-        for (int s = 0; s < 2; ++s) side[s].recurse = !side[s].e.empty();
-    }
-    std::future<std::unordered_map<int, int>> second;
+    std::vector<int> sub[2];
+    std::future<void> second;
     bool spawned = false;
-    if (side[0].recurse && side[1].recurse && side[1].e.size() >= 2048) {
+    if (!child[0].ea.empty() && child[1].ea.size() >= 2048) {
         if (g_cut_tasks.fetch_add(1) < 64) {
-            second = std::async(std::launch::async, [&] { return recursive_cut(side[1].e, side[1].w, node_weights, max_weight); });
+            second = std::async(std::launch::async, [&] { cut_rec(child[1], node_weights, max_weight, sub[1]); });
             spawned = true;
         } else g_cut_tasks.fetch_sub(1);
     }
-    if (side[0].recurse) side[0].sub = recursive_cut(side[0].e, side[0].w, node_weights, max_weight);
-    if (side[1].recurse) side[1].sub = spawned ? second.get() : recursive_cut(side[1].e, side[1].w, node_weights, max_weight);
-    if (spawned) g_cut_tasks.fetch_sub(1);
+    if (!child[0].ea.empty()) cut_rec(child[0], node_weights, max_weight, sub[0]);
+    if (spawned) { second.get(); g_cut_tasks.fetch_sub(1); }
+    else if (!child[1].ea.empty()) cut_rec(child[1], node_weights, max_weight, sub[1]);
+    out.assign(n, -1);
     int max_idx = 0;
-    std::unordered_map<int, int> final_map;
     for (int s = 0; s < 2; ++s) {
         if (subset_w[s] <= max_weight) {
-            for (int k : members[s]) final_map.emplace(k, max_idx);
+            for (int i = 0; i < n; ++i) if (side[i] == s) out[i] = max_idx;
             ++max_idx;
             continue;
         }
-        if (side[s].recurse) {
+        if (!child[s].ea.empty()) {
             int new_max = max_idx;
-            for (auto &it : side[s].sub) { final_map.emplace(it.first, max_idx + it.second); new_max = std::max(new_max, max_idx + it.second); }
+            for (size_t j = 0; j < sub[s].size(); ++j) { out[up[s][j]] = max_idx + sub[s][j]; new_max = std::max(new_max, max_idx + sub[s][j]); }
             max_idx = new_max + 1;
         }
-        for (int k : members[s]) if (!final_map.count(k)) { final_map.emplace(k, max_idx); ++max_idx; }
+        for (int i = 0; i < n; ++i) if (side[i] == s && out[i] < 0) out[i] = max_idx++;
     }
+}
+}  // namespace
+
+void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
+                  std::unordered_map<int, int> &part) {
+    part.clear();
+    const SubGraph g = compact(edges, weights);
+    std::vector<char> side;
+    bisect_core(g, side);
+    for (size_t i = 0; i < g.ids.size(); ++i) part[g.ids[i]] = side[i];
+}
+
+std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>> &edges,
+                                                  const std::vector<int> &weights,
+                                                  const std::vector<int64_t> &node_weights, int64_t max_weight) {
+    const SubGraph g = compact(edges, weights);
+    std::vector<int> out;
+    cut_rec(g, node_weights, max_weight, out);
+    std::unordered_map<int, int> final_map;
+    final_map.reserve(g.ids.size() * 2);
+    for (size_t i = 0; i < g.ids.size(); ++i) final_map.emplace(g.ids[i], out[i]);
     return final_map;
 }
 

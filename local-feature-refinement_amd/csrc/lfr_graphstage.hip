@@ -280,8 +280,10 @@ __global__ void k_round_eval(uint32_t n_in, const Pending *in, int32_t *parent, 
     if (!keep) return;
     out[at] = q;
     const unsigned long long key = round_hi | q.k;                // a later round's bid beats every stale entry
-    atomicMin(&minpos[q.ra], key);
-    atomicMin(&minpos[q.rb], key);
+    // thousands of matches bid for the root of a grown track and all but one lose: look before bidding (the value only
+    // decreases, so a bid that does not beat what is already there could not have won)
+    if (key < __hip_atomic_load(&minpos[q.ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.ra], key);
+    if (key < __hip_atomic_load(&minpos[q.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.rb], key);
 }
 // a bidder that holds both of its roots is the earliest pending match touching either: accept (solve.cc:513-521)
 __global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigned long long round_hi, const unsigned long long *minpos,
@@ -542,7 +544,7 @@ int Problem::ensure_host_labels() const {
 int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p) {
     const int64_t N = g.n_nodes(), M = g.n_matches();
     const char *vb = getenv("LFR_VERBOSE");
-    const bool trace = vb && vb[0] == '2';
+    const int trace = vb ? atoi(vb) >= 2 ? atoi(vb) : 0 : 0;      // LFR_VERBOSE=2: lap times, 3: + every round of the parallel greedy
     const auto tr0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (trace) fprintf(stderr, "lfr graph stage: %8.3f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count(), what);
@@ -669,6 +671,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
             hipLaunchKernelGGL(k_round_accept, grid_for(n_in), dim3(kThreads), 0, st, n_out, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
             LFR_HIP_TRY(hipMemcpyAsync(h_ctr, n_out, 4, hipMemcpyDeviceToHost, st));
             LFR_HIP_TRY(stream_wait(st));
+            if (trace > 2) fprintf(stderr, "lfr graph stage:   round %lld: %u pending in, %u eligible out\n", (long long)rounds, n_in, h_ctr[0]);
             n_in = h_ctr[0];
             std::swap(pa, pb);
         }
