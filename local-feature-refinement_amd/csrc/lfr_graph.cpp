@@ -117,20 +117,37 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     int n0 = 0;
     // region growing: always absorb the outside node with the largest attachment to the region (ties ->
     // smallest id; a node nobody is attached to yet has attachment 0, so an emptied frontier restarts from the
-    // smallest unvisited id).  Lazy-deletion max-heap keyed (attachment, -id): O(E log n) instead of the
-    // O(n^2) arg-max scan per absorbed node.
-    typedef std::pair<double, int> HeapKey;              // (attachment, -id)
-    std::priority_queue<HeapKey> heap;
-    for (int i = 0; i < n; ++i) heap.push(HeapKey(0.0, -i));
-    while (vol0 * 2 < volume && n0 < n - 1 && !heap.empty()) {
-        const HeapKey top = heap.top();
-        heap.pop();
-        const int best = -top.second;
-        if (in[best] || top.first != attach[best]) continue;      // stale entry
+    // smallest unvisited id).  Indexed binary max-heap over the n nodes keyed (attachment, -id) with increase-key:
+    // O(E log n) with n entries (a lazy-deletion queue held 2 E of them; the O(n^2) arg-max scan before that).
+    std::vector<int> heap(n), pos(n);
+    for (int i = 0; i < n; ++i) { heap[i] = i; pos[i] = i; }                  // all keys (0, -i): already a heap
+    int hn = n;
+    auto above = [&](int a, int b) { return attach[a] > attach[b] || (attach[a] == attach[b] && a < b); };
+    auto sift_up = [&](int i) {
+        const int v = heap[i];
+        while (i > 0) { const int p = (i - 1) >> 1; if (!above(v, heap[p])) break; heap[i] = heap[p]; pos[heap[i]] = i; i = p; }
+        heap[i] = v; pos[v] = i;
+    };
+    auto sift_down = [&](int i) {
+        const int v = heap[i];
+        for (;;) {
+            int c = 2 * i + 1;
+            if (c >= hn) break;
+            if (c + 1 < hn && above(heap[c + 1], heap[c])) ++c;
+            if (!above(heap[c], v)) break;
+            heap[i] = heap[c]; pos[heap[i]] = i; i = c;
+        }
+        heap[i] = v; pos[v] = i;
+    };
+    while (vol0 * 2 < volume && n0 < n - 1 && hn > 0) {
+        const int best = heap[0];
+        heap[0] = heap[--hn]; pos[heap[0]] = 0;
+        if (hn > 0) sift_down(0);
         in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
         for (uint32_t q = off[best]; q < off[best + 1]; ++q) {
-            attach[nb[q]] += nw[q];
-            if (!in[nb[q]]) heap.push(HeapKey(attach[nb[q]], -nb[q]));
+            const int v = nb[q];
+            attach[v] += nw[q];
+            if (!in[v]) sift_up(pos[v]);
         }
     }
     // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
