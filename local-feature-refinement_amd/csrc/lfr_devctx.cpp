@@ -147,7 +147,7 @@ void DevCtx::pinned_release(void *p, size_t bytes) {
 
 hipStream_t DevCtx::side_stream(int i) {
     if (i < 0 || i >= kSideStreams) { set_error("side stream %d out of range", i); return nullptr; }
-    std::lock_guard<std::mutex> lk(mu);
+    std::lock_guard<std::mutex> lk(side_mu);
     if (!s_side[i]) {
         (void)hipSetDevice(device);
         if (hipStreamCreateWithFlags(&s_side[i], hipStreamNonBlocking) != hipSuccess) {

@@ -67,6 +67,7 @@ struct DevCtx {
     // own five spent 18 ms of a 23 ms batch creation there); created on first use, shared by the batches of this device
     static constexpr int kSideStreams = 12;
     hipStream_t s_side[kSideStreams] = {nullptr};
+    std::mutex side_mu;                // (not `mu`: a stream creation must not hold up slab acquisitions of a running pipeline)
     hipStream_t side_stream(int i);    // nullptr + set_error() on failure
     std::mutex mu;
     struct Slab { void *p; size_t bytes; };

@@ -1490,7 +1490,6 @@ int lfr_hip_warmup(int device) {
     int level = 2;                                   // LFR_WARMUP_LEVEL: 0 = context only, 1 = + toy graph, 2 = + a million matches
     if (const char *e = getenv("LFR_WARMUP_LEVEL")) level = atoi(e);
     if (level < 1) return LFR_OK;
-    for (int i = 0; i <= lfr::KC_COUNT; ++i) (void)ctx->side_stream(i);     // a few ms each; the toy graph below only needs two
     // HIP also resolves every kernel on its first launch (~1 ms each; the graph stage and the assembly launch
     // about forty different ones, rocPRIM's included): push a toy graph - one 18-node track (workgroup kernel)
     // and one 3-node track (packed kernel) - through the whole device pipeline once.  Best effort.
@@ -1564,6 +1563,7 @@ int lfr_hip_warmup(int device) {
         }
         lfr_batch_free(bt); lfr_problem_free(pr); lfr_graph_free(g);
     }
+    for (int i = 0; i <= lfr::KC_COUNT; ++i) (void)ctx->side_stream(i);     // last: a few ms each, and only long-track inputs need them
     return LFR_OK;
 }
 

@@ -150,20 +150,23 @@ def main(argv=None):
         return 2
 
     ctx_ready = threading.Event()
+    wait_all = os.environ.get("LFR_WAIT_WARMUP") == "1"
+    # the warm-up is not waited for, so its million-match pass (level 2) would run beside the pipeline: measured 22-39 ms
+    # "Total time" against 18-24 ms with the toy-graph pass only (level 1); with LFR_WAIT_WARMUP=1 the full warm-up pays (9-10 ms)
+    os.environ.setdefault("LFR_WARMUP_LEVEL", "2" if wait_all else "1")
 
     def _warm():
         t0 = time.perf_counter()
         if nbytes > 0:      # creates the context (~0.2 s) and the slab caches; everything after it is optional
             raw.lfr_hip_reserve(ctypes.c_int(device), ctypes.c_int64(int(nbytes / 230 / 2.8 * 1.1)), ctypes.c_int64(int(nbytes / 230 * 1.1)))
         ctx_ready.set()
-        # kernel resolution with a toy graph and a million-match graph (~0.35 s): whatever is done when the parse ends is
-        # time the pipeline does not spend loading code; the rest simply runs beside it (LFR_WAIT_WARMUP=1: wait for all of it,
-        # the steadiest "Total time"; LFR_WARMUP_LEVEL=0: context only)
+        # kernel resolution with a toy graph (and, at level 2, a million-match graph: ~0.35 s): whatever is done when the parse
+        # ends is time the pipeline does not spend loading code (LFR_WAIT_WARMUP=1: wait for all of it, the steadiest
+        # "Total time"; LFR_WARMUP_LEVEL=0: context only)
         raw.lfr_hip_warmup(ctypes.c_int(device))
         warm_ms[0] = (time.perf_counter() - t0) * 1e3
     warm = threading.Thread(target=_warm, daemon=True)
     warm.start()
-    wait_all = os.environ.get("LFR_WAIT_WARMUP") == "1"
 
     def warm_join():
         (warm.join if wait_all else ctx_ready.wait)()

@@ -22,6 +22,18 @@ with open(out + "/r02_bench_kernel_stats.csv", "w") as f:
         w.writerow([r["Name"][:160], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r.get("Percentage", "")])
 for r in rows[:12]:
     print("%-70s calls %5s avg %10.1f us" % (r["Name"][:70], r["Calls"], float(r["AverageNs"]) / 1e3))
+# the stats file averages every launch of a kernel name (warm-up toys, the config-5 leg's small packed part): the dominant kernel's
+# full-size launches on their own, from the kernel trace
+tr = glob.glob(out + "/trace/*kernel_trace.csv")
+if tr:
+    by = collections.defaultdict(list)
+    for row in csv.DictReader(open(tr[0])):
+        if "solve_packed_kernel" in row["Kernel_Name"]:
+            by[int(row["Grid_Size_X"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    dom = {str(g): {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3} for g, v in sorted(by.items(), key=lambda kv: -len(kv[1]))}
+    json.dump({"kernel": "solve_packed_kernel", "by_grid_size_x": dom,
+               "note": "the config-4 batch is the grid with the most launches (timed steps + warm-up + one-shot spans)"}, open(out + "/r02_dominant_kernel_launches.json", "w"), indent=1)
+    print(json.dumps(dom))
 pm = {}
 for d in glob.glob(out + "/pmc_*/"):
     fs = glob.glob(d + "*counter_collection.csv")
