@@ -187,6 +187,7 @@ DevCtx *dev_ctx(int device) {
         set_error("hipStreamCreate failed on device %d: %s", device, hipGetErrorString(hipGetLastError()));
         return nullptr;
     }
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = cu; else (void)hipGetLastError(); }
     c->limit_dev = env_mb("LFR_SLAB_CACHE_MB", c->limit_dev);
     c->limit_pinned = env_mb("LFR_PINNED_CACHE_MB", c->limit_pinned);
     ctxs[device] = c.release();

@@ -61,6 +61,7 @@ private:
 // ---- per-device context ----
 struct DevCtx {
     int device = -1;
+    int n_cu = 256;                   // compute units of the device (sizes the persistent launches)
     hipStream_t s_main = nullptr;     // graph stage, assembly
     hipStream_t s_copy = nullptr;     // bulk H2D of the flows, beside s_main
     // streams the solve forks its concurrent kernel launches onto (hipStreamCreate costs milliseconds: a batch that created its

@@ -14,6 +14,7 @@
 //                              or in an HBM workspace (GLOBAL variant), owner-computes assembly, blocked LDL^T;
 //                              edges re-streamed from L2/HBM per pass.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <array>
@@ -55,6 +56,9 @@ struct KernelArgs {
     const uint64_t *ws_off;     // per desc: packed-matrix offset (HBM variant)
     const uint64_t *es_off;     // per desc: per-edge scratch offset (8 doubles per edge)
     unsigned long long *prof;   // -DLFR_PROFILE_PHASES: per-class cycle counters [cls*8 + phase]
+    unsigned int *queue;        // workgroup classes: next component of the class (one counter per class, zeroed per solve)
+    const uint32_t *wg_order;   // workgroup classes: descriptors in the order the queue hands them out (longest expected first)
+    int wg_begin;               // first descriptor of the workgroup classes (wg_order[0] belongs to it)
     int desc_begin, desc_end;
     int tukey_variant;
     int cls;
@@ -624,16 +628,13 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 // (two waves per SIMD = 256 registers each, VGPRs + the MFMA accumulators: what the 4 / 2 workgroups per CU of the two smaller
 // LDS classes need; without the attribute the allocator takes 264)
 template <bool GLOBAL_MATRIX, int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+__device__ __forceinline__ void solve_component(const KernelArgs &a, const int max_rows, const int ci, double *dyn, BlockShared &sh) {
     constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
 #ifdef LFR_PROFILE_WGTIME
     const unsigned long long wg_t0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long wg_r0_ = wall_clock64();          // 100 MHz, the same counter on every XCD
 #endif
-    extern __shared__ double dyn[];
-    __shared__ BlockShared sh;
     const int tid = threadIdx.x;
-    const int ci = a.desc_begin + (int)blockIdx.x;
     const CompDesc d = a.descs[ci];
     const int n_var = d.n_var, n = 2 * n_var, E = (int)d.n_edges;
     const int tv = a.tukey_variant;
@@ -1182,6 +1183,46 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
     }
 }
 
+// Order in which a class hands out its components: by expected duration, longest first.  The batch order inside a class is by
+// edge count, which predicts a workgroup's lifetime hardly better than a random order (list-scheduling the measured lifetimes of
+// the config-5 class of 131-192 rows on 256 CUs: 6.9 ms by edges, 6.6 random, 4.9 with the lifetimes known).  Rows (the
+// factorization is cubic in them) and whether the component joins several tracks (its Tukey edges cost iterations: 6.3 against
+// 4.2 on average, Spearman 0.58) give 5.8 ms.  key = class, then rows x (1 + [more than one track]) descending; a component
+// has one constant node (the root) per track.
+__global__ void k_wg_order_keys(const CompDesc *descs, int n, int b1, int b2, int b3, uint32_t *keys, uint32_t *vals, int wg_begin) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const CompDesc d = descs[i];
+    const uint32_t cls = (i >= b1) + (i >= b2) + (i >= b3);                   // boundaries of the four classes, relative
+    const uint32_t work = (uint32_t)d.n_var * (1u + ((uint32_t)d.n_nodes - d.n_var > 1u ? 1u : 0u));
+    keys[i] = (cls << 24) | (0xffffffu - min(work, 0xffffffu));
+    vals[i] = (uint32_t)(wg_begin + i);
+}
+
+// Persistent workgroups: the launch holds as many workgroups as the chip can keep resident for the class and each of them
+// takes the next component of the class from an atomic queue until the class is empty.  A workgroup per component left the
+// order to the hardware dispatcher, which deals workgroups to the XCDs round-robin whatever they cost: a CU sat idle 0.16 ms on
+// average (up to 1.3 ms) before its next 160-KB workgroup while the queue was still full, and CUs ended up with one to seven
+// components each (`scripts/c5_timeline.py`).  Here a free CU always takes the largest component left.
+template <bool GLOBAL_MATRIX, int kBlockThreads>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+    extern __shared__ double dyn[];
+    __shared__ BlockShared sh;
+    __shared__ int next_ci;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int k = a.desc_begin + (int)atomicAdd(a.queue + a.cls, 1u);
+            next_ci = k < a.desc_end ? (int)a.wg_order[k - a.wg_begin] : -1;
+        }
+        __syncthreads();
+        const int ci = next_ci;
+        __syncthreads();                              // everyone has read it before the next round overwrites it
+        if (ci < 0) break;
+        solve_component<GLOBAL_MATRIX, kBlockThreads>(a, max_rows, ci, dyn, sh);
+        __syncthreads();                              // the component's last LDS reads are done
+    }
+}
+
 #ifndef LFR_THREADS_S
 #define LFR_THREADS_S 128
 #endif
@@ -1216,6 +1257,8 @@ size_t block_lds_bytes(int max_rows, bool global_matrix) {
 // =============================================================================================
 // batch management + C ABI
 // =============================================================================================
+constexpr size_t kProfWords = 8 * lfr::KC_COUNT + 8;      // phase counters of -DLFR_PROFILE_PHASES + 16 32-bit class queues
+
 struct lfr_batch {
     int device = 0;
     lfr::DevCtx *ctx = nullptr;
@@ -1259,6 +1302,9 @@ struct lfr_batch {
     int64_t n_solves = 0;
     bool serial = false;                               // LFR_SERIAL_CLASSES=1: all classes on the caller's stream
     hipEvent_t ev_fork = nullptr;
+    lfr::DevArena order_slab;                          // hand-out order of the workgroup classes + the sort's temporaries
+    uint32_t *d_wg_order = nullptr;
+    hipEvent_t ev_order = nullptr;                     // the order is sorted on the context's stream: solves wait for it
     hipStream_t side_stream = nullptr;                 // the packed launch runs beside the workgroup-per-component kernels
     hipStream_t wg_stream[lfr::KC_COUNT] = {nullptr};  // one stream per further workgroup class (all owned by the device context)
     hipStream_t last_stream = nullptr;                 // stream of the latest solve (downloads wait for it)
@@ -1279,6 +1325,7 @@ struct lfr_batch {
         }
         for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_order) (void)hipEventDestroy(ev_order);
         // slab / ws_slab return to the context's cache in their destructors
     }
 };
@@ -1330,15 +1377,15 @@ int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
     HIP_TRY(hipEventRecord(a0, st));
     const size_t fixed = sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1) + sizeof(CompInfoDev) * (size_t)(C + 1) +
-                         8 * lfr::KC_COUNT * sizeof(unsigned long long) + ((size_t)1 << 16);
+                         kProfWords * sizeof(unsigned long long) + ((size_t)1 << 16);
     if (!b->slab.init(b->ctx, lfr::assembly_output_bytes(N, M, C) + fixed)) return LFR_ERR_NOMEM;
     TAKE_B(d_positions, double, 2 * std::max<int64_t>(N, 1));
     TAKE_B(d_infos, CompInfoDev, C + 1);
-    TAKE_B(d_prof, unsigned long long, 8 * lfr::KC_COUNT);
+    TAKE_B(d_prof, unsigned long long, kProfWords);
     // Roots, constants and nodes outside every solved component stay at 0 for the life of the batch
     // (solve.cc:609-612); the kernels overwrite every variable on every solve, so no per-solve memset.
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1), st));
-    HIP_TRY(hipMemsetAsync(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(b->d_prof, 0, kProfWords * sizeof(unsigned long long), st));
     lfr::DeviceAssembly dev;
     const int rc = lfr::assemble_on_device(p, *dp, shard_rank, shard_world, b->slab, dev);     // ends with the one synchronisation
     if (rc != LFR_OK) return rc;
@@ -1423,14 +1470,14 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     const size_t nd = std::max<size_t>(b->descs.size(), 1), ne = std::max<size_t>(edges.size(), 1), nn = std::max<size_t>(b->node_ids.size(), 1);
     const size_t npos = 2 * (size_t)std::max<int64_t>(b->n_graph_nodes, 1);
     const size_t bytes = nd * (sizeof(CompDesc) + sizeof(CompInfoDev) + 16) + ne * (sizeof(EdgeRec) + 4) + nn * (4 + sizeof(lfr::NodeInc)) +
-                         npos * sizeof(double) + 8 * lfr::KC_COUNT * sizeof(unsigned long long) + ((size_t)1 << 16);
+                         npos * sizeof(double) + kProfWords * sizeof(unsigned long long) + ((size_t)1 << 16);
     if (!b->slab.init(b->ctx, bytes)) return LFR_ERR_NOMEM;
     TAKE_B(d_descs, CompDesc, nd); TAKE_B(d_edges, EdgeRec, ne); TAKE_B(d_node_ids, uint32_t, nn);
     TAKE_B(d_node_inc, lfr::NodeInc, nn); TAKE_B(d_in_idx, uint32_t, ne);
     TAKE_B(d_positions, double, npos); TAKE_B(d_infos, CompInfoDev, nd);
-    TAKE_B(d_ws_off, uint64_t, nd); TAKE_B(d_es_off, uint64_t, nd); TAKE_B(d_prof, unsigned long long, 8 * lfr::KC_COUNT);
+    TAKE_B(d_ws_off, uint64_t, nd); TAKE_B(d_es_off, uint64_t, nd); TAKE_B(d_prof, unsigned long long, kProfWords);
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, npos * sizeof(double), st));        // solve.cc:609-612, see create_on_device
-    HIP_TRY(hipMemsetAsync(b->d_prof, 0, 8 * lfr::KC_COUNT * sizeof(unsigned long long), st));
+    HIP_TRY(hipMemsetAsync(b->d_prof, 0, kProfWords * sizeof(unsigned long long), st));
     if (ws) {
         if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
         b->d_workspace = (double *)b->ws_slab.base;
@@ -1714,6 +1761,25 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         if (!(b->side_stream = ctx->side_stream(0))) return LFR_ERR_HIP;
         for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls)
             if (b->class_begin[cls + 1] > b->class_begin[cls] && !(b->wg_stream[cls] = ctx->side_stream(1 + cls))) return LFR_ERR_HIP;
+        {   // hand-out order of the persistent launches
+            const int wg_begin = b->class_begin[lfr::KC_BLOCK], n_wg = b->class_begin[lfr::KC_COUNT] - wg_begin;
+            hipStream_t so = ctx->s_main;
+            size_t tmp_bytes = 0;
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                                       (uint32_t *)nullptr, n_wg, 0, 27, so));
+            if (!b->order_slab.init(ctx, 16 * (size_t)n_wg + tmp_bytes + 4096)) return LFR_ERR_NOMEM;
+            b->d_wg_order = b->order_slab.take_n<uint32_t>(n_wg);
+            uint32_t *keys = b->order_slab.take_n<uint32_t>(n_wg), *keys_sorted = b->order_slab.take_n<uint32_t>(n_wg), *vals = b->order_slab.take_n<uint32_t>(n_wg);
+            void *tmp = b->order_slab.take(tmp_bytes);
+            if (!b->d_wg_order || !keys || !keys_sorted || !vals || !tmp) { lfr::set_error("order slab exhausted"); return LFR_ERR_NOMEM; }
+            hipLaunchKernelGGL(k_wg_order_keys, dim3((n_wg + 255) / 256), dim3(256), 0, so, b->d_descs + wg_begin, n_wg,
+                               b->class_begin[lfr::KC_BLOCK_M] - wg_begin, b->class_begin[lfr::KC_BLOCK_L] - wg_begin, b->class_begin[lfr::KC_GLOBAL] - wg_begin,
+                               keys, vals, wg_begin);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, vals, b->d_wg_order, n_wg, 0, 27, so));
+            HIP_TRY(hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(b->ev_order, so));
+        }
         const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
         const int lds_m = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_M], 2), false);
         const int lds_l = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_L], 2), false);
@@ -1738,6 +1804,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
     a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.es_off = b->d_es_off;
     a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
+    a.queue = reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT);
+    a.wg_order = b->d_wg_order; a.wg_begin = b->class_begin[lfr::KC_BLOCK];
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
     uint32_t &recorded = b->ev_recorded[b->n_solves % lfr_batch::kSlots];
     recorded = 0;
@@ -1745,6 +1813,10 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     b->last_stream = st;
     if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
     HIP_TRY(hipEventRecord(b->ev[0], st));
+    if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {
+        HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
+        HIP_TRY(hipMemsetAsync(a.queue, 0, 64, st));                       // the classes' component queues
+    }
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
@@ -1757,11 +1829,15 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         if (n <= 0) return LFR_OK;
         const int rows = b->class_max_rows[cls];
         const size_t lds = block_lds_bytes(rows, cls == lfr::KC_GLOBAL);
+        // persistent workgroups: what the chip keeps resident for the class (by LDS, and 8 waves of 256 registers per CU)
+        const int threads = cls == lfr::KC_BLOCK ? kThreadsS : cls == lfr::KC_BLOCK_M ? kThreadsM : cls == lfr::KC_BLOCK_L ? kThreadsL : kThreadsG;
+        const int by_waves = std::max(1, 512 / threads), by_lds = lds ? std::max(1, (int)((size_t)160 * 1024 / (lds + 256))) : by_waves;
+        const int wgs = std::min(n, b->ctx->n_cu * std::min(by_waves, by_lds));
         switch (cls) {
-            case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<false, kThreadsS>), dim3(n), dim3(kThreadsS), lds, cs, a, rows); break;
-            case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsM>), dim3(n), dim3(kThreadsM), lds, cs, a, rows); break;
-            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(n), dim3(kThreadsL), lds, cs, a, rows); break;
-            default:              hipLaunchKernelGGL((solve_block_kernel<true, kThreadsG>), dim3(n), dim3(kThreadsG), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<false, kThreadsS>), dim3(wgs), dim3(kThreadsS), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
+            default:              hipLaunchKernelGGL((solve_block_kernel<true, kThreadsG>), dim3(wgs), dim3(kThreadsG), lds, cs, a, rows); break;
         }
         HIP_TRY(hipGetLastError());
         return LFR_OK;
@@ -1826,12 +1902,14 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             if (nb > 0) { const int rc = launch_packed(st); if (rc != LFR_OK) return rc; }
         } else {
             // Every workgroup class on its own stream (the first on the caller's).  Dispatch order = issue order: the HBM-matrix
-            // class first (its components run longest), then the LDS classes from the smallest footprint up.  A 160 KB
-            // workgroup only starts on an empty CU, so issued first it keeps the smaller classes out until its queue drains,
-            // and a slow component among THEM (iteration counts vary 8x) then starts late and ends the solve alone:
-            // config 5 measured 17.0 ms with the largest class first, LFR_WG_ORDER overrides for experiments.
+            // class first (its components run longest), then the 130-row class, the 192-row class, the 88-row class.  A 160 KB
+            // workgroup only starts on an empty CU: issued first, the largest class kept the others out until its queue drained,
+            // and the one slow component among THEM (iteration counts vary 8x) then ended the solve alone (config 5: 17.0 ms
+            // against 13.8 at the time).  With persistent workgroups the middle class takes the whole chip for its 1.5 ms, the
+            // large class follows, and the small class fills the CUs the large one's tail leaves (measured 9.15 ms against
+            // 9.4-9.5 smallest-first and 12.4 largest-first); LFR_WG_ORDER overrides for experiments.
             static const std::array<int, 4> kBigOrder = [] {
-                std::array<int, 4> o = {lfr::KC_GLOBAL, lfr::KC_BLOCK, lfr::KC_BLOCK_M, lfr::KC_BLOCK_L};
+                std::array<int, 4> o = {lfr::KC_GLOBAL, lfr::KC_BLOCK_M, lfr::KC_BLOCK_L, lfr::KC_BLOCK};
                 if (const char *e = getenv("LFR_WG_ORDER")) {
                     int v[4];
                     if (sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4) {

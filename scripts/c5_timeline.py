@@ -25,3 +25,17 @@ for i in range(24):
     mid = 0.5 * (edges[i] + edges[i + 1])
     run = (t0 <= mid) & (t1 > mid)
     print("  t=%6.2f ms: running S %3d M %3d L %3d  -> CUs busy %3d" % (mid, (run & (cls == 0)).sum(), (run & (cls == 1)).sum(), (run & (cls == 2)).sum(), len(np.unique(hw[run]))))
+# per-CU view: how many L workgroups each CU ran, and how long it sat idle between two of them while the queue was not empty
+L = cls == 2
+last_start = t0[L].max()
+gaps = []
+per_cu = {}
+for cu in np.unique(hw):
+    m = (hw == cu)
+    order = np.argsort(t0[m]); a = t0[m][order]; b = t1[m][order]; c = cls[m][order]
+    per_cu[cu] = int((c == 2).sum())
+    for k in range(1, len(a)):
+        if c[k] == 2 and a[k] <= last_start: gaps.append(a[k] - b[:k].max())
+gaps = np.array(gaps)
+print(" L workgroups per CU: min %d median %d max %d; idle gap before an L workgroup starts (ms): median %.3f mean %.3f p90 %.3f max %.3f, sum over CUs %.1f ms" %
+      (min(per_cu.values()), int(np.median(list(per_cu.values()))), max(per_cu.values()), np.median(gaps), gaps.mean(), np.percentile(gaps, 90), gaps.max(), gaps.clip(0).sum()))
