@@ -171,6 +171,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     const int row = sl % NV, part = sl / NV;
     const int ci0 = a.desc_begin + (block_in_class * kPackedWaves + wave) * G;
     if (ci0 >= a.desc_end) return;                    // wave-uniform
+#if defined(LFR_PROFILE_WGTIME) && LFR_PROFILE_WGTIME == 3
+    const unsigned long long wave_r0_ = wall_clock64();
+#endif
     const int ci = ci0 + gid;
     const bool have = ci < a.desc_end;
     GroupLds<NV> &L = reinterpret_cast<GroupLds<NV> *>(lds_raw)[wave * G + gid];
@@ -532,6 +535,14 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
             inf.iterations = iteration; inf.termination = term; inf.n_successful = L.n_successful;
             inf.n_ls_evals = L.n_ls_evals; inf.n_cand_evals = L.n_cand; inf.exec_passes = L.exec_passes;
             inf.final_cost = cost;
+#if defined(LFR_PROFILE_WGTIME) && LFR_PROFILE_WGTIME == 3      // diagnostic builds: when and where the wave ran (scripts/c4_timeline.py)
+            inf.final_cost = (double)wave_r0_;
+            inf.n_ls_evals = inf.iterations;
+            inf.iterations = (int)(wall_clock64() - wave_r0_);
+            const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+            const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+            inf.termination = (int)((hw & 0xffffu) | ((xcc & 0xfu) << 16));     // wave [3:0] simd [5:4] cu [11:8] sh [12] se [15:13] xcc [19:16]
+#endif
             a.infos[ci] = inf;
         }
     }
@@ -557,6 +568,10 @@ struct PackedRanges {
 };
 __global__ __launch_bounds__(64 * kPackedWaves, LFR_GROUP_WAVES) void solve_packed_kernel(KernelArgs a, const PackedRanges r) {
     __shared__ __attribute__((aligned(16))) unsigned char lds_raw[kPackedLdsBytes];
+    // (one workgroup per block, dealt by the hardware: the wave timeline of config 4 shows the chip full from the first
+    // microsecond, 95 % of the 2048 wave slots busy in the steady state and a 15-us tail; resident waves pulling blocks from an
+    // atomic queue - what pays for the 160-KB workgroups of the long-track classes - cost this kernel 76 spilled VGPRs
+    // and 38 %: 0.650 against 0.470 ms)
     const int b = (int)blockIdx.x;
     if (b < r.blk_begin[1]) {
         a.desc_begin = r.desc_begin[0]; a.desc_end = r.desc_end[0]; a.cls = lfr::KC_G64_4;
@@ -1817,6 +1832,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
         HIP_TRY(hipMemsetAsync(a.queue, 0, 64, st));                       // the classes' component queues
     }
+
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
     // workgroup-per-component problems run beside it on a side stream.  LFR_SERIAL_CLASSES=1
     // launches every class separately on the caller's stream (per-class timings for diagnostics).
