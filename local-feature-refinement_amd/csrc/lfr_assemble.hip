@@ -90,22 +90,25 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uin
 }
 
 // per component: solvable? class; the three sort keys of the batch order
+// batch order = class, then edges descending, then variables descending, then id: one 52-bit key (a stable sort keeps the ids
+// ascending inside ties).  Three LSD passes over 32-bit keys cost three block sorts and thirty merge launches of ~6 us each.
 __global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges,
-                            uint32_t *key_var, uint32_t *key_edges, uint32_t *key_class, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
+                            unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
     if (solvable && c_nodes[c] > 32767) *too_big = 1u;
-    key_var[c] = 0xffffu - min(c_var[c], 0xffffu);             // descending
-    key_edges[c] = 0xffffffffu - c_edges[c];                   // descending
-    key_class[c] = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c], block_max) : kNoClass;
+    const unsigned long long kv = 0xffffu - min(c_var[c], 0xffffu);             // descending
+    const unsigned long long ke = 0xffffffffu - c_edges[c];                     // descending
+    const unsigned long long kc = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c], block_max) : kNoClass;
+    key[c] = (kc << 48) | (ke << 16) | kv;
     ids[c] = (uint32_t)c;
 }
-
-__global__ void k_gather_u32(int64_t n, const uint32_t *idx, const uint32_t *src, uint32_t *dst) {
+__global__ void k_class_of_key(int64_t n, const unsigned long long *key, uint32_t *cls) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[idx[i]];
+    if (i < n) cls[i] = (uint32_t)(key[i] >> 48);
 }
+
 
 // after the sort: per desc sizes (0 for unsolvable) + inverse permutation
 __global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, const uint32_t *key_class_sorted, const uint32_t *c_nodes,
@@ -420,16 +423,12 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, ts, tc, ct);
 
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
-    TAKE(kv, uint32_t, C + 1); TAKE(ke, uint32_t, C + 1); TAKE(kc, uint32_t, C + 1);
+    TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, kv, ke, kc, id0, &sum->too_big, (uint32_t)block_max_rows());
+    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
     int rc;
-    // LSD over the three keys (each pass stable): variables, edges, class
-    if ((rc = sort_pairs(arena, kv, k0, id0, id1, C, 0, 16, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id1, ke, k0);
-    if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, 32, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u32, grid_for(C), dim3(kThreads), 0, st, C, id0, kc, k0);
-    if ((rc = sort_pairs(arena, k0, k1, id0, id1, C, 0, kClassBits, st)) != LFR_OK) return rc;
+    if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
     uint32_t *perm = id1;                  // perm[i] = component of desc i
     uint32_t *class_sorted = k1;
     if (shard_world > 1) {                 // keep this shard's components (same relative order), the rest becomes class 7
