@@ -174,3 +174,60 @@ def test_shards_partition_the_solvable_components(lfr_lib):
         assert len(merged) == len(all_c) and set(merged) == set(all_c)          # disjoint cover
         loads = np.array([e.sum() for _, e in parts], float)
         assert loads.max() / loads.mean() < 1.02                                  # LPT balance by edges
+
+
+def _bisect_spec(edges, weights):
+    """The product's two-way cut as DESIGN.md section 3 / lfr_graph.cpp describe it, restated naively (O(n^2)):
+    nodes = sorted endpoints; weights max(w, 1) as doubles; maximum-adjacency region growing from attachment 0 (ties ->
+    smallest node) until half of the edge-weight volume is inside (or one node is left outside); then ONE sweep in node
+    order moving a node when that lowers cut/vol0 + cut/vol1 (never emptying a side)."""
+    ids = sorted({a for a, _ in edges} | {b for _, b in edges})
+    n = len(ids)
+    loc = {v: i for i, v in enumerate(ids)}
+    adj = [[] for _ in range(n)]
+    deg = [0.0] * n
+    volume = 0.0
+    for (a, b), w in zip(edges, weights):
+        w = float(max(int(w), 1)); a = loc[a]; b = loc[b]
+        adj[a].append((b, w)); adj[b].append((a, w)); deg[a] += w; deg[b] += w; volume += 2 * w
+    side = [1] * n; attach = [0.0] * n; inside = [False] * n
+    vol0, n0 = 0.0, 0
+    while vol0 * 2 < volume and n0 < n - 1:
+        best = max((i for i in range(n) if not inside[i]), key=lambda i: (attach[i], -i))
+        inside[best] = True; side[best] = 0; vol0 += deg[best]; n0 += 1
+        for v, w in adj[best]:
+            attach[v] += w
+    cut = sum(w for i in range(n) if side[i] == 0 for v, w in adj[i] if side[v] == 1)
+
+    def ncut(c, v0):
+        v1 = volume - v0
+        return c / v0 + c / v1 if v0 > 0 and v1 > 0 else 1e300
+    for i in range(n):
+        same = sum(w for v, w in adj[i] if side[v] == side[i]); other = sum(w for v, w in adj[i] if side[v] != side[i])
+        c2 = cut + same - other
+        v2 = vol0 - deg[i] if side[i] == 0 else vol0 + deg[i]
+        cnt0 = n0 - 1 if side[i] == 0 else n0 + 1
+        if cnt0 <= 0 or cnt0 >= n:
+            continue
+        if ncut(c2, v2) < ncut(cut, vol0):
+            side[i] ^= 1; cut, vol0, n0 = c2, v2, cnt0
+    return {ids[i]: side[i] for i in range(n)}
+
+
+def test_bisection_equals_its_naive_restatement(lfr_lib):
+    """The C++ cut (indexed heap, CSR adjacency) against the O(n^2) restatement of its own specification: random multigraphs
+    with duplicate edges, zero / equal weights (ties everywhere), disconnected pieces, sparse node ids."""
+    rng = np.random.default_rng(77)
+    for case in range(300):
+        n = int(rng.integers(2, 40))
+        ids = np.sort(rng.choice(1000, n, replace=False))
+        m = int(rng.integers(1, 4 * n))
+        a = ids[rng.integers(0, n, m)]; b = ids[rng.integers(0, n, m)]
+        keep = a != b
+        if not keep.any():
+            continue
+        e = np.stack([a[keep], b[keep]], 1).astype(np.int32)
+        w = rng.choice([0, 1, 1, 5, 5, 50, 100], len(e)).astype(np.int32)
+        got = capi.bisect_graph(e, w)
+        want = _bisect_spec([tuple(map(int, x)) for x in e], [int(x) for x in w])
+        assert got == want, (case, e.tolist(), w.tolist())
