@@ -6,6 +6,7 @@
 // Image names are interned to integers at ingest: every use in the reference is an equality
 // test (std::set<std::string> intersection/union, solve.cc:493-519).
 #include <algorithm>
+#include <climits>
 #include <future>
 #include <atomic>
 #include <chrono>
@@ -169,12 +170,26 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
 // nodes = endpoints of the edges, ascending; edges in local indices
 SubGraph compact(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights) {
     SubGraph g;
+    g.ea.resize(edges.size()); g.eb.resize(edges.size()); g.w = weights;
+    int lo = INT32_MAX, hi = -1;
+    for (auto &e : edges) { lo = std::min({lo, e.first, e.second}); hi = std::max({hi, e.first, e.second}); }
+    if (!edges.empty() && lo >= 0 && (size_t)hi - lo <= 8 * edges.size() + 1024) {
+        // ids in a dense range (track ids are): mark, rank, look up - sorting 2 E ids and two binary searches per edge were a
+        // quarter of the whole cut
+        std::vector<int> rank((size_t)hi - lo + 2, 0);
+        for (auto &e : edges) { rank[e.first - lo + 1] = 1; rank[e.second - lo + 1] = 1; }
+        for (size_t i = 1; i < rank.size(); ++i) {
+            if (rank[i]) g.ids.push_back((int)(i - 1) + lo);
+            rank[i] += rank[i - 1];
+        }
+        for (size_t k = 0; k < edges.size(); ++k) { g.ea[k] = rank[edges[k].first - lo]; g.eb[k] = rank[edges[k].second - lo]; }
+        return g;
+    }
     g.ids.reserve(2 * edges.size());
     for (auto &e : edges) { g.ids.push_back(e.first); g.ids.push_back(e.second); }
     std::sort(g.ids.begin(), g.ids.end());
     g.ids.erase(std::unique(g.ids.begin(), g.ids.end()), g.ids.end());
     auto local = [&](int id) { return (int)(std::lower_bound(g.ids.begin(), g.ids.end(), id) - g.ids.begin()); };
-    g.ea.resize(edges.size()); g.eb.resize(edges.size()); g.w = weights;
     for (size_t k = 0; k < edges.size(); ++k) { g.ea[k] = local(edges[k].first); g.eb[k] = local(edges[k].second); }
     return g;
 }
