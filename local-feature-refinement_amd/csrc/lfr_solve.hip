@@ -658,15 +658,19 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     // LDS variant: vectors + packed matrix in dynamic LDS.  HBM variant: packed matrix, then the
     // vectors, in this component's workspace (L2-resident); no dynamic LDS at all, so the row count
     // is only bounded by the 32767-node limit of the batch format.
-    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : (dyn + 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows);
+    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : (dyn + 2 * (size_t)(max_rows + 2) + 7 * (size_t)max_rows);
     double *vx = GLOBAL_MATRIX ? (Mat + tri(n, 0) + (tri(n, 0) & 1)) : dyn;   // x (n + 2, zero slot at n)
     double *vxc = vx + max_rows + 2;  // trial point
     double *vg = vxc + max_rows + 2;  // gradient at x
     double *vgn = vg + max_rows;      // gradient at trial point
     double *vscale = vgn + max_rows;
     double *vdiag = vscale + max_rows;
-    double *vstep = vdiag + max_rows; // rhs -> step
-    double *vD = vstep + max_rows;
+    // rhs -> step.  LDS variant: row n of the matrix - the right-hand side rides through the factorization as one more row
+    // (LDL^T of [[A, g], [g^T, .]]: the unscaled entries of that row come out as L^-1 g), so the forward substitution, n
+    // dependent steps per solve, is gone; the (n, n) entry is never used.
+    double *vstep = GLOBAL_MATRIX ? vdiag + max_rows : Mat + tri(n, 0);
+    double *vD = GLOBAL_MATRIX ? vstep + max_rows : vdiag + max_rows;
+    const int n1 = GLOBAL_MATRIX ? n : n + 1;        // rows the factorization carries
     double *vadiag = vD + max_rows;   // diagonal of unscaled J^T J at x
     double *vdelta = vadiag + max_rows;
 
@@ -900,12 +904,12 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
             __syncthreads();
             PROF_FACTOR_MARK(3);                      // 3: diagonal blocks of the factorization (one thread)
             if (sh.flag) break;                                           // uniform
-            if (ke < n) {
+            if (ke < n1) {
                 double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
                 load_block(kb, nb, B);
 #pragma unroll
                 for (int k = 0; k < kPanel; ++k) inv[k] = k < nb ? vinv[kb + k] : 1.0;
-                for (int i = ke + tid; i < n; i += kBlockThreads) {       // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
+                for (int i = ke + tid; i < n1; i += kBlockThreads) {      // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
                     double r[kPanel];
 #pragma unroll
                     for (int c = 0; c < kPanel; ++c) r[c] = c < nb ? Mat[tri(i, kb + c)] : 0.0;
@@ -933,21 +937,21 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                 const bool k0 = kq < nb, k1 = 4 + kq < nb;
                 const int kc0 = kb + min(kq, nb - 1), kc1 = kb + min(4 + kq, nb - 1);
                 const double ninv0 = -vinv[kc0], ninv1 = -vinv[kc1];
-                const int mt = (n - ke + 15) >> 4;
+                const int mt = ke < n ? (n1 - ke + 15) >> 4 : 0;         // (only the right-hand-side row left: nothing to update)
                 struct Tile { double a0, a1, b0, b1; f64x4 c; bool ok[4]; int row0, jb; };
                 auto load_tile = [&](int I, int J, Tile &T) {
-                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n - 1), jbc = min(jb, n - 1);
+                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n1 - 1), jbc = min(jb, n1 - 1);
                     T.row0 = ke + 16 * I + kq; T.jb = jb;
                     const double a0 = Mat[tri(iac, kc0)], a1 = Mat[tri(iac, kc1)], b0 = Mat[tri(jbc, kc0)], b1 = Mat[tri(jbc, kc1)];
                     double cv[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int row = T.row0 + 4 * r, rc = min(row, n - 1);
-                        T.ok[r] = row < n && jb <= row;
+                        const int row = T.row0 + 4 * r, rc = min(row, n1 - 1);
+                        T.ok[r] = row < n1 && jb <= row;
                         cv[r] = Mat[tri(rc, min(jbc, rc))];
                     }
-                    T.a0 = (ia < n && k0) ? a0 : 0.0; T.a1 = (ia < n && k1) ? a1 : 0.0;
-                    T.b0 = (jb < n && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n && k1) ? b1 * ninv1 : 0.0;
+                    T.a0 = (ia < n1 && k0) ? a0 : 0.0; T.a1 = (ia < n1 && k1) ? a1 : 0.0;
+                    T.b0 = (jb < n1 && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n1 && k1) ? b1 * ninv1 : 0.0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
                 };
@@ -973,7 +977,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     const int I1 = I, J1 = J;
                     J += kWaves; while (J > I) { J -= I + 1; ++I; }
                     Tile t0, t1;
-                    if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n) {       // (I0 <= I1)
+                    if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n1) {       // (I0 <= I1)
                         load_full(I0, J0, t0);
                         load_full(I1, J1, t1);
                     } else {
@@ -996,11 +1000,10 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         bool valid = sh.flag == 0;
         if (valid) {
             if constexpr (!GLOBAL_MATRIX) {
-                // Triangular solves by ONE wave with the vector in registers (n <= 192: three values per lane): a step is a
+                // Back substitution by ONE wave with the vector in registers (n <= 192: three values per lane): a step is a
                 // v_readlane broadcast and one multiply-add per register - ~50 cycles against the ~270 of a step that crosses a
                 // workgroup barrier and an LDS round trip, and there are 2 n steps per solve.  The matrix entries do not depend
-                // on the running vector, so four steps' worth is loaded ahead of the dependent chain.  Same operations per element
-                // as the barrier version below: the results are bitwise the same.
+                // on the running vector, so four steps' worth is loaded ahead of the dependent chain.
                 if (tid < 64) {
                     constexpr int kR = 3;
                     double x[kR], inv[kR];
@@ -1010,26 +1013,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                         x[r] = i < n ? vstep[i] : 0.0;
                         inv[r] = i < n ? vinv[i] : 0.0;
                     }
-#pragma unroll
-                    for (int r0 = 0; r0 < kR; ++r0) {                                 // forward: L z = rhs
-                        for (int k4 = 64 * r0; k4 < min(n, 64 * r0 + 64); k4 += 4) {
-                            double l[4][kR];
-#pragma unroll
-                            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                                for (int r = r0; r < kR; ++r) {
-                                    const int i = tid + 64 * r, k = k4 + u;
-                                    const double m = Mat[tri(min(i, n - 1), min(k, n - 1))];     // unconditional: the loads overlap
-                                    l[u][r] = (i > k && i < n) ? m : 0.0;
-                                }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const double t = readlane_f64(x[r0] * inv[r0], (k4 + u) & 63);
-#pragma unroll
-                                for (int r = r0; r < kR; ++r) x[r] -= l[u][r] * t;
-                            }
-                        }
-                    }
+                    // (no forward substitution: vstep = row n of the factored matrix already holds L^-1 rhs)
 #pragma unroll
                     for (int r = 0; r < kR; ++r) x[r] *= inv[r];
 #pragma unroll
@@ -1255,7 +1239,8 @@ constexpr int kThreadsS = LFR_THREADS_S, kThreadsM = LFR_THREADS_M, kThreadsL = 
 size_t block_vector_doubles(int max_rows) { return 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows; }
 size_t block_lds_bytes(int max_rows, bool global_matrix) {
     if (global_matrix) return 0;                       // matrix and vectors live in the HBM workspace
-    return (block_vector_doubles(max_rows) + (size_t)max_rows * (max_rows + 1) / 2) * sizeof(double);
+    // nine vectors (the step is row max_rows of the matrix) + the packed triangle of max_rows + 1 rows
+    return (block_vector_doubles(max_rows) - (size_t)max_rows + (size_t)(max_rows + 1) * (max_rows + 2) / 2) * sizeof(double);
 }
 
 #define HIP_TRY(expr)                                                                         \
