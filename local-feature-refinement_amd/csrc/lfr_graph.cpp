@@ -98,23 +98,23 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     std::vector<uint32_t> off(n + 1, 0);                          // CSR adjacency, neighbours in edge order
     for (size_t k = 0; k < E; ++k) { ++off[g.ea[k] + 1]; ++off[g.eb[k] + 1]; }
     for (int i = 0; i < n; ++i) off[i + 1] += off[i];
-    std::vector<int> nb(2 * E);
-    std::vector<double> nw(2 * E);
+    struct Nb { int node, w; };                                   // (integer weights: every sum below is exact in doubles)
+    std::vector<Nb> nbr(2 * E);
     std::vector<double> deg(n, 0.0);
     double volume = 0.0;
     {
         std::vector<uint32_t> fill(off.begin(), off.end() - 1);
         for (size_t k = 0; k < E; ++k) {
-            const int a = g.ea[k], b = g.eb[k];
-            const double w = (double)std::max(g.w[k], 1);
-            nb[fill[a]] = b; nw[fill[a]++] = w;
-            nb[fill[b]] = a; nw[fill[b]++] = w;
+            const int a = g.ea[k], b = g.eb[k], wi = std::max(g.w[k], 1);
+            const double w = (double)wi;
+            nbr[fill[a]++] = Nb{b, wi};
+            nbr[fill[b]++] = Nb{a, wi};
             deg[a] += w; deg[b] += w; volume += 2 * w;
         }
     }
     std::vector<double> attach(n, 0.0);
     std::vector<char> in(n, 0);
-    double vol0 = 0.0;
+    double vol0 = 0.0, cut = 0.0;
     int n0 = 0;
     // region growing: always absorb the outside node with the largest attachment to the region (ties ->
     // smallest id; a node nobody is attached to yet has attachment 0, so an emptied frontier restarts from the
@@ -145,19 +145,18 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
         heap[0] = heap[--hn]; pos[heap[0]] = 0;
         if (hn > 0) sift_down(0);
         in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
+        cut += deg[best] - 2.0 * attach[best];            // its edges to the outside enter the cut, those to the region leave it
         for (uint32_t q = off[best]; q < off[best + 1]; ++q) {
-            const int v = nb[q];
-            attach[v] += nw[q];
+            const int v = nbr[q].node;
+            attach[v] += (double)nbr[q].w;
             if (!in[v]) sift_up(pos[v]);
         }
     }
     // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
-    double cut = 0.0;
-    for (int i = 0; i < n; ++i) if (side[i] == 0) for (uint32_t q = off[i]; q < off[i + 1]; ++q) if (side[nb[q]] == 1) cut += nw[q];
     auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
     for (int i = 0; i < n; ++i) {
         double to_same = 0.0, to_other = 0.0;
-        for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nb[q]] == side[i] ? to_same : to_other) += nw[q];
+        for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nbr[q].node] == side[i] ? to_same : to_other) += (double)nbr[q].w;
         const double ncut_now = ncut(cut, vol0);
         const double c2 = cut + to_same - to_other;
         const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
@@ -208,14 +207,19 @@ void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_
     // the half of an oversized side that still has edges: nodes with an internal edge, in ascending order
     SubGraph child[2];
     std::vector<int> up[2];                                        // child index -> index here
-    for (int s = 0; s < 2; ++s) {
-        if (subset_w[s] <= max_weight) continue;
+    const bool over[2] = {subset_w[0] > max_weight, subset_w[1] > max_weight};
+    if (over[0] || over[1]) {                                      // one pass over the edges for both sides (a node has one side)
         std::vector<int> down(n, -1);
-        for (size_t k = 0; k < g.ea.size(); ++k)
-            if (side[g.ea[k]] == s && side[g.eb[k]] == s) { down[g.ea[k]] = 0; down[g.eb[k]] = 0; }
-        for (int i = 0; i < n; ++i) if (down[i] == 0) { down[i] = (int)up[s].size(); up[s].push_back(i); child[s].ids.push_back(g.ids[i]); }
-        for (size_t k = 0; k < g.ea.size(); ++k)
-            if (side[g.ea[k]] == s && side[g.eb[k]] == s) { child[s].ea.push_back(down[g.ea[k]]); child[s].eb.push_back(down[g.eb[k]]); child[s].w.push_back(g.w[k]); }
+        for (int s = 0; s < 2; ++s) if (over[s]) { child[s].ea.reserve(g.ea.size() / 3); child[s].eb.reserve(g.ea.size() / 3); child[s].w.reserve(g.ea.size() / 3); }
+        for (size_t k = 0; k < g.ea.size(); ++k) {
+            const int a = g.ea[k], b = g.eb[k], sa = side[a];
+            if (sa != side[b] || !over[sa]) continue;
+            down[a] = 0; down[b] = 0;
+            child[sa].ea.push_back(a); child[sa].eb.push_back(b); child[sa].w.push_back(g.w[k]);
+        }
+        for (int i = 0; i < n; ++i) if (down[i] == 0) { const int s = side[i]; down[i] = (int)up[s].size(); up[s].push_back(i); child[s].ids.push_back(g.ids[i]); }
+        for (int s = 0; s < 2; ++s)
+            for (size_t k = 0; k < child[s].ea.size(); ++k) { child[s].ea[k] = down[child[s].ea[k]]; child[s].eb[k] = down[child[s].eb[k]]; }
     }
     std::vector<int> sub[2];
     std::future<void> second;
