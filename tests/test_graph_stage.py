@@ -231,3 +231,20 @@ def test_bisection_equals_its_naive_restatement(lfr_lib):
         got = capi.bisect_graph(e, w)
         want = _bisect_spec([tuple(map(int, x)) for x in e], [int(x) for x in w])
         assert got == want, (case, e.tolist(), w.tolist())
+
+
+def test_parallel_cut_is_schedule_independent(lfr_lib):
+    """The two halves of a bisection are cut on two threads (big halves only): the labels must not depend on the schedule -
+    the same dense meta graph (one giant component, thousands of edges per half) cut eight times gives the same components,
+    and they equal the C oracle's sequential recursion around the same two-way cut."""
+    ma = synthetic.generate(seed=61, n_images=24, n_tracks=700, len_dist="uniform", len_lo=8, len_hi=20, eps_out=0.03)
+    g = capi.Graph.from_arrays(ma)
+    labels = []
+    for _ in range(8):
+        p = capi.Problem(g, device_assembly=True)
+        labels.append(p.labels()[2].copy())
+    assert p.stats()["n_cut_components"] >= 1
+    for c in labels[1:]:
+        assert (c == labels[0]).all()
+    o = O.run(ma, solve=False, bisect=bisect_ptr())
+    assert (o["comp"] == labels[0]).all() and o["n_oversized"] == p.stats()["n_cut_components"]
