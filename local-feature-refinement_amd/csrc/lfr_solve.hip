@@ -164,8 +164,6 @@ template <int NV, int LPR, int EPL>
 __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int block_in_class, unsigned char *lds_raw) {
     constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
     static_assert(S <= 64 && (LPR == 1 || LPR == 2), "group geometry");
-    // swizzle mask that keeps the lane's part (and, for S < 32, its group) and replaces the row
-    constexpr int kPartAnd = (NV == 8) ? 0x18 : (NV == 16) ? 0x10 : 0x00;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = lane / S, sl = lane % S;
     const int row = sl % NV, part = sl / NV;

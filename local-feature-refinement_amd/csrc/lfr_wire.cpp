@@ -766,7 +766,6 @@ struct Out {
     void bytes(int field, const void *p, size_t n) { tag(field, 2); varint(n); const size_t o = buf.size(); buf.resize(o + n); if (n) memcpy(&buf[o], p, n); }
     void str(int field, const std::string &s) { if (!s.empty()) bytes(field, s.data(), s.size()); }
 };
-static inline size_t varint_size(uint64_t v) { size_t n = 1; while (v >= 0x80) { v >>= 7; ++n; } return n; }
 
 static bool write_file(const char *path, const std::vector<const std::vector<uint8_t> *> &chunks) {
     FILE *f = fopen(path, "wb");
