@@ -157,10 +157,12 @@ def _labels_equal(ma, **kw):
     dict(seed=202, n_images=200, n_tracks=6000, eps_out=0.03, sim_lo=0.3),
     dict(seed=203, n_images=96, n_tracks=80, len_dist="uniform", len_lo=40, len_hi=96, eps_out=0.02),   # long tracks, dense
 ])
-def test_giant_connected_component_runs_in_parallel_rounds(lfr_lib, kw):
+def test_giant_connected_component_runs_in_parallel_rounds(lfr_lib, kw, monkeypatch):
     """One connected component holds most matches (what real match graphs look like): the device stage runs the
     constrained union-find in rounds (solve.cc:499-523 semantics, union for union) - labels bit-identical to the
-    host stage, also where components exceed the cap (host bisection fed with the device's tracks)."""
+    host stage, also where components exceed the cap (host bisection fed with the device's tracks).  The ordered list
+    goes through the rounds in prefix blocks (5000 positions, then doubling: several blocks at this size)."""
+    monkeypatch.setenv("LFR_ROUNDS_FIRST_BLOCK", "5000")
     ma = synthetic.generate(**kw)
     ph, pd = _labels_equal(ma)
     assert pd.stats()["kruskal_rounds"] > 0
@@ -181,6 +183,7 @@ def test_round_based_union_find_fuzz(lfr_lib, monkeypatch):
     image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523."""
     from test_graph_stage import fuzz_pairs
     monkeypatch.setenv("LFR_SERIAL_SEGMENT_EDGES", "0")
+    monkeypatch.setenv("LFR_ROUNDS_FIRST_BLOCK", "3")          # block boundaries inside every component, ties across them
     n_ok = 0
     for seed in range(3000, 3150):
         ma = synthetic.pairs_to_arrays(fuzz_pairs(seed))
