@@ -131,16 +131,20 @@ typedef struct lfr_problem_stats {
 int lfr_problem_build(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
                       lfr_problem **out);
 /* Same graph stage (tracks, roots, components) without the host-side batch assembly: the 80-byte
- * edge records, descriptors and incidence lists are then built on the GPU by lfr_batch_create
- * (whole problems only, shard_world = 1): the flows cross PCIe once in match order and no host-side
- * record array is ever materialised.  Results are bit-identical to the host-assembled batch. */
+ * edge records, descriptors and incidence lists are then built on the GPU by lfr_batch_create - the
+ * whole problem (shard_world = 1: the flows cross PCIe once in match order) or one shard of it
+ * (shard_world > 1: the device filters its components and gathers only their flow rows); no host-side
+ * record array is ever materialised.  Results are bit-identical to the host-assembled batch / shard. */
 int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component, const int64_t *component_override,
                              lfr_problem **out);
 /* As lfr_problem_build_labels, with the graph stage itself on HIP device `device`: radix sort of the
- * matches, connected components, one GPU thread per connected component for the order-dependent
- * constrained union-find (solve.cc:499-523), roots, components.  Bit-identical labels.  Falls back
- * to the host stage when a component exceeds the size cap (graph cut), when a connected component
- * is too large to be processed by one thread, or when component_override is given. */
+ * matches, connected components, the order-dependent constrained union-find (solve.cc:499-523) by one
+ * GPU thread per small connected component and by exact parallel rounds over prefix blocks for large
+ * ones, roots, components; components above the size cap are cut on the host from meta edges the
+ * device compacts and sums, and re-labelled on the device.  Bit-identical labels.  Falls back to the
+ * host stage only when component_override is given, for >= 2^31 nodes or >= 2^30 matches, when the
+ * image bitsets of the parallel rounds would exceed 24 GB, or after 100000 rounds (a path-shaped
+ * dependency chain). */
 int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component,
                           const int64_t *component_override, lfr_problem **out);
 /* flags: LFR_BUILD_FLOWS_STAY_ON_HOST - do not stage the flows in HBM; a sharded lfr_batch_create then gathers

@@ -1,7 +1,8 @@
 // Batched per-component Levenberg-Marquardt on MI355X (gfx950) — replaces the hot loop of the
 // reference, solve.cc:614-635 -> create_and_solve_problem (solve.cc:79-160) -> ceres::Solve,
 // with the cost model of cost.cc:13-48,78-90.  Control flow mirrors Ceres' trust-region loop
-// decision for decision; fp64 throughout; no MFMA (2N-variable blocks are tiny).
+// decision for decision; fp64 throughout.  The packed kernel uses no MFMA (its 2N-variable blocks are tiny);
+// the workgroup kernels run the trailing updates of their factorizations on the fp64 matrix cores.
 //
 // Kernels:
 //   solve_packed_kernel        ONE launch for every component of up to 32 rows: a wave64 hosts 64/S components
@@ -10,8 +11,9 @@
 //                              of a match sit in neighbouring lanes and exchange their terms through DPP before
 //                              7 ds_add_f64 per edge assemble J^T J in LDS, the damped system is eliminated in
 //                              registers (lane = row) with ds_swizzle broadcasts, sized per wave.
-//   solve_block_kernel         one 512-thread workgroup per larger component; packed J^T J in LDS (<=192 rows)
-//                              or in an HBM workspace (GLOBAL variant), owner-computes assembly, blocked LDL^T;
+//   solve_block_kernel         one persistent 128/256/512-thread workgroup per larger component; packed J^T J in LDS
+//                              (<=192 rows, three LDS-footprint classes) or in an HBM workspace (GLOBAL variant),
+//                              owner-computes assembly, blocked LDL^T (16-column panels, fp64 MFMA trailing update);
 //                              edges re-streamed from L2/HBM per pass.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -610,6 +612,7 @@ struct BlockShared {
     double red[8];
     double bcast[4];
     int flag;
+    int ready;               // factor_lds: last panel whose diagonal block wave 0 has factored and published
 };
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
@@ -635,6 +638,251 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 #pragma unroll
     for (int w = 1; w < kBlockThreads / 64; ++w) s = fmax(s, sh.red[w]);
     return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Blocked LDL^T of the damped normal matrix in LDS (packed lower triangle, the right-hand side riding as row n), in place.
+// Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal, 1/d_k goes to vinv[k].
+//
+// Right-looking over panels of 16 columns with ONE workgroup barrier per panel (round 2: 8 columns, three barriers, the
+// diagonal block on one thread).  Phase k starts with column block k final and
+//   * wave 0 brings the next diagonal tile (k+1, k+1) up to date (fp64 MFMA, K = 16) and factors it with lane = row
+//     (v_readlane broadcasts of the pivot column, 16 dependent steps of ~300 cycles: the kernel issues one VALU instruction per
+//     ~4.8 cycles and wave, scripts/probes/diag16_probe.hip).  Every step PUBLISHES its column - entries, 1/d_k, then a
+//     step counter in LDS (a wave's LDS operations execute in program order);
+//   * the other waves meanwhile apply panel k to the tiles right of column block k+1 (two 16x16 tiles in flight per wave,
+//     4 + 4 v_mfma_f64_16x16x4_f64), then to THEIR tiles of column block k+1, re-read those with lane = row and run the
+//     rows' substitution against the diagonal block step by step BEHIND wave 0 (a step waits for the counter): the
+//     substitution ends a few hundred cycles after the diagonal block does, instead of starting there;
+//   * the barrier at the end of the phase leaves column block k+1 final.
+// The diagonal blocks are the critical path (12 x ~8000 cycles for 190 rows); wave 0 does nothing else.
+// scripts/emul_factor_v2.py is a lane-level CPU model of the tile schedule (random wave order + a race detector).
+// A non-positive pivot only raises sh.flag: the phases run to the end on whatever values there are (no data-dependent
+// exit, so no wave can miss a barrier), the caller rejects the step.
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef LFR_PROFILE_FACTOR      // diagnostic builds: where the waves of a factorization spend their cycles (waves 0 and 1, six slots each)
+#define FPROF_DECL unsigned long long ft_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long ft0_ = __builtin_amdgcn_s_memtime();
+#define FPROF_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); ft_[i] += t_ - ft0_; ft0_ = t_; } while (0)
+#define FPROF_RESET() do { ft0_ = __builtin_amdgcn_s_memtime(); } while (0)
+#define FPROF_FLUSH() do { if (lane == 0 && wave < 2 && fprof) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&fprof[wave * 8 + i_], ft_[i_]); atomicAdd(&fprof[wave * 8 + 7], 1ull); } } while (0)
+#else
+#define FPROF_DECL
+#define FPROF_MARK(i)
+#define FPROF_RESET()
+#define FPROF_FLUSH()
+#endif
+#ifndef LFR_FINE_READY
+#define LFR_FINE_READY 0      // 1: the rows' substitution follows the diagonal block column by column (measured: the 15 polls cost ~270 spilled registers)
+#endif
+template <int kBlockThreads>
+__device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int n, BlockShared &sh, unsigned long long *fprof) {
+    constexpr int kWaves = kBlockThreads / 64;
+    static_assert(kWaves >= 2, "factor_lds needs a wave beside the one that factors the diagonal blocks");
+    constexpr int kWorkers = kWaves - 1;        // waves 1.. : everything but the diagonal blocks
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (an SGPR: tile indices and loops are SALU)
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n1 = n + 1;                       // rows carried (row n = right-hand side)
+    const int P = (n + 15) >> 4;                // panels
+    const int RT = (n1 + 15) >> 4;              // 16-row tiles
+    FPROF_DECL
+    volatile int *ready = &sh.ready;            // 16 * panel + (columns of that panel's diagonal block published)
+    const __attribute__((address_space(3))) int *ready_lds = (const __attribute__((address_space(3))) int *)&sh.ready;
+
+    // diagonal tile at kb (up to date in LDS): lane = row, every 16-lane group of the wave computes the same thing
+    auto factor_diag = [&](const int kb, const int panel) {
+        const int nbp = min(16, n - kb);                            // pivots; a row beyond them is the right-hand side or padding
+        const int row = kb + r16;
+        const bool rv = row < n1;
+        const uint32_t base = tri(rv ? row : kb, kb);
+        double a[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const double v = Mat[base + (rv ? min(j, r16) : 0)];
+            a[j] = (rv && j <= r16) ? v : (j == r16 ? 1.0 : 0.0);
+        }
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            if (k < nbp) {                                          // wave-uniform
+                const double dk = readlane_f64(a[k], k);
+                bad = bad || !(dk > 0.0);
+                const double ik = fast_rcp(dk);
+                // publish column k: its entries are final since step k - 1, the updates below touch columns > k only
+                if (lane < 16 && rv && r16 >= k) Mat[base + k] = a[k];
+                if (lane == k) vinv[kb + k] = ik;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only: the counter goes out after the data; the LDS keeps a wave's order)
+                if (lane == 0) *ready = 16 * panel + k + 1;
+                const double lik = a[k] * ik;                       // rows below the pivot (the others only touch their padding)
+#pragma unroll
+                for (int j = k + 1; j < 16; ++j) a[j] = fma(-lik, readlane_f64(a[k], j), a[j]);
+            }
+        }
+        if (bad && lane == 0) sh.flag = 1;
+    };
+    // rows of the tiles R0 (lanes 0-15) and R1 (lanes 16-31; -1: none) against the diagonal tile at kb (a full panel) while wave 0
+    // is still factoring it: a_ic -= sum_{k<c} (a_ik / d_k) a_ck, right-looking over k (the 15 - k updates of a step are independent);
+    // step k starts when column k of the diagonal tile is out
+    auto finish_rows = [&](const int kb, const int panel, const int R0, const int R1) {
+        const int R = kq == 0 ? R0 : (kq == 1 ? R1 : -1);
+        const int row = 16 * R + r16;
+        const bool act = R >= 0 && row < n1;
+        const uint32_t base = tri(act ? row : kb + 15, kb);
+        double r[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) r[c] = Mat[base + c];
+        // (broadcast reads: the same address in every lane; one pointer per row of the diagonal tile, the column is an immediate offset)
+        const double *brow[16];
+#pragma unroll
+        for (int c = 1; c < 16; ++c) brow[c] = Mat + tri(kb + c, kb);
+        const double *vi = vinv + kb;
+        int have = -1;
+#pragma unroll
+        for (int k = 0; k < 15; ++k) {
+            const int need = 16 * panel + (LFR_FINE_READY ? k + 1 : 16);
+            if (LFR_FINE_READY || k == 0) {
+                // spin until wave 0 has published column k.  One opaque instruction sequence: as C++ loops inside the unrolled steps
+                // the 15 polls cost the kernel ~270 spilled registers.
+                int tmp;
+                asm volatile("LFR_POLL_%=:\n\t"
+                             "ds_read_b32 %0, %2\n\t"
+                             "s_waitcnt lgkmcnt(0)\n\t"
+                             "v_readfirstlane_b32 %1, %0\n\t"
+                             "s_cmp_ge_i32 %1, %3\n\t"
+                             "s_cbranch_scc1 LFR_POLLED_%=\n\t"
+                             "s_sleep 1\n\t"
+                             "s_branch LFR_POLL_%=\n"
+                             "LFR_POLLED_%=:"
+                             : "=&v"(tmp), "=&s"(have)
+                             : "v"((uint32_t)(uintptr_t)ready_lds), "s"(need)
+                             : "memory", "scc");
+            }
+            const double tk = r[k] * vi[k];
+#pragma unroll
+            for (int c = k + 1; c < 16; ++c) r[c] = fma(-tk, brow[c][k], r[c]);
+        }
+        if (act) {
+#pragma unroll
+            for (int c = 1; c < 16; ++c) Mat[base + c] = r[c];
+        }
+    };
+    // tile (R, J) -= (rows R of panel kb) (rows J of panel kb / d)^T on the matrix cores: lane l feeds A[l&15][4kk + (l>>4)] and
+    // B[4kk + (l>>4)][l&15] of chunk kk and holds D[(l>>4) + 4r][l&15], r = 0..3
+    struct Tile { double a[4], b[4]; f64x4 c; bool ok[4]; int row0, jb; };
+    double ninv[4];
+    auto load_tile = [&](const int kb, const int R, const int J, Tile &T) {        // any tile: clamped loads, values selected afterwards
+        const int ia = 16 * R + r16, jb = 16 * J + r16, iac = min(ia, n1 - 1), jbc = min(jb, n1 - 1);
+        T.row0 = 16 * R + kq; T.jb = jb;
+        const uint32_t oa = tri(iac, kb + kq), ob = tri(jbc, kb + kq);
+        double av[4], bv[4], cv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { av[kk] = Mat[oa + 4 * kk]; bv[kk] = Mat[ob + 4 * kk]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = T.row0 + 4 * r, rc = min(row, n1 - 1);
+            T.ok[r] = row < n1 && jb <= row;
+            cv[r] = Mat[tri(rc, min(jbc, rc))];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { T.a[kk] = ia < n1 ? av[kk] : 0.0; T.b[kk] = jb < n1 ? bv[kk] * ninv[kk] : 0.0; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
+    };
+    auto load_full = [&](const int kb, const int R, const int J, Tile &T) {        // every row < n1, strictly below the diagonal
+        const int ia = 16 * R + r16, jb = 16 * J + r16;
+        T.row0 = 16 * R + kq; T.jb = jb;
+        const uint32_t oa = tri(ia, kb + kq), ob = tri(jb, kb + kq);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { T.a[kk] = Mat[oa + 4 * kk]; T.b[kk] = Mat[ob + 4 * kk] * ninv[kk]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { T.ok[r] = true; T.c[r] = Mat[tri(T.row0 + 4 * r, jb)]; }
+    };
+    auto store_tile = [&](const Tile &T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
+    };
+    auto update_pair = [&](const int kb, const int Ra, const int Ja, const bool two, const int Rb, const int Jb) {
+        Tile t0, t1;
+        if (two && Ja < Ra && Jb < Rb && 16 * max(Ra, Rb) + 15 < n1) {
+            load_full(kb, Ra, Ja, t0);
+            load_full(kb, Rb, Jb, t1);
+        } else {
+            load_tile(kb, Ra, Ja, t0);
+            load_tile(kb, two ? Rb : Ra, two ? Jb : Ja, t1);       // (no second tile: the first again, not stored)
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a[kk], t0.b[kk], t0.c, 0, 0, 0);
+            t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a[kk], t1.b[kk], t1.c, 0, 0, 0);
+        }
+        store_tile(t0);
+        if (two) store_tile(t1);
+    };
+    // the tiles (R, J) of column block J = kcol of this worker wave, two at a time: update by panel kb (kb < 0: none, column block 0),
+    // then the rows' substitution behind the diagonal block of panel `kcol`
+    auto column_tiles = [&](const int kb, const int kcol) {
+        for (int R0 = kcol + wave; R0 < RT; R0 += 2 * kWorkers) {                 // (wave >= 1: R0 starts at kcol + 1)
+            const int R1 = R0 + kWorkers < RT ? R0 + kWorkers : -1;
+            if (kb >= 0) {
+                update_pair(kb, R0, kcol, R1 >= 0, R1, kcol);
+                wave_lds_sync();
+            }
+            FPROF_MARK(3);                            // 3: tiles of the next column block (update)
+            finish_rows(16 * kcol, kcol, R0, R1);
+            FPROF_MARK(4);                            // 4: rows of the next column block (substitution behind the diagonal block)
+        }
+    };
+
+    if (tid == 0) { sh.flag = 0; sh.ready = -1; }
+    __syncthreads();
+    FPROF_RESET();
+    // ---- column block 0 ----
+    if (wave == 0) { factor_diag(0, 0); FPROF_MARK(0); }                            // 0: diagonal blocks (wave 0)
+    else column_tiles(-1, 0);
+    __syncthreads();
+    FPROF_MARK(5);                                    // 5: barrier
+    // ---- phases: panel k updates what is right of it, column block k+1 comes out final ----
+    for (int k = 0; k + 1 < P; ++k) {
+        const int kb = 16 * k;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) ninv[kk] = -vinv[kb + 4 * kk + kq];
+        if (wave == 0) {
+            // the next diagonal tile: two accumulator chains of two MFMAs instead of one of four (the chain is on the critical path)
+            Tile t;
+            load_tile(kb, k + 1, k + 1, t);
+            f64x4 c2 = {0.0, 0.0, 0.0, 0.0};
+            t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[0], t.b[0], t.c, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[2], t.b[2], c2, 0, 0, 0);
+            t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[1], t.b[1], t.c, 0, 0, 0);
+            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[3], t.b[3], c2, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t.c[r] += c2[r];
+            store_tile(t);
+            wave_lds_sync();
+            factor_diag(kb + 16, k + 1);
+            FPROF_MARK(0);
+        } else {
+            // tiles (R, J), k + 2 <= J <= R < RT, J a column block that exists: t-th tile of the row-major lower triangle, dealt
+            // round-robin over the worker waves
+            const int m = RT - (k + 2);
+            int T = m > 0 ? (m * (m + 1)) >> 1 : 0;
+            if (T > 0 && RT > P) --T;                                 // (the last tile would be columns >= n of the right-hand-side row)
+            int I = 0, J = 0, tcur = 0;
+            auto seek = [&](const int tt) { J += tt - tcur; tcur = tt; while (J > I) { J -= I + 1; ++I; } };
+            for (int t = wave - 1; t < T; t += 2 * kWorkers) {        // wave-uniform
+                seek(t);
+                const int Ra = k + 2 + I, Ja = k + 2 + J;
+                const bool two = t + kWorkers < T;
+                int Rb = Ra, Jb = Ja;
+                if (two) { seek(t + kWorkers); Rb = k + 2 + I; Jb = k + 2 + J; }
+                update_pair(kb, Ra, Ja, two, Rb, Jb);
+            }
+            FPROF_MARK(1);                            // 1: trailing tiles
+            column_tiles(kb, k + 1);
+        }
+        __syncthreads();
+        FPROF_MARK(5);
+    }
+    FPROF_FLUSH();
 }
 
 // vectors live in LDS for both variants: 8 vectors of n doubles
@@ -685,10 +933,29 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     double *es = a.workspace + a.es_off[ci];
     const int lane = tid;     // PROF_FLUSH uses `lane == 0`
     (void)lane;
+    // Two threads per matrix row in the assembly walk (out-edges / in-edges) keep the sums bitwise reproducible only while every
+    // off-diagonal entry gets ONE term from each of them, i.e. while no node pair is matched twice inside the component (the
+    // reference keeps duplicated matches, solve.cc:476-478; they are rare).  Duplicates sit next to each other in a node's in-edge
+    // list (sorted by record index = by source node): one scan per solve decides, components with duplicates take the one-thread walk.
+#ifndef LFR_SPLIT_WALK
+#define LFR_SPLIT_WALK 1
+#endif
+    bool split_walk = LFR_SPLIT_WALK != 0;
+    if (split_walk) {
+        int dup = 0;
+        for (int i = tid; i + 1 < E; i += kBlockThreads) {
+            const uint32_t e0 = in_idx[i], e1 = in_idx[i + 1];
+            const uint32_t k0 = *reinterpret_cast<const uint32_t *>(&edges[e0].src), k1 = *reinterpret_cast<const uint32_t *>(&edges[e1].src);
+            dup |= ((k0 ^ k1) & 0x7fffffffu) == 0u;                 // same source, same destination (the kind bit aside)
+        }
+        split_walk = block_max<kBlockThreads>((double)dup, sh) == 0.0;
+    }
     PROF_DECL
     auto sweep = [&](const double *xv, double *gout, bool want_matrix) -> double {
         double cost = 0.0;
         PROF_SWEEP_MARK(4);
+        // the matrix starts at zero: cleared by everybody, coalesced, under the edge evaluation (the walk's barrier orders it)
+        if (want_matrix) for (uint32_t i = tid; i < tri(n, 0); i += kBlockThreads) Mat[i] = 0.0;
         uint4 q[5], qn[5];                           // the next record is in flight while this one is evaluated
         if (tid < E) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(edges + tid);
@@ -721,20 +988,17 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #pragma unroll
             for (int i = 0; i < 5; ++i) q[i] = qn[i];
         }
-        const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch is complete)
+        const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch is complete, Mat is zero)
         PROF_SWEEP_MARK(3);
-        for (int row = tid; row < n; row += kBlockThreads) {
-            const int v = row >> 1, c = row & 1;
-            const lfr::NodeInc ni = inc[v];
-            if (want_matrix) for (int j = 0; j <= row; ++j) Mat[tri(row, j)] = 0.0;
-            double gacc = 0.0, dsame = 0.0, dlow = 0.0;     // A[row][row], A[2v+1][2v] (c == 1 only)
-            // The scratch and the edge records live in HBM/L2: the loads of kAhead edges are issued together
-            // (one latency per batch instead of one per edge), then consumed in the fixed order.
+        // The scratch and the edge records live in HBM/L2: the loads of kAhead edges are issued together
+        // (one latency per batch instead of one per edge), then consumed in the fixed order.
 #ifndef LFR_AHEAD
 #define LFR_AHEAD 8
 #endif
-            constexpr int kAhead = LFR_AHEAD;
-            for (uint32_t k0 = 0; k0 < ni.out_count; k0 += kAhead) {   // edges v -> w : J1 = d r / d x_v
+        constexpr int kAhead = LFR_AHEAD;
+        auto walk_out = [&](const int row, const lfr::NodeInc &ni, double &gacc, double &dsame, double &dlow) {   // edges v -> w : J1 = d r / d x_v
+            const int v = row >> 1, c = row & 1;
+            for (uint32_t k0 = 0; k0 < ni.out_count; k0 += kAhead) {
                 double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
                 int wn_[kAhead];
 #pragma unroll
@@ -761,7 +1025,10 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     }
                 }
             }
-            for (uint32_t k0 = 0; k0 < ni.in_count; k0 += kAhead) {    // edges w -> v : d r / d x_v = sq * I
+        };
+        auto walk_in = [&](const int row, const lfr::NodeInc &ni, double &gacc, double &dsame) {                 // edges w -> v : d r / d x_v = sq * I
+            const int v = row >> 1, c = row & 1;
+            for (uint32_t k0 = 0; k0 < ni.in_count; k0 += kAhead) {
                 double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
                 int wn_[kAhead];
                 uint32_t e_[kAhead];
@@ -789,14 +1056,59 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     }
                 }
             }
-            gout[row] = gacc;
-            if (want_matrix) {
-                Mat[tri(row, row)] = dsame;
-                if (c) Mat[tri(row, row - 1)] = dlow;
-                vadiag[row] = dsame;
+        };
+        if (!split_walk) {
+            // one thread per matrix row: its out-edges, then its in-edges (components with duplicated matches: see split_walk)
+            for (int row = tid; row < n; row += kBlockThreads) {
+                const lfr::NodeInc ni = inc[row >> 1];
+                double gacc = 0.0, dsame = 0.0, dlow = 0.0;     // A[row][row], A[2v+1][2v] (c == 1 only)
+                walk_out(row, ni, gacc, dsame, dlow);
+                walk_in(row, ni, gacc, dsame);
+                gout[row] = gacc;
+                if (want_matrix) {
+                    Mat[tri(row, row)] = dsame;
+                    if (row & 1) Mat[tri(row, row - 1)] = dlow;
+                    vadiag[row] = dsame;
+                }
             }
+            __syncthreads();
+        } else {
+            // two threads per matrix row, in different waves (rows padded to whole waves: a wave runs ONE of the two loops): the
+            // first takes the node's out-edges, the second its in-edges.  An off-diagonal entry receives one term from each
+            // (x + y = y + x on top of an exact zero: the order of the two atomics is immaterial); diagonal and gradient partial
+            // sums meet in a fixed order after the barrier.
+            const int n_pad = (n + 63) & ~63;
+            double *part_g = vstep, *part_d = vD;              // free during a sweep (rewritten at the next iteration's start)
+            for (int item = tid; item < 2 * n_pad; item += kBlockThreads) {
+                const bool in_half = item >= n_pad;              // wave-uniform
+                const int row = item - (in_half ? n_pad : 0);
+                if (row >= n) continue;
+                const lfr::NodeInc ni = inc[row >> 1];
+                double gacc = 0.0, dsame = 0.0, dlow = 0.0;
+                if (!in_half) {
+                    walk_out(row, ni, gacc, dsame, dlow);
+                    gout[row] = gacc;
+                    if (want_matrix) {
+                        vadiag[row] = dsame;
+                        if (row & 1) Mat[tri(row, row - 1)] = dlow;
+                    }
+                } else {
+                    walk_in(row, ni, gacc, dsame);
+                    part_g[row] = gacc;
+                    part_d[row] = dsame;
+                }
+            }
+            __syncthreads();
+            for (int row = tid; row < n; row += kBlockThreads) {
+                gout[row] += part_g[row];
+                if (want_matrix) {
+                    const double dd = vadiag[row] + part_d[row];
+                    vadiag[row] = dd;
+                    Mat[tri(row, row)] = dd;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         return total;
     };
 
@@ -851,147 +1163,151 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         matrix_valid = false;
         __syncthreads();
         PROF_MARK(5);                                 // 5: scaling
-        // ---- blocked LDL^T in place (right-looking, panels of kPanel columns) ----
-        // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal and 1/d_k
-        // goes to vinv[k].  Every sequential step of a factorization costs an LDS round trip (~10^3 cycles
-        // with its barrier) whatever it computes, so the work is cut into n/kPanel steps: (1) one thread
-        // factors the kPanel x kPanel diagonal block IN REGISTERS, (2) one thread per row below finishes the
-        // row's panel entries in registers, (3) the trailing matrix takes the rank-kPanel update in 4x4
-        // register tiles.
-        constexpr int kPanel = 8;
-        constexpr int kPT = kPanel * (kPanel + 1) / 2;
         double *vinv = vgn;            // free until the line search
-        if (tid == 0) sh.flag = 0;
-        __syncthreads();
-        // the diagonal block [kb, kb+nb) as packed lower registers; rows/columns >= nb are identity padding
-        auto load_block = [&](int kb, int nb, double (&B)[kPT]) {
-#pragma unroll
-            for (int i = 0; i < kPanel; ++i)
-#pragma unroll
-                for (int j = 0; j <= i; ++j)
-                    B[i * (i + 1) / 2 + j] = (i < nb) ? Mat[tri(kb + i, kb + j)] : (i == j ? 1.0 : 0.0);
-        };
-        for (int kb = 0; kb < n; kb += kPanel) {
-            const int nb = min(kPanel, n - kb), ke = kb + nb;
-            if (tid == 0) {
-                double B[kPT], inv[kPanel];
-                load_block(kb, nb, B);
-                bool bad = false;
-#pragma unroll
-                for (int k = 0; k < kPanel; ++k) {
-                    const double dk = B[k * (k + 1) / 2 + k];
-                    bad = bad || !(dk > 0.0);
-                    inv[k] = fast_rcp(dk);
-#pragma unroll
-                    for (int i = k + 1; i < kPanel; ++i) {
-                        const double lik = B[i * (i + 1) / 2 + k] * inv[k];
-#pragma unroll
-                        for (int j = k + 1; j <= i; ++j) B[i * (i + 1) / 2 + j] -= lik * B[j * (j + 1) / 2 + k];
-                    }
-                }
-                if (bad) sh.flag = 1;
-#pragma unroll
-                for (int i = 0; i < kPanel; ++i) {
-                    if (i < nb) {
-                        vinv[kb + i] = inv[i];
-#pragma unroll
-                        for (int j = 1; j <= i; ++j) Mat[tri(kb + i, kb + j)] = B[i * (i + 1) / 2 + j];
-                    }
-                }
-            }
+        if constexpr (!GLOBAL_MATRIX) {
+            factor_lds<kBlockThreads>(Mat, vinv, n, sh, a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr);        // 16-column panels, one barrier per panel (see factor_lds)
+        } else {
+            // ---- blocked LDL^T in place (right-looking, panels of kPanel columns) ----
+            // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal and 1/d_k
+            // goes to vinv[k].  Every sequential step of a factorization costs an LDS round trip (~10^3 cycles
+            // with its barrier) whatever it computes, so the work is cut into n/kPanel steps: (1) one thread
+            // factors the kPanel x kPanel diagonal block IN REGISTERS, (2) one thread per row below finishes the
+            // row's panel entries in registers, (3) the trailing matrix takes the rank-kPanel update in 4x4
+            // register tiles.
+            constexpr int kPanel = 8;
+            constexpr int kPT = kPanel * (kPanel + 1) / 2;
+            if (tid == 0) sh.flag = 0;
             __syncthreads();
-            PROF_FACTOR_MARK(3);                      // 3: diagonal blocks of the factorization (one thread)
-            if (sh.flag) break;                                           // uniform
-            if (ke < n1) {
-                double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
-                load_block(kb, nb, B);
-#pragma unroll
-                for (int k = 0; k < kPanel; ++k) inv[k] = k < nb ? vinv[kb + k] : 1.0;
-                for (int i = ke + tid; i < n1; i += kBlockThreads) {      // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
-                    double r[kPanel];
-#pragma unroll
-                    for (int c = 0; c < kPanel; ++c) r[c] = c < nb ? Mat[tri(i, kb + c)] : 0.0;
-#pragma unroll
-                    for (int c = 1; c < kPanel; ++c) {
-#pragma unroll
-                        for (int k = 0; k < c; ++k) r[c] -= (r[k] * inv[k]) * B[c * (c + 1) / 2 + k];
+            // the diagonal block [kb, kb+nb) as packed lower registers; rows/columns >= nb are identity padding
+            auto load_block = [&](int kb, int nb, double (&B)[kPT]) {
+    #pragma unroll
+                for (int i = 0; i < kPanel; ++i)
+    #pragma unroll
+                    for (int j = 0; j <= i; ++j)
+                        B[i * (i + 1) / 2 + j] = (i < nb) ? Mat[tri(kb + i, kb + j)] : (i == j ? 1.0 : 0.0);
+            };
+            for (int kb = 0; kb < n; kb += kPanel) {
+                const int nb = min(kPanel, n - kb), ke = kb + nb;
+                if (tid == 0) {
+                    double B[kPT], inv[kPanel];
+                    load_block(kb, nb, B);
+                    bool bad = false;
+    #pragma unroll
+                    for (int k = 0; k < kPanel; ++k) {
+                        const double dk = B[k * (k + 1) / 2 + k];
+                        bad = bad || !(dk > 0.0);
+                        inv[k] = fast_rcp(dk);
+    #pragma unroll
+                        for (int i = k + 1; i < kPanel; ++i) {
+                            const double lik = B[i * (i + 1) / 2 + k] * inv[k];
+    #pragma unroll
+                            for (int j = k + 1; j <= i; ++j) B[i * (i + 1) / 2 + j] -= lik * B[j * (j + 1) / 2 + k];
+                        }
                     }
-#pragma unroll
-                    for (int c = 1; c < kPanel; ++c) if (c < nb) Mat[tri(i, kb + c)] = r[c];
+                    if (bad) sh.flag = 1;
+    #pragma unroll
+                    for (int i = 0; i < kPanel; ++i) {
+                        if (i < nb) {
+                            vinv[kb + i] = inv[i];
+    #pragma unroll
+                            for (int j = 1; j <= i; ++j) Mat[tri(kb + i, kb + j)] = B[i * (i + 1) / 2 + j];
+                        }
+                    }
                 }
-            }
-            __syncthreads();
-            PROF_FACTOR_MARK(4);                      // (profile builds: row panels land in slot 4)
-            {   // trailing matrix -= (panel columns) (panel columns / d)^T: a rank-nb update of the lower triangle, one 16x16
-                // tile per wave and step on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4] and
-                // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
-                // of the kernel: 0.75 LDS accesses per multiply-add with 4-8-way bank conflicts on the packed rows; a tile step
-                // here is 14 LDS accesses for 2048 multiply-adds, the tile's rows are contiguous in LDS.
-                // A wave works on two tiles at a time and every load is unconditional (clamped index, value selected
-                // afterwards): the 20 LDS reads of a pair are in flight together and the four MFMAs of the two independent
-                // accumulators alternate, instead of one load -> multiply -> MFMA -> store chain per tile.
-                const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-                constexpr int kWaves = kBlockThreads / 64;
-                const bool k0 = kq < nb, k1 = 4 + kq < nb;
-                const int kc0 = kb + min(kq, nb - 1), kc1 = kb + min(4 + kq, nb - 1);
-                const double ninv0 = -vinv[kc0], ninv1 = -vinv[kc1];
-                const int mt = ke < n ? (n1 - ke + 15) >> 4 : 0;         // (only the right-hand-side row left: nothing to update)
-                struct Tile { double a0, a1, b0, b1; f64x4 c; bool ok[4]; int row0, jb; };
-                auto load_tile = [&](int I, int J, Tile &T) {
-                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n1 - 1), jbc = min(jb, n1 - 1);
-                    T.row0 = ke + 16 * I + kq; T.jb = jb;
-                    const double a0 = Mat[tri(iac, kc0)], a1 = Mat[tri(iac, kc1)], b0 = Mat[tri(jbc, kc0)], b1 = Mat[tri(jbc, kc1)];
-                    double cv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int row = T.row0 + 4 * r, rc = min(row, n1 - 1);
-                        T.ok[r] = row < n1 && jb <= row;
-                        cv[r] = Mat[tri(rc, min(jbc, rc))];
+                __syncthreads();
+                PROF_FACTOR_MARK(3);                      // 3: diagonal blocks of the factorization (one thread)
+                if (sh.flag) break;                                           // uniform
+                if (ke < n1) {
+                    double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
+                    load_block(kb, nb, B);
+    #pragma unroll
+                    for (int k = 0; k < kPanel; ++k) inv[k] = k < nb ? vinv[kb + k] : 1.0;
+                    for (int i = ke + tid; i < n1; i += kBlockThreads) {      // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
+                        double r[kPanel];
+    #pragma unroll
+                        for (int c = 0; c < kPanel; ++c) r[c] = c < nb ? Mat[tri(i, kb + c)] : 0.0;
+    #pragma unroll
+                        for (int c = 1; c < kPanel; ++c) {
+    #pragma unroll
+                            for (int k = 0; k < c; ++k) r[c] -= (r[k] * inv[k]) * B[c * (c + 1) / 2 + k];
+                        }
+    #pragma unroll
+                        for (int c = 1; c < kPanel; ++c) if (c < nb) Mat[tri(i, kb + c)] = r[c];
                     }
-                    T.a0 = (ia < n1 && k0) ? a0 : 0.0; T.a1 = (ia < n1 && k1) ? a1 : 0.0;
-                    T.b0 = (jb < n1 && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n1 && k1) ? b1 * ninv1 : 0.0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
-                };
-                auto store_tile = [&](const Tile &T) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
-                };
-                // interior tiles of a full panel (every row < n, strictly below the diagonal): no clamps, no selects
-                auto load_full = [&](int I, int J, Tile &T) {
-                    const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16;
-                    T.row0 = ke + 16 * I + kq; T.jb = jb;
-                    const uint32_t oa = tri(ia, kb + kq), ob = tri(jb, kb + kq);
-                    T.a0 = Mat[oa]; T.a1 = Mat[oa + 4]; T.b0 = Mat[ob] * ninv0; T.b1 = Mat[ob + 4] * ninv1;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { T.ok[r] = true; T.c[r] = Mat[tri(T.row0 + 4 * r, jb)]; }
-                };
-                int I = 0, J = wave;                                     // tile t = wave, wave + kWaves, ... of the row-major lower triangle
-                while (J > I) { J -= I + 1; ++I; }
-                while (I < mt) {                                         // wave-uniform
-                    const int I0 = I, J0 = J;
-                    J += kWaves; while (J > I) { J -= I + 1; ++I; }
-                    const bool two = I < mt;
-                    const int I1 = I, J1 = J;
-                    J += kWaves; while (J > I) { J -= I + 1; ++I; }
-                    Tile t0, t1;
-                    if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n1) {       // (I0 <= I1)
-                        load_full(I0, J0, t0);
-                        load_full(I1, J1, t1);
-                    } else {
-                        load_tile(I0, J0, t0);
-                        load_tile(I1, J1, t1);                           // (past the end: clamped loads, nothing stored)
-                    }
-                    t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a0, t0.b0, t0.c, 0, 0, 0);
-                    t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a0, t1.b0, t1.c, 0, 0, 0);
-                    t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a1, t0.b1, t0.c, 0, 0, 0);
-                    t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a1, t1.b1, t1.c, 0, 0, 0);
-                    store_tile(t0);
-                    if (two) store_tile(t1);
                 }
+                __syncthreads();
+                PROF_FACTOR_MARK(4);                      // (profile builds: row panels land in slot 4)
+                {   // trailing matrix -= (panel columns) (panel columns / d)^T: a rank-nb update of the lower triangle, one 16x16
+                    // tile per wave and step on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4] and
+                    // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
+                    // of the kernel: 0.75 LDS accesses per multiply-add with 4-8-way bank conflicts on the packed rows; a tile step
+                    // here is 14 LDS accesses for 2048 multiply-adds, the tile's rows are contiguous in LDS.
+                    // A wave works on two tiles at a time and every load is unconditional (clamped index, value selected
+                    // afterwards): the 20 LDS reads of a pair are in flight together and the four MFMAs of the two independent
+                    // accumulators alternate, instead of one load -> multiply -> MFMA -> store chain per tile.
+                    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+                    constexpr int kWaves = kBlockThreads / 64;
+                    const bool k0 = kq < nb, k1 = 4 + kq < nb;
+                    const int kc0 = kb + min(kq, nb - 1), kc1 = kb + min(4 + kq, nb - 1);
+                    const double ninv0 = -vinv[kc0], ninv1 = -vinv[kc1];
+                    const int mt = ke < n ? (n1 - ke + 15) >> 4 : 0;         // (only the right-hand-side row left: nothing to update)
+                    struct Tile { double a0, a1, b0, b1; f64x4 c; bool ok[4]; int row0, jb; };
+                    auto load_tile = [&](int I, int J, Tile &T) {
+                        const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n1 - 1), jbc = min(jb, n1 - 1);
+                        T.row0 = ke + 16 * I + kq; T.jb = jb;
+                        const double a0 = Mat[tri(iac, kc0)], a1 = Mat[tri(iac, kc1)], b0 = Mat[tri(jbc, kc0)], b1 = Mat[tri(jbc, kc1)];
+                        double cv[4];
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int row = T.row0 + 4 * r, rc = min(row, n1 - 1);
+                            T.ok[r] = row < n1 && jb <= row;
+                            cv[r] = Mat[tri(rc, min(jbc, rc))];
+                        }
+                        T.a0 = (ia < n1 && k0) ? a0 : 0.0; T.a1 = (ia < n1 && k1) ? a1 : 0.0;
+                        T.b0 = (jb < n1 && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n1 && k1) ? b1 * ninv1 : 0.0;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
+                    };
+                    auto store_tile = [&](const Tile &T) {
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
+                    };
+                    // interior tiles of a full panel (every row < n, strictly below the diagonal): no clamps, no selects
+                    auto load_full = [&](int I, int J, Tile &T) {
+                        const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16;
+                        T.row0 = ke + 16 * I + kq; T.jb = jb;
+                        const uint32_t oa = tri(ia, kb + kq), ob = tri(jb, kb + kq);
+                        T.a0 = Mat[oa]; T.a1 = Mat[oa + 4]; T.b0 = Mat[ob] * ninv0; T.b1 = Mat[ob + 4] * ninv1;
+    #pragma unroll
+                        for (int r = 0; r < 4; ++r) { T.ok[r] = true; T.c[r] = Mat[tri(T.row0 + 4 * r, jb)]; }
+                    };
+                    int I = 0, J = wave;                                     // tile t = wave, wave + kWaves, ... of the row-major lower triangle
+                    while (J > I) { J -= I + 1; ++I; }
+                    while (I < mt) {                                         // wave-uniform
+                        const int I0 = I, J0 = J;
+                        J += kWaves; while (J > I) { J -= I + 1; ++I; }
+                        const bool two = I < mt;
+                        const int I1 = I, J1 = J;
+                        J += kWaves; while (J > I) { J -= I + 1; ++I; }
+                        Tile t0, t1;
+                        if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n1) {       // (I0 <= I1)
+                            load_full(I0, J0, t0);
+                            load_full(I1, J1, t1);
+                        } else {
+                            load_tile(I0, J0, t0);
+                            load_tile(I1, J1, t1);                           // (past the end: clamped loads, nothing stored)
+                        }
+                        t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a0, t0.b0, t0.c, 0, 0, 0);
+                        t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a0, t1.b0, t1.c, 0, 0, 0);
+                        t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a1, t0.b1, t0.c, 0, 0, 0);
+                        t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a1, t1.b1, t1.c, 0, 0, 0);
+                        store_tile(t0);
+                        if (two) store_tile(t1);
+                    }
+                }
+                __syncthreads();
+                PROF_MARK(1);                             // 1: trailing updates of the factorization
             }
-            __syncthreads();
-            PROF_MARK(1);                             // 1: trailing updates of the factorization
         }
         __syncthreads();
         PROF_MARK(1);
@@ -1003,40 +1319,70 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                 // workgroup barrier and an LDS round trip, and there are 2 n steps per solve.  The matrix entries do not depend
                 // on the running vector, so four steps' worth is loaded ahead of the dependent chain.
                 if (tid < 64) {
+                    // L D L^T y = g with w = L^-1 g already in row n of the factored matrix (it rode through the factorization):
+                    // z = w; for k = n-1 .. 0: y_k = z_k / d_k, z_j -= a_kj y_k for j < k (a_kj: the UNSCALED row k, so no per-entry
+                    // scaling).  ONE wave, z in registers (n <= 192: three values per lane); a step is a multiply, a v_readlane
+                    // broadcast and one multiply-add per register with a one-instruction address (row base + lane): the kernel is
+                    // VALU-issue bound (one instruction per ~4.8 cycles and wave, scripts/probes/diag16_probe.hip), so the
+                    // instruction count of the step is what counts - the round-2 loop spent ~28 instructions per step, mostly
+                    // index arithmetic and selects, this one ~12.
                     constexpr int kR = 3;
-                    double x[kR], inv[kR];
+                    double z[kR], inv[kR], yo[kR];
 #pragma unroll
                     for (int r = 0; r < kR; ++r) {
                         const int i = tid + 64 * r;
-                        x[r] = i < n ? vstep[i] : 0.0;
+                        z[r] = i < n ? vstep[i] : 0.0;
                         inv[r] = i < n ? vinv[i] : 0.0;
+                        yo[r] = 0.0;
                     }
-                    // (no forward substitution: vstep = row n of the factored matrix already holds L^-1 rhs)
+#ifndef LFR_BACKSUB_BATCH
+#define LFR_BACKSUB_BATCH 8
+#endif
+                    constexpr int kBsB = LFR_BACKSUB_BATCH;
+                    const double *mlane = Mat + tid;                               // + row base (wave-uniform) + 64 r (immediate)
+                    auto back_block = [&](auto r0_tag) {
+                        constexpr int r0 = decltype(r0_tag)::value;
+                        const int lo = 64 * r0;
+                        if (lo >= n) return;
+                        auto load = [&](const int kt, double (&m)[kBsB][r0 + 1]) {
 #pragma unroll
-                    for (int r = 0; r < kR; ++r) x[r] *= inv[r];
+                            for (int u = 0; u < kBsB; ++u) {
+                                const double *row = mlane + tri(min(kt - u, n), 0);          // (rows above n - 1 only pad the first batch)
 #pragma unroll
-                    for (int r0 = kR - 1; r0 >= 0; --r0) {                            // backward: L^T y = w
-                        if (64 * r0 >= n) continue;
-                        for (int k4 = min(n - 1, 64 * r0 + 63) | 3; k4 >= 64 * r0; k4 -= 4) {
-                            double w[4][kR];
+                                for (int r = 0; r <= r0; ++r) m[u][r] = row[64 * r];
+                            }
+                        };
+                        auto apply = [&](const int kt, const double (&m)[kBsB][r0 + 1]) {
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
+                            for (int u = 0; u < kBsB; ++u) {
+                                const int k = kt - u;
+                                const double yv = z[r0] * inv[r0];
+                                double yk = readlane_f64(yv, k & 63);
+                                if (k >= n) yk = 0.0;                                       // wave-uniform
+                                yo[r0] = (tid == (k & 63)) ? yv : yo[r0];
 #pragma unroll
-                                for (int r = 0; r <= r0; ++r) {
-                                    const int j = tid + 64 * r, k = k4 - u;
-                                    const double m = Mat[tri(min(k, n - 1), min(j, n - 1))];
-                                    w[u][r] = (j < k && k < n) ? m * inv[r] : 0.0;
-                                }
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const double yk = readlane_f64(x[r0], (k4 - u) & 63);
-#pragma unroll
-                                for (int r = 0; r <= r0; ++r) x[r] -= w[u][r] * yk;
+                                for (int r = 0; r < r0; ++r) z[r] = fma(-m[u][r], yk, z[r]);
+                                z[r0] = fma(-((tid + lo < k) ? m[u][r0] : 0.0), yk, z[r0]);  // (right of column k - 1 the row's storage is the next row)
+                            }
+                        };
+                        int kt = min(n - 1, lo + 63) | (kBsB - 1);                         // batches [kt - kBsB + 1, kt], aligned: never straddle 64 r0
+                        double ma[kBsB][r0 + 1], mb[kBsB][r0 + 1];
+                        load(kt, ma);
+                        for (; kt >= lo; kt -= 2 * kBsB) {
+                            const bool more = kt - kBsB >= lo;
+                            if (more) load(kt - kBsB, mb);
+                            apply(kt, ma);
+                            if (more) {
+                                if (kt - 2 * kBsB >= lo) load(kt - 2 * kBsB, ma);
+                                apply(kt - kBsB, mb);
                             }
                         }
-                    }
+                    };
+                    back_block(std::integral_constant<int, 2>{});
+                    back_block(std::integral_constant<int, 1>{});
+                    back_block(std::integral_constant<int, 0>{});
 #pragma unroll
-                    for (int r = 0; r < kR; ++r) if (tid + 64 * r < n) vstep[tid + 64 * r] = x[r];
+                    for (int r = 0; r < kR; ++r) if (tid + 64 * r < n) vstep[tid + 64 * r] = yo[r];
                 }
                 __syncthreads();
             } else {
@@ -1202,7 +1548,7 @@ __global__ void k_wg_order_keys(const CompDesc *descs, int n, int b1, int b2, in
 // average (up to 1.3 ms) before its next 160-KB workgroup while the queue was still full, and CUs ended up with one to seven
 // components each (`scripts/c5_timeline.py`).  Here a free CU always takes the largest component left.
 template <bool GLOBAL_MATRIX, int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+__device__ __forceinline__ void block_kernel_body(const KernelArgs &a, int max_rows) {
     extern __shared__ double dyn[];
     __shared__ BlockShared sh;
     __shared__ int next_ci;
@@ -1212,12 +1558,24 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
             next_ci = k < a.desc_end ? (int)a.wg_order[k - a.wg_begin] : -1;
         }
         __syncthreads();
-        const int ci = next_ci;
+        // (readfirstlane: the compiler cannot know that an LDS load is wave-uniform; with the index in an SGPR the descriptor, the
+        // sizes and every pointer derived from it are scalar loads / SALU arithmetic instead of ~40 VGPRs carried through the solve)
+        const int ci = __builtin_amdgcn_readfirstlane(next_ci);
         __syncthreads();                              // everyone has read it before the next round overwrites it
         if (ci < 0) break;
         solve_component<GLOBAL_MATRIX, kBlockThreads>(a, max_rows, ci, dyn, sh);
         __syncthreads();                              // the component's last LDS reads are done
     }
+}
+template <bool GLOBAL_MATRIX, int kBlockThreads>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+    block_kernel_body<GLOBAL_MATRIX, kBlockThreads>(a, max_rows);
+}
+// the same with ONE wave per SIMD (a 256-thread workgroup that owns its CU): 512 registers per wave - 256 VGPRs and the accumulation
+// registers as spill space (v_accvgpr moves) instead of scratch memory
+template <int kBlockThreads>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_block_kernel_w1(const KernelArgs a, int max_rows) {
+    block_kernel_body<false, kBlockThreads>(a, max_rows);
 }
 
 #ifndef LFR_THREADS_S
@@ -1255,7 +1613,7 @@ size_t block_lds_bytes(int max_rows, bool global_matrix) {
 // =============================================================================================
 // batch management + C ABI
 // =============================================================================================
-constexpr size_t kProfWords = 8 * lfr::KC_COUNT + 8;      // phase counters of -DLFR_PROFILE_PHASES + 16 32-bit class queues
+constexpr size_t kProfWords = 8 * lfr::KC_COUNT + 8 + 64;  // phase counters of -DLFR_PROFILE_PHASES + 16 32-bit class queues + -DLFR_PROFILE_FACTOR (16 per workgroup class)
 
 struct lfr_batch {
     int device = 0;
@@ -1785,6 +2143,9 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     std::max(lds_l, std::max(kThreadsL == kThreadsM ? lds_m : 0, kThreadsL == kThreadsS ? lds_s : 0))));
+#ifdef LFR_L_W1
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel_w1<kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_l));
+#endif
     }
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
@@ -1835,7 +2196,11 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         switch (cls) {
             case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<false, kThreadsS>), dim3(wgs), dim3(kThreadsS), lds, cs, a, rows); break;
             case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
+#ifdef LFR_L_W1
+            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel_w1<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
+#else
             case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
+#endif
             default:              hipLaunchKernelGGL((solve_block_kernel<true, kThreadsG>), dim3(wgs), dim3(kThreadsG), lds, cs, a, rows); break;
         }
         HIP_TRY(hipGetLastError());
@@ -1948,6 +2313,18 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     if (!stats) return LFR_OK;
 
     HIP_TRY(lfr::stream_wait(st));
+#ifdef LFR_PROFILE_FACTOR
+    {
+        unsigned long long h[64];
+        HIP_TRY(hipMemcpy(h, b->d_prof + 8 * lfr::KC_COUNT + 8, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(b->d_prof + 8 * lfr::KC_COUNT + 8, 0, sizeof h));
+        for (int c = 0; c < 4; ++c) for (int w = 0; w < 2; ++w) if (h[16 * c + 8 * w + 7])
+            fprintf(stderr, "lfr-fprof class %d wave %d: factorizations %llu  cycles each: diag %.0f  trailing %.0f  wait %.0f  col-update %.0f  col-finish %.0f  barrier %.0f\n",
+                    lfr::KC_BLOCK + c, w, h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 1] / h[16 * c + 8 * w + 7],
+                    (double)h[16 * c + 8 * w + 2] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 3] / h[16 * c + 8 * w + 7],
+                    (double)h[16 * c + 8 * w + 4] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 5] / h[16 * c + 8 * w + 7]);
+    }
+#endif
 #ifdef LFR_PROFILE_PHASES
     {
         unsigned long long h[8 * lfr::KC_COUNT];

@@ -125,13 +125,28 @@ struct Cursor {
         if (!ok || (uint64_t)(end - p) < n) { ok = false; return Cursor{p, p}; }
         Cursor c{p, p + n}; p += n; return c;
     }
-    void skip(int wt) {
+    // an unknown field (protobuf skips them; so does the reference's generated parser).  A group (wire type 3) runs to the END_GROUP
+    // tag (wire type 4) of the same field number, nested fields skipped on the way; a stray END_GROUP or wire types 6/7 are malformed.
+    void skip(int wt, int field, int depth = 0) {
         switch (wt) {
             case 0: varint(); break;
             case 1: if (end - p < 8) ok = false; else p += 8; break;
             case 2: sub(); break;
+            case 3:
+                if (depth >= 64) { ok = false; break; }
+                for (;;) {
+                    if (p >= end) { ok = false; break; }
+                    const uint64_t key = varint();
+                    if (!ok) break;
+                    const int f = (int)(key >> 3), w = (int)(key & 7);
+                    if (f == 0) { ok = false; break; }
+                    if (w == 4) { if (f != field) ok = false; break; }
+                    skip(w, f, depth + 1);
+                    if (!ok) break;
+                }
+                break;
             case 5: if (end - p < 4) ok = false; else p += 4; break;
-            default: ok = false;      // groups / invalid wire types
+            default: ok = false;      // stray END_GROUP / invalid wire types
         }
     }
 };
@@ -144,7 +159,7 @@ static bool parse_displacements(Cursor c, float *out, int &n) {   // one Displac
         if (field == 0) return false;
         if (field == 1 && wt == 5) di = c.f32();
         else if (field == 2 && wt == 5) dj = c.f32();
-        else c.skip(wt);
+        else c.skip(wt, field);
     }
     if (!c.ok) return false;
     if (n >= 9) { n = 10; return true; }        // > 9 grid points: the reference overruns its buffer
@@ -169,9 +184,11 @@ struct PairRec {
     float fact1 = 0.f, fact2 = 0.f;
     int32_t buf = 0;                     // which MatchBuf
     int64_t first = 0, count = 0;        // its matches inside that buffer
+    bool overflow = false;               // a match with more than 9 grid displacements: an error unless the pair is banned (the
+                                         // reference `continue`s past banned pairs without reading their matches, solve.cc:444-446)
 };
 
-static int parse_match(Cursor c, MatchBuf &out) {
+static int parse_match(Cursor c, MatchBuf &out, bool &overflow) {
     uint32_t f1 = 0, f2 = 0; float sim = 0.f;
     float d1[18], d2[18]; int n1 = 0, n2 = 0;
     memset(d1, 0, sizeof d1); memset(d2, 0, sizeof d2);
@@ -184,10 +201,10 @@ static int parse_match(Cursor c, MatchBuf &out) {
         else if (field == 3 && wt == 5) sim = c.f32();
         else if (field == 4 && wt == 2) { if (!parse_displacements(c.sub(), d1, n1)) return LFR_ERR_PARSE; }
         else if (field == 5 && wt == 2) { if (!parse_displacements(c.sub(), d2, n2)) return LFR_ERR_PARSE; }
-        else c.skip(wt);
+        else c.skip(wt, field);
     }
     if (!c.ok) return LFR_ERR_PARSE;
-    if (n1 > 9 || n2 > 9) return LFR_ERR_UNSUPPORTED;
+    if (n1 > 9 || n2 > 9) overflow = true;       // (the first 9 are kept; the caller rejects the file if the pair survives the banned filter)
     out.f1.push_back(f1); out.f2.push_back(f2); out.sim.push_back(sim);
     out.d1.insert(out.d1.end(), d1, d1 + 18); out.d2.insert(out.d2.end(), d2, d2 + 18);
     return LFR_OK;
@@ -206,9 +223,9 @@ static int parse_pair(Cursor c, PairRec &rec, MatchBuf &out) {
         else if (field == 5 && wt == 2) {
             Cursor m = c.sub();
             if (!c.ok) return LFR_ERR_PARSE;
-            const int rc = parse_match(m, out);
+            const int rc = parse_match(m, out, rec.overflow);
             if (rc != LFR_OK) return rc;
-        } else c.skip(wt);
+        } else c.skip(wt, field);
     }
     if (!c.ok) return LFR_ERR_PARSE;
     rec.count = (int64_t)out.sim.size() - rec.first;
@@ -238,7 +255,7 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
                 Cursor pc = c.sub();
                 if (!c.ok) return LFR_ERR_PARSE;
                 pairs.push_back(pc);
-            } else c.skip(wt);
+            } else c.skip(wt, field);
         }
         if (!c.ok) return LFR_ERR_PARSE;
     }
@@ -290,6 +307,10 @@ static int parse_matching_buffer(const uint8_t *data, size_t size, Graph &g, con
         const PairRec &r = recs[i];
         const std::string name1(r.name1 ? r.name1 : "", r.len1), name2(r.name2 ? r.name2 : "", r.len2);
         if (banned.count(name1) || banned.count(name2)) continue;        // solve.cc:444-446
+        if (r.overflow) {
+            set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
+            return LFR_ERR_UNSUPPORTED;
+        }
         const int32_t i1 = g.intern_image(name1, r.fact1);                // solve.cc:448-451
         const int32_t i2 = g.intern_image(name2, r.fact2);
         const MatchBuf &b = bufs[r.buf];
@@ -428,7 +449,7 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
                 Cursor pc = c.sub();
                 if (!c.ok) return LFR_ERR_PARSE;
                 out.push_back(pc);
-            } else { c.skip(wt); if (!c.ok) return LFR_ERR_PARSE; }
+            } else { c.skip(wt, field); if (!c.ok) return LFR_ERR_PARSE; }
         }
         stopped_at = c.p;
         return LFR_OK;
@@ -587,8 +608,13 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
         for (int t = 0; t < TB; ++t)
             for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
                 moff[i] = acc;
-                if (!(cbanned[t][loc1[i]] || cbanned[t][loc2[i]])) acc += recs[i].count;
-                else recs[i].count = -recs[i].count - 1;            // banned: remember it (count < 0)
+                if (!(cbanned[t][loc1[i]] || cbanned[t][loc2[i]])) {
+                    if (recs[i].overflow) {
+                        set_error("match with more than 9 grid displacements (the reference overflows flow_array, solve.cc:460-472)");
+                        return LFR_ERR_UNSUPPORTED;
+                    }
+                    acc += recs[i].count;
+                } else recs[i].count = -recs[i].count - 1;          // banned: remember it (count < 0)
             }
         moff[P] = acc;
     }

@@ -25,6 +25,8 @@ Environment (additions that default so the reference's scripts run unchanged):
   LFR_HOST_GRAPH_STAGE  1: tracks/roots/components on the host (batch assembly stays on the GPU)
   LFR_HOST_ASSEMBLY     1: graph stage and batch layout on the host
   LFR_HOST_THREADS      worker threads of the host graph stage / scanner (default min(cores, 32))
+  LFR_DETACH_TEARDOWN   (launcher) 1: return to the caller as soon as the output is written and let a detached child absorb the
+                        ~0.3 s the driver needs to tear the process down; default: one process, the caller waits for all of it
 """
 import os
 import sys
@@ -115,7 +117,19 @@ def parse_args(argv):
     return out
 
 
-def main(argv=None):
+def main(argv=None, exiting=False):
+    """exiting=True: the caller ends the process with os._exit right after (the launcher does): the kernel warm-up thread is
+    not waited for.  Otherwise main() joins it before it returns, so no HIP call of this run outlives the call."""
+    state = {}
+    try:
+        return _main(argv, state)
+    finally:
+        th = state.get("warm")
+        if th is not None and not exiting:
+            th.join()
+
+
+def _main(argv, state):
     t_main = time.perf_counter()
     argv = sys.argv[1:] if argv is None else argv
     try:
@@ -167,6 +181,7 @@ def main(argv=None):
         warm_ms[0] = (time.perf_counter() - t0) * 1e3
     warm = threading.Thread(target=_warm, daemon=True)
     warm.start()
+    state["warm"] = warm
 
     def warm_join():
         (warm.join if wait_all else ctx_ready.wait)()

@@ -74,7 +74,11 @@ def _file_descriptor_proto():
 
 def _build():
     pool = descriptor_pool.DescriptorPool()          # a private pool: a real generated types_pb2 may live in the default one
-    file_desc = pool.Add(_file_descriptor_proto()) if hasattr(pool, "Add") else None
+    fd = _file_descriptor_proto()
+    if hasattr(pool, "AddSerializedFile"):           # every backend (python, upb, cpp) has it; Add() is gone from some builds
+        pool.AddSerializedFile(fd.SerializeToString())
+    else:
+        pool.Add(fd)
     get = getattr(message_factory, "GetMessageClass", None)
     if get is None:                                   # protobuf < 4.21
         get = message_factory.MessageFactory(pool).GetPrototype

@@ -104,20 +104,55 @@ def test_first_fact_wins_and_short_grids(lfr_lib, tmp_path):
     assert g.n_nodes == 2 and g.n_edges == 2
 
 
-@pytest.mark.parametrize("damage", ["truncate", "bad_varint", "group"])
+@pytest.mark.parametrize("damage", ["truncate", "bad_varint", "stray_end_group", "mismatched_end_group", "open_group"])
 def test_malformed_input_is_a_parse_error(lfr_lib, tmp_path, damage):
     data = bytearray(wire.encode_matching_file(small_graph(seed=24).to_pairs()))
     if damage == "truncate":
         data = data[:len(data) // 2 + 1]
     elif damage == "bad_varint":
         data = bytearray(b"\x0a" + b"\xff" * 11)
+    elif damage == "stray_end_group":
+        data = bytearray(b"\x0c")
+    elif damage == "mismatched_end_group":
+        data = bytearray(b"\x0b\x14")                  # start-group of field 1, end-group of field 2
     else:
-        data = bytearray(b"\x0b\x0c")                  # start-group / end-group
+        data = bytearray(b"\x0b")
     path = str(tmp_path / "bad.pb")
     open(path, "wb").write(bytes(data))
     with pytest.raises(capi.LfrError) as e:
         capi.Graph.from_matches_file(path)
     assert e.value.code == -3 and "Failed to parse proto object." in str(e.value)
+
+
+def test_groups_are_skipped_like_any_unknown_field(lfr_lib, pb, tmp_path):
+    """protobuf skips unknown fields, groups (wire types 3/4) included: so does the reference's generated parser (solve.cc:427-436)."""
+    MatchingFile, _ = pb
+    body = wire.encode_matching_file(small_graph(seed=25).to_pairs())
+    ref = capi.Graph.from_arrays(small_graph(seed=25))
+    for extra in (b"\x0b\x0c", b"\x0b\x08\x01\x0c", b"\x13\x1b\x0d\x00\x00\x80\x3f\x1c\x14"):     # empty group, group with a varint, nested groups
+        for data in (extra + body, body + extra):
+            m = MatchingFile()
+            m.ParseFromString(data)                                               # google.protobuf accepts it
+            path = str(tmp_path / "g.pb")
+            open(path, "wb").write(data)
+            g = capi.Graph.from_matches_file(path)
+            assert (g.n_nodes, g.n_edges) == (ref.n_nodes, ref.n_edges) and g.n_edges == 2 * sum(len(p.matches) for p in m.image_pairs)
+
+
+def test_more_than_nine_grid_points_in_a_banned_pair_are_not_an_error(lfr_lib, tmp_path):
+    """The reference `continue`s past banned pairs before it reads their matches (solve.cc:444-446)."""
+    long_match = {"feature_idx1": 1, "feature_idx2": 2, "similarity": 0.9, "disp1": [(0.1, 0.2)] * 10, "disp2": []}
+    ok_match = {"feature_idx1": 3, "feature_idx2": 4, "similarity": 0.8, "disp1": [(0.1, 0.2)] * 9, "disp2": [(0.0, 0.1)] * 9}
+    pairs = [{"image_name1": "a", "fact1": 1.0, "image_name2": "x", "fact2": 1.0, "matches": [long_match]},
+             {"image_name1": "a", "fact1": 1.0, "image_name2": "b", "fact2": 1.0, "matches": [ok_match]}]
+    for name, segment in (("one.pb", None), ("many.pb", "64")):
+        path = str(tmp_path / name)
+        open(path, "wb").write(wire.encode_matching_file(pairs))
+        g = capi.Graph.from_matches_file(path, ["x"])
+        assert g.image_names() == ["a", "b"] and g.n_edges == 2
+        with pytest.raises(capi.LfrError) as e:
+            capi.Graph.from_matches_file(path)
+        assert e.value.code == -5
 
 
 def test_more_than_nine_grid_points_rejected(lfr_lib, tmp_path):
