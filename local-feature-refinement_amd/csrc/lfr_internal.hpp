@@ -169,6 +169,24 @@ std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>
 void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
                   std::unordered_map<int, int> &part);
 
+// ------------------------------------------------------------------------------------------
+// Block-envelope plan of a KC_GLOBAL component (lfr_order.cpp): the variable nodes renumbered so that the
+// normal matrix has a small envelope; the kernel stores the 16x16 tiles [fb[R], R] of every block row R.
+// ------------------------------------------------------------------------------------------
+constexpr int kSkyVectors = 12;              // vectors of n_pad doubles behind the tiles (x, trial x, g, trial g, scale, diag, step, D, diag(A), delta, 1/d, spare)
+struct SkyPlan {
+    int n_var = 0, n = 0, RT = 0;            // variable nodes, rows (2 n_var), 16-row blocks of the n + 1 rows carried (row n = right-hand side)
+    std::vector<uint16_t> pos, ipos;         // position of local node v / node at position p
+    std::vector<uint16_t> fb;                // first block column of block row R
+    std::vector<uint32_t> tilebase;          // RT + 1: index of the first tile of block row R
+    int order_used = 0;                      // 0: tracks in heavy-first postorder, 1: reverse Cuthill-McKee
+    uint64_t tiles_by_tracks = 0, tiles_rcm = 0;
+    uint64_t header_doubles() const, n_pad() const, doubles() const;
+    void write_header(void *dst) const;      // header_doubles() * 8 bytes
+};
+// src_dst_kind[e] = src | (dst | kind << 15) << 16 of the component's records (the last word of EdgeRec)
+void sky_plan(int n_var, int64_t n_edges, const uint32_t *src_dst_kind, SkyPlan &out);
+
 }  // namespace lfr
 
 struct lfr_graph { lfr::Graph g; };

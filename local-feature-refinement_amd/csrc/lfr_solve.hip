@@ -19,6 +19,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <array>
 #include <chrono>
 #include <memory>
@@ -64,6 +65,7 @@ struct KernelArgs {
     int desc_begin, desc_end;
     int tukey_variant;
     int cls;
+    int sky_lds;                // KC_GLOBAL: the back-substitution vector lives in dynamic LDS
 };
 
 // =============================================================================================
@@ -1526,6 +1528,472 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     }
 }
 
+// =============================================================================================
+// Components whose normal matrix does not fit LDS (> 192 rows): BLOCK-ENVELOPE LDL^T in an HBM workspace
+// =============================================================================================
+// The reference gives these systems to Ceres' SPARSE_NORMAL_CHOLESKY (solve.cc:147).  The variable nodes are renumbered on the
+// host when the batch is created (lfr_order.cpp: tracks in heavy-first postorder of their meta forest or reverse Cuthill-McKee,
+// whichever stores fewer tiles) so that every row's nonzeros start close to the diagonal; the matrix lives as row-major 16x16
+// tiles, block row R holding the block columns fb[R] .. R (an LDL^T without pivoting never fills outside that envelope), the
+// right-hand side riding as row n (its block row spans every column).  A cap-sized component of config-4-scale data
+// (1344 nodes, 2688 rows) keeps ~3 tiles per block row where the dense packed matrix of round 2 had 14 k.
+//
+// Workspace of a component (a.workspace + a.ws_off[ci], written by lfr_batch_create): u32 hdr[8] = {RT, tiles, offset of the
+// tiles, offset of the vectors (doubles), n_pad}, u32 tilebase[RT + 1], u16 fb[RT], u16 pos[n_var], u16 ipos[n_var]; the tiles;
+// kSkyVectors vectors of n_pad doubles.  Everything the solver touches is in MATRIX order (vector index 2 pos[v] + c).
+//
+// Right-looking over the 16-column panels: (a) wave 0 factors the diagonal tile (lane = row, v_readlane broadcasts) and leaves
+// it in LDS, (b) every active block row (fb[R] <= k < R) finishes its tile of the panel against it with lane = row (four tiles =
+// 64 rows per wave and pass), (c) the tiles (R, J) of every pair of active block rows take the rank-16 update on the fp64
+// matrix cores.  With a tree-like envelope two or three block rows are active per panel: the factorization is ~170 short
+// dependent panels (latency bound, ~10 k cycles each), not 6.5 GFLOP.  Back substitution walks the block rows upwards with
+// the vector in LDS.
+struct SkyShared {
+    double diag[256];           // the factored diagonal tile of the current panel (unscaled columns, d on the diagonal)
+    double inv[16];             // 1 / d of the panel's pivots
+    double y[16];               // back substitution: the block's solution
+    unsigned short act[256];    // active block rows of the panel
+    int n_act;
+};
+
+template <int kBlockThreads>
+__device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const int ci, double *zl_lds, BlockShared &sh, SkyShared &ss) {
+    constexpr int kWaves = kBlockThreads / 64;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const CompDesc d = a.descs[ci];
+    const int n_var = d.n_var, n = 2 * n_var, E = (int)d.n_edges;
+    const int tv = a.tukey_variant;
+    const EdgeRec *edges = a.edges + d.edge_off;
+    double *wsb = a.workspace + a.ws_off[ci];
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(wsb);
+    const int RT = (int)hdr[0], n_tiles = (int)hdr[1], n_pad = (int)hdr[4];
+    const uint32_t *tilebase = hdr + 8;
+    const uint16_t *fb = reinterpret_cast<const uint16_t *>(tilebase + RT + 1);
+    const uint16_t *pos = fb + RT, *ipos = pos + n_var;
+    double *tiles = wsb + hdr[2];
+    double *vec = wsb + hdr[3];
+    double *vx = vec, *vxc = vec + n_pad, *vg = vec + 2 * (size_t)n_pad, *vgn = vec + 3 * (size_t)n_pad, *vscale = vec + 4 * (size_t)n_pad,
+           *vdiag = vec + 5 * (size_t)n_pad, *vstep = vec + 6 * (size_t)n_pad, *vD = vec + 7 * (size_t)n_pad, *vadiag = vec + 8 * (size_t)n_pad,
+           *vdelta = vec + 9 * (size_t)n_pad, *vinv = vec + 10 * (size_t)n_pad;
+    double *zl = zl_lds ? zl_lds : vec + 11 * (size_t)n_pad;      // back-substitution vector: LDS, or the spare workspace vector for huge components
+    const int P = (n + 15) >> 4;                         // pivot panels
+    const int Rn = n >> 4;                               // block row of the right-hand side (row n)
+    auto tile_ptr = [&](const int R, const int J) -> double * { return tiles + ((size_t)(tilebase[R] + (uint32_t)(J - (int)fb[R])) << 8); };
+
+    for (int i = tid; i < n_pad; i += kBlockThreads) { vx[i] = 0.0; vxc[i] = 0.0; vscale[i] = 1.0; vD[i] = 0.0; vg[i] = 0.0; vgn[i] = 0.0; }
+    __syncthreads();
+
+    const lfr::NodeInc *inc = a.node_inc + d.node_off;
+    const uint32_t *in_idx = a.in_idx + d.edge_off;
+    double *es = a.workspace + a.es_off[ci];
+    // One sweep over the edges at xv (matrix order): the cost, gout = J^T r and the unscaled J^T J in the tiles.  Evaluation: one
+    // thread per edge, 64 B of corrected jacobian / residual to the scratch.  Assembly: every matrix row belongs to ONE thread that
+    // walks its node's out-edges, then its in-edges, in a fixed order (bitwise reproducible).
+    auto sweep = [&](const double *xv, double *gout) -> double {
+        double cost = 0.0;
+        for (size_t i = tid; i < ((size_t)n_tiles << 8); i += kBlockThreads) tiles[i] = 0.0;
+        for (int e = tid; e < E; e += kBlockThreads) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
+            uint4 q[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) q[i] = rp[i];
+            float flow[18];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                flow[4 * i] = __uint_as_float(q[i].x); flow[4 * i + 1] = __uint_as_float(q[i].y);
+                flow[4 * i + 2] = __uint_as_float(q[i].z); flow[4 * i + 3] = __uint_as_float(q[i].w);
+            }
+            flow[16] = __uint_as_float(q[4].x); flow[17] = __uint_as_float(q[4].y);
+            const float sim = __uint_as_float(q[4].z);
+            const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
+            const int dn = dk & 0x7fff, kind = dk >> 15;
+            const int xa = s < n_var ? 2 * (int)pos[s] : n, xb = dn < n_var ? 2 * (int)pos[dn] : n;     // constants read the zero slot
+            EdgeOut o;
+            eval_edge<true>(flow, sim, kind, tv, xv[xa], xv[xa + 1], xv[xb], xv[xb + 1], o);
+            cost += o.cost;
+            double2 *w = reinterpret_cast<double2 *>(es + 8 * (size_t)e);
+            w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
+            w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
+        }
+        const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch complete, tiles zero)
+        for (int row = tid; row < n; row += kBlockThreads) {
+            const int p = row >> 1, c = row & 1, v = (int)ipos[p], R = row >> 4;
+            const lfr::NodeInc ni = inc[v];
+            double *rowbase = tiles + ((size_t)(tilebase[R] - (uint32_t)fb[R]) << 8) + ((row & 15) << 4);   // + (block column << 8) + (column & 15)
+            double gacc = 0.0, dsame = 0.0, dlow = 0.0;
+            constexpr int kAhead = 4;
+            for (uint32_t k0 = 0; k0 < ni.out_count; k0 += kAhead) {   // edges v -> w : J1 = d r / d x_v
+                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
+                int wn_[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const uint32_t e = ni.out_begin + min(k0 + u, ni.out_count - 1);
+                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
+                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
+                    wn_[u] = (int)(edges[e].dst_kind & 0x7fff);
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (k0 + u >= ni.out_count) break;
+                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
+                    const double jc0 = c ? a0.y : a0.x, jc1 = c ? a1.y : a1.x;    // column c of J1
+                    gacc += jc0 * a2.y + jc1 * a3.x;
+                    dsame += jc0 * jc0 + jc1 * jc1;
+                    if (c) dlow += a0.y * a0.x + a1.y * a1.x;
+                    const int wn = wn_[u];
+                    if (wn < n_var) {
+                        const int pw = (int)pos[wn];
+                        if (pw < p) {                           // block (v, w) += J1^T * sq
+                            double *t = rowbase + ((size_t)(pw >> 3) << 8) + ((2 * pw) & 15);
+                            mat_add(t, jc0 * a2.x);
+                            mat_add(t + 1, jc1 * a2.x);
+                        }
+                    }
+                }
+            }
+            for (uint32_t k0 = 0; k0 < ni.in_count; k0 += kAhead) {    // edges w -> v : d r / d x_v = sq * I
+                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
+                int wn_[kAhead];
+                uint32_t e_[kAhead];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) e_[u] = in_idx[ni.in_begin + min(k0 + u, ni.in_count - 1)];
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e_[u]);
+                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
+                    wn_[u] = (int)edges[e_[u]].src;
+                }
+#pragma unroll
+                for (int u = 0; u < kAhead; ++u) {
+                    if (k0 + u >= ni.in_count) break;
+                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
+                    const double sq = a2.x, rc = c ? a3.x : a2.y;
+                    gacc += sq * rc;
+                    dsame += sq * sq;
+                    const int wn = wn_[u];
+                    if (wn < n_var) {
+                        const int pw = (int)pos[wn];
+                        if (pw < p) {                           // block (v, w) += sq * J1'
+                            double *t = rowbase + ((size_t)(pw >> 3) << 8) + ((2 * pw) & 15);
+                            mat_add(t, sq * (c ? a1.x : a0.x));
+                            mat_add(t + 1, sq * (c ? a1.y : a0.y));
+                        }
+                    }
+                }
+            }
+            gout[row] = gacc;
+            double *dg = rowbase + ((size_t)R << 8) + (row & 15);
+            dg[0] = dsame;
+            if (c) dg[-1] = dlow;
+            vadiag[row] = dsame;
+        }
+        __syncthreads();
+        return total;
+    };
+
+    // ---- H = S A S + D^2 over the stored tiles, right-hand side S g into row n ----
+    auto scale_matrix = [&]() {
+        for (int R = wave; R < RT; R += kWaves) {
+            for (int J = (int)fb[R]; J <= R; ++J) {
+                double *t = tile_ptr(R, J);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = lane + 64 * u, i = 16 * R + (idx >> 4), j = 16 * J + (idx & 15);
+                    double v = t[idx] * vscale[i] * vscale[j];
+                    if (i == j) v += vD[i] * vD[i];
+                    t[idx] = v;
+                }
+            }
+        }
+        __syncthreads();
+        for (int j = tid; j < n; j += kBlockThreads) tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)] = vscale[j] * vg[j];
+        __syncthreads();
+    };
+
+    // ---- block-envelope LDL^T in place.  Column k keeps the unscaled entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1/d_k in vinv ----
+    auto factor = [&]() -> bool {
+        if (tid == 0) sh.flag = 0;
+        for (int k = 0; k < P; ++k) {
+            const int kb = 16 * k, nbp = min(16, n - kb);
+            if (tid == 0) ss.n_act = 0;
+            __syncthreads();
+            for (int R = k + 1 + tid; R < RT; R += kBlockThreads)
+                if ((int)fb[R] <= k) ss.act[atomicAdd(&ss.n_act, 1)] = (unsigned short)R;
+            if (wave == 0) {            // (a) the diagonal tile: lane = row, every 16-lane group computes the same
+                double *T = tile_ptr(k, k);
+                double av[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) { const double v = T[(r16 << 4) + min(j, r16)]; av[j] = j <= r16 ? v : 0.0; }
+                bool bad = false;
+#pragma unroll
+                for (int kk = 0; kk < 16; ++kk) {
+                    if (kk < nbp) {
+                        const double dk = readlane_f64(av[kk], kk);
+                        bad = bad || !(dk > 0.0);
+                        const double ik = fast_rcp(dk);
+                        if (lane == kk) { ss.inv[kk] = ik; vinv[kb + kk] = ik; }
+                        const double lik = av[kk] * ik;
+#pragma unroll
+                        for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
+                    } else if (lane == kk) ss.inv[kk] = 0.0;
+                }
+                if (lane < 16) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) { ss.diag[(r16 << 4) + j] = av[j]; if (j <= r16) T[(r16 << 4) + j] = av[j]; }
+                }
+                if (bad && lane == 0) sh.flag = 1;
+            }
+            __syncthreads();
+            const int n_act = ss.n_act;
+            // (b) rows of the active tiles (R, k): a_ic -= sum_{j<c} (a_ij / d_j) a_cj, four tiles per wave and pass
+            for (int g4 = wave; 4 * g4 < n_act; g4 += kWaves) {
+                const int li = 4 * g4 + kq;
+                const bool act = li < n_act;
+                const int R = (int)ss.act[act ? li : 0];
+                double *rowp = tile_ptr(R, k) + (r16 << 4);
+                double r[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) r[c] = rowp[c];
+#pragma unroll
+                for (int j = 0; j < 15; ++j) {
+                    const double tj = r[j] * ss.inv[j];
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, ss.diag[(c << 4) + j], r[c]);
+                }
+                if (act) {
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) rowp[c] = r[c];
+                }
+            }
+            __syncthreads();
+            // (c) tiles (R_i, R_j) of every pair of active block rows -= U(R_i, k) (U(R_j, k) / d)^T  (fp64 MFMA, K = 16)
+            {
+                double ninv[4];
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) ninv[kk] = -ss.inv[4 * kk + kq];
+                const int T = (n_act * (n_act + 1)) >> 1;
+                int I = 0, J = 0, tcur = 0;
+                for (int t = wave; t < T; t += kWaves) {
+                    J += t - tcur; tcur = t;
+                    while (J > I) { J -= I + 1; ++I; }
+                    const int Ra = (int)ss.act[I], Rb = (int)ss.act[J];
+                    const int Rhi = max(Ra, Rb), Rlo = min(Ra, Rb);
+                    const double *ta = tile_ptr(Rhi, k) + (r16 << 4) + kq, *tb = tile_ptr(Rlo, k) + (r16 << 4) + kq;
+                    double *tc = tile_ptr(Rhi, Rlo) + (kq << 4) + r16;
+                    f64x4 c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = tc[r << 6];
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { av[kk] = ta[4 * kk]; bv[kk] = tb[4 * kk] * ninv[kk]; }
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
+                }
+            }
+            __syncthreads();
+        }
+        return sh.flag == 0;
+    };
+
+    // ---- L D L^T y = g with w = L^-1 g in row n: z = w; block rows upwards: y_K = solve within the diagonal tile, z_J -= tile(K, J)^T y_K ----
+    auto back_substitute = [&]() {
+        for (int j = tid; j < n; j += kBlockThreads) zl[j] = tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)];
+        __syncthreads();
+        for (int K = P - 1; K >= 0; --K) {
+            const int kb = 16 * K, nbp = min(16, n - kb);
+            if (wave == 0) {
+                const double *T = tile_ptr(K, K);
+                double m[16];                                    // column r16 of the rows below it
+#pragma unroll
+                for (int k = 0; k < 16; ++k) m[k] = T[(k << 4) + r16];
+                double z = r16 < nbp ? zl[kb + r16] : 0.0;
+                const double iv = r16 < nbp ? vinv[kb + r16] : 0.0;
+                double yo = 0.0;
+#pragma unroll
+                for (int k = 15; k >= 0; --k) {
+                    const double yv = z * iv;
+                    const double yk = readlane_f64(yv, k);
+                    yo = (r16 == k) ? yv : yo;
+                    z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
+                }
+                if (lane < 16) { ss.y[r16] = yo; if (r16 < nbp) vstep[kb + r16] = yo; }
+            }
+            __syncthreads();
+            for (int J = (int)fb[K] + wave; J < K; J += kWaves) {
+                const double *T = tile_ptr(K, J);
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part = fma(T[((kq + 4 * r) << 4) + r16], ss.y[kq + 4 * r], part);
+                part += __shfl_xor(part, 16, 64);
+                part += __shfl_xor(part, 32, 64);
+                if (kq == 0) zl[16 * J + r16] -= part;
+            }
+            __syncthreads();
+        }
+    };
+
+    // ---- the trust-region loop of solve_component, over vectors in matrix order ----
+    int exec_passes = 1;
+    double cost = sweep(vx, vg);
+    for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
+    __syncthreads();
+    auto grad_max = [&](const double *xv, const double *gv) {
+        double m = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) m = fmax(m, fabs(xv[i] - clampb(xv[i] - gv[i])));
+        return block_max<kBlockThreads>(m, sh);
+    };
+    double gmax = grad_max(vx, vg);
+    double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
+    bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
+    int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
+    int n_successful = 0, n_ls_evals = 0, n_cand = 0;
+    for (;;) {
+        if (iteration >= kMaxIterations) { term = LFR_TERM_NO_CONVERGENCE; break; }
+        if (step_successful && gmax <= kGradientTol) break;
+        if (radius <= kMinRadius) break;
+        ++iteration;
+        step_successful = false;
+        if (!matrix_valid) {           // the factorization of a rejected step overwrote J^T J: re-assemble
+            sweep(vx, vg);
+            ++exec_passes;
+            matrix_valid = true;
+        }
+        for (int i = tid; i < n; i += kBlockThreads) {
+            if (!reuse_diagonal) vdiag[i] = fmin(fmax(vscale[i] * vscale[i] * vadiag[i], kMinLmDiag), kMaxLmDiag);
+            vD[i] = sqrt(vdiag[i] / radius);
+        }
+        reuse_diagonal = true;
+        __syncthreads();
+        scale_matrix();
+        matrix_valid = false;
+        bool valid = factor();
+        if (valid) back_substitute();
+        double model_cost_change = 0.0;
+        if (valid) {
+            double part = 0.0, bad = 0.0;
+            for (int i = tid; i < n; i += kBlockThreads) {
+                const double rhs0 = vscale[i] * vg[i];
+                const double st = -vstep[i];
+                if (!isfinite(st)) bad = 1.0;
+                part += -rhs0 * st + vD[i] * vD[i] * st * st;
+            }
+            model_cost_change = 0.5 * block_sum<kBlockThreads>(part, sh);
+            bad = block_max<kBlockThreads>(bad, sh);
+            valid = bad == 0.0 && model_cost_change > 0.0;
+        }
+        if (!valid) {
+            if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+            continue;
+        }
+        n_invalid = 0;
+        double gd_part = 0.0, dm_part = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) {
+            const double dl = -vstep[i] * vscale[i];
+            vdelta[i] = dl;
+            gd_part += vg[i] * dl;
+            dm_part = fmax(dm_part, fabs(dl));
+        }
+        const double g_dot_delta = block_sum<kBlockThreads>(gd_part, sh);
+        const double dir_max = block_max<kBlockThreads>(dm_part, sh);
+        // ---- projected Armijo line search ----
+        double alpha = 1.0, cost_c = 0.0;
+        bool ls_ok = false;
+        {
+            LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
+            int n_iter = 0;
+            for (;;) {
+                for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
+                __syncthreads();
+                cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
+                ++exec_passes; ++n_ls_evals;
+                current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
+                current.gradient = 0.0; current.gradient_valid = false;
+                if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
+                if (current.value_valid) {
+                    double p = 0.0;
+                    for (int i = tid; i < n; i += kBlockThreads) p += vdelta[i] * vgn[i];
+                    current.gradient = block_sum<kBlockThreads>(p, sh);
+                    current.gradient_valid = isfinite(current.gradient);
+                }
+                const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
+                if (nstep < 0.0) break;
+                previous = current;
+                alpha = nstep;
+            }
+        }
+        if (!ls_ok) {
+            for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
+            __syncthreads();
+            cost_c = sweep(vxc, vgn);
+            ++exec_passes;
+        }
+        ++n_cand;
+        const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
+        double sn = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) sn += (vx[i] - vxc[i]) * (vx[i] - vxc[i]);
+        const double step_norm = sqrt(block_sum<kBlockThreads>(sn, sh));
+        if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
+        const double cost_change = cost - cost_cand;
+        if (fabs(cost_change) <= kFunctionTol * cost) break;
+        const double rel = cost_change / model_cost_change;
+        if (rel > kMinRelDecrease) {
+            double xn = 0.0;
+            __syncthreads();
+            for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; vg[i] = vgn[i]; }
+            x_norm = sqrt(block_sum<kBlockThreads>(xn, sh));
+            __syncthreads();
+            cost = cost_cand;
+            matrix_valid = true;              // the accepted candidate is the last evaluated point: its J^T J is in the tiles
+            gmax = grad_max(vx, vg);
+            step_successful = true;
+            ++n_successful;
+            const double t = 2.0 * rel - 1.0;
+            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            decrease_factor = 2.0;
+            reuse_diagonal = false;
+        } else {
+            radius = radius / decrease_factor;
+            decrease_factor *= 2.0;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += kBlockThreads)
+        a.positions[2 * (size_t)a.node_ids[d.node_off + (int)ipos[i >> 1]] + (i & 1)] = term != LFR_TERM_FAILURE ? vx[i] : 0.0;
+    if (tid == 0) {
+        CompInfoDev inf;
+        inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
+        inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
+        inf.final_cost = cost;
+        a.infos[ci] = inf;
+    }
+}
+
+// persistent workgroups over the class's queue, like solve_block_kernel
+template <int kBlockThreads>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_sky_kernel(const KernelArgs a) {
+    extern __shared__ double dyn[];
+    __shared__ BlockShared sh;
+    __shared__ SkyShared ss;
+    __shared__ int next_ci;
+    for (;;) {
+        if (threadIdx.x == 0) {
+            const int k = a.desc_begin + (int)atomicAdd(a.queue + a.cls, 1u);
+            next_ci = k < a.desc_end ? (int)a.wg_order[k - a.wg_begin] : -1;
+        }
+        __syncthreads();
+        const int ci = __builtin_amdgcn_readfirstlane(next_ci);
+        __syncthreads();
+        if (ci < 0) break;
+        solve_sky_component<kBlockThreads>(a, ci, a.sky_lds ? dyn : nullptr, sh, ss);
+        __syncthreads();
+    }
+}
+
 // Order in which a class hands out its components: by expected duration, longest first.  The batch order inside a class is by
 // edge count, which predicts a workgroup's lifetime hardly better than a random order (list-scheduling the measured lifetimes of
 // the config-5 class of 131-192 rows on 256 CUs: 6.9 ms by edges, 6.6 random, 4.9 with the lifetimes known).  Rows (the
@@ -1635,6 +2103,9 @@ struct lfr_batch {
     double *d_positions = nullptr;
     CompInfoDev *d_infos = nullptr;
     double *d_workspace = nullptr;
+    uint64_t es_doubles = 0;                             // per-edge scratch of the workgroup classes (8 doubles per edge), the head of the workspace
+    int sky_lds_doubles = 0;                             // KC_GLOBAL: back-substitution vector of the largest component (0: does not fit LDS, the kernel uses its workspace copy)
+    int64_t sky_tiles = 0, sky_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
     unsigned long long *d_prof = nullptr;
     lfr::NodeInc *d_node_inc = nullptr;
@@ -1754,11 +2225,7 @@ int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     for (int c = 0; c <= lfr::KC_COUNT; ++c) b->class_begin[c] = (int)s.class_begin[c];
     for (int c = 0; c < lfr::KC_COUNT; ++c) b->class_edges[c] = (int64_t)s.class_edges[c];
     for (int c = 0; c < lfr::KC_COUNT; ++c) b->class_max_rows[c] = (int)s.class_max_rows[c];
-    const uint64_t ws = s.es_doubles + s.ws_doubles;
-    if (ws) {
-        if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
-        b->d_workspace = (double *)b->ws_slab.base;
-    }
+    b->es_doubles = s.es_doubles;                        // (the workspace itself: finish_workspace)
     HIP_TRY(hipEventSynchronize(a1));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, a0, a1));
@@ -1801,13 +2268,7 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     const std::vector<EdgeRec> &edges = whole ? p.edges : edges_copy;
     const std::vector<uint32_t> &in_idx = whole ? p.in_idx : in_idx_copy;
     const std::vector<lfr::NodeInc> &node_inc = whole ? p.node_inc : node_inc_copy;
-    for (size_t i = 0; i < b->descs.size(); ++i)      // HBM variant: packed matrix + vectors per component
-        if (b->desc_class[i] == lfr::KC_GLOBAL) {
-            const uint64_t rows = 2 * (uint64_t)b->descs[i].n_var, mat = rows * (rows + 1) / 2;
-            ws += ws & 1;
-            ws_off[i] = ws;
-            ws += mat + (mat & 1) + block_vector_doubles(b->class_max_rows[lfr::KC_GLOBAL]);
-        }
+    b->es_doubles = ws;                                  // (KC_GLOBAL: the matrices' workspace is planned in finish_workspace)
     b->n_desc = (int)b->descs.size();
     {   // class ranges (descs are sorted by class)
         int c = 0;
@@ -1834,10 +2295,6 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     TAKE_B(d_ws_off, uint64_t, nd); TAKE_B(d_es_off, uint64_t, nd); TAKE_B(d_prof, unsigned long long, kProfWords);
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, npos * sizeof(double), st));        // solve.cc:609-612, see create_on_device
     HIP_TRY(hipMemsetAsync(b->d_prof, 0, kProfWords * sizeof(unsigned long long), st));
-    if (ws) {
-        if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
-        b->d_workspace = (double *)b->ws_slab.base;
-    }
     if (!b->descs.empty()) {
         HIP_TRY(hipMemcpyAsync(b->d_ws_off, ws_off.data(), ws_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(b->d_es_off, es_off.data(), es_off.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -1852,6 +2309,86 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
     b->h2d_ms = ms;
+    return LFR_OK;
+}
+
+// The workgroup kernels' workspace: per-edge scratch, then - for the components of the HBM class - the block-envelope plans
+// (lfr_order.cpp) with their tiles and vectors.  The plans need the components' (source, destination, kind) lists on the host: the
+// last word of every edge record, fetched with one strided copy when the batch was assembled on the device.
+int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
+    const int g0 = b->class_begin[lfr::KC_GLOBAL], g1 = b->class_begin[lfr::KC_COUNT];
+    hipStream_t st = b->ctx->s_main;
+    if (g1 <= g0) {
+        if (b->es_doubles) {
+            if (!b->ws_slab.init(b->ctx, b->es_doubles * sizeof(double))) return LFR_ERR_NOMEM;
+            b->d_workspace = (double *)b->ws_slab.base;
+        }
+        return LFR_OK;
+    }
+    { const int rc = ensure_mirrors(b); if (rc != LFR_OK) return rc; }
+    const int ng = g1 - g0;
+    const uint32_t e0 = b->descs[g0].edge_off;
+    uint64_t ne = 0;
+    for (int i = g0; i < g1; ++i) ne = std::max<uint64_t>(ne, (uint64_t)b->descs[i].edge_off + b->descs[i].n_edges - e0);
+    std::vector<uint32_t> words(ne);
+    if (p.host_batch && b->shard_world == 1) {
+        for (uint64_t e = 0; e < ne; ++e) words[e] = (uint32_t)p.edges[e0 + e].src | ((uint32_t)p.edges[e0 + e].dst_kind << 16);
+    } else if (ne) {
+        HIP_TRY(hipMemcpy2DAsync(words.data(), 4, reinterpret_cast<const char *>(b->d_edges + e0) + 76, sizeof(EdgeRec), 4, ne, hipMemcpyDeviceToHost, st));
+        HIP_TRY(lfr::stream_wait(st));
+    }
+    std::vector<lfr::SkyPlan> plans(ng);
+    {
+        std::atomic<int> next{0};
+        const int T = std::max(1, std::min(ng, (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+        auto work = [&] {
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= ng) break;
+                const CompDesc &d = b->descs[g0 + i];
+                lfr::sky_plan(d.n_var, d.n_edges, words.data() + (d.edge_off - e0), plans[i]);
+            }
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+    }
+    std::vector<uint64_t> off(ng);
+    uint64_t ws = (b->es_doubles + 31) / 32 * 32, hdr_total = 0;
+    int max_pad = 0;
+    b->sky_tiles = b->sky_dense_tiles = 0;
+    for (int i = 0; i < ng; ++i) {
+        off[i] = ws;
+        ws += (plans[i].doubles() + 31) / 32 * 32;
+        hdr_total += plans[i].header_doubles();
+        max_pad = std::max(max_pad, (int)plans[i].n_pad());
+        b->sky_tiles += plans[i].tilebase[plans[i].RT];
+        b->sky_dense_tiles += (int64_t)plans[i].RT * (plans[i].RT + 1) / 2;
+    }
+    b->sky_lds_doubles = (size_t)max_pad * sizeof(double) <= (size_t)140 * 1024 ? max_pad : 0;
+    if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
+    b->d_workspace = (double *)b->ws_slab.base;
+    // headers: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
+    size_t got = 0;
+    double *stage = (double *)b->ctx->pinned_acquire(std::max<uint64_t>(hdr_total, 1) * sizeof(double), &got);
+    if (!stage) return LFR_ERR_NOMEM;
+    uint64_t so = 0;
+    for (int i = 0; i < ng; ++i) {
+        plans[i].write_header(stage + so);
+        if (hipMemcpyAsync(b->d_workspace + off[i], stage + so, plans[i].header_doubles() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+            b->ctx->pinned_release(stage, got); lfr::set_error("hipMemcpyAsync of a plan failed"); return LFR_ERR_HIP;
+        }
+        so += plans[i].header_doubles();
+    }
+    hipError_t e1 = hipMemcpyAsync(b->d_ws_off + g0, off.data(), ng * sizeof(uint64_t), hipMemcpyHostToDevice, st);
+    hipError_t e2 = hipStreamSynchronize(st);
+    b->ctx->pinned_release(stage, got);
+    if (e1 != hipSuccess || e2 != hipSuccess) { lfr::set_error("upload of the block-envelope plans failed"); return LFR_ERR_HIP; }
+    if (getenv("LFR_VERBOSE"))
+        fprintf(stderr, "lfr: %d component(s) above %d rows: block-envelope plans keep %lld of %lld tiles (%.1f %%), workspace %.1f MB\n", ng,
+                lfr::block_max_rows(), (long long)b->sky_tiles, (long long)b->sky_dense_tiles, 100.0 * b->sky_tiles / std::max<int64_t>(1, b->sky_dense_tiles),
+                ws * 8e-6);
     return LFR_OK;
 }
 
@@ -2110,8 +2647,9 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     b->device = device; b->ctx = ctx; b->tukey_variant = tukey_variant; b->shard_world = shard_world;
     { const char *e = getenv("LFR_SERIAL_CLASSES"); b->serial = e && e[0] == '1'; }
     b->n_graph_nodes = p.g->n_nodes();
-    const int rc = p.host_batch ? create_from_host(b.get(), p, shard_rank, shard_world) : create_on_device(b.get(), p, shard_rank, shard_world);
+    int rc = p.host_batch ? create_from_host(b.get(), p, shard_rank, shard_world) : create_on_device(b.get(), p, shard_rank, shard_world);
     if (rc != LFR_OK) return rc;
+    if ((rc = finish_workspace(b.get(), p)) != LFR_OK) return rc;
     HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
         if (!(b->side_stream = ctx->side_stream(0))) return LFR_ERR_HIP;
@@ -2143,6 +2681,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     std::max(lds_l, std::max(kThreadsL == kThreadsM ? lds_m : 0, kThreadsL == kThreadsS ? lds_s : 0))));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_sky_kernel<kThreadsG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(b->sky_lds_doubles * sizeof(double))));
 #ifdef LFR_L_W1
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel_w1<kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_l));
 #endif
@@ -2165,6 +2704,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
     a.queue = reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT);
     a.wg_order = b->d_wg_order; a.wg_begin = b->class_begin[lfr::KC_BLOCK];
+    a.sky_lds = b->sky_lds_doubles > 0;
     b->ev = b->ev_ring + (b->n_solves % lfr_batch::kSlots) * lfr_batch::kEvPerSlot;
     uint32_t &recorded = b->ev_recorded[b->n_solves % lfr_batch::kSlots];
     recorded = 0;
@@ -2201,7 +2741,13 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
 #else
             case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
 #endif
-            default:              hipLaunchKernelGGL((solve_block_kernel<true, kThreadsG>), dim3(wgs), dim3(kThreadsG), lds, cs, a, rows); break;
+            default: {
+                // block-envelope kernel: LDS = the back-substitution vector (the workspace copy when it does not fit); two workgroups per CU
+                const size_t sky_lds = (size_t)b->sky_lds_doubles * sizeof(double);
+                const int per_cu = 1;                       // (built for one wave per SIMD: 512 registers, its spills live in the accumulation registers)
+                hipLaunchKernelGGL((solve_sky_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu * per_cu)), dim3(kThreadsG), sky_lds, cs, a);
+                break;
+            }
         }
         HIP_TRY(hipGetLastError());
         return LFR_OK;

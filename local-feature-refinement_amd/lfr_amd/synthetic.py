@@ -111,13 +111,23 @@ def _distinct_images(rng, n_rows, L, n_images):
 
 def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=None,
              eps_out=0.0, sigma_p=0.15, sigma_noise=0.02, sigma_A=0.05, sim_lo=0.8, sim_hi=1.0,
-             fact=1.0):
+             fact=1.0, track_degree=None, chain_links=0, ratio_sims=False, dup_frac=0.0):
     """Generate a synthetic match graph.
 
     len_dist = "poisson": L = min(n_images, 2 + Poisson(4)) (mean 6);
     len_dist = "uniform": L ~ U{len_lo..len_hi}.
     All L(L-1)/2 pairs inside a track are matched; ``eps_out`` adds that fraction
     of extra wrong matches between nodes of different tracks (different images).
+
+    Real match graphs are sparser than that: a feature is only matched along the image pairs
+    the match list holds.  ``track_degree=k``: inside a track node i is matched to its next k/2 track neighbours
+    (a ring lattice: every node has ~k partners, the track stays connected) instead of to all of them.
+    ``chain_links=c``: beside the ``eps_out`` random wrong matches, track t gets c wrong matches to track t+1 - the
+    tracks then form one long chain-like connected component that the size cap cuts into cap-sized pieces
+    (components of #images nodes made of many short tracks: the sparse systems real cap-sized components are).
+    ``ratio_sims``: similarities like the ratio-test matcher's (two-view-refinement/feature_matchers.py:42:
+    1 - d1/d2, spread over (0, 1) instead of U(sim_lo, sim_hi)).  ``dup_frac``: that fraction of the matches
+    is emitted twice (the reference keeps duplicates, solve.cc:476-478).
     """
     rng = np.random.Generator(np.random.PCG64(seed))
     if len_dist == "poisson":
@@ -148,11 +158,16 @@ def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=N
     node_p = np.clip(rng.normal(0.0, sigma_p, size=(N, 2)), -0.45, 0.45)
     node_track = np.repeat(np.arange(n_tracks), L)
 
-    # true matches: all pairs inside a track
+    # true matches: all pairs inside a track (or a ring lattice of degree track_degree)
     a_list, b_list = [], []
     for ell in np.unique(L):
         rows = np.nonzero(L == ell)[0]
         iu, ju = np.triu_indices(int(ell), k=1)
+        if track_degree is not None and ell > track_degree + 1:
+            half = max(1, int(track_degree) // 2)
+            d = ju - iu
+            keep = (d <= half) | (d >= ell - half)           # ring distance <= half
+            iu, ju = iu[keep], ju[keep]
         base = node_off[rows][:, None]
         a_list.append((base + iu[None, :]).ravel())
         b_list.append((base + ju[None, :]).ravel())
@@ -165,6 +180,7 @@ def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=N
 
     # wrong matches between different tracks
     n_out = int(round(eps_out * n_true))
+    wa = wb = np.zeros(0, np.int64)
     if n_out > 0:
         wa = rng.integers(0, N, size=n_out)
         wb = rng.integers(0, N, size=n_out)
@@ -174,9 +190,29 @@ def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=N
                 break
             wa[bad] = rng.integers(0, N, size=bad.size)
             wb[bad] = rng.integers(0, N, size=bad.size)
+    if chain_links > 0 and n_tracks > 1:
+        # track t -> track t + 1: a random node of each (different images)
+        t0 = np.repeat(np.arange(n_tracks - 1), chain_links)
+        ca = node_off[t0] + rng.integers(0, 1 << 30, size=t0.size) % L[t0]
+        cb = node_off[t0 + 1] + rng.integers(0, 1 << 30, size=t0.size) % L[t0 + 1]
+        for _ in range(64):
+            bad = np.nonzero(node_img[ca] == node_img[cb])[0]
+            if bad.size == 0:
+                break
+            cb[bad] = node_off[t0[bad] + 1] + rng.integers(0, 1 << 30, size=bad.size) % L[t0[bad] + 1]
+        ok = node_img[ca] != node_img[cb]
+        wa = np.concatenate([wa, ca[ok]])
+        wb = np.concatenate([wb, cb[ok]])
+    n_out = int(wa.size)
+    if n_out > 0:
         a = np.concatenate([a, wa])
         b = np.concatenate([b, wb])
         wrong = np.concatenate([wrong, np.ones(n_out, bool)])
+    if dup_frac > 0.0 and a.size:
+        pick = np.nonzero(rng.random(a.size) < dup_frac)[0]
+        a = np.concatenate([a, a[pick]])
+        b = np.concatenate([b, b[pick]])
+        wrong = np.concatenate([wrong, wrong[pick]])
 
     # orient so image1 < image2 (names are "%06d.png": index order == name order)
     swap = node_img[a] > node_img[b]
@@ -199,7 +235,11 @@ def generate(seed, n_images, n_tracks, len_dist="poisson", len_lo=None, len_hi=N
 
     disp2 = _flow(a, b)   # flow 1 -> 2
     disp1 = _flow(b, a)   # flow 2 -> 1
-    sim = rng.uniform(sim_lo, sim_hi, size=M).astype(np.float32)
+    if ratio_sims:       # 1 - d1/d2 of a ratio test: most mass at small values, correct matches higher than wrong ones
+        sim = np.where(wrong, rng.beta(1.2, 6.0, size=M), rng.beta(2.0, 3.0, size=M))
+        sim = np.clip(sim, 1e-3, 0.999).astype(np.float32)
+    else:
+        sim = rng.uniform(sim_lo, sim_hi, size=M).astype(np.float32)
 
     # group by image pair, lexicographic, stable
     i1, i2 = node_img[a], node_img[b]
@@ -239,6 +279,15 @@ def config3_standin():
     """Stand-in for BASELINE config 3 (Herzjesu, 8 images, SuperPoint matches): 8 images, 3000 tracks."""
     return generate(seed=13, n_images=8, n_tracks=3000, len_dist="uniform", len_lo=2, len_hi=8, eps_out=0.005,
                     sigma_noise=0.03, sim_lo=0.6)
+
+
+def capsized_sparse(n_images=1344, n_tracks=40_000, seed=7, track_degree=4, chain_links=1, eps_out=0.0005):
+    """Cap-sized SPARSE components: 1344 images, short tracks (mean 6) matched along a ring lattice of
+    degree 4, every track linked to the next by a wrong match plus a few random wrong matches: the tracks form giant connected
+    meta components which the size cap (#images nodes, solve.cc:586) cuts into pieces of up to 1344 nodes - ~2700-row systems
+    whose matrices are tree-plus-few-cycles sparse (what real config-4-scale data gives the solver)."""
+    return generate(seed=seed, n_images=n_images, n_tracks=n_tracks, track_degree=track_degree, chain_links=chain_links,
+                    eps_out=eps_out, ratio_sims=True)
 
 
 def config5():
