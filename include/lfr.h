@@ -143,6 +143,8 @@ int lfr_problem_build_labels(const lfr_graph *g, int64_t max_nodes_in_component,
  * ones, roots, components; components above the size cap are cut on the host from meta edges the
  * device compacts and sums, and re-labelled on the device.  Bit-identical labels.  Falls back to the
  * host stage only when component_override is given, for >= 2^31 nodes or >= 2^30 matches, when the
+ * similarities span more than 2^10 in magnitude or hold inf/nan (the device sums them with atomics, exact and
+ * therefore order independent only in a narrow exponent range; the host sums in the reference's order), when the
  * image bitsets of the parallel rounds would exceed 24 GB, or after 100000 rounds (a path-shaped
  * dependency chain). */
 int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component,

@@ -261,9 +261,10 @@ __global__ void k_large_pending(int64_t k_lo, int64_t k_hi, int64_t serial_limit
     }
 }
 // retire what can never be accepted (same root / shared image: monotone), bid for the roots with the rest
-__global__ void k_round_eval(uint32_t n_in, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
+__global__ void k_round_eval(const uint32_t *n_in_p, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
                              unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *n_in_p;                                // (the launch is sized by an upper bound: the count of an earlier round)
     bool keep = false;
     Pending q{0, 0, 0};
     if (i < n_in) {
@@ -284,6 +285,10 @@ __global__ void k_round_eval(uint32_t n_in, const Pending *in, int32_t *parent, 
     // decreases, so a bid that does not beat what is already there could not have won)
     if (key < __hip_atomic_load(&minpos[q.ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.ra], key);
     if (key < __hip_atomic_load(&minpos[q.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.rb], key);
+}
+// counters of a batch of rounds: c[j] = matches pending before round j of the batch; the last count of the previous batch moves to the front
+__global__ void k_round_counters_shift(uint32_t *c, int R) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = c[R]; for (int j = 1; j <= R; ++j) c[j] = 0u; }
 }
 // a bidder that holds both of its roots is the earliest pending match touching either: accept (solve.cc:513-521)
 __global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigned long long round_hi, const unsigned long long *minpos,
@@ -555,6 +560,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     { std::lock_guard<std::mutex> lk(p.label_mu); p.devs.clear(); }
     if (N == 0) { p.track.clear(); p.comp.clear(); p.is_root.clear(); p.host_labels_valid = true; return LFR_OK; }
     if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) return LFR_GRAPHSTAGE_USE_HOST;
+    if (!g.sims_sum_exactly) return LFR_GRAPHSTAGE_USE_HOST;      // atomics would round in an order-dependent way: the reference's sequential sums run on the host
     if (max_nodes <= 0) max_nodes = (int64_t)g.image_names.size();
     std::shared_ptr<DevGraph> dg;
     int rc = ensure_dev_graph(g, device, stage_flows, dg);       // endpoints on s_main now; the flows start travelling on s_copy
@@ -572,7 +578,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     DevArena arena;                                   // temporaries of this call
     if (!arena.init(ctx, (size_t)96 * M + (size_t)96 * N + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
     size_t pin_bytes = 0;
-    uint32_t *h_counts = (uint32_t *)ctx->pinned_acquire(4 * CNT_WORDS, &pin_bytes);
+    uint32_t *h_counts = (uint32_t *)ctx->pinned_acquire(4 * (CNT_WORDS + 16), &pin_bytes);     // + the counters of a batch of union-find rounds
     if (!h_counts) return LFR_ERR_NOMEM;
     struct PinGuard { DevCtx *c; void *p; size_t b; ~PinGuard() { c->pinned_release(p, b); } } pin_guard{ctx, h_counts, pin_bytes};
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -656,7 +662,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(hipMemsetAsync(bits, 0, bits_bytes, st));
         LFR_HIP_TRY(hipMemsetAsync(minpos, 0xff, 8 * (size_t)N, st));
         LFR_HIP_TRY(hipMemsetAsync(ctr, 0, 4 * 64, st));
-        uint32_t *h_ctr = h_counts + 8;                 // (the pinned block has 16 words; the counts proper use 6)
+        uint32_t *h_ctr = h_counts + CNT_WORDS;        // (16 more words behind the counts proper)
         // The ordered list goes through the rounds in PREFIX BLOCKS (2 N positions, then doubling): the sequential rule finishes
         // a prefix before it looks at the rest, so rounds over a block alone are exact, and a match is only carried through the
         // rounds of its own block.  With the whole list pending at once every match was re-evaluated each round until its
@@ -665,27 +671,36 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         // simulation of this schedule, a few rounds more.
         int64_t first_block = std::max<int64_t>(2 * N, 1024);
         if (const char *e = getenv("LFR_ROUNDS_FIRST_BLOCK")) first_block = std::max<int64_t>(1, atoll(e));
-        int64_t rounds = 0;
+        // Rounds run in batches of kRoundBatch without a host round trip: every round takes its input count from the device
+        // (the launches are sized by the count of the last read-back: counts only shrink), a round with nothing pending is two
+        // empty launches.  Round 2 read the count back after every round: 76 synchronisations for config 5's giant component.
+        constexpr int kRoundBatch = 8;
+        uint32_t *rc_ = rounds_arena.take_n<uint32_t>(kRoundBatch + 2);
+        if (!rc_) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
+        LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
+        int64_t rounds = 0, launched = 0;
         for (int64_t k_lo = 0, size = first_block; k_lo < M; k_lo += size, size *= 2) {
             const int64_t k_hi = std::min(M, k_lo + size);
-            LFR_HIP_TRY(hipMemsetAsync(ctr, 0, 4, st));
+            LFR_HIP_TRY(hipMemsetAsync(rc_ + kRoundBatch, 0, 4, st));
             hipLaunchKernelGGL(k_large_pending, grid_for(k_hi - k_lo), dim3(kThreads), 0, st, k_lo, k_hi, serial_limit, flags, segid, starts, order, n1, n2,
-                               dg->node_image, W, bits, pa, ctr);
-            LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr, 4, hipMemcpyDeviceToHost, st));
+                               dg->node_image, W, bits, pa, rc_ + kRoundBatch);
+            LFR_HIP_TRY(hipMemcpyAsync(h_ctr, rc_ + kRoundBatch, 4, hipMemcpyDeviceToHost, st));
             LFR_HIP_TRY(stream_wait(st));
-            uint32_t n_in = h_ctr[0];
-            for (; n_in > 0; ++rounds) {
-                if (rounds >= kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;   // a path-shaped dependency chain: sequential anyway
-                const unsigned long long round_hi = (unsigned long long)(kMaxRounds - rounds) << 32;
-                uint32_t *n_out = ctr + 1 + (rounds & 1);
-                LFR_HIP_TRY(hipMemsetAsync(n_out, 0, 4, st));
-                hipLaunchKernelGGL(k_round_eval, grid_for(n_in), dim3(kThreads), 0, st, n_in, pa, par, bits, W, round_hi, minpos, pb, n_out);
-                hipLaunchKernelGGL(k_round_accept, grid_for(n_in), dim3(kThreads), 0, st, n_out, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
-                LFR_HIP_TRY(hipMemcpyAsync(h_ctr, n_out, 4, hipMemcpyDeviceToHost, st));
+            uint32_t bound = h_ctr[0];
+            while (bound > 0) {
+                if (launched + kRoundBatch > kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;   // a path-shaped dependency chain: sequential anyway
+                hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
+                for (int j = 0; j < kRoundBatch; ++j, ++launched) {
+                    const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;
+                    hipLaunchKernelGGL(k_round_eval, grid_for(bound), dim3(kThreads), 0, st, rc_ + j, pa, par, bits, W, round_hi, minpos, pb, rc_ + j + 1);
+                    hipLaunchKernelGGL(k_round_accept, grid_for(bound), dim3(kThreads), 0, st, rc_ + j + 1, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
+                    std::swap(pa, pb);
+                }
+                LFR_HIP_TRY(hipMemcpyAsync(h_ctr, rc_, 4 * (kRoundBatch + 1), hipMemcpyDeviceToHost, st));
                 LFR_HIP_TRY(stream_wait(st));
-                if (trace > 2) fprintf(stderr, "lfr graph stage:   block [%lld, %lld) round %lld: %u pending in, %u eligible out\n", (long long)k_lo, (long long)k_hi, (long long)rounds, n_in, h_ctr[0]);
-                n_in = h_ctr[0];
-                std::swap(pa, pb);
+                for (int j = 0; j < kRoundBatch; ++j) rounds += h_ctr[j] > 0 ? 1 : 0;
+                if (trace > 2) fprintf(stderr, "lfr graph stage:   block [%lld, %lld) rounds ..%lld: pending %u -> %u\n", (long long)k_lo, (long long)k_hi, (long long)rounds, h_ctr[0], h_ctr[kRoundBatch]);
+                bound = h_ctr[kRoundBatch];
             }
         }
         p.stats.kruskal_rounds = (double)rounds;

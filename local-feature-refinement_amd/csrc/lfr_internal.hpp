@@ -57,6 +57,12 @@ struct Graph {
     mutable std::vector<std::shared_ptr<DevGraph>> devgs;      // indexed by HIP device ordinal
     mutable std::mutex dev_mu;
 
+    // The device graph stage sums similarities with atomics (root scores, meta-edge weights): order independent - and therefore
+    // bit-identical to the reference's sequential sums (solve.cc:557-562, 268-289) - only while the fp64 sums of the float32
+    // values are EXACT, i.e. while the similarities share a narrow exponent range.  finish() checks it (max |sim| / min |sim| of
+    // the non-zero, finite values <= 2^10: then 2^18 terms still sum exactly in 53 bits); otherwise the host stage runs.
+    bool sims_sum_exactly = true;
+
     int64_t n_nodes() const { return (int64_t)node_image.size(); }
     int64_t n_matches() const { return (int64_t)m_sim.size(); }
     int32_t intern_image(const std::string &name, float fact);

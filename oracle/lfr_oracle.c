@@ -415,16 +415,34 @@ static int cholesky(double *A, int n) {
     return 0;
 }
 
+/* Per-thread scratch that survives from one component to the next (the timed CPU baseline solves ~150 k small components:
+ * a calloc/free pair per buffer and component was a visible part of its time).  Slots grow, never shrink. */
+enum { TL_BUF = 0, TL_EJ, TL_VIDX, TL_EDGES, TL_X, TL_SLOTS };
+static __thread void *tl_ptr[TL_SLOTS];
+static __thread size_t tl_cap[TL_SLOTS];
+static void *tl_get(int slot, size_t bytes, int zero) {
+    if (bytes > tl_cap[slot]) {
+        free(tl_ptr[slot]);
+        size_t cap = tl_cap[slot] ? tl_cap[slot] : 4096;
+        while (cap < bytes) cap *= 2;
+        tl_ptr[slot] = malloc(cap);
+        tl_cap[slot] = cap;
+    }
+    if (zero) memset(tl_ptr[slot], 0, bytes);
+    return tl_ptr[slot];
+}
+static void tl_release(void) { for (int i = 0; i < TL_SLOTS; ++i) { free(tl_ptr[i]); tl_ptr[i] = NULL; tl_cap[i] = 0; } }
+
 /* A10: ceres::Solve on one reduced program.  x_out: 2*nv (zeros when the solve FAILS). */
 static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) {
     const int n = 2 * p->nv;
     memset(info, 0, sizeof *info);
     if (n == 0) return;
-    double *buf = (double *)calloc((size_t)n * n + 12 * (size_t)n, sizeof(double));
+    double *buf = (double *)tl_get(TL_BUF, ((size_t)n * n + 12 * (size_t)n) * sizeof(double), 1);
     double *H = buf, *x = H + (size_t)n * n, *g = x + n, *scale = g + n, *diagonal = scale + n, *D = diagonal + n,
            *rhs = D + n, *step = rhs + n, *delta = step + n, *xc = delta + n, *gs = xc + n, *best = gs + n,
            *colsq = best + n;
-    p->eJ1 = (double *)malloc(sizeof(double) * 7 * (size_t)(p->ne > 0 ? p->ne : 1));
+    p->eJ1 = (double *)tl_get(TL_EJ, sizeof(double) * 7 * (size_t)(p->ne > 0 ? p->ne : 1), 0);
     p->ej2 = p->eJ1 + 4 * (size_t)p->ne;
     p->er = p->ej2 + p->ne;
 
@@ -597,8 +615,6 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
     info->n_jac_evals = p->n_jac_evals;
     if (term == TERM_FAILURE) memset(x_out, 0, sizeof(double) * n);
     else memcpy(x_out, best, sizeof(double) * n);
-    free(p->eJ1);
-    free(buf);
 }
 
 
@@ -669,7 +685,7 @@ typedef struct lfro {
     int tukey_variant;
     int64_t *comp_off, *comp_nodes;        /* nodes per component, ascending node idx */
     int64_t *order;                        /* components sorted by size descending */
-    volatile int64_t next;                 /* work queue cursor */
+    int64_t next;                          /* work queue cursor (atomic fetch-add) */
     pthread_mutex_t mu;
     int64_t trace_comp; Trace *trace;
 } lfro;
@@ -725,8 +741,8 @@ static void solve_one_component(lfro *o, int64_t c) {
     /* will_be_optimized + variable numbering (roots are constant, solve.cc:131-143) */
     int64_t ne_all = 0;
     for (int64_t k = 0; k < nn; ++k) ne_all += o->out_off[nodes[k] + 1] - o->out_off[nodes[k]];
-    int32_t *vidx = (int32_t *)malloc(sizeof(int32_t) * nn);
-    OEdge *edges = (OEdge *)malloc(sizeof(OEdge) * (ne_all > 0 ? ne_all : 1));
+    int32_t *vidx = (int32_t *)tl_get(TL_VIDX, sizeof(int32_t) * nn, 0);
+    OEdge *edges = (OEdge *)tl_get(TL_EDGES, sizeof(OEdge) * (ne_all > 0 ? ne_all : 1), 0);
     int nv = 0;
     for (int64_t k = 0; k < nn; ++k) {
         const int64_t n = nodes[k];
@@ -758,23 +774,21 @@ static void solve_one_component(lfro *o, int64_t c) {
     }
     Problem p; memset(&p, 0, sizeof p);
     p.nv = nv; p.ne = ne; p.edges = edges; p.tukey_variant = o->tukey_variant;
-    double *x = (double *)calloc((size_t)(2 * nv + 1), sizeof(double));
+    double *x = (double *)tl_get(TL_X, (size_t)(2 * nv + 1) * sizeof(double), 1);
     solve_problem(&p, x, &o->infos[c], (o->trace && o->trace_comp == c) ? o->trace : NULL);
     o->comp_nvar[c] = nv; o->comp_nedges[c] = ne;
     for (int64_t k = 0; k < nn; ++k)
         if (vidx[k] >= 0) { o->positions[2 * nodes[k]] = x[2 * vidx[k]]; o->positions[2 * nodes[k] + 1] = x[2 * vidx[k] + 1]; }
-    free(x); free(edges); free(vidx);
 }
 
 static void *worker(void *arg) {
     lfro *o = (lfro *)arg;
     for (;;) {
-        pthread_mutex_lock(&o->mu);
-        const int64_t i = o->next++;
-        pthread_mutex_unlock(&o->mu);
+        const int64_t i = __atomic_fetch_add(&o->next, 1, __ATOMIC_RELAXED);     /* (round 2: a mutex around the cursor) */
         if (i >= o->n_components) break;
         solve_one_component(o, o->order[i]);
     }
+    tl_release();
     return NULL;
 }
 

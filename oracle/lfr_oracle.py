@@ -12,7 +12,20 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "lfr_oracle.c")
 _SO = os.path.join(_HERE, "_build", "liblfr_oracle.so")
+def _cpu_tag():
+    """model + flags of this machine's CPU: a -march=native build is only ever loaded where it was built"""
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        keep = [l for l in txt.split("\n") if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        keep = []
+    return hashlib.sha1("|".join(keep).encode()).hexdigest()[:10]
+
+
+_SO_NATIVE = os.path.join(_HERE, "_build", "liblfr_oracle_native_%s.so" % _cpu_tag())    # -O3 -march=native: built ON the machine that times it (bench.py)
 _lib = None
+_libs = {}
 
 INFO_DTYPE = np.dtype([("iterations", "<i4"), ("termination", "<i4"), ("n_successful", "<i4"),
                        ("n_ls_evals", "<i4"), ("n_cost_evals", "<i8"), ("n_jac_evals", "<i8"),
@@ -32,11 +45,26 @@ def build(force=False):
     return _SO
 
 
-def lib():
+def build_native(force=False):
+    """The same source at -O3 -march=native for the timed CPU baseline (bench.py's cpu_baseline leg).  Never shipped between
+    machines: the instruction set is the build host's.  IEEE semantics as in build() (no -ffast-math, no contraction)."""
+    if not force and os.path.exists(_SO_NATIVE) and os.path.getmtime(_SO_NATIVE) >= os.path.getmtime(_SRC):
+        try:
+            C.CDLL(_SO_NATIVE)
+            return _SO_NATIVE
+        except OSError:
+            pass
+    os.makedirs(os.path.dirname(_SO_NATIVE), exist_ok=True)
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-std=gnu99", "-fPIC", "-shared", "-ffp-contract=off", "-o", _SO_NATIVE, _SRC,
+                           "-lm", "-lpthread"])
+    return _SO_NATIVE
+
+
+def lib(native=False):
     global _lib
-    if _lib is None:
-        build()
-        L = C.CDLL(_SO)
+    if native not in _libs:
+        path = build_native() if native else build()
+        L = C.CDLL(path)
         L.lfro_build.restype = C.c_int
         L.lfro_solve.restype = C.c_int
         for n in ("n_nodes", "n_tracks", "max_track_size", "n_components", "max_component_size", "n_oversized"):
@@ -55,8 +83,10 @@ def lib():
         L.lfro_eval_edge.restype = C.c_double
         L.lfro_minimize_poly.restype = C.c_double
         assert L.lfro_info_size() == INFO_DTYPE.itemsize
-        _lib = L
-    return _lib
+        _libs[native] = L
+        if not native:
+            _lib = L
+    return _libs[native]
 
 
 def _ptr(a):
@@ -95,12 +125,12 @@ BISECT_FN = C.CFUNCTYPE(C.c_int64, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.
 
 
 def run(ma, banned=(), n_threads=1, tukey_variant="ceres1", comp_override=None, trace_comp=None,
-        solve=True, bisect=None):
+        solve=True, bisect=None, native=False):
     """Run graph stage (+ solve) of the C oracle on a MatchArrays.  Returns a dict.
     bisect: address (int / ctypes function pointer) of a two-way cut with the signature of lfr_bisect_graph, standing
     in for colmap::ComputeNormalizedMinGraphCut (solve.cc:192) when a component exceeds the size cap; without it such
     inputs return rc != 0 (the Graclus cut cannot be restated)."""
-    L = lib()
+    L = lib(native)
     L.lfro_set_bisect(None if bisect is None else C.c_void_p(bisect) if isinstance(bisect, int) else C.cast(bisect, C.c_void_p))
     i1, i2, keep, names = flatten(ma, banned)
     f1 = np.ascontiguousarray(ma.feat1[keep], np.uint32)

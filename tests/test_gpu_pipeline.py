@@ -224,3 +224,25 @@ def test_bench_two_ranks_on_one_gpu(lfr_lib, scaling):
         assert abs(out["config"]["edges_per_gpu"] * 2 - total) / total < 0.05                                # one graph, two shards
     for k in ("solver_span", "total_span", "total_span_resident_graph"):
         assert out[k]["ms"] > 0
+
+
+def test_bench_two_gpus_over_rccl(lfr_lib):
+    """The first multi-GPU lease should exercise RCCL, not discover it: bench.py --gpus 2 with the default backend (nccl = RCCL on
+    ROCm), one rank per GPU.  Skipped on one-GPU boxes."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LFR_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--tracks", "20000",
+                        "--span-reps", "2", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["strong_scaling"]["edges"] > 0
+    assert out["solve"]["failed"] == 0
