@@ -368,16 +368,26 @@ def main():
             fact_flops = float((rows5[wg5] ** 3 / 3.0 * info5["iterations"][wg5]).sum())
             eval_flops = float(st5["exec_passes_edges"]) * FLOP_PER_EDGE_EVAL
             prof5 = pmc_numbers("r03_pmc_config5.json")
+            traffic5 = (prof5 or {}).get("hbm_bytes_per_solve")
+            alg_bytes5 = float(st5["exec_passes_edges"]) * (80 + 64 + 128)
             res["long_tracks_workload"] = {
                 # fp64 roof of the solve as a whole (the three LDS classes run concurrently): n^3/3 per factorization (one per LM
                 # iteration) on the fp64 matrix cores + 200 flop per executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak
-                "roofline": {"bound": "fp64", "achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                             "factorization_flops": fact_flops, "edge_evaluation_flops": eval_flops,
-                             "factorizations": int(info5["iterations"][wg5].sum()), "edge_evaluations_executed": int(st5["exec_passes_edges"]),
-                             "traffic": (prof5 or {}).get("hbm_bytes_per_solve"),
-                             "traffic_source": "profiles/r03_pmc_config5.json (committed rocprofv3 PMC passes over this workload; not measured in this run)" if prof5 else None,
-                             "pmc": {k: prof5[k] for k in prof5 if k.startswith("SQ_")} if prof5 else None},
+                # Two roofs of the solve as a whole (the three LDS classes run concurrently).  HBM: every sweep re-streams the 80-byte
+                # records and sends 64 B of corrected jacobian per edge through a scratch array (written once, read by the out- and the
+                # in-walk): bytes from the committed PMC passes.  fp64: n^3/3 per factorization (one per LM iteration) on the fp64 matrix
+                # cores + 200 flop per executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak.
+                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                             "traffic": traffic5,
+                             "achieved": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9, "frac": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "algorithmic_bytes": alg_bytes5,
+                             "algorithmic_bytes_what": "per executed sweep and edge: 80 B record + 64 B scratch written + 2 x 64 B scratch read",
+                             "traffic_source": "profiles/r03_pmc_config5.json (committed rocprofv3 PMC passes over this workload, 2*FETCH_SIZE + WRITE_SIZE; not measured in this run)" if traffic5 else None,
+                             "fp64": {"achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                      "factorization_flops": fact_flops, "edge_evaluation_flops": eval_flops,
+                                      "factorizations": int(info5["iterations"][wg5].sum()), "edge_evaluations_executed": int(st5["exec_passes_edges"])},
+                             "pmc": {k: prof5[k] for k in prof5 if k.startswith("SQ_") or k in ("valu_busy", "wait_fraction")} if prof5 else None},
                 "workload": "config5 stand-in: synthetic match graph, 96 images, 2000 tracks of 48-96 nodes, 2 %% wrong matches (components above the "
                             "size cap are cut), %d directed edges, %d components" % (st5["n_edges"], st5["n_components"]),
                 "ms_per_step": ms5, "edges_per_s": st5["n_edges"] / (ms5 * 1e-3), "tracks_per_s": st5["n_tracks"] / (ms5 * 1e-3), "steps": n5,

@@ -61,15 +61,18 @@ __global__ void k_mark_var(int64_t n_nodes, const uint8_t *opt, const uint8_t *i
     t_comp[track[n]] = comp[n];
 }
 
-__global__ void k_count_edges(int64_t n_dir, const uint32_t *node1, const uint32_t *node2, const int32_t *comp,
+// one thread per MATCH: both directions are kept or dropped together (same track / same component and "an end is variable" are
+// symmetric), so one atomic of 2 per match instead of one per directed edge (5 M atomics on 147 k addresses were 0.38 ms)
+__global__ void k_count_edges(int64_t n_matches, const uint32_t *node1, const uint32_t *node2, const int32_t *comp,
                               const uint8_t *is_var, uint8_t *kept, uint32_t *c_edges) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_dir) return;
-    uint32_t s, d;
-    edge_ends(node1, node2, e, s, d);
-    const bool k = kept[e] && (is_var[s] || is_var[d]);      // both ends constant: not in the reduced program
-    kept[e] = k;
-    if (k) atomicAdd(&c_edges[comp[s]], 1u);
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_matches) return;
+    const uint32_t a = node1[m], b = node2[m];
+    const bool var = is_var[a] || is_var[b];                 // both ends constant: not in the reduced program
+    const bool k0 = kept[2 * m] && var, k1 = kept[2 * m + 1] && var;
+    kept[2 * m] = k0; kept[2 * m + 1] = k1;
+    if (k0) atomicAdd(&c_edges[comp[a]], 1u + (k1 && comp[b] == comp[a] ? 1u : 0u));
+    if (k1 && !(k0 && comp[b] == comp[a])) atomicAdd(&c_edges[comp[b]], 1u);
 }
 
 __global__ void k_count_tracks(int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks) {
@@ -183,11 +186,13 @@ __global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const 
 template <bool ALIGNED8>     // flow rows are 72 bytes: 8-byte aligned when the arrays are (ours always are; a caller's device flows may not be)
 __global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
-                             const uint32_t *local_of, const uint32_t *flow_row, int64_t row_lo, int64_t row_hi, uint4 *records) {
+                             const uint32_t *local_of, const uint32_t *flow_row, int64_t row_lo, int64_t row_hi, uint4 *records,
+                             const uint32_t *skip_below_p) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / 5;
     const int chunk = (int)(t - 5 * p);
     if (p >= cap || p >= (int64_t)*total_edges_p) return;
+    if (skip_below_p && p < (int64_t)*skip_below_p) return;       // fused gather: the packed classes' records are never read
     const uint32_t e = edge_sorted[p];
     const int64_t m = (int64_t)(e >> 1);
     if (m < row_lo || m >= row_hi) return;
@@ -212,6 +217,17 @@ __global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const u
         q.w = ls | ((ld | (kind << 15)) << 16);
     }
     records[5 * p + chunk] = q;
+}
+
+// fused gather: the 4-byte word of every record (local source | (local destination | kind << 15) << 16)
+__global__ void k_edge_words(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
+                             const int32_t *track, const uint32_t *local_of, uint32_t *words) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= cap || p >= (int64_t)*total_edges_p) return;
+    uint32_t s, d;
+    edge_ends(node1, node2, edge_sorted[p], s, d);
+    const uint32_t kind = track[s] != track[d] ? 1u : 0u;
+    words[p] = local_of[s] | ((local_of[d] | (kind << 15)) << 16);
 }
 
 // Incidence lists of the workgroup-class components (the owner-computes assembly of solve_block_kernel walks a
@@ -327,6 +343,7 @@ __global__ void k_offsets(int64_t n_comp, const uint32_t *class_sorted, const un
     if (i > n_comp) return;
     if (i == n_comp) {
         sum->es_doubles = es_scan[n_comp]; sum->ws_doubles = ws_scan[n_comp];
+        sum->packed_edges = edge_off[min((int64_t)sum->class_begin[KC_BLOCK], n_comp)];
         sum->n_desc = sum->class_begin[KC_COUNT];
         sum->total_nodes = node_off[n_comp]; sum->total_edges = edge_off[n_comp];
         for (int kc = 0; kc < KC_COUNT; ++kc)           // descs are sorted by class: a class is one range of the edge scan
@@ -376,7 +393,7 @@ int exclusive_sum(DevArena &arena, const T *in, T *out, int64_t n, hipStream_t s
 
 size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C) {
     const size_t E2 = (size_t)2 * M, n = (size_t)N, c = (size_t)C + 1;
-    return sizeof(CompDesc) * c + sizeof(EdgeRec) * E2 + 4 * n + sizeof(NodeInc) * n + 4 * E2 + 16 * c + 12 * c + 256 * 16;
+    return sizeof(CompDesc) * c + sizeof(EdgeRec) * E2 + 4 * n + sizeof(NodeInc) * n + 4 * E2 + 8 * E2 + 16 * c + 12 * c + 256 * 18;
 }
 
 static inline int nbits(uint64_t x) { int b = 1; while (x >>= 1) ++b; return b; }      // bits needed for values 0..x
@@ -406,6 +423,14 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE_OUT(out.d_node_ids, uint32_t, N); TAKE_OUT(out.d_node_inc, NodeInc, N); TAKE_OUT(out.d_in_idx, uint32_t, E2);
     TAKE_OUT(out.d_ws_off, uint64_t, C + 1); TAKE_OUT(out.d_es_off, uint64_t, C + 1);
     TAKE_OUT(out.d_desc_class, uint32_t, C + 1); TAKE_OUT(out.d_desc_tracks, uint32_t, C + 1); TAKE_OUT(out.d_desc_component, uint32_t, C + 1);
+    const bool aligned8 = (((uintptr_t)dg.disp1 | (uintptr_t)dg.disp2) & 7u) == 0;
+    // Fused gather: a whole batch over flows that live in HBM lets the packed kernel read its edges from the graph's own arrays
+    // (72-byte flow rows, 8-byte aligned) - the 400 MB of records for config 4 are neither written nor re-read.  Shards gather zero-copy
+    // from pinned host memory (once, into records); LFR_FUSED_GATHER=0 switches the path off.
+    bool fused = shard_world == 1 && !dg.flows_zero_copy && aligned8 && dg.disp1 && dg.disp2;
+    if (const char *e = getenv("LFR_FUSED_GATHER")) fused = fused && e[0] != '0';
+    out.fused = fused;
+    if (fused) { TAKE_OUT(out.d_edge_ref, uint32_t, E2); TAKE_OUT(out.d_edge_word, uint32_t, E2); }
 
     // ---- which edges are kept, which nodes are variables, per-component sizes ----
     // (everything that starts at zero sits in one block: one memset instead of a dozen)
@@ -419,7 +444,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
     hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
-    hipLaunchKernelGGL(k_count_edges, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, is_var, kept, ce);
+    hipLaunchKernelGGL(k_count_edges, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, ce);
     hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, ts, tc, ct);
 
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
@@ -461,8 +486,13 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);
     hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
                        (uint64_t)C << node_bits, ek0, ei0);
+    if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
     if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_check_pairs, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted, eo, &sum->unpaired);
+    // (both directions of a match are kept or dropped together by construction - k_count_edges - and the sort is stable on the edge
+    // id, so the pair check only runs on request or on the path that materialises records)
+    if (!fused || getenv("LFR_CHECK_PAIRS"))
+        hipLaunchKernelGGL(k_check_pairs, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted, eo, &sum->unpaired);
+    if (fused) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
 
     // ---- descriptors + the device copies behind the lazily fetched host mirrors ----
     hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks);
@@ -487,9 +517,11 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- records: gather the flows (their first consumer); staged flows arrive in chunks on the copy stream ----
     // Every launch walks the whole edge list and keeps the edges of its rows, so chunks whose upload has already finished
     // (all of them when the graph is resident) go out as ONE launch: four filtered passes were 40 % of the gather.
-    const bool aligned8 = (((uintptr_t)dg.disp1 | (uintptr_t)dg.disp2) & 7u) == 0;
     const int n_chunks = dg.flows_staged ? kFlowChunks : 1;
-    for (int c = 0; c < n_chunks;) {
+    const bool emit = !fused || expect_workgroup_classes;          // (fused and no workgroup class expected: nothing to write; the summary has the last word)
+    if (!emit && dg.flows_staged)                                     // the solve reads the flows themselves: every chunk must have landed
+        for (int c = 0; c < n_chunks; ++c) if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
+    for (int c = 0; emit && c < n_chunks;) {
         int c2 = c + 1;
         if (dg.flows_staged) {
             auto landed = [&](int k) {
@@ -505,10 +537,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         if (hi > lo || (c == 0 && n_chunks == 1)) {
             if (aligned8)
                 hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges));
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr);
             else
                 hipLaunchKernelGGL(k_emit_edges<false>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges));
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr);
         }
         c = c2;
     }
@@ -522,6 +554,14 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
     if (!expect_workgroup_classes && out.summary.class_begin[KC_BLOCK] < out.summary.n_desc) {
         if ((rc = build_incidence()) != LFR_OK) return rc;
+        if (!emit) {                              // the records of the unexpected workgroup-class components after all (every chunk has landed)
+            if (aligned8)
+                hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges);
+            else
+                hipLaunchKernelGGL(k_emit_edges<false>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges);
+        }
         LFR_HIP_TRY(stream_wait(st));         // the temporaries go back to the cache at return
     }
     return LFR_OK;

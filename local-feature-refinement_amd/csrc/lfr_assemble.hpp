@@ -69,7 +69,8 @@ struct AsmSummary {
     uint32_t n_desc, total_nodes, total_edges, n_tracks;
     uint32_t class_begin[KC_COUNT + 1];
     uint32_t class_max_rows[KC_COUNT];   // largest system (rows) of every workgroup class
-    uint32_t too_big, unpaired, pad_;
+    uint32_t too_big, unpaired;
+    uint32_t packed_edges;               // records of the packed classes = the head of the edge order (the workgroup classes follow)
     uint64_t class_edges[KC_COUNT];
     uint64_t es_doubles, ws_doubles;     // per-edge scratch, + HBM matrices of the global class
 };
@@ -82,6 +83,11 @@ struct DeviceAssembly {                  // arrays inside the batch's slab (capa
     uint32_t *d_in_idx = nullptr;
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
     uint32_t *d_desc_component = nullptr, *d_desc_class = nullptr, *d_desc_tracks = nullptr;
+    // fused gather (whole batches over device-resident flows): the packed kernel reads its edges straight from the match-ordered
+    // arrays of the graph through edge_ref[p] = directed edge id of record p and edge_word[p] = src | (dst | kind << 15) << 16; the
+    // 80-byte records are only written for the workgroup classes
+    bool fused = false;
+    uint32_t *d_edge_ref = nullptr, *d_edge_word = nullptr;
     AsmSummary summary{};
 };
 // bytes of batch slab the assembly's outputs need for a graph of N nodes, M matches, C components

@@ -1,0 +1,70 @@
+"""Post-process the rocprofv3 output of scripts/profile_round3.sh (gpurun_out/prof_r03) into the summaries under profiles/ (runs here)."""
+import collections, csv, glob, json, os, re, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "prof_r03")
+prof = os.path.join(ROOT, "profiles")
+
+
+def short(name):
+    m = re.search(r"(solve_block_kernel<[^>]*>|solve_packed_kernel(<[^>]*>)?|solve_sky_kernel<[^>]*>|solve_group_kernel<[^>]*>)", name)
+    return m.group(1).replace(" ", "") if m else None
+
+
+def collect(prefix):
+    pm = collections.defaultdict(dict)
+    for d in sorted(glob.glob(os.path.join(out, prefix + "_*/"))):
+        fs = glob.glob(d + "*counter_collection.csv")
+        if not fs:
+            continue
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for row in csv.DictReader(open(fs[0])):
+            kn = short(row["Kernel_Name"])
+            if kn:
+                agg[kn][row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for kn, cs in agg.items():
+            for k, v in cs.items():
+                big = [x for x in v if x > 0.2 * max(v)] if max(v) > 0 else v      # drop the warm-up's toy launches
+                pm[kn][k] = {"dispatches": len(big), "mean_per_dispatch": sum(big) / max(1, len(big))}
+    return pm
+
+
+p4 = collect("pmc4")
+json.dump(p4, open(os.path.join(prof, "r03_pmc_solve_packed_kernel.json"), "w"), indent=1)
+p5 = collect("pmc5")
+blocks = {k: v for k, v in p5.items() if k.startswith("solve_block_kernel")}
+summary = {"workload": "config5 stand-in (scripts/prof_c5.py): one solve = the three LDS classes of solve_block_kernel, concurrent (+ a tiny packed launch)",
+           "source": "scripts/profile_round3.sh: separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; "
+                     "SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT; SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES) over python scripts/prof_c5.py; "
+                     "per-dispatch means per kernel, summed over the three kernels for the per-solve figures",
+           "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); units KB; WRITE_SIZE uncorrected",
+           "kernels": blocks}
+summary["hbm_bytes_per_solve"] = sum((2 * c["FETCH_SIZE"]["mean_per_dispatch"] + c["WRITE_SIZE"]["mean_per_dispatch"]) * 1024 for c in blocks.values() if "FETCH_SIZE" in c and "WRITE_SIZE" in c)
+for c in ("SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_WAIT_ANY", "SQ_INSTS_LDS", "SQ_LDS_BANK_CONFLICT", "SQ_BUSY_CYCLES", "SQ_INSTS_VALU_MFMA_MOPS_F64", "SQ_VALU_MFMA_BUSY_CYCLES"):
+    s = sum(cs[c]["mean_per_dispatch"] for cs in blocks.values() if c in cs)
+    if s:
+        summary[c] = s
+if summary.get("SQ_WAVE_CYCLES"):
+    summary["valu_busy"] = summary.get("SQ_ACTIVE_INST_VALU", 0) / summary["SQ_WAVE_CYCLES"]
+    summary["wait_fraction"] = summary.get("SQ_WAIT_ANY", 0) / summary["SQ_WAVE_CYCLES"]
+json.dump(summary, open(os.path.join(prof, "r03_pmc_config5.json"), "w"), indent=1)
+print(json.dumps({k: v for k, v in summary.items() if k not in ("kernels", "source", "correction", "workload")}, indent=1))
+# config 4: what bench.py reads for roofline.traffic
+pk = next((v for k, v in p4.items() if k.startswith("solve_packed_kernel")), None)
+dom = json.load(open(os.path.join(out, "r03_dominant_kernel_launches.json"))) if os.path.exists(os.path.join(out, "r03_dominant_kernel_launches.json")) else None
+if pk and "FETCH_SIZE" in pk:
+    old = json.load(open(os.path.join(prof, "pmc_traffic.json")))
+    full = max(dom["by_grid_size_x"].items(), key=lambda kv: kv[1]["launches"]) if dom else None
+    new = {"kernel": "solve_packed_kernel", "edges_per_launch": old["edges_per_launch"],
+           "FETCH_SIZE_KB": pk["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KB": pk["WRITE_SIZE"]["mean_per_dispatch"],
+           "hbm_bytes_per_launch": int((2 * pk["FETCH_SIZE"]["mean_per_dispatch"] + pk["WRITE_SIZE"]["mean_per_dispatch"]) * 1024),
+           "correction": old["correction"],
+           "valu_busy": pk["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pk["SQ_WAVE_CYCLES"]["mean_per_dispatch"] if "SQ_WAVE_CYCLES" in pk else None,
+           "sq": {k: v["mean_per_dispatch"] for k, v in pk.items() if k.startswith("SQ_")},
+           "rocprof_avg_launch_us": full[1]["avg_us"] if full else None, "rocprof_launches": full[1]["launches"] if full else None,
+           "source": "round 3: scripts/profile_round3.sh (rocprofv3 --kernel-trace --stats of python bench.py --steps 20 --warmup 3 --no-cpu-baseline; separate --pmc passes of "
+                     "python bench.py --steps 5 --warmup 1 --span-reps 1 --no-cpu-baseline --no-long-tracks --no-sparse), summarised by scripts/pmc_summarize.py"}
+    json.dump(new, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
+    print("pmc_traffic.json:", {k: new[k] for k in ("hbm_bytes_per_launch", "valu_busy", "rocprof_avg_launch_us")})
+for f in ("r03_bench_kernel_stats.csv", "r03_dominant_kernel_launches.json", "r03_bench_line_under_rocprof.json", "r03_bench_line.json"):
+    if os.path.exists(os.path.join(out, f)):
+        shutil.copy(os.path.join(out, f), os.path.join(prof, f))
