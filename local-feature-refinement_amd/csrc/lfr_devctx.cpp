@@ -158,6 +158,24 @@ hipStream_t DevCtx::side_stream(int i) {
     return s_side[i];
 }
 
+hipEvent_t DevCtx::event_acquire(bool timing) {
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        std::vector<hipEvent_t> &pool = timing ? free_ev_timing : free_ev_plain;
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    const hipError_t rc = timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    if (rc != hipSuccess) { set_error("hipEventCreate failed: %s", hipGetErrorString(rc)); return nullptr; }
+    return e;
+}
+void DevCtx::event_release(hipEvent_t e, bool timing) {
+    if (!e) return;
+    std::lock_guard<std::mutex> lk(mu);
+    std::vector<hipEvent_t> &pool = timing ? free_ev_timing : free_ev_plain;
+    if (pool.size() < 4096) pool.push_back(e); else (void)hipEventDestroy(e);
+}
+
 void DevCtx::trim() {
     std::vector<Slab> d, h;
     {

@@ -82,6 +82,11 @@ struct DevCtx {
     void *pinned_acquire(size_t bytes, size_t *got);
     void pinned_release(void *p, size_t bytes);
     void trim();                       // hipFree / hipHostFree everything cached
+    // events: a one-shot pipeline created ~25 of them per batch (a timing ring slot, fork/join) at 3-10 us apiece; they are pooled like
+    // the slabs.  A released event must have completed (the batch synchronises its streams before it lets go).
+    std::vector<hipEvent_t> free_ev_timing, free_ev_plain;
+    hipEvent_t event_acquire(bool timing);          // nullptr + set_error() on failure
+    void event_release(hipEvent_t e, bool timing);
 };
 // Wait for a stream the way a latency-bound pipeline wants it: poll hipStreamQuery for up to ~200 ms (the blocking
 // hipStreamSynchronize was measured returning 20-30 ms after the GPU had finished when the process had just run many

@@ -2187,9 +2187,13 @@ struct lfr_batch {
             (void)hipStreamSynchronize(ctx->s_main);
             if (h_positions) ctx->pinned_release(h_positions, h_positions_bytes);
         }
-        for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
-        if (ev_fork) (void)hipEventDestroy(ev_fork);
-        if (ev_order) (void)hipEventDestroy(ev_order);
+        if (ctx) {                                      // (every stream this batch used has been waited for above: the events are idle)
+            for (auto &e : ev_ring) ctx->event_release(e, true);
+            ctx->event_release(ev_fork, false);
+            ctx->event_release(ev_order, false);
+        } else {
+            for (auto &e : ev_ring) if (e) (void)hipEventDestroy(e);
+        }
         // slab / ws_slab return to the context's cache in their destructors
     }
 };
@@ -2236,9 +2240,9 @@ int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     const lfr::DevGraph &dg = *dp->graph;
     const int64_t N = dg.N, M = dg.M, C = p.stats.n_components;
     hipStream_t st = b->ctx->s_main;
-    hipEvent_t a0 = nullptr, a1 = nullptr;
-    struct EvGuard { hipEvent_t &x, &y; ~EvGuard() { if (x) (void)hipEventDestroy(x); if (y) (void)hipEventDestroy(y); } } guard{a0, a1};
-    HIP_TRY(hipEventCreate(&a0)); HIP_TRY(hipEventCreate(&a1));
+    hipEvent_t a0 = b->ctx->event_acquire(true), a1 = b->ctx->event_acquire(true);
+    struct EvGuard { lfr::DevCtx *c; hipEvent_t &x, &y; ~EvGuard() { c->event_release(x, true); c->event_release(y, true); } } guard{b->ctx, a0, a1};
+    if (!a0 || !a1) return LFR_ERR_HIP;
     HIP_TRY(hipEventRecord(a0, st));
     const size_t fixed = sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1) + sizeof(CompInfoDev) * (size_t)(C + 1) +
                          kProfWords * sizeof(unsigned long long) + ((size_t)1 << 16);
@@ -2689,7 +2693,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     int rc = p.host_batch ? create_from_host(b.get(), p, shard_rank, shard_world) : create_on_device(b.get(), p, shard_rank, shard_world);
     if (rc != LFR_OK) return rc;
     if ((rc = finish_workspace(b.get(), p)) != LFR_OK) return rc;
-    HIP_TRY(hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+    if (!(b->ev_fork = ctx->event_acquire(false))) return LFR_ERR_HIP;
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
         if (!(b->side_stream = ctx->side_stream(0))) return LFR_ERR_HIP;
         for (int cls = lfr::KC_BLOCK; cls < lfr::KC_COUNT; ++cls)
@@ -2710,7 +2714,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
                                keys, vals, wg_begin);
             HIP_TRY(hipGetLastError());
             HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, vals, b->d_wg_order, n_wg, 0, 27, so));
-            HIP_TRY(hipEventCreateWithFlags(&b->ev_order, hipEventDisableTiming));
+            if (!(b->ev_order = ctx->event_acquire(false))) return LFR_ERR_HIP;
             HIP_TRY(hipEventRecord(b->ev_order, so));
         }
         const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
@@ -2762,7 +2766,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     recorded = 0;
     ++b->n_solves;
     b->last_stream = st;
-    if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) HIP_TRY(hipEventCreate(&b->ev[i]));
+    if (!b->ev[0]) for (int i = 0; i < lfr_batch::kEvPerSlot; ++i) if (!(b->ev[i] = b->ctx->event_acquire(true))) return LFR_ERR_HIP;
     HIP_TRY(hipEventRecord(b->ev[0], st));
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {
         HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
