@@ -140,29 +140,54 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
         }
         heap[i] = v; pos[v] = i;
     };
-    while (vol0 * 2 < volume && n0 < n - 1 && hn > 0) {
+    // Round 3: the region does not stop at half of the volume - it grows on to three quarters and the prefix of the growth order
+    // with the SMALLEST normalized cut between a quarter and three quarters of the volume wins (ties -> the earliest); a graph
+    // that is a chain of clusters is then cut at a bottleneck instead of wherever half of the volume happens to be reached.
+    // scripts/cut_quality.py measures what that buys against a spectral sweep cut (profiles/r03_cut_quality.json).
+    auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
+    std::vector<int> order;
+    order.reserve(n);
+    int best_len = -1, half_len = -1;
+    double best_val = 1e300, best_cut = 0.0, best_vol = 0.0, half_cut = 0.0, half_vol = 0.0;
+    while (vol0 * 4 < 3 * volume && n0 < n - 1 && hn > 0) {
         const int best = heap[0];
         heap[0] = heap[--hn]; pos[heap[0]] = 0;
         if (hn > 0) sift_down(0);
-        in[best] = 1; side[best] = 0; vol0 += deg[best]; ++n0;
+        in[best] = 1; vol0 += deg[best]; ++n0;
+        order.push_back(best);
         cut += deg[best] - 2.0 * attach[best];            // its edges to the outside enter the cut, those to the region leave it
         for (uint32_t q = off[best]; q < off[best + 1]; ++q) {
             const int v = nbr[q].node;
             attach[v] += (double)nbr[q].w;
             if (!in[v]) sift_up(pos[v]);
         }
+        if (half_len < 0 && vol0 * 2 >= volume) { half_len = n0; half_cut = cut; half_vol = vol0; }
+        if (vol0 * 4 >= volume && vol0 * 4 <= 3 * volume) {
+            const double val = ncut(cut, vol0);
+            if (val < best_val) { best_val = val; best_len = n0; best_cut = cut; best_vol = vol0; }
+        }
     }
-    // one refinement sweep: move a node if it lowers cut/vol0 + cut/vol1
-    auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
-    for (int i = 0; i < n; ++i) {
-        double to_same = 0.0, to_other = 0.0;
-        for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nbr[q].node] == side[i] ? to_same : to_other) += (double)nbr[q].w;
-        const double ncut_now = ncut(cut, vol0);
-        const double c2 = cut + to_same - to_other;
-        const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
-        const int cnt0 = side[i] == 0 ? n0 - 1 : n0 + 1;
-        if (cnt0 <= 0 || cnt0 >= n) continue;
-        if (ncut(c2, v2) < ncut_now) { side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; }
+    if (best_len < 0) {                                   // no prefix inside the window (a node of huge degree): the round-2 rule
+        if (half_len < 0) { half_len = n0; half_cut = cut; half_vol = vol0; }
+        best_len = half_len; best_cut = half_cut; best_vol = half_vol;
+    }
+    for (int i = 0; i < best_len; ++i) side[order[i]] = 0;
+    cut = best_cut; vol0 = best_vol; n0 = best_len;
+    // refinement sweeps in node order: move a node if that lowers cut/vol0 + cut/vol1 (never emptying a side); up to eight sweeps,
+    // stopping with the first one that moves nothing
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        bool moved = false;
+        for (int i = 0; i < n; ++i) {
+            double to_same = 0.0, to_other = 0.0;
+            for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nbr[q].node] == side[i] ? to_same : to_other) += (double)nbr[q].w;
+            const double ncut_now = ncut(cut, vol0);
+            const double c2 = cut + to_same - to_other;
+            const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
+            const int cnt0 = side[i] == 0 ? n0 - 1 : n0 + 1;
+            if (cnt0 <= 0 || cnt0 >= n) continue;
+            if (ncut(c2, v2) < ncut_now) { side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; moved = true; }
+        }
+        if (!moved) break;
     }
 }
 

@@ -179,8 +179,10 @@ def test_shards_partition_the_solvable_components(lfr_lib):
 def _bisect_spec(edges, weights):
     """The product's two-way cut as DESIGN.md section 3 / lfr_graph.cpp describe it, restated naively (O(n^2)):
     nodes = sorted endpoints; weights max(w, 1) as doubles; maximum-adjacency region growing from attachment 0 (ties ->
-    smallest node) until half of the edge-weight volume is inside (or one node is left outside); then ONE sweep in node
-    order moving a node when that lowers cut/vol0 + cut/vol1 (never emptying a side)."""
+    smallest node) until three quarters of the edge-weight volume are inside (or one node is left outside); the prefix of the
+    growth order with the smallest normalized cut among those holding between a quarter and three quarters of the volume wins
+    (ties -> the earliest; no such prefix: the first one holding half of the volume, or the whole growth); then up to eight sweeps
+    in node order moving a node when that lowers cut/vol0 + cut/vol1 (never emptying a side), ending with the first idle sweep."""
     ids = sorted({a for a, _ in edges} | {b for _, b in edges})
     n = len(ids)
     loc = {v: i for i, v in enumerate(ids)}
@@ -190,27 +192,48 @@ def _bisect_spec(edges, weights):
     for (a, b), w in zip(edges, weights):
         w = float(max(int(w), 1)); a = loc[a]; b = loc[b]
         adj[a].append((b, w)); adj[b].append((a, w)); deg[a] += w; deg[b] += w; volume += 2 * w
-    side = [1] * n; attach = [0.0] * n; inside = [False] * n
-    vol0, n0 = 0.0, 0
-    while vol0 * 2 < volume and n0 < n - 1:
-        best = max((i for i in range(n) if not inside[i]), key=lambda i: (attach[i], -i))
-        inside[best] = True; side[best] = 0; vol0 += deg[best]; n0 += 1
-        for v, w in adj[best]:
-            attach[v] += w
-    cut = sum(w for i in range(n) if side[i] == 0 for v, w in adj[i] if side[v] == 1)
 
     def ncut(c, v0):
         v1 = volume - v0
         return c / v0 + c / v1 if v0 > 0 and v1 > 0 else 1e300
-    for i in range(n):
-        same = sum(w for v, w in adj[i] if side[v] == side[i]); other = sum(w for v, w in adj[i] if side[v] != side[i])
-        c2 = cut + same - other
-        v2 = vol0 - deg[i] if side[i] == 0 else vol0 + deg[i]
-        cnt0 = n0 - 1 if side[i] == 0 else n0 + 1
-        if cnt0 <= 0 or cnt0 >= n:
-            continue
-        if ncut(c2, v2) < ncut(cut, vol0):
-            side[i] ^= 1; cut, vol0, n0 = c2, v2, cnt0
+    attach = [0.0] * n; inside = [False] * n
+    vol0, n0, cut = 0.0, 0, 0.0
+    order = []
+    best, half = None, None
+    while vol0 * 4 < 3 * volume and n0 < n - 1:
+        pick = max((i for i in range(n) if not inside[i]), key=lambda i: (attach[i], -i))
+        inside[pick] = True; vol0 += deg[pick]; n0 += 1; order.append(pick)
+        cut += deg[pick] - 2.0 * attach[pick]
+        for v, w in adj[pick]:
+            attach[v] += w
+        if half is None and vol0 * 2 >= volume:
+            half = (n0, cut, vol0)
+        if vol0 * 4 >= volume and vol0 * 4 <= 3 * volume:
+            val = ncut(cut, vol0)
+            if best is None or val < best[0]:
+                best = (val, n0, cut, vol0)
+    if best is None:
+        if half is None:
+            half = (n0, cut, vol0)
+        n0, cut, vol0 = half
+    else:
+        _, n0, cut, vol0 = best
+    side = [1] * n
+    for i in order[:n0]:
+        side[i] = 0
+    for _ in range(8):
+        moved = False
+        for i in range(n):
+            same = sum(w for v, w in adj[i] if side[v] == side[i]); other = sum(w for v, w in adj[i] if side[v] != side[i])
+            c2 = cut + same - other
+            v2 = vol0 - deg[i] if side[i] == 0 else vol0 + deg[i]
+            cnt0 = n0 - 1 if side[i] == 0 else n0 + 1
+            if cnt0 <= 0 or cnt0 >= n:
+                continue
+            if ncut(c2, v2) < ncut(cut, vol0):
+                side[i] ^= 1; cut, vol0, n0 = c2, v2, cnt0; moved = True
+        if not moved:
+            break
     return {ids[i]: side[i] for i in range(n)}
 
 
