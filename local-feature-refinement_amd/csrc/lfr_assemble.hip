@@ -391,6 +391,31 @@ int exclusive_sum(DevArena &arena, const T *in, T *out, int64_t n, hipStream_t s
 
 }  // namespace
 
+int warm_assembly_primitives(DevCtx *ctx) {
+    hipStream_t st = ctx->s_main;
+    LFR_HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t sizes[2] = {100000, (int64_t)4 << 20};
+    DevArena arena;
+    if (!arena.init(ctx, (size_t)sizes[1] * 64 + ((size_t)64 << 20))) return LFR_ERR_NOMEM;
+    const int64_t nmax = sizes[1];
+    uint64_t *k64a = arena.take_n<uint64_t>(nmax), *k64b = arena.take_n<uint64_t>(nmax);
+    uint32_t *k32a = arena.take_n<uint32_t>(nmax), *k32b = arena.take_n<uint32_t>(nmax), *v32a = arena.take_n<uint32_t>(nmax), *v32b = arena.take_n<uint32_t>(nmax);
+    if (!k64a || !k64b || !k32a || !k32b || !v32a || !v32b) { set_error("warm-up arena exhausted"); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipMemsetAsync(k64a, 0x5a, 8 * (size_t)nmax, st));
+    LFR_HIP_TRY(hipMemsetAsync(k32a, 0x3c, 4 * (size_t)nmax, st));
+    LFR_HIP_TRY(hipMemsetAsync(v32a, 0, 4 * (size_t)nmax, st));
+    int rc = LFR_OK;
+    for (const int64_t n : sizes) {
+        if ((rc = sort_pairs(arena, k32a, k32b, v32a, v32b, n, 0, 20, st)) != LFR_OK) return rc;
+        if ((rc = sort_pairs(arena, k64a, k64b, v32a, v32b, n, 0, 44, st)) != LFR_OK) return rc;
+        if ((rc = sort_pairs(arena, reinterpret_cast<unsigned long long *>(k64a), reinterpret_cast<unsigned long long *>(k64b), v32a, v32b, n, 0, 52, st)) != LFR_OK) return rc;
+        if ((rc = exclusive_sum(arena, v32a, v32b, n, st)) != LFR_OK) return rc;
+        if ((rc = exclusive_sum(arena, reinterpret_cast<unsigned long long *>(k64a), reinterpret_cast<unsigned long long *>(k64b), n, st)) != LFR_OK) return rc;
+    }
+    LFR_HIP_TRY(stream_wait(st));
+    return rc;
+}
+
 size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C) {
     const size_t E2 = (size_t)2 * M, n = (size_t)N, c = (size_t)C + 1;
     return sizeof(CompDesc) * c + sizeof(EdgeRec) * E2 + 4 * n + sizeof(NodeInc) * n + 4 * E2 + 8 * E2 + 16 * c + 12 * c + 256 * 18;

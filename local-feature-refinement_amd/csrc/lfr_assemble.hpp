@@ -96,6 +96,13 @@ size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C);
 // out of `slab`; synchronises s_main once, at the end.
 int assemble_on_device(const Problem &p, const DevProblem &labels, int shard_rank, int shard_world, DevArena &slab, DeviceAssembly &out);
 
+// Warm-up: rocPRIM picks other kernels once its inputs are large (one-sweep radix sort above ~1 M items, block + merge sort below,
+// look-back scans) and HIP loads every kernel's code on its first launch; a toy graph never reaches the large-input variants, so a
+// one-shot caller's "Total time" was spent loading them (tracks 28 ms against 2 ms).  These run every sort / scan instantiation of
+// their translation unit once at both sizes over scratch memory (a few ms of GPU time, no host-side graph).
+int warm_graphstage_primitives(DevCtx *ctx);
+int warm_assembly_primitives(DevCtx *ctx);
+
 // shard of the i-th solvable component in batch order (class, edges descending, ...): dealt out and back
 // (0..W-1, W-1..0, ...), so every shard receives the same mix of kernel classes and sizes
 __host__ __device__ inline int snake_shard(int64_t i, int world) {

@@ -2506,6 +2506,8 @@ int lfr_hip_warmup(int device) {
         }
         lfr_batch_free(bt); lfr_problem_free(pr); lfr_graph_free(g);
     }
+    // the large-input sort / scan kernels of the graph stage and of the assembly (the toy graph only reached the small-input ones)
+    if (lfr::warm_graphstage_primitives(ctx) != LFR_OK || lfr::warm_assembly_primitives(ctx) != LFR_OK) return LFR_OK;     // best effort
     if (level < 2) return LFR_OK;
     // rocPRIM picks other kernels (one-sweep radix sort, look-back scans) once the inputs are large: a second pass with a
     // million matches (170 k four-node tracks, zero flows) resolves those as well, so that a one-shot caller's
@@ -3084,15 +3086,21 @@ int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iter
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions, lfr_solve_stats *stats) {
     if (!p || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     lfr_batch *b = nullptr;
+    const auto tc0 = std::chrono::steady_clock::now();
     int rc = lfr_batch_create(p, device, 0, 1, tukey_variant, &b);
     if (rc != LFR_OK) return rc;
     std::unique_ptr<lfr_batch> guard(b);
-    lfr_solve_stats local;
-    rc = lfr_batch_solve(b, b->ctx->s_main, stats ? stats : &local);
+    const auto tc1 = std::chrono::steady_clock::now();
+    rc = lfr_batch_solve(b, b->ctx->s_main, stats);         // (no statistics asked for: nothing but the positions leaves the device)
     if (rc != LFR_OK) return rc;
     const auto t0 = std::chrono::steady_clock::now();
     rc = lfr_batch_download(b, positions);
-    if (stats) stats->d2h_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    const auto t1 = std::chrono::steady_clock::now();
+    if (stats) stats->d2h_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (getenv("LFR_VERBOSE") || getenv("LFR_TIMING"))
+        fprintf(stderr, "lfr: lfr_solve_hip wall: batch creation %.3f ms, solve (+ statistics) %.3f ms, download %.3f ms\n",
+                std::chrono::duration<double, std::milli>(tc1 - tc0).count(), std::chrono::duration<double, std::milli>(t0 - tc1).count(),
+                std::chrono::duration<double, std::milli>(t1 - t0).count());
     return rc;
 }
 

@@ -374,13 +374,14 @@ class Problem:
         lib().lfr_problem_shard_components(self._h, rank, world, _ptr(comps), _ptr(edges))
         return comps, edges
 
-    def solve_hip(self, device=0, tukey_variant="ceres1"):
-        """Upload + solve + download on one GPU.  Returns (positions[n,2], stats dict)."""
+    def solve_hip(self, device=0, tukey_variant="ceres1", want_stats=True):
+        """Upload + solve + download on one GPU.  Returns (positions[n,2], stats dict or None).  want_stats=False skips the statistics
+        (they fetch every descriptor and per-component record to the host: 15-20 ms for 147 k components, several times the solve)."""
         n = self.graph.n_nodes
-        pos = np.zeros((n, 2), np.float64)
+        pos = np.empty((n, 2), np.float64)                  # (fully written by the download: every node, zeros where nothing was solved)
         st = SolveStats()
-        _check(lib().lfr_solve_hip(self._h, device, TUKEY[tukey_variant], _ptr(pos), C.byref(st)))
-        return pos, st.as_dict()
+        _check(lib().lfr_solve_hip(self._h, device, TUKEY[tukey_variant], _ptr(pos), C.byref(st) if want_stats else None))
+        return pos, (st.as_dict() if want_stats else None)
 
 
 def solve_hip_multi(problem, devices, tukey_variant="ceres1"):

