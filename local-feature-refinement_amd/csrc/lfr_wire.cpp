@@ -566,6 +566,13 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
     run_threads(TB, [&](int t) {
         MatchBuf &b = bufs[t];
         ChunkNames &cn = cnames[t];
+        {   // one allocation per array instead of geometric growth (a match is >= ~170 bytes on the wire with its two 9-point grids;
+            // re-growing 5 x ~20 MB vectors per thread cost a third of the decode)
+            size_t bytes = 0;
+            for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) bytes += (size_t)(pairs[i].end - pairs[i].p);
+            const size_t est = bytes / 170 + 64;
+            b.f1.reserve(est); b.f2.reserve(est); b.sim.reserve(est); b.d1.reserve(18 * est); b.d2.reserve(18 * est);
+        }
         const char *last1 = nullptr; uint32_t last1_len = 0; int32_t last1_id = -1;
         for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
             recs[i].buf = t;
@@ -655,17 +662,60 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
         });
     });
     const int64_t n_new = M - M0;
+    const int64_t N0 = g.n_nodes();
+    // (image, feature) -> slot.  Feature indices are dense small integers per image in real inputs (the running index of the
+    // extractor's keypoint list), so the slot is img_off[image] + feature in a table of sum(max feature + 1) entries - 7 MB for
+    // config 4, cache resident - instead of a 120 MB open-addressing table whose every touch and lookup misses (round 2: 100 of
+    // the scanner's 270 ms).  Inputs with sparse feature indices (the table would exceed 4 slots per endpoint) keep the hash table.
+    const size_t n_img = g.image_names.size();
+    std::vector<uint64_t> img_off(n_img + 1, 0);
+    bool dense = true;
+    {
+        std::vector<std::vector<uint32_t>> tmax(TB, std::vector<uint32_t>());
+        std::vector<uint32_t> gmax(n_img, 0);
+        std::vector<uint8_t> seen(n_img, 0);
+        run_threads(TB, [&](int t) {
+            std::vector<uint32_t> &mx = tmax[t];
+            mx.assign(2 * n_img, 0);                                     // [2 i] = max feature, [2 i + 1] = seen
+            for (int64_t i = cuts[t]; i < cuts[t + 1]; ++i) {
+                const PairRec &r = recs[i];
+                if (r.count <= 0) continue;
+                const size_t a1 = (size_t)cglobal[t][loc1[i]], a2 = (size_t)cglobal[t][loc2[i]];
+                const MatchBuf &bb = bufs[r.buf];
+                uint32_t m1 = mx[2 * a1], m2 = mx[2 * a2];
+                for (int64_t k = 0; k < r.count; ++k) { m1 = std::max(m1, bb.f1[r.first + k]); m2 = std::max(m2, bb.f2[r.first + k]); }
+                mx[2 * a1] = std::max(mx[2 * a1], m1); mx[2 * a1 + 1] = 1;
+                mx[2 * a2] = std::max(mx[2 * a2], m2); mx[2 * a2 + 1] = 1;
+            }
+        });
+        for (int t = 0; t < TB; ++t)
+            for (size_t i = 0; i < n_img; ++i) if (tmax[t][2 * i + 1]) { gmax[i] = std::max(gmax[i], tmax[t][2 * i]); seen[i] = 1; }
+        for (int64_t n = 0; n < N0; ++n) { const size_t im = (size_t)g.node_image[n]; gmax[im] = std::max(gmax[im], g.node_feat[n]); seen[im] = 1; }
+        const uint64_t budget = 4 * (uint64_t)(2 * n_new + N0) + ((uint64_t)1 << 20);
+        for (size_t i = 0; i < n_img; ++i) {
+            img_off[i + 1] = img_off[i] + (seen[i] ? (uint64_t)gmax[i] + 1 : 0);
+            if (img_off[i + 1] > budget) { dense = false; break; }
+        }
+        if (const char *e = getenv("LFR_SCANNER_DENSE_NODES")) dense = dense && e[0] != '0';       // (tests: force the hash table)
+    }
     // existing nodes of the graph (an earlier call on the same handle): seed the map with their ids
     uint64_t cap = 1024;
-    while (cap < (uint64_t)(2 * n_new + g.n_nodes()) * 3 / 2 + 16) cap <<= 1;        // load <= 2/3 even if every endpoint is a new node
+    if (dense) cap = std::max<uint64_t>(img_off[n_img], 1);
+    else while (cap < (uint64_t)(2 * n_new + g.n_nodes()) * 3 / 2 + 16) cap <<= 1;     // load <= 2/3 even if every endpoint is a new node
     std::unique_ptr<NodeSlot[]> slots(new NodeSlot[cap]);
     const uint64_t mask = cap - 1;
     run_threads(TB, [&](int t) {
         const uint64_t lo = cap / TB * t, hi = t == TB - 1 ? cap : cap / TB * (t + 1);
         for (uint64_t k = lo; k < hi; ++k) { slots[k].key.store(0, std::memory_order_relaxed); slots[k].val.store(~0ull, std::memory_order_relaxed); }
     });
-    const int64_t N0 = g.n_nodes();
+    auto dense_slot = [&](uint64_t key) -> uint64_t { return img_off[(size_t)(key >> 32)] + (uint32_t)key; };
     auto touch = [&](uint64_t key, uint64_t pos) {
+        if (dense) {
+            std::atomic<uint64_t> &val = slots[dense_slot(key)].val;
+            uint64_t v = val.load(std::memory_order_relaxed);
+            while (pos < v && !val.compare_exchange_weak(v, pos, std::memory_order_relaxed)) {}
+            return;
+        }
         uint64_t h = mix64(key) & mask;
         for (;;) {
             uint64_t cur = slots[h].key.load(std::memory_order_acquire);
@@ -704,8 +754,10 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
     if (cap >= ((uint64_t)1 << 32)) { mover.join(); set_error("matches file too large for the node table"); return LFR_ERR_UNSUPPORTED; }
     run_threads(TB, [&](int t) {
         const uint64_t lo = cap / TB * t, hi = t == TB - 1 ? cap : cap / TB * (t + 1);
-        for (uint64_t k = lo; k < hi; ++k)
-            if (slots[k].key.load(std::memory_order_relaxed)) slot_at[slots[k].val.load(std::memory_order_relaxed)] = (uint32_t)k + 1;
+        for (uint64_t k = lo; k < hi; ++k) {
+            const uint64_t v = slots[k].val.load(std::memory_order_relaxed);
+            if (dense ? v != ~0ull : slots[k].key.load(std::memory_order_relaxed) != 0) slot_at[v] = (uint32_t)k + 1;
+        }
     });
     std::vector<int64_t> chunk_count(TB + 1, 0);
     run_threads(TB, [&](int t) {
@@ -721,14 +773,20 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
         int64_t n = chunk_count[t];
         for (uint64_t q = n_pos * t / TB; q < n_pos * (t + 1) / TB; ++q) {
             if (!slot_at[q]) continue;
-            NodeSlot &sl = slots[slot_at[q] - 1];
-            const uint64_t key = sl.key.load(std::memory_order_relaxed) - 1;
+            const uint64_t k = slot_at[q] - 1;
+            NodeSlot &sl = slots[k];
+            uint64_t key;
+            if (dense) {
+                const size_t im = (size_t)(std::upper_bound(img_off.begin(), img_off.end(), k) - img_off.begin()) - 1;
+                key = ((uint64_t)im << 32) | (uint32_t)(k - img_off[im]);
+            } else key = sl.key.load(std::memory_order_relaxed) - 1;
             sl.val.store((uint64_t)n, std::memory_order_relaxed);                        // position -> node id
             if (n >= N0) { g.node_image[n] = (int32_t)(key >> 32); g.node_feat[n] = (uint32_t)key; }
             ++n;
         }
     });
     auto lookup = [&](uint64_t key) -> uint32_t {
+        if (dense) return (uint32_t)slots[dense_slot(key)].val.load(std::memory_order_relaxed);
         uint64_t h = mix64(key) & mask;
         while (slots[h].key.load(std::memory_order_relaxed) != key + 1) h = (h + 1) & mask;
         return (uint32_t)slots[h].val.load(std::memory_order_relaxed);

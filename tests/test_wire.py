@@ -225,7 +225,8 @@ def _graph_signature(g):
 
 @pytest.mark.parametrize("n_parts", [1, 3])
 @pytest.mark.parametrize("banned", [(), ("000003.png", "000011.png")])
-def test_parallel_scanner_equals_the_sequential_one(lfr_lib, tmp_path, monkeypatch, n_parts, banned):
+@pytest.mark.parametrize("features", ["dense", "sparse"])
+def test_parallel_scanner_equals_the_sequential_one(lfr_lib, tmp_path, monkeypatch, n_parts, banned, features):
     """the whole-input parallel scanner (first-appearance = minimum position: images, first facts,
     node ids) against the file-by-file scanner with the sequential numbering pass, on `.part.N` files (solve.cc:416-424),
     with banned images (solve.cc:444-446), differing facts for one image (first wins, solve.cc:449-451) and
@@ -233,6 +234,9 @@ def test_parallel_scanner_equals_the_sequential_one(lfr_lib, tmp_path, monkeypat
     import numpy as np
     from lfr_amd import capi, synthetic
     ma = synthetic.generate(seed=31, n_images=16, n_tracks=400, eps_out=0.02)
+    if features == "sparse":        # feature indices all over 32 bits: the node table is the hash map, not the per-image dense table
+        ma.feat1 = ((ma.feat1.astype(np.uint64) * 1000003 + 17) % (1 << 32)).astype(np.uint32)
+        ma.feat2 = ((ma.feat2.astype(np.uint64) * 1000003 + 17) % (1 << 32)).astype(np.uint32)
     pairs = ma.to_pairs()
     pairs[5]["fact1"] = 0.5                                   # a later, different fact for an image seen before: ignored
     pairs[7]["matches"] = pairs[7]["matches"] + pairs[7]["matches"][:2]      # duplicates are kept (solve.cc:476-478)
