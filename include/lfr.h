@@ -62,6 +62,13 @@ int lfr_graph_from_files(const char *const *paths, int n_paths, const char *cons
  * then behave as lfr_graph_from_files. */
 int lfr_graph_from_matches_file(const char *path, const char *const *banned, int n_banned, lfr_graph **out);
 
+/* lfr_graph_from_matches_file + lfr_graph_to_device(device) in one call, with the two overlapped: the flows (144 of the 164 bytes per
+ * match) start their way to HBM as soon as the scanner has them in place, while it still numbers the nodes; endpoints, similarities and
+ * node images follow before the call returns (asynchronously: the pipeline's stream waits for them, the caller does not).  The graph and
+ * every result are identical to the two-call form; a device that cannot be initialised is LFR_ERR_HIP.  This is the ingest the `solve`
+ * drop-in uses: the reference's "Total time" (solve.cc:487) starts after the file is in memory, ours after it is in HBM or on its way. */
+int lfr_graph_from_matches_file_device(const char *path, const char *const *banned, int n_banned, int device, lfr_graph **out);
+
 /* Same graph from flat arrays — the producer contract of compute_match_graph.py:163-187 without
  * the protobuf hop.  pair_img1/2[p]: image index of ImagePair p; matches of pair p are
  * [pair_off[p], pair_off[p+1]); disp1/disp2: n_matches x 18 float32 (grid_idx*2 + {di,dj}),

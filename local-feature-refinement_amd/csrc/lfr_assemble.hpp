@@ -35,6 +35,8 @@ struct DevGraph {
     uint32_t *flow_row = nullptr;        // caller-owned device flows are indexed by their original row
     const float *disp1 = nullptr, *disp2 = nullptr;   // flows in match order: HBM (staged / caller-owned) or pinned host (zero copy)
     bool flows_staged = false, flows_zero_copy = false, flows_external = false;
+    bool endpoints_pending = false;      // created by prestage_flows while the scanner was still numbering nodes: n1/n2/sim/node_image not sent yet
+    int64_t N_cap = 0;                   // nodes the slab has room for (prestage_flows sizes it from a bound)
     // staged flows travel in kFlowChunks chunks of matches [chunk_row[c], chunk_row[c+1]) on s_copy; ev_flows[c] fires
     // when chunk c has landed, so the assembly gathers a chunk while the next one is still on the wire
     hipEvent_t ev_flows[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -45,6 +47,9 @@ struct DevGraph {
 // stage_flows: copy the flows to HBM asynchronously on s_copy; otherwise leave them where they are
 // (pinned host memory is read zero-copy by the assembly; pageable memory is staged after all).
 int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_ptr<DevGraph> &out);
+// prestage_flows (lfr_internal.hpp; lfr_graph_from_matches_file_device): called by the scanner the moment the flow arrays are complete - the
+// node numbering is still running - so that the 144 B per match are in HBM when the parse returns.  n_bound >= the final node count.
+// Failures are not errors: the graph simply is not resident yet and ensure_dev_graph does everything later.
 
 struct DevProblem {
     DevCtx *ctx = nullptr;

@@ -449,10 +449,53 @@ static int stage_flows_now(const Graph &g, DevGraph &dg) {
     return LFR_OK;
 }
 
+static int send_endpoints(const Graph &g, DevGraph &dg) {
+    const int64_t N = g.n_nodes(), M = dg.M;
+    hipStream_t st = dg.ctx->s_main;
+    if (M > 0) {
+        LFR_HIP_TRY(hipMemcpyAsync(dg.n1, g.m_node1.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+        LFR_HIP_TRY(hipMemcpyAsync(dg.n2, g.m_node2.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+        LFR_HIP_TRY(hipMemcpyAsync(dg.sim, g.m_sim.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+    }
+    if (N > 0) LFR_HIP_TRY(hipMemcpyAsync(dg.node_image, g.node_image.data(), (size_t)4 * N, hipMemcpyHostToDevice, st));
+    dg.N = N;
+    dg.endpoints_pending = false;
+    return LFR_OK;
+}
+
+void prestage_flows(const Graph &g, int device, int64_t n_bound) {
+    const int64_t M = (int64_t)(g.m_disp1.size() / 18);
+    if (device < 0 || M <= 0 || M >= ((int64_t)1 << 30) || n_bound >= ((int64_t)1 << 31)) return;
+    if (!(g.m_disp1.pinned() && g.m_disp2.pinned()) || g.dev_disp1) return;
+    std::lock_guard<std::mutex> lk(g.dev_mu);
+    if ((int)g.devgs.size() <= device) g.devgs.resize(device + 1);
+    if (g.devgs[device]) return;
+    DevCtx *ctx = dev_ctx(device);
+    if (!ctx || hipSetDevice(device) != hipSuccess) return;
+    std::shared_ptr<DevGraph> dg(new DevGraph());
+    dg->ctx = ctx; dg->N = 0; dg->N_cap = n_bound; dg->M = M;
+    const size_t bytes = (size_t)16 * M + (size_t)4 * n_bound + (size_t)144 * M + ((size_t)1 << 16);
+    if (!dg->slab.init(ctx, bytes)) return;
+    dg->n1 = dg->slab.take_n<uint32_t>(M); dg->n2 = dg->slab.take_n<uint32_t>(M);
+    dg->sim = dg->slab.take_n<float>(M); dg->node_image = dg->slab.take_n<int32_t>(n_bound);
+    if (stage_flows_now(g, *dg) != LFR_OK) return;
+    dg->endpoints_pending = true;
+    g.devgs[device] = dg;
+}
+
 int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_ptr<DevGraph> &out) {
     if (device < 0) { set_error("bad device ordinal %d", device); return LFR_ERR_ARG; }
     std::lock_guard<std::mutex> lk(g.dev_mu);
     if ((int)g.devgs.size() <= device) g.devgs.resize(device + 1);
+    if (g.devgs[device] && g.devgs[device]->endpoints_pending) {          // the scanner sent the flows ahead
+        DevGraph &dg = *g.devgs[device];
+        if (dg.M != g.n_matches() || g.n_nodes() > dg.N_cap) g.devgs[device].reset();     // (cannot happen; rebuild rather than trust it)
+        else {
+            LFR_HIP_TRY(hipSetDevice(device));
+            const int rc = send_endpoints(g, dg);
+            if (rc != LFR_OK) { g.devgs[device].reset(); return rc; }
+        }
+    }
     if (g.devgs[device]) {
         if (stage_flows && g.devgs[device]->flows_zero_copy) g.devgs[device].reset();   // a whole-problem batch after a sharded one: rebuild with staged flows
         else { out = g.devgs[device]; return LFR_OK; }
@@ -467,7 +510,7 @@ int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_p
     const int64_t N = g.n_nodes(), M = g.n_matches();
     if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) { set_error("graph too large for the device pipeline"); return LFR_ERR_UNSUPPORTED; }
     std::shared_ptr<DevGraph> dg(new DevGraph());
-    dg->ctx = ctx; dg->N = N; dg->M = M;
+    dg->ctx = ctx; dg->N = N; dg->N_cap = N; dg->M = M;
     const bool external = g.dev_disp1 && g.dev_disp2;
     const bool host_pinned = g.m_disp1.pinned() && g.m_disp2.pinned();
     const bool stage = !external && (stage_flows || !host_pinned);      // pageable flows cannot be read zero-copy
@@ -476,12 +519,10 @@ int ensure_dev_graph(const Graph &g, int device, bool stage_flows, std::shared_p
     dg->n1 = dg->slab.take_n<uint32_t>(M); dg->n2 = dg->slab.take_n<uint32_t>(M);
     dg->sim = dg->slab.take_n<float>(M); dg->node_image = dg->slab.take_n<int32_t>(N);
     hipStream_t st = ctx->s_main;
-    if (M > 0) {
-        LFR_HIP_TRY(hipMemcpyAsync(dg->n1, g.m_node1.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
-        LFR_HIP_TRY(hipMemcpyAsync(dg->n2, g.m_node2.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
-        LFR_HIP_TRY(hipMemcpyAsync(dg->sim, g.m_sim.data(), (size_t)4 * M, hipMemcpyHostToDevice, st));
+    {
+        const int rc = send_endpoints(g, *dg);
+        if (rc != LFR_OK) return rc;
     }
-    if (N > 0) LFR_HIP_TRY(hipMemcpyAsync(dg->node_image, g.node_image.data(), (size_t)4 * N, hipMemcpyHostToDevice, st));
     if (external) {
         dg->disp1 = g.dev_disp1; dg->disp2 = g.dev_disp2; dg->flows_external = true;
         if (!g.m_flow_row.empty()) {
@@ -895,6 +936,11 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     return LFR_OK;
 }
 
+int graph_make_resident(const Graph &g, int device) {
+    std::shared_ptr<DevGraph> dg;
+    return ensure_dev_graph(g, device, true, dg);
+}
+
 }  // namespace lfr
 
 // =================================================================================================
@@ -904,8 +950,7 @@ extern "C" {
 
 int lfr_graph_to_device(const lfr_graph *g, int device) {
     if (!g) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
-    std::shared_ptr<lfr::DevGraph> dg;
-    return lfr::ensure_dev_graph(g->g, device, true, dg);
+    return lfr::graph_make_resident(g->g, device);
 }
 
 int lfr_graph_evict_device(const lfr_graph *g) {

@@ -55,6 +55,7 @@ struct Graph {
     // the graph's copy in HBM (lfr_assemble.hpp), created on first use by the device pipeline or by
     // lfr_graph_to_device, dropped by lfr_graph_evict_device
     mutable std::vector<std::shared_ptr<DevGraph>> devgs;      // indexed by HIP device ordinal
+    int prefetch_device = -1;          // ingest straight to this device: the scanner starts the flows' upload when they are in place
     mutable std::mutex dev_mu;
 
     // The device graph stage sums similarities with atomics (root scores, meta-edge weights): order independent - and therefore
@@ -174,6 +175,10 @@ std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>
 // (solve.cc:192): returns part (0/1) per node id appearing in `edges`.
 void bisect_graph(const std::vector<std::pair<int, int>> &edges, const std::vector<int> &weights,
                   std::unordered_map<int, int> &part);
+
+// device residency of a graph, callable from host-only translation units (defined in lfr_graphstage.hip)
+void prestage_flows(const Graph &g, int device, int64_t n_bound);   // scanner: the flows are complete, start their upload (best effort)
+int graph_make_resident(const Graph &g, int device);                // = lfr_graph_to_device
 
 // ------------------------------------------------------------------------------------------
 // Block-envelope plan of a KC_GLOBAL component (lfr_order.cpp): the variable nodes renumbered so that the

@@ -2508,6 +2508,21 @@ int lfr_hip_warmup(int device) {
     }
     // the large-input sort / scan kernels of the graph stage and of the assembly (the toy graph only reached the small-input ones)
     if (lfr::warm_graphstage_primitives(ctx) != LFR_OK || lfr::warm_assembly_primitives(ctx) != LFR_OK) return LFR_OK;     // best effort
+    // The first LARGE device-to-host copy of a process takes ~7 ms longer than the next one (the toy graph's 300 bytes take another
+    // path; measured with the kernel trace of the CLI: the positions' copy started 7.3 ms after the solve kernel had ended): one 8-MB
+    // copy between scratch buffers here.
+    {
+        size_t db = 0, hb = 0;
+        const size_t bytes = (size_t)8 << 20;
+        void *d = ctx->dev_acquire(bytes, &db);
+        void *h = ctx->pinned_acquire(bytes, &hb);
+        if (d && h) {
+            (void)hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->s_main);
+            (void)hipStreamSynchronize(ctx->s_main);
+        }
+        if (d) ctx->dev_release(d, db);
+        if (h) ctx->pinned_release(h, hb);
+    }
     if (level < 2) return LFR_OK;
     // rocPRIM picks other kernels (one-sweep radix sort, look-back scans) once the inputs are large: a second pass with a
     // million matches (170 k four-node tracks, zero flows) resolves those as well, so that a one-shot caller's

