@@ -170,6 +170,11 @@ void lfr_problem_free(lfr_problem *p);
  * ascending order and their side (0/1) - 2 * n_edges entries are always enough - and returns their count. */
 int64_t lfr_bisect_graph(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
                          int32_t *nodes, int32_t *part);
+/* The whole size-cap recursion (the product's restatement of recursive_graph_cut, solve.cc:185-250, around lfr_bisect_graph): subset index
+ * of every node that has an edge, nodes ascending; node_weights[id] for every id below n_node_weights.  For checkers (the oracles run their
+ * own literal recursion around lfr_bisect_graph; the two must agree) and for timing the host part of the cut.  Returns the node count. */
+int64_t lfr_debug_recursive_cut(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
+                                int64_t n_node_weights, const int64_t *node_weights, int64_t max_weight, int32_t *nodes, int32_t *subset);
 /* The fill-reducing order + block envelope the solver gives a component whose normal matrix does not fit LDS (the
  * reference hands such systems to Ceres' SPARSE_NORMAL_CHOLESKY, solve.cc:147): exposed so that a checker can measure the
  * envelope.  src_dst_kind[e] = src | (dst | kind << 15) << 16 over the component's directed edges (local node indices,

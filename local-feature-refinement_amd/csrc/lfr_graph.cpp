@@ -90,20 +90,35 @@ struct SubGraph {
     std::vector<int> ea, eb, w;
 };
 
+// Scratch of bisect_core, one per thread, grown and kept: a cut recursion calls it thousands of times, and fresh multi-megabyte vectors
+// (mapped, faulted in, unmapped every call) cost more than the arithmetic on them.
+struct BisectScratch {
+    struct Nb { int node, w; };                                   // (integer weights: every sum below is exact in doubles)
+    std::vector<uint32_t> off, fill;
+    std::vector<Nb> nbr;
+    std::vector<double> deg, attach, ext;
+    std::vector<char> in;
+    std::vector<int> heap, pos, order;
+};
+
 void bisect_core(const SubGraph &g, std::vector<char> &side) {
     const int n = (int)g.ids.size();
     side.assign(n, 1);
     if (n == 0) return;
     const size_t E = g.ea.size();
-    std::vector<uint32_t> off(n + 1, 0);                          // CSR adjacency, neighbours in edge order
+    static thread_local BisectScratch ws;
+    using Nb = BisectScratch::Nb;
+    std::vector<uint32_t> &off = ws.off, &fill = ws.fill;
+    off.assign(n + 1, 0);                                         // CSR adjacency, neighbours in edge order
     for (size_t k = 0; k < E; ++k) { ++off[g.ea[k] + 1]; ++off[g.eb[k] + 1]; }
     for (int i = 0; i < n; ++i) off[i + 1] += off[i];
-    struct Nb { int node, w; };                                   // (integer weights: every sum below is exact in doubles)
-    std::vector<Nb> nbr(2 * E);
-    std::vector<double> deg(n, 0.0);
+    if (ws.nbr.size() < 2 * E) ws.nbr.resize(2 * E);
+    Nb *nbr = ws.nbr.data();
+    std::vector<double> &deg = ws.deg;
+    deg.assign(n, 0.0);
     double volume = 0.0;
     {
-        std::vector<uint32_t> fill(off.begin(), off.end() - 1);
+        fill.assign(off.begin(), off.end() - 1);
         for (size_t k = 0; k < E; ++k) {
             const int a = g.ea[k], b = g.eb[k], wi = std::max(g.w[k], 1);
             const double w = (double)wi;
@@ -112,15 +127,18 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
             deg[a] += w; deg[b] += w; volume += 2 * w;
         }
     }
-    std::vector<double> attach(n, 0.0);
-    std::vector<char> in(n, 0);
+    std::vector<double> &attach = ws.attach;
+    attach.assign(n, 0.0);
+    std::vector<char> &in = ws.in;
+    in.assign(n, 0);
     double vol0 = 0.0, cut = 0.0;
     int n0 = 0;
     // region growing: always absorb the outside node with the largest attachment to the region (ties ->
     // smallest id; a node nobody is attached to yet has attachment 0, so an emptied frontier restarts from the
     // smallest unvisited id).  Indexed binary max-heap over the n nodes keyed (attachment, -id) with increase-key:
     // O(E log n) with n entries (a lazy-deletion queue held 2 E of them; the O(n^2) arg-max scan before that).
-    std::vector<int> heap(n), pos(n);
+    std::vector<int> &heap = ws.heap, &pos = ws.pos;
+    heap.resize(n); pos.resize(n);
     for (int i = 0; i < n; ++i) { heap[i] = i; pos[i] = i; }                  // all keys (0, -i): already a heap
     int hn = n;
     auto above = [&](int a, int b) { return attach[a] > attach[b] || (attach[a] == attach[b] && a < b); };
@@ -145,7 +163,8 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     // that is a chain of clusters is then cut at a bottleneck instead of wherever half of the volume happens to be reached.
     // scripts/cut_quality.py measures what that buys against a spectral sweep cut (profiles/r03_cut_quality.json).
     auto ncut = [&](double c, double v0) { const double v1 = volume - v0; return (v0 > 0 && v1 > 0) ? c / v0 + c / v1 : 1e300; };
-    std::vector<int> order;
+    std::vector<int> &order = ws.order;
+    order.clear();
     order.reserve(n);
     int best_len = -1, half_len = -1;
     double best_val = 1e300, best_cut = 0.0, best_vol = 0.0, half_cut = 0.0, half_vol = 0.0;
@@ -174,18 +193,33 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     for (int i = 0; i < best_len; ++i) side[order[i]] = 0;
     cut = best_cut; vol0 = best_vol; n0 = best_len;
     // refinement sweeps in node order: move a node if that lowers cut/vol0 + cut/vol1 (never emptying a side); up to eight sweeps,
-    // stopping with the first one that moves nothing
+    // stopping with the first one that moves nothing.  ext[i] = weight of i's edges to the other side, kept up to date move by move
+    // (integers in doubles: the same values a fresh count over the neighbours would give).
+    std::vector<double> &ext = ws.ext;
+    ext.assign(n, 0.0);
+    for (size_t k = 0; k < E; ++k) {
+        const int a = g.ea[k], b = g.eb[k];
+        if (side[a] != side[b]) { const double w = (double)std::max(g.w[k], 1); ext[a] += w; ext[b] += w; }
+    }
     for (int sweep = 0; sweep < 8; ++sweep) {
         bool moved = false;
         for (int i = 0; i < n; ++i) {
-            double to_same = 0.0, to_other = 0.0;
-            for (uint32_t q = off[i]; q < off[i + 1]; ++q) (side[nbr[q].node] == side[i] ? to_same : to_other) += (double)nbr[q].w;
+            const double to_other = ext[i], to_same = deg[i] - ext[i];
             const double ncut_now = ncut(cut, vol0);
             const double c2 = cut + to_same - to_other;
             const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
             const int cnt0 = side[i] == 0 ? n0 - 1 : n0 + 1;
             if (cnt0 <= 0 || cnt0 >= n) continue;
-            if (ncut(c2, v2) < ncut_now) { side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; moved = true; }
+            if (ncut(c2, v2) < ncut_now) {
+                const char was = side[i];
+                side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; moved = true;
+                ext[i] = to_same;
+                for (uint32_t q = off[i]; q < off[i + 1]; ++q) {
+                    const int v = nbr[q].node;
+                    if (v == i) continue;
+                    ext[v] += side[v] == was ? (double)nbr[q].w : -(double)nbr[q].w;
+                }
+            }
         }
         if (!moved) break;
     }
@@ -249,7 +283,9 @@ void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_
     std::vector<int> sub[2];
     std::future<void> second;
     bool spawned = false;
-    if (!child[0].ea.empty() && child[1].ea.size() >= 2048) {
+    // (a thread costs 0.1-1 ms to start: only halves whose own bisection takes longer than that; LFR_CUT_SPAWN_MIN overrides)
+    static const size_t spawn_min = getenv("LFR_CUT_SPAWN_MIN") ? (size_t)atoll(getenv("LFR_CUT_SPAWN_MIN")) : 16384;
+    if (!child[0].ea.empty() && child[1].ea.size() >= spawn_min) {
         if (g_cut_tasks.fetch_add(1) < 64) {
             second = std::async(std::launch::async, [&] { cut_rec(child[1], node_weights, max_weight, sub[1]); });
             spawned = true;
@@ -725,6 +761,25 @@ int64_t lfr_bisect_graph(int64_t n_edges, const int32_t *edge_a, const int32_t *
     for (auto &it : split) keys.push_back(it.first);
     std::sort(keys.begin(), keys.end());
     for (size_t k = 0; k < keys.size(); ++k) { if (nodes) nodes[k] = keys[k]; if (part) part[k] = split[keys[k]]; }
+    return (int64_t)keys.size();
+}
+
+int64_t lfr_debug_recursive_cut(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
+                                int64_t n_node_weights, const int64_t *node_weights, int64_t max_weight, int32_t *nodes, int32_t *subset) {
+    if (n_edges < 0 || n_node_weights < 0 || (n_edges > 0 && (!edge_a || !edge_b || !weights || !node_weights))) { set_error("bad argument"); return LFR_ERR_ARG; }
+    std::vector<std::pair<int, int>> e((size_t)n_edges);
+    std::vector<int> w(weights, weights + n_edges);
+    for (int64_t k = 0; k < n_edges; ++k) {
+        if (edge_a[k] < 0 || edge_b[k] < 0 || edge_a[k] >= n_node_weights || edge_b[k] >= n_node_weights) { set_error("node id without a weight"); return LFR_ERR_ARG; }
+        e[k] = {edge_a[k], edge_b[k]};
+    }
+    const std::vector<int64_t> nw(node_weights, node_weights + n_node_weights);
+    const auto split = recursive_cut(e, w, nw, max_weight);
+    std::vector<int> keys;
+    keys.reserve(split.size());
+    for (auto &it : split) keys.push_back(it.first);
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < keys.size(); ++k) { if (nodes) nodes[k] = keys[k]; if (subset) subset[k] = split.at(keys[k]); }
     return (int64_t)keys.size();
 }
 

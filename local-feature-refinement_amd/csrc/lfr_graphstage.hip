@@ -261,14 +261,11 @@ __global__ void k_large_pending(int64_t k_lo, int64_t k_hi, int64_t serial_limit
     }
 }
 // retire what can never be accepted (same root / shared image: monotone), bid for the roots with the rest
-__global__ void k_round_eval(const uint32_t *n_in_p, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
-                             unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t n_in = *n_in_p;                                // (the launch is sized by an upper bound: the count of an earlier round)
+// (one call per wave-wide slice of the pending list: every lane of the wave calls it, `valid` says whether it holds an entry)
+__device__ __forceinline__ void round_eval_one(bool valid, Pending q, int32_t *parent, const unsigned long long *bits, int W,
+                                               unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
     bool keep = false;
-    Pending q{0, 0, 0};
-    if (i < n_in) {
-        q = in[i];
+    if (valid) {
         q.ra = par_find(parent, q.ra); q.rb = par_find(parent, q.rb);
         if (q.ra != q.rb) {
             const unsigned long long *A = bits + (size_t)q.ra * W, *B = bits + (size_t)q.rb * W;
@@ -286,16 +283,20 @@ __global__ void k_round_eval(const uint32_t *n_in_p, const Pending *in, int32_t 
     if (key < __hip_atomic_load(&minpos[q.ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.ra], key);
     if (key < __hip_atomic_load(&minpos[q.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.rb], key);
 }
+__global__ void k_round_eval(const uint32_t *n_in_p, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
+                             unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n_in = *n_in_p;                                // (the launch is sized by an upper bound: the count of an earlier round)
+    const bool valid = i < n_in;
+    round_eval_one(valid, valid ? in[i] : Pending{0, 0, 0}, parent, bits, W, round_hi, minpos, out, n_out);
+}
 // counters of a batch of rounds: c[j] = matches pending before round j of the batch; the last count of the previous batch moves to the front
 __global__ void k_round_counters_shift(uint32_t *c, int R) {
     if (threadIdx.x == 0 && blockIdx.x == 0) { c[0] = c[R]; for (int j = 1; j <= R; ++j) c[j] = 0u; }
 }
 // a bidder that holds both of its roots is the earliest pending match touching either: accept (solve.cc:513-521)
-__global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigned long long round_hi, const unsigned long long *minpos,
-                               int32_t *parent, int32_t *count, unsigned long long *bits, int W, uint32_t *n_accepted) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= *n_p) return;
-    const Pending q = pend[i];
+__device__ __forceinline__ void round_accept_one(const Pending q, unsigned long long round_hi, const unsigned long long *minpos,
+                                                 int32_t *parent, int32_t *count, unsigned long long *bits, int W, uint32_t *n_accepted) {
     const unsigned long long key = round_hi | q.k;
     if (minpos[q.ra] != key || minpos[q.rb] != key) return;
     int32_t big = q.ra, small = q.rb;                              // r1 = root of n1, r2 = root of n2
@@ -306,6 +307,95 @@ __global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigne
     const unsigned long long *B = bits + (size_t)small * W;
     for (int w = 0; w < W; ++w) A[w] |= B[w];
     atomicAdd(n_accepted, 1u);
+}
+__global__ void k_round_accept(const uint32_t *n_p, const Pending *pend, unsigned long long round_hi, const unsigned long long *minpos,
+                               int32_t *parent, int32_t *count, unsigned long long *bits, int W, uint32_t *n_accepted) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_p) return;
+    round_accept_one(pend[i], round_hi, minpos, parent, count, bits, W, n_accepted);
+}
+
+// Every prefix block and every round of the parallel greedy rule in ONE cooperative launch (opt-in, LFR_ROUNDS_COOPERATIVE=1: see the
+// measurements at its launch site): the phases that are kernels in the default path (first pending list of a block, evaluation,
+// acceptance) are separated by grid-wide barriers instead of launches and read-backs.  c[0], c[1]: entries in list A / list B; c[2]: rounds run; c[3]: matches accepted; c[4]: 1 = the round limit was hit.
+// Grid barrier of k_rounds_all (the launch is cooperative, so every workgroup is resident): one monotonic arrival counter per
+// eighth of the grid (one cache line each) and a release word; the last arrival of the last group releases.  Agent-scope fences on both
+// sides: the XCDs' L2 caches are not coherent with each other inside a kernel.  (cooperative_groups' grid.sync() took ~130 us per
+// barrier here - 20 ms for config 5's 76 rounds against 4.4 ms for launch-per-round.)
+__device__ __forceinline__ void rounds_barrier(uint32_t *bar, uint32_t &gen) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++gen;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const uint32_t grp = blockIdx.x & 7u, in_grp = (gridDim.x - grp + 7u) >> 3;
+        if (__hip_atomic_fetch_add(&bar[16 * (1 + grp)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gen * in_grp) {
+            const uint32_t groups = gridDim.x < 8u ? gridDim.x : 8u;
+            if (__hip_atomic_fetch_add(&bar[16 * 9], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gen * groups)
+                __hip_atomic_store(&bar[0], gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        while (__hip_atomic_load(&bar[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+}
+struct RoundsArgs {
+    int64_t M, first_block, serial_limit;
+    const uint32_t *flags, *seg_id, *starts, *order, *n1, *n2;
+    const int32_t *node_image;
+    int W, max_rounds;
+    unsigned long long *bits, *minpos;
+    Pending *pa, *pb;
+    int32_t *parent, *count;
+    uint32_t *c;
+    uint32_t *bar;           // 160 zeroed words
+};
+__global__ void __launch_bounds__(kPipeThreads) k_rounds_all(RoundsArgs a) {
+    uint32_t gen = 0;
+    const uint32_t n_thr = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    Pending *pa = a.pa, *pb = a.pb;
+    int cur = 0;                                                  // c[cur] counts pa; both counters are 0 between blocks
+    int launched = 0;
+    for (int64_t k_lo = 0, size = a.first_block; k_lo < a.M; k_lo += size, size *= 2) {
+        const int64_t k_hi = k_lo + size < a.M ? k_lo + size : a.M;
+        for (int64_t b = k_lo + (tid - lane); b < k_hi; b += n_thr) {          // (wave-uniform trip count: wave_append is a wave operation)
+            const int64_t k = b + lane;
+            bool large = false;
+            uint32_t m = 0;
+            if (k < k_hi) {
+                const uint32_t sg = a.seg_id[k] + a.flags[k] - 1u;
+                large = (int64_t)(a.starts[sg + 1] - a.starts[sg]) > a.serial_limit;
+                m = a.order[k];
+            }
+            const uint32_t at = wave_append(large, &a.c[cur]);
+            if (large) {
+                const uint32_t x = a.n1[m], y = a.n2[m];
+                pa[at] = Pending{(uint32_t)k, (int32_t)x, (int32_t)y};
+                atomicOr(&a.bits[(size_t)x * a.W + (a.node_image[x] >> 6)], 1ull << (a.node_image[x] & 63));
+                atomicOr(&a.bits[(size_t)y * a.W + (a.node_image[y] >> 6)], 1ull << (a.node_image[y] & 63));
+            }
+        }
+        rounds_barrier(a.bar, gen);
+        for (;;) {
+            const uint32_t n_in = __hip_atomic_load(&a.c[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n_in == 0) break;
+            if (launched >= a.max_rounds) { if (tid == 0) a.c[4] = 1u; return; }        // (uniform: every thread read the same count)
+            const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;
+            for (uint32_t b = tid - lane; b < n_in; b += n_thr) {
+                const uint32_t i = b + lane;
+                const bool valid = i < n_in;
+                round_eval_one(valid, valid ? pa[i] : Pending{0, 0, 0}, a.parent, a.bits, a.W, round_hi, a.minpos, pb, &a.c[cur ^ 1]);
+            }
+            rounds_barrier(a.bar, gen);
+            const uint32_t n_out = __hip_atomic_load(&a.c[cur ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t i = tid; i < n_out; i += n_thr) round_accept_one(pb[i], round_hi, a.minpos, a.parent, a.count, a.bits, a.W, &a.c[3]);
+            if (tid == 0) a.c[cur] = 0u;                          // (everybody read n_in before the barrier above)
+            rounds_barrier(a.bar, gen);
+            Pending *t = pa; pa = pb; pb = t;
+            cur ^= 1;
+            ++launched;
+        }
+    }
+    if (tid == 0) a.c[2] = (uint32_t)launched;
 }
 
 // ---- size cap (solve.cc:311-364): the cut itself runs on the host, on the handful of inter-track matches it needs ----
@@ -606,6 +696,15 @@ int warm_graphstage_primitives(DevCtx *ctx) {
         if ((rc = sort_pairs(arena, k64a, k64b, v32a, v32b, n, 0, 52, st)) != LFR_OK) return rc;
         if ((rc = exclusive_sum(arena, v32a, v32b, n, st)) != LFR_OK) return rc;
     }
+    if (const char *e = getenv("LFR_ROUNDS_COOPERATIVE"); e && e[0] == '1') {   // the cooperative launch of the union-find rounds: an empty list
+        uint32_t *c = arena.take_n<uint32_t>(16 + 160);
+        if (c) {
+            LFR_HIP_TRY(hipMemsetAsync(c, 0, 4 * (16 + 160), st));
+            RoundsArgs ra{0, 1024, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, kMaxRounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c, c + 16};
+            void *kargs[1] = {&ra};
+            if (hipLaunchCooperativeKernel((const void *)k_rounds_all, dim3(256), dim3(kThreads), kargs, 0, st) != hipSuccess) (void)hipGetLastError();
+        }
+    }
     LFR_HIP_TRY(stream_wait(st));
     return rc;
 }
@@ -735,15 +834,52 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         // simulation of this schedule, a few rounds more.
         int64_t first_block = std::max<int64_t>(2 * N, 1024);
         if (const char *e = getenv("LFR_ROUNDS_FIRST_BLOCK")) first_block = std::max<int64_t>(1, atoll(e));
+        int64_t rounds = 0;
+        // LFR_ROUNDS_COOPERATIVE=1: one cooperative launch runs every prefix block and every round (k_rounds_all, grid barriers instead
+        // of launches).  Measured on config 5 (76 rounds, profiles/r03_rounds_cooperative.txt): 4.4 ms with one workgroup per CU, 5.8 / 8.0
+        // with two / four, against 4.3 ms for the launch-per-round loop below - a barrier needs the same agent-scope write-back and
+        // invalidate of the eight L2s as a kernel boundary and costs ~28 us; with cooperative_groups' grid.sync() ~130 us (20 ms).  So
+        // the loop stays the default and this path is kept as the measured alternative.
+        bool done = false;
+        const char *hl = getenv("LFR_ROUNDS_COOPERATIVE");
+        if (hl && hl[0] == '1') {
+            static int blocks_per_cu = -1, n_cu = 0;
+            if (blocks_per_cu < 0) {
+                int nb = 0;
+                hipDeviceProp_t prop;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rounds_all, kThreads, 0) == hipSuccess && nb > 0 &&
+                    hipGetDeviceProperties(&prop, device) == hipSuccess && prop.cooperativeLaunch) { const char *eb = getenv("LFR_ROUNDS_BLOCKS_PER_CU"); blocks_per_cu = std::max(1, std::min(nb, eb ? atoi(eb) : 1)); n_cu = prop.multiProcessorCount; }
+                else blocks_per_cu = 0;
+            }
+            if (blocks_per_cu > 0) {
+                uint32_t *bar = rounds_arena.take_n<uint32_t>(160);
+                if (!bar) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
+                LFR_HIP_TRY(hipMemsetAsync(bar, 0, 4 * 160, st));
+                RoundsArgs ra{M, first_block, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, kMaxRounds, bits, minpos, pa, pb, par, cnt, ctr + 8, bar};
+                void *kargs[1] = {&ra};
+                const hipError_t e = hipLaunchCooperativeKernel((const void *)k_rounds_all, dim3((unsigned)(blocks_per_cu * n_cu)), dim3(kThreads), kargs, 0, st);
+                if (e == hipSuccess) {
+                    LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
+                    LFR_HIP_TRY(stream_wait(st));
+                    if (h_ctr[4]) return LFR_GRAPHSTAGE_USE_HOST;                      // a path-shaped dependency chain: sequential anyway
+                    rounds = h_ctr[2];
+                    if (trace > 2) fprintf(stderr, "lfr graph stage:   %u rounds in one cooperative launch, %u matches accepted\n", h_ctr[2], h_ctr[3]);
+                    done = true;
+                } else {
+                    (void)hipGetLastError();
+                    blocks_per_cu = 0;
+                }
+            }
+        }
         // Rounds run in batches of kRoundBatch without a host round trip: every round takes its input count from the device
         // (the launches are sized by the count of the last read-back: counts only shrink), a round with nothing pending is two
         // empty launches.  Round 2 read the count back after every round: 76 synchronisations for config 5's giant component.
         constexpr int kRoundBatch = 8;
         uint32_t *rc_ = rounds_arena.take_n<uint32_t>(kRoundBatch + 2);
         if (!rc_) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
-        LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
-        int64_t rounds = 0, launched = 0;
-        for (int64_t k_lo = 0, size = first_block; k_lo < M; k_lo += size, size *= 2) {
+        int64_t launched = 0;
+        if (!done) LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
+        for (int64_t k_lo = 0, size = first_block; !done && k_lo < M; k_lo += size, size *= 2) {
             const int64_t k_hi = std::min(M, k_lo + size);
             LFR_HIP_TRY(hipMemsetAsync(rc_ + kRoundBatch, 0, 4, st));
             hipLaunchKernelGGL(k_large_pending, grid_for(k_hi - k_lo), dim3(kThreads), 0, st, k_lo, k_hi, serial_limit, flags, segid, starts, order, n1, n2,

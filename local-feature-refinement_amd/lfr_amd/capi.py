@@ -88,6 +88,7 @@ def lib():
         "lfr_problem_build_hip_ex": (C.c_int, [vp, C.c_int, i64, vp, C.c_int, pp]),
         "lfr_problem_free": (None, [vp]),
         "lfr_bisect_graph": (i64, [i64, vp, vp, vp, vp, vp]),
+        "lfr_debug_recursive_cut": (i64, [i64, vp, vp, vp, i64, vp, i64, vp, vp]),
         "lfr_problem_get_stats": (C.c_int, [vp, C.POINTER(ProblemStats)]),
         "lfr_problem_get_labels": (C.c_int, [vp, vp, vp, vp]),
         "lfr_problem_shard_components": (i64, [vp, C.c_int, C.c_int, vp, vp]),
@@ -120,7 +121,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_sky_plan", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_sky_plan", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -319,6 +320,20 @@ def bisect_graph(edges, weights):
     if n < 0:
         _check(int(n))
     return {int(nodes[i]): int(part[i]) for i in range(n)}
+
+
+def recursive_cut(edges, weights, node_weights, max_weight):
+    """The product's size-cap recursion (lfr_debug_recursive_cut): (nodes ascending, subset of each)."""
+    e = np.ascontiguousarray(edges, np.int32).reshape(-1, 2)
+    a, b = np.ascontiguousarray(e[:, 0]), np.ascontiguousarray(e[:, 1])
+    w = np.ascontiguousarray(weights, np.int32)
+    nw = np.ascontiguousarray(node_weights, np.int64)
+    nodes = np.zeros(2 * len(w) + 1, np.int32)
+    sub = np.zeros(2 * len(w) + 1, np.int32)
+    n = lib().lfr_debug_recursive_cut(len(w), _ptr(a), _ptr(b), _ptr(w), len(nw), _ptr(nw), int(max_weight), _ptr(nodes), _ptr(sub))
+    if n < 0:
+        _check(int(n))
+    return nodes[:n].copy(), sub[:n].copy()
 
 
 def write_matching_file(path, ma):

@@ -200,10 +200,13 @@ def test_real_shaped_configs_stay_on_the_device_stage(lfr_lib, maker):
     assert pd.stats()["tracks_ms"] > 0 and pd.stats()["assemble_ms"] == 0    # device stage ran (the host stage fills assemble_ms only when it assembles)
 
 
-def test_round_based_union_find_fuzz(lfr_lib, monkeypatch):
+@pytest.mark.parametrize("cooperative", ["0", "1"])
+def test_round_based_union_find_fuzz(lfr_lib, monkeypatch, cooperative):
     """Every connected component through the rounds (LFR_SERIAL_SEGMENT_EDGES=0): ties, duplicated matches,
-    image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523."""
+    image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523.  Both schedules of the rounds: one
+    launch per round (default) and the single cooperative launch with grid barriers (LFR_ROUNDS_COOPERATIVE=1)."""
     from test_graph_stage import fuzz_pairs
+    monkeypatch.setenv("LFR_ROUNDS_COOPERATIVE", cooperative)
     monkeypatch.setenv("LFR_SERIAL_SEGMENT_EDGES", "0")
     monkeypatch.setenv("LFR_ROUNDS_FIRST_BLOCK", "3")          # block boundaries inside every component, ties across them
     n_ok = 0

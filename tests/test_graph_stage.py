@@ -123,6 +123,29 @@ def test_size_cap_recursion_against_literal_restatement(lfr_lib, seed, cap):
         assert len(set(t2[c2 == c])) == 1
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_product_recursion_equals_literal_recursion_on_random_meta_graphs(lfr_lib, seed):
+    """lfr_debug_recursive_cut (the product's recursion: compact sub-graphs, per-thread scratch, halves on threads) against the literal
+    recursive_graph_cut of oracle/lfr_ref.py around the same primitive, on random weighted graphs with clusters, isolated edges and
+    uneven node weights; the subset NUMBERS must agree too (solve.cc:205-246 numbers subset 0's parts first)."""
+    rng = np.random.default_rng(900 + seed)
+    n = int(rng.integers(20, 160))
+    cl = rng.integers(0, max(2, n // 12), n)
+    a = rng.integers(0, n, 6 * n); b = rng.integers(0, n, 6 * n)
+    keep = (a < b) & ((cl[a] == cl[b]) | (rng.random(6 * n) < 0.08))
+    e = np.unique(np.stack([a[keep], b[keep]], 1), axis=0)
+    w = rng.integers(0, 400, len(e))                                  # zero weights included (the primitive clamps them to 1)
+    nw = rng.integers(1, 30, n)
+    cap = int(rng.integers(30, 120))
+    nodes, sub = capi.recursive_cut(e, w, nw, cap)
+    want = R.recursive_graph_cut([tuple(map(int, x)) for x in e], [int(x) for x in w], {i: int(nw[i]) for i in range(n)}, cap, capi.bisect_graph)
+    assert sorted(want) == [int(x) for x in nodes]
+    assert [want[int(x)] for x in nodes] == [int(x) for x in sub]
+    weights = np.bincount(sub, weights=nw[nodes])
+    members = np.bincount(sub)
+    assert ((weights <= cap) | (members == 1)).all()                  # only a single node may stay above the cap
+
+
 def test_graph_cut_of_a_huge_component_is_fast_and_respects_the_cap(lfr_lib):
     """the region growing scanned all nodes per absorbed node (O(n^2) per bisection: 357 ms at 40 k tracks,
     minutes at 10^6).  One meta-component of ~10^5 two-node tracks chained by rejected matches, cap 8."""
