@@ -369,19 +369,18 @@ def main():
             eval_flops = float(st5["exec_passes_edges"]) * FLOP_PER_EDGE_EVAL
             prof5 = pmc_numbers("r03_pmc_config5.json")
             traffic5 = (prof5 or {}).get("hbm_bytes_per_solve")
-            alg_bytes5 = float(st5["exec_passes_edges"]) * (80 + 64 + 128)
+            alg_bytes5 = float(st5["exec_passes_edges"]) * 80
             res["long_tracks_workload"] = {
-                # fp64 roof of the solve as a whole (the three LDS classes run concurrently): n^3/3 per factorization (one per LM
-                # iteration) on the fp64 matrix cores + 200 flop per executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak
                 # Two roofs of the solve as a whole (the three LDS classes run concurrently).  HBM: every sweep re-streams the 80-byte
-                # records and sends 64 B of corrected jacobian per edge through a scratch array (written once, read by the out- and the
-                # in-walk): bytes from the committed PMC passes.  fp64: n^3/3 per factorization (one per LM iteration) on the fp64 matrix
-                # cores + 200 flop per executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak.
+                # records (the fused sweep of round 3 keeps everything else in registers and LDS; until then 64 B of corrected jacobian
+                # per edge went through a scratch array, written once and read twice: 272 B per edge and sweep); bytes from the
+                # committed PMC passes.  fp64: n^3/3 per factorization (one per LM iteration) on the fp64 matrix cores + 200 flop per
+                # executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak.
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                              "traffic": traffic5,
                              "achieved": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9, "frac": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "algorithmic_bytes": alg_bytes5,
-                             "algorithmic_bytes_what": "per executed sweep and edge: 80 B record + 64 B scratch written + 2 x 64 B scratch read",
+                             "algorithmic_bytes_what": "per executed sweep and edge: the 80 B record (nothing else leaves the CU)",
                              "traffic_source": "profiles/r03_pmc_config5.json (committed rocprofv3 PMC passes over this workload, 2*FETCH_SIZE + WRITE_SIZE; not measured in this run)" if traffic5 else None,
                              "fp64": {"achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
