@@ -64,6 +64,7 @@ struct KernelArgs {
     int wg_begin;               // first descriptor of the workgroup classes (wg_order[0] belongs to it)
     int desc_begin, desc_end;
     int tukey_variant;
+    int scratch_sweep;         // 1: the workgroup kernels use the scratch sweep of rounds 1-2 (LFR_SCRATCH_SWEEP=1 at batch creation; A/B and tests)
     int cls;
     int sky_lds;                // KC_GLOBAL: the back-substitution vector lives in dynamic LDS
     // fused gather (packed classes of a device-assembled whole batch): record p is directed edge edge_ref[p] of the graph - flow row
@@ -1138,7 +1139,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #ifndef LFR_FUSED_SWEEP
 #define LFR_FUSED_SWEEP 1
 #endif
-    bool fused_sweep = !GLOBAL_MATRIX && LFR_FUSED_SWEEP != 0 && split_walk;
+    bool fused_sweep = !GLOBAL_MATRIX && LFR_FUSED_SWEEP != 0 && split_walk && !a.scratch_sweep;
     auto sweep_fused = [&](const double *xv, double *gout, bool want_matrix, bool &overflow) -> double {
         constexpr double kFx = 0x1p40, kFxInv = 0x1p-40;
         unsigned long long *fx_g = reinterpret_cast<unsigned long long *>(vstep), *fx_d = reinterpret_cast<unsigned long long *>(vD);
@@ -2888,6 +2889,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.descs = b->d_descs; a.edges = b->d_edges; a.node_ids = b->d_node_ids; a.positions = b->d_positions;
     a.infos = b->d_infos; a.workspace = b->d_workspace; a.ws_off = b->d_ws_off; a.es_off = b->d_es_off;
     a.node_inc = b->d_node_inc; a.in_idx = b->d_in_idx; a.tukey_variant = b->tukey_variant; a.prof = b->d_prof;
+    { const char *e = getenv("LFR_SCRATCH_SWEEP"); a.scratch_sweep = (e && e[0] == '1') ? 1 : 0; }
     a.queue = reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT);
     a.wg_order = b->d_wg_order; a.wg_begin = b->class_begin[lfr::KC_BLOCK];
     a.sky_lds = b->sky_lds_doubles > 0;
@@ -3017,7 +3019,10 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             // and the one slow component among THEM (iteration counts vary 8x) then ended the solve alone (config 5: 17.0 ms
             // against 13.8 at the time).  With persistent workgroups the middle class takes the whole chip for its 1.5 ms, the
             // large class follows, and the small class fills the CUs the large one's tail leaves (measured 9.15 ms against
-            // 9.4-9.5 smallest-first and 12.4 largest-first); LFR_WG_ORDER overrides for experiments.
+            // 9.4-9.5 smallest-first and 12.4 largest-first); LFR_WG_ORDER overrides for experiments.  Round 3, with the fused sweep
+            // (5.1 ms): largest-first 7.9 ms; largest-first with only its share of the CUs (by rows x threads x components) and full
+            // grids behind it 5.8-7.2 ms - the pending workgroups of the later launches do not take the CUs the first one frees, and
+            // the packed launch starves; the order stays.
             static const std::array<int, 4> kBigOrder = [] {
                 std::array<int, 4> o = {lfr::KC_GLOBAL, lfr::KC_BLOCK_M, lfr::KC_BLOCK_L, lfr::KC_BLOCK};
                 if (const char *e = getenv("LFR_WG_ORDER")) {
