@@ -290,6 +290,17 @@ def main():
                                      "edges_per_s": sst["n_edges"] / (sp["ms"] * 1e-3), "tracks_per_s": sst["n_tracks"] / (sp["ms"] * 1e-3),
                                      "what": "solve.cc:487-641 on ONE config-4 graph (seed 2): every rank runs the integer graph stage, assembles and "
                                              "solves its shard (flows gathered zero-copy from pinned host memory), positions of the shard on the host"}
+            # what the design predicts for this span: every rank repeats the serial part - endpoints / similarities / node
+            # images over PCIe (20 B per match + 4 B per node) and the graph stage - and gets 1/N of the rest: the flows it gathers over its
+            # own PCIe link (144 B per match of its shard) and the Solver span of rank 0's own one-GPU run
+            pcie = 57e9
+            n_m, n_n = sst["n_edges"] / 2.0, float(graph.n_nodes)
+            serial_ms = (sp_total_res["ms"] - sp_solver["ms"]) + (20.0 * n_m + 4.0 * n_n) / pcie * 1e3
+            parallel_ms = sp_solver["ms"] + 144.0 * n_m / pcie * 1e3
+            res["strong_scaling"].update({"predicted_ms": serial_ms + parallel_ms / world, "predicted_serial_ms": serial_ms,
+                                          "predicted_parallel_ms": parallel_ms,
+                                          "model": "serial (graph stage + 20 B/match + 4 B/node over PCIe at 57 GB/s, repeated by every rank) + "
+                                                   "(one-GPU Solver span + 144 B/match of flows over PCIe) / N"})
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             sys.path.insert(0, os.path.join(ROOT, "oracle"))

@@ -394,10 +394,10 @@ int exclusive_sum(DevArena &arena, const T *in, T *out, int64_t n, hipStream_t s
 int warm_assembly_primitives(DevCtx *ctx) {
     hipStream_t st = ctx->s_main;
     LFR_HIP_TRY(hipSetDevice(ctx->device));
-    const int64_t sizes[2] = {100000, (int64_t)4 << 20};
+    const int64_t sizes[4] = {100000, 300000, 1000000, (int64_t)4 << 20};   // (merge-sort levels and radix paths differ by size)
     DevArena arena;
-    if (!arena.init(ctx, (size_t)sizes[1] * 64 + ((size_t)64 << 20))) return LFR_ERR_NOMEM;
-    const int64_t nmax = sizes[1];
+    if (!arena.init(ctx, (size_t)sizes[3] * 64 + ((size_t)64 << 20))) return LFR_ERR_NOMEM;
+    const int64_t nmax = sizes[3];
     uint64_t *k64a = arena.take_n<uint64_t>(nmax), *k64b = arena.take_n<uint64_t>(nmax);
     uint32_t *k32a = arena.take_n<uint32_t>(nmax), *k32b = arena.take_n<uint32_t>(nmax), *v32a = arena.take_n<uint32_t>(nmax), *v32b = arena.take_n<uint32_t>(nmax);
     if (!k64a || !k64b || !k32a || !k32b || !v32a || !v32b) { set_error("warm-up arena exhausted"); return LFR_ERR_NOMEM; }

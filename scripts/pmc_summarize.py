@@ -49,8 +49,21 @@ if summary.get("SQ_WAVE_CYCLES"):
 json.dump(summary, open(os.path.join(prof, "r03_pmc_config5.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in summary.items() if k not in ("kernels", "source", "correction", "workload")}, indent=1))
 # config 4: what bench.py reads for roofline.traffic
-pk = next((v for k, v in p4.items() if k.startswith("solve_packed_kernel")), None)
-dom = json.load(open(os.path.join(out, "r03_dominant_kernel_launches.json"))) if os.path.exists(os.path.join(out, "r03_dominant_kernel_launches.json")) else None
+# (solve_packed_kernel<false> reads the batch's 80-byte records: the timed steps; <true> gathers from the graph's arrays: the FIRST solve of a batch)
+pk = p4.get("solve_packed_kernel<false>") or next((v for k, v in p4.items() if k.startswith("solve_packed_kernel")), None)
+pk_gather = p4.get("solve_packed_kernel<true>")
+dom = None
+tr = glob.glob(os.path.join(out, "trace", "*kernel_trace.csv"))
+if tr:
+    by = collections.defaultdict(list)
+    for row in csv.DictReader(open(tr[0])):
+        if short(row["Kernel_Name"]) == "solve_packed_kernel<false>":
+            by[int(row["Grid_Size_X"])].append(int(row["End_Timestamp"]) - int(row["Start_Timestamp"]))
+    if by:
+        dom = {"kernel": "solve_packed_kernel<false>", "by_grid_size_x": {str(g): {"launches": len(v), "avg_us": sum(v) / len(v) / 1e3, "min_us": min(v) / 1e3, "max_us": max(v) / 1e3}
+                                                                         for g, v in sorted(by.items(), key=lambda kv: -len(kv[1]))},
+               "note": "the config-4 batch is the grid with the most launches (timed steps + warm-up); the first solve of every batch runs the gathering variant <true>"}
+        json.dump(dom, open(os.path.join(out, "r03_dominant_kernel_launches.json"), "w"), indent=1)
 if pk and "FETCH_SIZE" in pk:
     old = json.load(open(os.path.join(prof, "pmc_traffic.json")))
     full = max(dom["by_grid_size_x"].items(), key=lambda kv: kv[1]["launches"]) if dom else None
@@ -61,6 +74,10 @@ if pk and "FETCH_SIZE" in pk:
            "valu_busy": pk["SQ_ACTIVE_INST_VALU"]["mean_per_dispatch"] / pk["SQ_WAVE_CYCLES"]["mean_per_dispatch"] if "SQ_WAVE_CYCLES" in pk else None,
            "sq": {k: v["mean_per_dispatch"] for k, v in pk.items() if k.startswith("SQ_")},
            "rocprof_avg_launch_us": full[1]["avg_us"] if full else None, "rocprof_launches": full[1]["launches"] if full else None,
+           "gather_variant_first_solve": ({"FETCH_SIZE_KB": pk_gather["FETCH_SIZE"]["mean_per_dispatch"], "WRITE_SIZE_KB": pk_gather["WRITE_SIZE"]["mean_per_dispatch"],
+                                           "note": "solve_packed_kernel<true>: 8-byte loads of isolated 72-byte flow rows (FETCH_SIZE not doubled: the correction is for 16 B/lane reads); "
+                                                   "a row straddles cache lines, ~2x the bytes it needs - the price of not writing and re-reading 400 MB of records in a one-shot run"}
+                                          if pk_gather and "FETCH_SIZE" in pk_gather else None),
            "source": "round 3: scripts/profile_round3.sh (rocprofv3 --kernel-trace --stats of python bench.py --steps 20 --warmup 3 --no-cpu-baseline; separate --pmc passes of "
                      "python bench.py --steps 5 --warmup 1 --span-reps 1 --no-cpu-baseline --no-long-tracks --no-sparse), summarised by scripts/pmc_summarize.py"}
     json.dump(new, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)

@@ -27,11 +27,19 @@ CASES = {
     # many line-search contractions (cubic and quintic interpolation), rejected steps, active bounds
     "linesearch": dict(seed=341, n_images=20, n_tracks=8, sigma_p=0.7, sigma_noise=0.15),
     "linesearch2": dict(seed=289, n_images=20, n_tracks=8, sigma_noise=0.3),
+    # round 3: real-shaped inputs - every node matched to ~4-5 track neighbours instead of all pairs,
+    # ratio-test-like similarities (feature_matchers.py:42), duplicated matches (solve.cc:476-478 keeps them)
+    "sparse_ratio": dict(seed=511, n_images=120, n_tracks=10, track_degree=4, ratio_sims=True, dup_frac=0.05, eps_out=0.02),
+    "sparse_long": dict(seed=512, n_images=160, n_tracks=4, len_dist="uniform", len_lo=20, len_hi=40, track_degree=5, eps_out=0.004,
+                        ratio_sims=True, dup_frac=0.03),        # long sparse tracks (workgroup classes), a few joined by wrong matches; no component above the cap
 }
 
 
 def main():
+    only = sys.argv[1:]
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         ma = synthetic.generate(**kw)
         pairs = ma.to_pairs()
         open(os.path.join(HERE, name + ".pb"), "wb").write(wire.encode_matching_file(pairs))

@@ -12,7 +12,7 @@ from lfr_amd import capi, synthetic, wire
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
-NAMES = ["clean", "outliers", "noisy", "bounds", "linesearch", "linesearch2"]
+NAMES = ["clean", "outliers", "noisy", "bounds", "linesearch", "linesearch2", "sparse_ratio", "sparse_long"]
 TOL_UNITS = 6.25e-6          # 1e-4 px at fact = 1 (colmap_utils.py:135-136); north_star tolerance
 
 
