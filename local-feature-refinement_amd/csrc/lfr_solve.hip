@@ -686,7 +686,8 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 #define FPROF_FLUSH()
 #endif
 #ifndef LFR_FINE_READY
-#define LFR_FINE_READY 0      // 1: the rows' substitution follows the diagonal block column by column (measured: the 15 polls cost ~270 spilled registers)
+#define LFR_FINE_READY 0      // g > 0: the rows' substitution follows the diagonal block in groups of g columns.  Measured: every poll inside the
+                              // unrolled substitution costs registers (g = 1: 414 spilled VGPRs, g = 4: 396, g = 8: 297, one wait up front: 67)
 #endif
 template <int kBlockThreads>
 __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int n, BlockShared &sh, unsigned long long *fprof) {
@@ -752,8 +753,10 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
         int have = -1;
 #pragma unroll
         for (int k = 0; k < 15; ++k) {
-            const int need = 16 * panel + (LFR_FINE_READY ? k + 1 : 16);
-            if (LFR_FINE_READY || k == 0) {
+            // LFR_FINE_READY = g > 0: the substitution follows the diagonal block in groups of g columns (a poll every g steps)
+            constexpr int kGroup = LFR_FINE_READY > 0 ? LFR_FINE_READY : 16;
+            const int need = 16 * panel + min(16, (k / kGroup + 1) * kGroup);
+            if (k % kGroup == 0) {
                 // spin until wave 0 has published column k.  One opaque instruction sequence: as C++ loops inside the unrolled steps
                 // the 15 polls cost the kernel ~270 spilled registers.
                 int tmp;
