@@ -1692,8 +1692,8 @@ struct SkyShared {
     double diag[256];           // the factored diagonal tile of the current panel (unscaled columns, d on the diagonal)
     double inv[16];             // 1 / d of the panel's pivots
     double y[16];               // back substitution: the block's solution
-    unsigned short act[256];    // active block rows of the panel
-    int n_act;
+    unsigned short act[2][4096];   // active block rows of the current / the next panel (a component has at most 4096 block rows)
+    int n_act[2];
 };
 
 template <int kBlockThreads>
@@ -1853,18 +1853,35 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
 
     // ---- block-envelope LDL^T in place.  Column k keeps the unscaled entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1/d_k in vinv ----
     auto factor = [&]() -> bool {
-        if (tid == 0) sh.flag = 0;
-        for (int k = 0; k < P; ++k) {
-            const int kb = 16 * k, nbp = min(16, n - kb);
-            if (tid == 0) ss.n_act = 0;
-            __syncthreads();
+        // the active block rows of panel k (fb[R] <= k < R) are listed while panel k - 1 runs its updates (two lists)
+        auto list_active = [&](const int k, const int buf) {
             for (int R = k + 1 + tid; R < RT; R += kBlockThreads)
-                if ((int)fb[R] <= k) ss.act[atomicAdd(&ss.n_act, 1)] = (unsigned short)R;
-            if (wave == 0) {            // (a) the diagonal tile: lane = row, every 16-lane group computes the same
-                double *T = tile_ptr(k, k);
+                if ((int)fb[R] <= k) ss.act[buf][atomicAdd(&ss.n_act[buf], 1)] = (unsigned short)R;
+        };
+        if (tid == 0) { sh.flag = 0; ss.n_act[0] = 0; ss.n_act[1] = 0; }
+        __syncthreads();
+        list_active(0, 0);
+        __syncthreads();
+        for (int k = 0; k < P; ++k) {
+            const int kb = 16 * k, nbp = min(16, n - kb), cur = k & 1;
+            const int n_act = ss.n_act[cur];
+            const unsigned short *act_list = ss.act[cur];
+            constexpr int kOwn = 3;                       // active tiles wave 0 finishes inside the diagonal tile's elimination
+            if (wave == 0) {
+                // (a) the diagonal tile: lane = row in lanes 0-15.  Lanes 16-63 carry the rows of the first three active tiles (R, k)
+                // through the same elimination steps - a_ic -= (a_ij / d_j) a_cj with a_cj read from lane c IS their substitution - so a
+                // narrow envelope (<= 3 active block rows: the usual case after the fill-reducing order) needs no substitution pass
+                // and one barrier less per panel.
+                const int li = kq - 1;
+                const bool below = kq > 0, on = below && li < n_act;
+                double *T = below ? tile_ptr((int)act_list[on ? li : 0], k) : tile_ptr(k, k);
+                if (!on && below) T = tile_ptr(k, k);
                 double av[16];
 #pragma unroll
-                for (int j = 0; j < 16; ++j) { const double v = T[(r16 << 4) + min(j, r16)]; av[j] = j <= r16 ? v : 0.0; }
+                for (int j = 0; j < 16; ++j) {
+                    const double v = T[(r16 << 4) + (below ? j : min(j, r16))];
+                    av[j] = below ? (on ? v : 0.0) : (j <= r16 ? v : 0.0);
+                }
                 bool bad = false;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
@@ -1881,33 +1898,40 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                 if (lane < 16) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) { ss.diag[(r16 << 4) + j] = av[j]; if (j <= r16) T[(r16 << 4) + j] = av[j]; }
+                } else if (on) {
+#pragma unroll
+                    for (int c = 1; c < 16; ++c) T[(r16 << 4) + c] = av[c];
                 }
                 if (bad && lane == 0) sh.flag = 1;
             }
+            if (tid == 0) ss.n_act[cur ^ 1] = 0;          // (the other list was last read in panel k - 1)
             __syncthreads();
-            const int n_act = ss.n_act;
-            // (b) rows of the active tiles (R, k): a_ic -= sum_{j<c} (a_ij / d_j) a_cj, four tiles per wave and pass
-            for (int g4 = wave; 4 * g4 < n_act; g4 += kWaves) {
-                const int li = 4 * g4 + kq;
-                const bool act = li < n_act;
-                const int R = (int)ss.act[act ? li : 0];
-                double *rowp = tile_ptr(R, k) + (r16 << 4);
-                double r[16];
+            // (b) rows of the remaining active tiles (R, k): a_ic -= sum_{j<c} (a_ij / d_j) a_cj, four tiles per wave and pass
+            if (n_act > kOwn) {                           // (uniform)
+                for (int g4 = wave; kOwn + 4 * g4 < n_act; g4 += kWaves) {
+                    const int li = kOwn + 4 * g4 + kq;
+                    const bool act = li < n_act;
+                    const int R = (int)act_list[act ? li : 0];
+                    double *rowp = tile_ptr(R, k) + (r16 << 4);
+                    double r[16];
 #pragma unroll
-                for (int c = 0; c < 16; ++c) r[c] = rowp[c];
+                    for (int c = 0; c < 16; ++c) r[c] = rowp[c];
 #pragma unroll
-                for (int j = 0; j < 15; ++j) {
-                    const double tj = r[j] * ss.inv[j];
+                    for (int j = 0; j < 15; ++j) {
+                        const double tj = r[j] * ss.inv[j];
 #pragma unroll
-                    for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, ss.diag[(c << 4) + j], r[c]);
+                        for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, ss.diag[(c << 4) + j], r[c]);
+                    }
+                    if (act) {
+#pragma unroll
+                        for (int c = 1; c < 16; ++c) rowp[c] = r[c];
+                    }
                 }
-                if (act) {
-#pragma unroll
-                    for (int c = 1; c < 16; ++c) rowp[c] = r[c];
-                }
+                __syncthreads();
             }
-            __syncthreads();
-            // (c) tiles (R_i, R_j) of every pair of active block rows -= U(R_i, k) (U(R_j, k) / d)^T  (fp64 MFMA, K = 16)
+            // (c) tiles (R_i, R_j) of every pair of active block rows -= U(R_i, k) (U(R_j, k) / d)^T  (fp64 MFMA, K = 16); the next
+            // panel's list meanwhile
+            if (k + 1 < P) list_active(k + 1, cur ^ 1);
             {
                 double ninv[4];
 #pragma unroll
@@ -1917,7 +1941,7 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                 for (int t = wave; t < T; t += kWaves) {
                     J += t - tcur; tcur = t;
                     while (J > I) { J -= I + 1; ++I; }
-                    const int Ra = (int)ss.act[I], Rb = (int)ss.act[J];
+                    const int Ra = (int)act_list[I], Rb = (int)act_list[J];
                     const int Rhi = max(Ra, Rb), Rlo = min(Ra, Rb);
                     const double *ta = tile_ptr(Rhi, k) + (r16 << 4) + kq, *tb = tile_ptr(Rlo, k) + (r16 << 4) + kq;
                     double *tc = tile_ptr(Rhi, Rlo) + (kq << 4) + r16;
