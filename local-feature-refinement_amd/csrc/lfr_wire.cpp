@@ -10,6 +10,7 @@
 #include <chrono>
 #include <atomic>
 #include <memory>
+#include <new>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -187,9 +188,32 @@ static bool parse_displacements(Cursor c, float *out, int &n) {   // one Displac
 // (sequential, order-dependent): banned-image filter, image interning (first fact wins), node
 // numbering in order of first appearance (solve.cc:444-451,474-475).  Pass D (parallel): move the
 // similarities and flow grids into the graph's arrays.
+// Large scanner buffers ask for transparent huge pages (this image runs THP in `madvise` mode): 1.3 GB of decode buffers are 340 k
+// first-touch faults in 4-KB pages, taken by 32 threads against the address-space lock that the HIP runtime's start-up on the side
+// thread holds for its own mappings - the CLI's parse ran 2x slower than the same parse in a process without a GPU context.
+template <class T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <class U> HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < ((size_t)4 << 20)) { if (void *p = malloc(bytes ? bytes : 1)) return (T *)p; throw std::bad_alloc(); }
+        void *p = nullptr;
+        const size_t len = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+        if (posix_memalign(&p, (size_t)2 << 20, len) != 0 || !p) throw std::bad_alloc();
+        (void)madvise(p, len, MADV_HUGEPAGE);
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <class T> using HugeVec = std::vector<T, HugeAlloc<T>>;
+
 struct MatchBuf {
-    std::vector<uint32_t> f1, f2;
-    std::vector<float> sim, d1, d2;      // 18 floats per match, zero padded
+    HugeVec<uint32_t> f1, f2;
+    HugeVec<float> sim, d1, d2;          // 18 floats per match, zero padded
     int rc = LFR_OK;
 };
 struct PairRec {
@@ -560,7 +584,7 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
         std::unordered_map<std::string, int32_t> index;
     };
     std::vector<MatchBuf> bufs(TB);
-    std::vector<PairRec> recs(P);
+    HugeVec<PairRec> recs(P);
     std::vector<ChunkNames> cnames(TB);
     std::vector<int32_t> loc1(P), loc2(P);       // chunk-local image ids of the pair
     run_threads(TB, [&](int t) {
@@ -752,7 +776,7 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
     // occupied slots in order of first position = node ids.  Positions are distinct integers below N0 + 2 * n_new: every
     // slot drops its index at its position, a prefix count over the positions ranks them - no sort.
     const uint64_t n_pos = (uint64_t)N0 + 2 * (uint64_t)n_new;
-    std::vector<uint32_t> slot_at(n_pos, 0);                   // slot index + 1 (the table has < 2^32 slots: checked below)
+    HugeVec<uint32_t> slot_at(n_pos, 0);                   // slot index + 1 (the table has < 2^32 slots: checked below)
     if (cap >= ((uint64_t)1 << 32)) { mover.join(); set_error("matches file too large for the node table"); return LFR_ERR_UNSUPPORTED; }
     run_threads(TB, [&](int t) {
         const uint64_t lo = cap / TB * t, hi = t == TB - 1 ? cap : cap / TB * (t + 1);
@@ -817,7 +841,7 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
         const char *early = getenv("LFR_FREE_INGEST_EARLY");
         if (!(early && early[0] == '1')) {
             struct Keep {
-                std::vector<MatchBuf> bufs; std::vector<PairRec> recs; std::vector<uint32_t> slot_at;
+                std::vector<MatchBuf> bufs; HugeVec<PairRec> recs; HugeVec<uint32_t> slot_at;
                 std::unique_ptr<NodeSlot[]> slots; std::vector<MappedFile> files;
             };
             auto keep = std::make_shared<Keep>();
