@@ -1,6 +1,8 @@
 // Per-device streams + slab caches, pinned host arrays (see lfr_devctx.hpp).
 #include "lfr_devctx.hpp"
 
+#include <sys/mman.h>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -45,9 +47,14 @@ hipError_t stream_wait(hipStream_t st) {
     return hipStreamSynchronize(st);
 }
 
-void *host_alloc(size_t bytes, bool *pinned) {
+void *host_alloc(size_t bytes, bool *pinned, bool allow_pin) {
     *pinned = false;
-    if (bytes >= kPinThreshold && hip_device_count() > 0) {
+    if (!allow_pin && bytes >= ((size_t)4 << 20)) {             // large and not to be pinned: transparent huge pages (THP runs in madvise mode here)
+        void *p = nullptr;
+        const size_t len = (bytes + (((size_t)2 << 20) - 1)) & ~(((size_t)2 << 20) - 1);
+        if (posix_memalign(&p, (size_t)2 << 20, len) == 0 && p) { (void)madvise(p, len, MADV_HUGEPAGE); return p; }
+    }
+    if (allow_pin && bytes >= kPinThreshold && hip_device_count() > 0) {
         void *p = nullptr;
         if (hipHostMalloc(&p, bytes, hipHostMallocPortable) == hipSuccess && p) { *pinned = true; return p; }
         (void)hipGetLastError();

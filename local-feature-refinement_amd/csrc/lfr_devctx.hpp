@@ -18,7 +18,7 @@
 namespace lfr {
 
 // ---- host arrays: pinned (hipHostMalloc, portable) when a HIP device exists and the array is large ----
-void *host_alloc(size_t bytes, bool *pinned);
+void *host_alloc(size_t bytes, bool *pinned, bool allow_pin = true);
 void host_free(void *p, bool pinned);
 
 template <class T>
@@ -38,7 +38,7 @@ public:
     void reserve(size_t n) {
         if (n <= cap_) return;
         bool pin = false;
-        T *q = (T *)host_alloc(n * sizeof(T), &pin);
+        T *q = (T *)host_alloc(n * sizeof(T), &pin, allow_pin_);
         if (n_) memcpy(q, p_, n_ * sizeof(T));
         if (p_) host_free(p_, pinned_);
         p_ = q; cap_ = n; pinned_ = pin;
@@ -50,12 +50,14 @@ public:
     }
     void push_back(const T &v) { grow(n_ + 1); p_[n_++] = v; }
     void clear() { n_ = 0; }
+    // false: plain (huge-page) memory even for a large array - for data that is copied to HBM once, right away (ingest straight to a device)
+    void allow_pinning(bool b) { allow_pin_ = b; }
 
 private:
     void grow(size_t n) { if (n > cap_) reserve(n > 2 * cap_ ? (n < 1024 ? 1024 : n) : 2 * cap_); }
     T *p_ = nullptr;
     size_t n_ = 0, cap_ = 0;
-    bool pinned_ = false;
+    bool pinned_ = false, allow_pin_ = true;
 };
 
 // ---- per-device context ----

@@ -556,7 +556,7 @@ static int send_endpoints(const Graph &g, DevGraph &dg) {
 void prestage_flows(const Graph &g, int device, int64_t n_bound) {
     const int64_t M = (int64_t)(g.m_disp1.size() / 18);
     if (device < 0 || M <= 0 || M >= ((int64_t)1 << 30) || n_bound >= ((int64_t)1 << 31)) return;
-    if (!(g.m_disp1.pinned() && g.m_disp2.pinned()) || g.dev_disp1) return;
+    if (g.dev_disp1) return;                                     // (pageable flows are fine: the copies below are staged by the runtime, on the scanner's helper thread)
     std::lock_guard<std::mutex> lk(g.dev_mu);
     if ((int)g.devgs.size() <= device) g.devgs.resize(device + 1);
     if (g.devgs[device]) return;

@@ -667,6 +667,10 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
     const double t_d = wall_ms();
     // ---- E: node numbering (concurrent first-position map) beside the allocation + move of similarities and flows
     std::thread mover([&] {
+        // ingest straight to a device: the flows go to HBM once, right away - pinning 144 B per match for that (hipHostMalloc of 360 MB
+        // for config 4: tens of ms under the address-space lock, and as long again when the process is torn down) buys nothing
+        static const bool pin_anyway = [] { const char *e = getenv("LFR_PIN_FLOWS"); return e && e[0] == '1'; }();
+        if (g.prefetch_device >= 0 && M0 == 0 && !pin_anyway) { g.m_disp1.allow_pinning(false); g.m_disp2.allow_pinning(false); }
         g.m_sim.resize((size_t)M); g.m_disp1.resize((size_t)18 * M); g.m_disp2.resize((size_t)18 * M);
         std::atomic<int64_t> next{0};
         run_threads(TB, [&](int) {
