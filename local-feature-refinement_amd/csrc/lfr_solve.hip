@@ -1157,13 +1157,22 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
             ovf = ovf || !(fabs(v) < 128.0);
             __hip_atomic_fetch_add(p, (unsigned long long)__double2ll_rn(v * kFx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
-        const int part = tid & 3, n_nodes = (int)d.n_nodes;
-        for (int v0 = 0; v0 < n_nodes; v0 += kBlockThreads / 4) {             // (uniform trip count: the quad reduction is a wave operation)
-            const int v = v0 + (tid >> 2);
-            const bool have_v = v < n_nodes;
+        // lanes per node: as many as let every node of the component have its lanes in one pass (a wave holds 64 / P whole nodes),
+        // eight at most; bigger components take four lanes per node and several passes
+        const int n_nodes = (int)d.n_nodes;
+        constexpr int kWavesT = kBlockThreads / 64;
+        int P = 4;
+#pragma unroll
+        for (int q = 8; q >= 5; --q) if (P == 4 && (64 / q) * kWavesT >= n_nodes) P = q;
+        const int npw = 64 / P, wl = tid & 63;
+        const int slot = wl / P, part = wl - slot * P;
+        const bool lane_on = slot < npw;
+        for (int v0 = 0; v0 < n_nodes; v0 += kWavesT * npw) {                 // (uniform trip count: the reduction below is a wave operation)
+            const int v = v0 + (tid >> 6) * npw + slot;
+            const bool have_v = lane_on && v < n_nodes;
             const lfr::NodeInc ni = inc[have_v ? v : 0];
             const uint32_t cnt = have_v ? ni.out_count : 0u;
-            const bool v_var = v < n_var;
+            const bool v_var = have_v && v < n_var;
             double d00 = 0.0, d10 = 0.0, d11 = 0.0, g0 = 0.0, g1 = 0.0;
             uint4 q[5], qn[5];
             if ((uint32_t)part < cnt) {
@@ -1171,9 +1180,9 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #pragma unroll
                 for (int i = 0; i < 5; ++i) q[i] = rp[i];
             }
-            for (uint32_t k = part; k < cnt; k += 4) {
-                if (k + 4 < cnt) {
-                    const uint4 *rp = reinterpret_cast<const uint4 *>(edges + ni.out_begin + k + 4);
+            for (uint32_t k = part; k < cnt; k += P) {
+                if (k + P < cnt) {
+                    const uint4 *rp = reinterpret_cast<const uint4 *>(edges + ni.out_begin + k + P);
 #pragma unroll
                     for (int i = 0; i < 5; ++i) qn[i] = rp[i];
                 }
@@ -1219,8 +1228,16 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #pragma unroll
                 for (int i = 0; i < 5; ++i) q[i] = qn[i];
             }
-            // the four lanes of the node, in a fixed tree: (p0 + p1) + (p2 + p3)
-            auto quad = [&](double x) { x += __shfl_xor(x, 1, 64); x += __shfl_xor(x, 2, 64); return x; };
+            // the P lanes of the node, in a fixed tree: ((p0 + p1) + (p2 + p3)) + ((p4 + p5) + (p6 + p7)), absent parts left out; the sum
+            // lands in part 0
+            auto quad = [&](double x) {
+#pragma unroll
+                for (int off = 1; off < 8; off <<= 1) {
+                    const double y = __shfl_down(x, off, 64);
+                    if (off < P && (part & (2 * off - 1)) == 0 && part + off < P) x += y;
+                }
+                return x;
+            };
             g0 = quad(g0); g1 = quad(g1);
             if (want_matrix) { d00 = quad(d00); d10 = quad(d10); d11 = quad(d11); }
             if (v_var && part == 0) {
