@@ -204,7 +204,8 @@ def _bisect_spec(edges, weights):
     nodes = sorted endpoints; weights max(w, 1) as doubles; maximum-adjacency region growing from attachment 0 (ties ->
     smallest node) until three quarters of the edge-weight volume are inside (or one node is left outside); the prefix of the
     growth order with the smallest normalized cut among those holding between a quarter and three quarters of the volume wins
-    (ties -> the earliest; no such prefix: the first one holding half of the volume, or the whole growth); then up to eight sweeps
+    (ties -> the earliest) provided its normalized cut is below 0.6 x that of the first prefix holding half of the volume - otherwise, or
+    without a prefix in the window, that balanced prefix (or the whole growth); then up to eight sweeps
     in node order moving a node when that lowers cut/vol0 + cut/vol1 (never emptying a side), ending with the first idle sweep."""
     ids = sorted({a for a, _ in edges} | {b for _, b in edges})
     n = len(ids)
@@ -239,6 +240,8 @@ def _bisect_spec(edges, weights):
         if half is None:
             half = (n0, cut, vol0)
         n0, cut, vol0 = half
+    elif half is not None and not (best[0] < 0.6 * ncut(half[1], half[2])):
+        n0, cut, vol0 = half            # a lopsided prefix must beat the balanced one by 0.6x
     else:
         _, n0, cut, vol0 = best
     side = [1] * n
