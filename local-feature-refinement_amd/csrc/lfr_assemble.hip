@@ -512,7 +512,12 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
                        (uint64_t)C << node_bits, ek0, ei0);
     if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
-    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
+    // Packed classes carry zeros in the source-node bits (their order is component, then edge id - the sort is stable): when the graph
+    // stage's largest component says that no workgroup class can exist, only the component bits are sorted - three radix passes over the
+    // 5 M keys of config 4 instead of five.  A small component with > 320 edges still lands in a workgroup class: the summary below has
+    // the last word and the full sort is redone then.
+    const bool expect_workgroup_classes = p.stats.max_component_size > 17;
+    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, expect_workgroup_classes ? 0 : node_bits, node_bits + comp_bits, st)) != LFR_OK) return rc;
     // (both directions of a match are kept or dropped together by construction - k_count_edges - and the sort is stable on the edge
     // id, so the pair check only runs on request or on the path that materialises records)
     if (!fused || getenv("LFR_CHECK_PAIRS"))
@@ -536,7 +541,6 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, eo, no, out.d_node_inc);
         return LFR_OK;
     };
-    const bool expect_workgroup_classes = p.stats.max_component_size > 17;
     if (expect_workgroup_classes && (rc = build_incidence()) != LFR_OK) return rc;
 
     // ---- records: gather the flows (their first consumer); staged flows arrive in chunks on the copy stream ----
@@ -578,8 +582,12 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (out.summary.too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
     if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
     if (!expect_workgroup_classes && out.summary.class_begin[KC_BLOCK] < out.summary.n_desc) {
+        // the unexpected workgroup classes need their edges by source node: the full sort (packed classes keep their order), the words again
+        if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
+        if (fused) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
         if ((rc = build_incidence()) != LFR_OK) return rc;
-        if (!emit) {                              // the records of the unexpected workgroup-class components after all (every chunk has landed)
+        {                                         // the records again, in the new order (fused: the unexpected workgroup classes' only)
+            if (dg.flows_staged) for (int c = 0; c < n_chunks; ++c) if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
             if (aligned8)
                 hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
                                    dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges);

@@ -271,3 +271,25 @@ def test_bench_two_gpus_over_rccl(lfr_lib):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["strong_scaling"]["edges"] > 0
     assert out["solve"]["failed"] == 0
+
+
+def test_small_component_with_many_edges_takes_the_late_workgroup_path(lfr_lib):
+    """No component above 17 nodes, so the device assembly expects packed classes only (three-pass edge sort, no incidence lists, no
+    records) - but duplicated matches push one 17-node track beyond 320 edges, into a workgroup class: the assembly's summary has the last
+    word and redoes the sort by source node, the words, the incidence lists and the records.  Same positions as the host-assembled batch."""
+    ma = synthetic.generate(seed=41, n_images=17, n_tracks=40, len_dist="uniform", len_lo=3, len_hi=17)
+    pairs = ma.to_pairs()
+    for pr in pairs:                                              # every match three times (solve.cc:476-478 keeps duplicates)
+        pr["matches"] = pr["matches"] + [m for m in pr["matches"] for _ in range(2)]
+    ma2 = synthetic.pairs_to_arrays(pairs)
+    g = capi.Graph.from_arrays(ma2)
+    ph = capi.Problem(g)                                          # host assembly
+    want, _ = ph.solve_hip(0)
+    pd = capi.Problem(g, device_graph_stage=0)
+    assert pd.stats()["max_component_size"] <= 17
+    bd = capi.Batch(pd, 0)
+    bd.solve()
+    got = bd.download()
+    info = bd.component_info()
+    assert (info["n_edges"] > 320).any() and (2 * info["n_var_nodes"] <= 32).all()      # the case this test is about
+    assert (got == want).all()
