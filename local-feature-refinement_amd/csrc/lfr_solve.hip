@@ -626,6 +626,8 @@ struct BlockShared {
     double bcast[4];
     int flag;
     int ready;               // factor_lds: last panel whose diagonal block wave 0 has factored and published
+    int lead;                // factor_lds: column blocks whose first tile below the diagonal wave 1 has finished (what wave 0 waits for)
+    int wbar;                // factor_lds: arrivals at the worker waves' own barrier
     int ovf;                 // fused sweep: a term left the fixed-point range of the in-edge accumulators
 };
 
@@ -845,17 +847,36 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             }
             FPROF_MARK(3);                            // 3: tiles of the next column block (update)
             finish_rows(16 * kcol, kcol, R0, R1);
+            // tile (kcol + 1, kcol) is wave 1's first: wave 0 waits for it (and for the trailing update of the next diagonal tile, which
+            // wave 1 did before it came here) - a wave's LDS operations execute in program order
+            if (wave == 1 && R0 == kcol + 1 && lane == 0) __hip_atomic_store(&sh.lead, kcol + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             FPROF_MARK(4);                            // 4: rows of the next column block (substitution behind the diagonal block)
         }
     };
+    // bounded spin on an LDS word (a miscount must not hang the GPU: the step is rejected instead)
+    auto spin_until = [&](int *word, const int need) {
+        int spins = 0;
+        while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 22)) { if (lane == 0) sh.flag = 1; break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // the worker waves' own barrier (wave 0 is busy with a diagonal tile and does not take part)
+    auto worker_barrier = [&](const int target) {
+        if constexpr (kWorkers > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) __hip_atomic_fetch_add(&sh.wbar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            spin_until(&sh.wbar, target);
+        }
+    };
 
-    if (tid == 0) { sh.flag = 0; sh.ready = -1; }
+    if (tid == 0) { sh.flag = 0; sh.ready = -1; sh.lead = 0; sh.wbar = 0; }
     __syncthreads();
     FPROF_RESET();
     // ---- column block 0 ----
     if (wave == 0) { factor_diag(0, 0); FPROF_MARK(0); }                            // 0: diagonal blocks (wave 0)
-    else column_tiles(-1, 0);
-    __syncthreads();
+    else { column_tiles(-1, 0); worker_barrier(kWorkers); }
     FPROF_MARK(5);                                    // 5: barrier
     // ---- phases: panel k updates what is right of it, column block k+1 comes out final ----
     for (int k = 0; k + 1 < P; ++k) {
@@ -863,6 +884,10 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ninv[kk] = -vinv[kb + 4 * kk + kq];
         if (wave == 0) {
+            // Wave 0 runs AHEAD of the others: it does not wait at the end of a phase, only here for what the next diagonal tile needs -
+            // tile (k+1, k) substituted and panel k-1 applied to tile (k+1, k+1), both wave 1's first tasks of the phase before.
+            spin_until(&sh.lead, k + 1);
+            FPROF_MARK(2);                            // 2: wave 0 waiting for wave 1
             // the next diagonal tile: two accumulator chains of two MFMAs instead of one of four (the chain is on the critical path)
             Tile t;
             load_tile(kb, k + 1, k + 1, t);
@@ -895,10 +920,11 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             }
             FPROF_MARK(1);                            // 1: trailing tiles
             column_tiles(kb, k + 1);
+            worker_barrier(kWorkers * (k + 2));       // column block k+1 is final for every worker
         }
-        __syncthreads();
         FPROF_MARK(5);
     }
+    __syncthreads();
     FPROF_FLUSH();
 }
 
