@@ -626,7 +626,8 @@ struct BlockShared {
     double bcast[4];
     int flag;
     int ready;               // factor_lds: last panel whose diagonal block wave 0 has factored and published
-    int lead;                // factor_lds: column blocks whose first tile below the diagonal wave 1 has finished (what wave 0 waits for)
+    int lead;                // factor_lds: column blocks c for which wave 1 has substituted tile (c+2, c) and applied panel c to tile (c+2, c+1)
+    int lead_t;              // factor_lds: panels whose update wave 1 has applied to the next two tiles wave 0 will take
     int wbar;                // factor_lds: arrivals at the worker waves' own barrier
     int ovf;                 // fused sweep: a term left the fixed-point range of the in-edge accumulators
 };
@@ -660,19 +661,25 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 // Blocked LDL^T of the damped normal matrix in LDS (packed lower triangle, the right-hand side riding as row n), in place.
 // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal, 1/d_k goes to vinv[k].
 //
-// Right-looking over panels of 16 columns with ONE workgroup barrier per panel (round 2: 8 columns, three barriers, the
-// diagonal block on one thread).  Phase k starts with column block k final and
-//   * wave 0 brings the next diagonal tile (k+1, k+1) up to date (fp64 MFMA, K = 16) and factors it with lane = row
-//     (v_readlane broadcasts of the pivot column, 16 dependent steps of ~300 cycles: the kernel issues one VALU instruction per
-//     ~4.8 cycles and wave, scripts/probes/diag16_probe.hip).  Every step PUBLISHES its column - entries, 1/d_k, then a
-//     step counter in LDS (a wave's LDS operations execute in program order);
-//   * the other waves meanwhile apply panel k to the tiles right of column block k+1 (two 16x16 tiles in flight per wave,
-//     4 + 4 v_mfma_f64_16x16x4_f64), then to THEIR tiles of column block k+1, re-read those with lane = row and run the
-//     rows' substitution against the diagonal block step by step BEHIND wave 0 (a step waits for the counter): the
-//     substitution ends a few hundred cycles after the diagonal block does, instead of starting there;
-//   * the barrier at the end of the phase leaves column block k+1 final.
-// The diagonal blocks are the critical path (12 x ~8000 cycles for 190 rows); wave 0 does nothing else.
-// scripts/emul_factor_v2.py is a lane-level CPU model of the tile schedule (random wave order + a race detector).
+// Right-looking over panels of 16 columns (round 2: 8 columns, three barriers, the diagonal block on one thread).  The serial pieces
+// of a panel - the diagonal tile's elimination and the substitution of the rows below it, 16 dependent steps of ~300 cycles each (the
+// kernel issues one VALU instruction per ~4.8 cycles and wave, scripts/probes/diag16_probe.hip) - are kept off each other's path:
+//   * WAVE 0 owns the diagonal tiles and runs AHEAD of the other waves (no barrier inside the factorization).  Step k: apply panel k to
+//     the diagonal tile (k+1, k+1) (fp64 MFMA, K = 16; rows k+1 of panel k are its own), then factor it with lane = row in lanes 0-15
+//     while lanes 16-31 carry the rows of the tile below, (k+2, k+1), through the same steps - a_ic -= (a_ik / d_k) a_ck with a_ck read
+//     from lane c: the diagonal tile's elimination IS their substitution - so the rows the NEXT step's update needs come out final with
+//     the diagonal tile, not ~3000 cycles after it.  Then it stores both tiles and 1/d and publishes `ready`.
+//   * WAVE 1 feeds wave 0: in every phase it first applies the panel to the two tiles wave 0 takes next (`lead_t`), and as soon as the
+//     diagonal tile is out it substitutes tile (k+3, k+1), applies panel k+1 to tile (k+3, k+2) - the tile wave 0 carries next - and
+//     says so (`lead`).  With three or more workers it takes no other trailing tile.
+//   * the OTHER waves apply panel k to the tiles right of column block k+1 (two 16x16 tiles in flight per wave, 4 + 4
+//     v_mfma_f64_16x16x4_f64), then to their tiles of column block k+1, wait for `ready`, substitute their rows (lane = row), and meet
+//     at a barrier of their own (an LDS counter; wave 0 is not part of it).
+// Cycles per panel of the 190-row class: 14.3 k with one workgroup barrier per panel and the rows' substitution after the diagonal
+// tile (round 3, first half), 12.6 k now (wave 0: update 1.8 k, waiting for wave 1 3.7 k, elimination + loads/stores 7.0 k) - wave 1's
+// substitution of ONE tile plus its update is what wave 0 still waits for; the other workers are as loaded as wave 0 (11-12 k per phase).
+// scripts/emul_factor_v2.py is a lane-level CPU model of the FIRST round-3 schedule (one barrier per panel; random wave order + a race
+// detector); the hand-off flags of the current one are argued in the comments at their uses.
 // A non-positive pivot only raises sh.flag: the phases run to the end on whatever values there are (no data-dependent
 // exit, so no wave can miss a barrier), the caller rejects the step.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -705,17 +712,20 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
     volatile int *ready = &sh.ready;            // 16 * panel + (columns of that panel's diagonal block published)
     const __attribute__((address_space(3))) int *ready_lds = (const __attribute__((address_space(3))) int *)&sh.ready;
 
-    // diagonal tile at kb (up to date in LDS): lane = row, every 16-lane group of the wave computes the same thing
+    // diagonal tile at kb (up to date in LDS): lane = row in lanes 0-15.  Lanes 16-31 hold the rows of the tile BELOW it, (panel+1, panel),
+    // up to date as well: the elimination steps that factor the diagonal tile are exactly the rows' substitution for them
+    // (a_ic -= (a_ik / d_k) a_ck with a_ck read from lane c), so the tile the NEXT diagonal tile's update needs comes out final together
+    // with the diagonal tile instead of ~3000 cycles after it.  Everything is stored, then `ready` says so.
     auto factor_diag = [&](const int kb, const int panel) {
         const int nbp = min(16, n - kb);                            // pivots; a row beyond them is the right-hand side or padding
-        const int row = kb + r16;
-        const bool rv = row < n1;
+        const int row = kb + 16 * kq + r16;                         // group 0: the diagonal tile, group 1: the tile below
+        const bool rv = row < n1 && kq <= 1;
         const uint32_t base = tri(rv ? row : kb, kb);
         double a[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const double v = Mat[base + (rv ? min(j, r16) : 0)];
-            a[j] = (rv && j <= r16) ? v : (j == r16 ? 1.0 : 0.0);
+            const double v = Mat[base + (kq == 0 ? (rv ? min(j, r16) : 0) : j)];
+            a[j] = kq == 0 ? ((rv && j <= r16) ? v : (j == r16 ? 1.0 : 0.0)) : (rv ? v : 0.0);
         }
         bool bad = false;
 #pragma unroll
@@ -724,16 +734,18 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
                 const double dk = readlane_f64(a[k], k);
                 bad = bad || !(dk > 0.0);
                 const double ik = fast_rcp(dk);
-                // publish column k: its entries are final since step k - 1, the updates below touch columns > k only
-                if (lane < 16 && rv && r16 >= k) Mat[base + k] = a[k];
                 if (lane == k) vinv[kb + k] = ik;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (compiler only: the counter goes out after the data; the LDS keeps a wave's order)
-                if (lane == 0) *ready = 16 * panel + k + 1;
                 const double lik = a[k] * ik;                       // rows below the pivot (the others only touch their padding)
 #pragma unroll
                 for (int j = k + 1; j < 16; ++j) a[j] = fma(-lik, readlane_f64(a[k], j), a[j]);
             }
         }
+        if (rv) {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) if (kq == 0 ? c <= r16 : c >= 1) Mat[base + c] = a[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (compiler only: the counter goes out after the data; the LDS keeps a wave's order)
+        if (lane == 0) *ready = 16 * panel + 16;
         if (bad && lane == 0) sh.flag = 1;
     };
     // rows of the tiles R0 (lanes 0-15) and R1 (lanes 16-31; -1: none) against the diagonal tile at kb (a full panel) while wave 0
@@ -836,10 +848,13 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
         store_tile(t0);
         if (two) store_tile(t1);
     };
-    // the tiles (R, J) of column block J = kcol of this worker wave, two at a time: update by panel kb (kb < 0: none, column block 0),
-    // then the rows' substitution behind the diagonal block of panel `kcol`
+    // the tiles (R, kcol), R >= kcol + 2, of this worker wave, two at a time (tile (kcol + 1, kcol) is wave 0's: substituted inside the
+    // diagonal tile's elimination): update by panel kb (kb < 0: none, column block 0), then the rows' substitution against the diagonal
+    // tile of panel `kcol`.  Wave 1's first tile is (kcol + 2, kcol): with it final, wave 1 applies panel kcol to tile (kcol + 2, kcol + 1) -
+    // the tile wave 0 carries through the NEXT diagonal tile's elimination - and tells wave 0.
     auto column_tiles = [&](const int kb, const int kcol) {
-        for (int R0 = kcol + wave; R0 < RT; R0 += 2 * kWorkers) {                 // (wave >= 1: R0 starts at kcol + 1)
+        bool told = false;
+        for (int R0 = kcol + 1 + wave; R0 < RT; R0 += 2 * kWorkers) {             // (wave >= 1: R0 starts at kcol + 2)
             const int R1 = R0 + kWorkers < RT ? R0 + kWorkers : -1;
             if (kb >= 0) {
                 update_pair(kb, R0, kcol, R1 >= 0, R1, kcol);
@@ -847,11 +862,23 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             }
             FPROF_MARK(3);                            // 3: tiles of the next column block (update)
             finish_rows(16 * kcol, kcol, R0, R1);
-            // tile (kcol + 1, kcol) is wave 1's first: wave 0 waits for it (and for the trailing update of the next diagonal tile, which
-            // wave 1 did before it came here) - a wave's LDS operations execute in program order
-            if (wave == 1 && R0 == kcol + 1 && lane == 0) __hip_atomic_store(&sh.lead, kcol + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (wave == 1 && !told) {
+                told = true;
+                if (kcol + 1 < P) {                   // (a next diagonal tile exists; R0 = kcol + 2 < RT here)
+                    double keep[4];
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) { keep[kk] = ninv[kk]; ninv[kk] = -vinv[16 * kcol + 4 * kk + kq]; }
+                    wave_lds_sync();
+                    update_pair(16 * kcol, kcol + 2, kcol + 1, false, kcol + 2, kcol + 1);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) ninv[kk] = keep[kk];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&sh.lead, kcol + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
             FPROF_MARK(4);                            // 4: rows of the next column block (substitution behind the diagonal block)
         }
+        if (wave == 1 && !told && lane == 0) __hip_atomic_store(&sh.lead, kcol + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (no tile below: nothing to wait for)
     };
     // bounded spin on an LDS word (a miscount must not hang the GPU: the step is rejected instead)
     auto spin_until = [&](int *word, const int need) {
@@ -871,7 +898,7 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
         }
     };
 
-    if (tid == 0) { sh.flag = 0; sh.ready = -1; sh.lead = 0; sh.wbar = 0; }
+    if (tid == 0) { sh.flag = 0; sh.ready = -1; sh.lead = 0; sh.lead_t = 0; sh.wbar = 0; }
     __syncthreads();
     FPROF_RESET();
     // ---- column block 0 ----
@@ -884,11 +911,11 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) ninv[kk] = -vinv[kb + 4 * kk + kq];
         if (wave == 0) {
-            // Wave 0 runs AHEAD of the others: it does not wait at the end of a phase, only here for what the next diagonal tile needs -
-            // tile (k+1, k) substituted and panel k-1 applied to tile (k+1, k+1), both wave 1's first tasks of the phase before.
-            spin_until(&sh.lead, k + 1);
-            FPROF_MARK(2);                            // 2: wave 0 waiting for wave 1
-            // the next diagonal tile: two accumulator chains of two MFMAs instead of one of four (the chain is on the critical path)
+            // Wave 0 runs AHEAD of the others: no barrier at the end of a phase.  The next diagonal tile needs panel k - its rows k+1 are
+            // wave 0's own (substituted inside the previous elimination) - on top of the earlier panels (wave 1's first trailing pair of
+            // the phase before: lead_t); the tile below it, carried through the elimination, needs wave 1's special update (lead).
+            spin_until(&sh.lead_t, k);
+            // two accumulator chains of two MFMAs instead of one of four (the chain is on the critical path)
             Tile t;
             load_tile(kb, k + 1, k + 1, t);
             f64x4 c2 = {0.0, 0.0, 0.0, 0.0};
@@ -899,23 +926,36 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
 #pragma unroll
             for (int r = 0; r < 4; ++r) t.c[r] += c2[r];
             store_tile(t);
+            FPROF_MARK(3);                            // 3 (wave 0): the diagonal tile's update
+            spin_until(&sh.lead, k + 1);
+            FPROF_MARK(2);                            // 2: wave 0 waiting for wave 1
             wave_lds_sync();
             factor_diag(kb + 16, k + 1);
             FPROF_MARK(0);
         } else {
-            // tiles (R, J), k + 2 <= J <= R < RT, J a column block that exists: t-th tile of the row-major lower triangle, dealt
-            // round-robin over the worker waves
+            // tiles (R, J), k + 2 <= J <= R < RT, J a column block that exists: t-th tile of the row-major lower triangle.  Tiles 0 and 1,
+            // (k+2, k+2) and (k+3, k+2), are what wave 0 takes next: wave 1 does them first and says so; the others are dealt round-robin.
             const int m = RT - (k + 2);
             int T = m > 0 ? (m * (m + 1)) >> 1 : 0;
             if (T > 0 && RT > P) --T;                                 // (the last tile would be columns >= n of the right-hand-side row)
+            if (wave == 1) {
+                if (T > 0) update_pair(kb, k + 2, k + 2, T > 1, k + 3, k + 2);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&sh.lead_t, k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            const int Tw = T > 2 ? T - 2 : 0;
             int I = 0, J = 0, tcur = 0;
             auto seek = [&](const int tt) { J += tt - tcur; tcur = tt; while (J > I) { J -= I + 1; ++I; } };
-            for (int t = wave - 1; t < T; t += 2 * kWorkers) {        // wave-uniform
-                seek(t);
+            // (wave 1 has the lead tiles, the special update and wave 0 waiting for it: with three or more workers it takes no other
+            // trailing tile)
+            constexpr int kDeal = kWorkers >= 3 ? kWorkers - 1 : kWorkers;
+            const int first = kWorkers >= 3 ? wave - 2 : wave - 1;
+            for (int u = first; u >= 0 && u < Tw; u += 2 * kDeal) {   // wave-uniform
+                seek(u + 2);
                 const int Ra = k + 2 + I, Ja = k + 2 + J;
-                const bool two = t + kWorkers < T;
+                const bool two = u + kDeal < Tw;
                 int Rb = Ra, Jb = Ja;
-                if (two) { seek(t + kWorkers); Rb = k + 2 + I; Jb = k + 2 + J; }
+                if (two) { seek(u + kDeal + 2); Rb = k + 2 + I; Jb = k + 2 + J; }
                 update_pair(kb, Ra, Ja, two, Rb, Jb);
             }
             FPROF_MARK(1);                            // 1: trailing tiles
