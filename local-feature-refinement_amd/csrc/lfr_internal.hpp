@@ -117,7 +117,13 @@ enum KernelClass : int {
 };
 constexpr uint32_t kNoClass = 15;            // sort key of components that are not solved (by this shard)
 constexpr int kClassBits = 4;
-constexpr int kBlockRowsS = 88, kBlockRowsM = 130;
+#ifndef LFR_ROWS_S
+#define LFR_ROWS_S 88
+#endif
+#ifndef LFR_ROWS_M
+#define LFR_ROWS_M 130
+#endif
+constexpr int kBlockRowsS = LFR_ROWS_S, kBlockRowsM = LFR_ROWS_M;      // (overridable for class-boundary experiments)
 inline bool is_lds_class(int cls) { return cls >= KC_BLOCK && cls <= KC_BLOCK_L; }
 constexpr int kBlockMaxRows = 192;   // packed lower triangle 192*193/2*8 B = 148.2 KB + 15.4 KB of vectors <= 160 KiB of LDS
 // rows above which a component's matrix lives in the HBM workspace instead of LDS: kBlockMaxRows, or LFR_BLOCK_MAX_ROWS (0..192)
