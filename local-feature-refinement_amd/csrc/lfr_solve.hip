@@ -973,7 +973,7 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
 // vectors live in LDS for both variants: 8 vectors of n doubles
 // (two waves per SIMD = 256 registers each, VGPRs + the MFMA accumulators: what the 4 / 2 workgroups per CU of the two smaller
 // LDS classes need; without the attribute the allocator takes 264)
-template <bool GLOBAL_MATRIX, int kBlockThreads>
+template <int kBlockThreads>
 __device__ __forceinline__ void solve_component(const KernelArgs &a, const int max_rows, const int ci, double *dyn, BlockShared &sh) {
     constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
 #ifdef LFR_PROFILE_WGTIME
@@ -989,8 +989,8 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     // LDS variant: vectors + packed matrix in dynamic LDS.  HBM variant: packed matrix, then the
     // vectors, in this component's workspace (L2-resident); no dynamic LDS at all, so the row count
     // is only bounded by the 32767-node limit of the batch format.
-    double *Mat = GLOBAL_MATRIX ? (a.workspace + a.ws_off[ci]) : (dyn + 2 * (size_t)(max_rows + 2) + 7 * (size_t)max_rows);
-    double *vx = GLOBAL_MATRIX ? (Mat + tri(n, 0) + (tri(n, 0) & 1)) : dyn;   // x (n + 2, zero slot at n)
+    double *Mat = dyn + 2 * (size_t)(max_rows + 2) + 7 * (size_t)max_rows;
+    double *vx = dyn;                 // x (n + 2, zero slot at n)
     double *vxc = vx + max_rows + 2;  // trial point
     double *vg = vxc + max_rows + 2;  // gradient at x
     double *vgn = vg + max_rows;      // gradient at trial point
@@ -999,9 +999,9 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     // rhs -> step.  LDS variant: row n of the matrix - the right-hand side rides through the factorization as one more row
     // (LDL^T of [[A, g], [g^T, .]]: the unscaled entries of that row come out as L^-1 g), so the forward substitution, n
     // dependent steps per solve, is gone; the (n, n) entry is never used.
-    double *vstep = GLOBAL_MATRIX ? vdiag + max_rows : Mat + tri(n, 0);
-    double *vD = GLOBAL_MATRIX ? vstep + max_rows : vdiag + max_rows;
-    const int n1 = GLOBAL_MATRIX ? n : n + 1;        // rows the factorization carries
+    double *vstep = Mat + tri(n, 0);
+    double *vD = vdiag + max_rows;
+    const int n1 = n + 1;             // rows the factorization carries
     double *vadiag = vD + max_rows;   // diagonal of unscaled J^T J at x
     double *vdelta = vadiag + max_rows;
 
@@ -1210,7 +1210,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #ifndef LFR_FUSED_SWEEP
 #define LFR_FUSED_SWEEP 1
 #endif
-    bool fused_sweep = !GLOBAL_MATRIX && LFR_FUSED_SWEEP != 0 && split_walk && !a.scratch_sweep;
+    bool fused_sweep = LFR_FUSED_SWEEP != 0 && split_walk && !a.scratch_sweep;
     auto sweep_fused = [&](const double *xv, double *gout, bool want_matrix, bool &overflow) -> double {
         constexpr double kFx = 0x1p40, kFxInv = 0x1p-40;
         unsigned long long *fx_g = reinterpret_cast<unsigned long long *>(vstep), *fx_d = reinterpret_cast<unsigned long long *>(vD);
@@ -1391,156 +1391,14 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         __syncthreads();
         PROF_MARK(5);                                 // 5: scaling
         double *vinv = vgn;            // free until the line search
-        if constexpr (!GLOBAL_MATRIX) {
+        {
             factor_lds<kBlockThreads>(Mat, vinv, n, sh, a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr);        // 16-column panels, one barrier per panel (see factor_lds)
-        } else {
-            // ---- blocked LDL^T in place (right-looking, panels of kPanel columns) ----
-            // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal and 1/d_k
-            // goes to vinv[k].  Every sequential step of a factorization costs an LDS round trip (~10^3 cycles
-            // with its barrier) whatever it computes, so the work is cut into n/kPanel steps: (1) one thread
-            // factors the kPanel x kPanel diagonal block IN REGISTERS, (2) one thread per row below finishes the
-            // row's panel entries in registers, (3) the trailing matrix takes the rank-kPanel update in 4x4
-            // register tiles.
-            constexpr int kPanel = 8;
-            constexpr int kPT = kPanel * (kPanel + 1) / 2;
-            if (tid == 0) sh.flag = 0;
-            __syncthreads();
-            // the diagonal block [kb, kb+nb) as packed lower registers; rows/columns >= nb are identity padding
-            auto load_block = [&](int kb, int nb, double (&B)[kPT]) {
-    #pragma unroll
-                for (int i = 0; i < kPanel; ++i)
-    #pragma unroll
-                    for (int j = 0; j <= i; ++j)
-                        B[i * (i + 1) / 2 + j] = (i < nb) ? Mat[tri(kb + i, kb + j)] : (i == j ? 1.0 : 0.0);
-            };
-            for (int kb = 0; kb < n; kb += kPanel) {
-                const int nb = min(kPanel, n - kb), ke = kb + nb;
-                if (tid == 0) {
-                    double B[kPT], inv[kPanel];
-                    load_block(kb, nb, B);
-                    bool bad = false;
-    #pragma unroll
-                    for (int k = 0; k < kPanel; ++k) {
-                        const double dk = B[k * (k + 1) / 2 + k];
-                        bad = bad || !(dk > 0.0);
-                        inv[k] = fast_rcp(dk);
-    #pragma unroll
-                        for (int i = k + 1; i < kPanel; ++i) {
-                            const double lik = B[i * (i + 1) / 2 + k] * inv[k];
-    #pragma unroll
-                            for (int j = k + 1; j <= i; ++j) B[i * (i + 1) / 2 + j] -= lik * B[j * (j + 1) / 2 + k];
-                        }
-                    }
-                    if (bad) sh.flag = 1;
-    #pragma unroll
-                    for (int i = 0; i < kPanel; ++i) {
-                        if (i < nb) {
-                            vinv[kb + i] = inv[i];
-    #pragma unroll
-                            for (int j = 1; j <= i; ++j) Mat[tri(kb + i, kb + j)] = B[i * (i + 1) / 2 + j];
-                        }
-                    }
-                }
-                __syncthreads();
-                PROF_FACTOR_MARK(3);                      // 3: diagonal blocks of the factorization (one thread)
-                if (sh.flag) break;                                           // uniform
-                if (ke < n1) {
-                    double B[kPT], inv[kPanel];                               // (broadcast reads: same addresses in every lane)
-                    load_block(kb, nb, B);
-    #pragma unroll
-                    for (int k = 0; k < kPanel; ++k) inv[k] = k < nb ? vinv[kb + k] : 1.0;
-                    for (int i = ke + tid; i < n1; i += kBlockThreads) {      // a_ic -= sum_{k<c} (a_ik / d_k) a_ck
-                        double r[kPanel];
-    #pragma unroll
-                        for (int c = 0; c < kPanel; ++c) r[c] = c < nb ? Mat[tri(i, kb + c)] : 0.0;
-    #pragma unroll
-                        for (int c = 1; c < kPanel; ++c) {
-    #pragma unroll
-                            for (int k = 0; k < c; ++k) r[c] -= (r[k] * inv[k]) * B[c * (c + 1) / 2 + k];
-                        }
-    #pragma unroll
-                        for (int c = 1; c < kPanel; ++c) if (c < nb) Mat[tri(i, kb + c)] = r[c];
-                    }
-                }
-                __syncthreads();
-                PROF_FACTOR_MARK(4);                      // (profile builds: row panels land in slot 4)
-                {   // trailing matrix -= (panel columns) (panel columns / d)^T: a rank-nb update of the lower triangle, one 16x16
-                    // tile per wave and step on the fp64 matrix cores (v_mfma_f64_16x16x4_f64: lane l feeds A[l&15][l>>4] and
-                    // B[l>>4][l&15] and holds D[(l>>4)+4r][l&15], r = 0..3).  The VALU version of this loop (4x4 register tiles) took 44 %
-                    // of the kernel: 0.75 LDS accesses per multiply-add with 4-8-way bank conflicts on the packed rows; a tile step
-                    // here is 14 LDS accesses for 2048 multiply-adds, the tile's rows are contiguous in LDS.
-                    // A wave works on two tiles at a time and every load is unconditional (clamped index, value selected
-                    // afterwards): the 20 LDS reads of a pair are in flight together and the four MFMAs of the two independent
-                    // accumulators alternate, instead of one load -> multiply -> MFMA -> store chain per tile.
-                    const int lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
-                    constexpr int kWaves = kBlockThreads / 64;
-                    const bool k0 = kq < nb, k1 = 4 + kq < nb;
-                    const int kc0 = kb + min(kq, nb - 1), kc1 = kb + min(4 + kq, nb - 1);
-                    const double ninv0 = -vinv[kc0], ninv1 = -vinv[kc1];
-                    const int mt = ke < n ? (n1 - ke + 15) >> 4 : 0;         // (only the right-hand-side row left: nothing to update)
-                    struct Tile { double a0, a1, b0, b1; f64x4 c; bool ok[4]; int row0, jb; };
-                    auto load_tile = [&](int I, int J, Tile &T) {
-                        const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16, iac = min(ia, n1 - 1), jbc = min(jb, n1 - 1);
-                        T.row0 = ke + 16 * I + kq; T.jb = jb;
-                        const double a0 = Mat[tri(iac, kc0)], a1 = Mat[tri(iac, kc1)], b0 = Mat[tri(jbc, kc0)], b1 = Mat[tri(jbc, kc1)];
-                        double cv[4];
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int row = T.row0 + 4 * r, rc = min(row, n1 - 1);
-                            T.ok[r] = row < n1 && jb <= row;
-                            cv[r] = Mat[tri(rc, min(jbc, rc))];
-                        }
-                        T.a0 = (ia < n1 && k0) ? a0 : 0.0; T.a1 = (ia < n1 && k1) ? a1 : 0.0;
-                        T.b0 = (jb < n1 && k0) ? b0 * ninv0 : 0.0; T.b1 = (jb < n1 && k1) ? b1 * ninv1 : 0.0;
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) T.c[r] = T.ok[r] ? cv[r] : 0.0;
-                    };
-                    auto store_tile = [&](const Tile &T) {
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) if (T.ok[r]) Mat[tri(T.row0 + 4 * r, T.jb)] = T.c[r];
-                    };
-                    // interior tiles of a full panel (every row < n, strictly below the diagonal): no clamps, no selects
-                    auto load_full = [&](int I, int J, Tile &T) {
-                        const int ia = ke + 16 * I + r16, jb = ke + 16 * J + r16;
-                        T.row0 = ke + 16 * I + kq; T.jb = jb;
-                        const uint32_t oa = tri(ia, kb + kq), ob = tri(jb, kb + kq);
-                        T.a0 = Mat[oa]; T.a1 = Mat[oa + 4]; T.b0 = Mat[ob] * ninv0; T.b1 = Mat[ob + 4] * ninv1;
-    #pragma unroll
-                        for (int r = 0; r < 4; ++r) { T.ok[r] = true; T.c[r] = Mat[tri(T.row0 + 4 * r, jb)]; }
-                    };
-                    int I = 0, J = wave;                                     // tile t = wave, wave + kWaves, ... of the row-major lower triangle
-                    while (J > I) { J -= I + 1; ++I; }
-                    while (I < mt) {                                         // wave-uniform
-                        const int I0 = I, J0 = J;
-                        J += kWaves; while (J > I) { J -= I + 1; ++I; }
-                        const bool two = I < mt;
-                        const int I1 = I, J1 = J;
-                        J += kWaves; while (J > I) { J -= I + 1; ++I; }
-                        Tile t0, t1;
-                        if (nb == kPanel && two && J0 < I0 && J1 < I1 && ke + 16 * I1 + 15 < n1) {       // (I0 <= I1)
-                            load_full(I0, J0, t0);
-                            load_full(I1, J1, t1);
-                        } else {
-                            load_tile(I0, J0, t0);
-                            load_tile(I1, J1, t1);                           // (past the end: clamped loads, nothing stored)
-                        }
-                        t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a0, t0.b0, t0.c, 0, 0, 0);
-                        t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a0, t1.b0, t1.c, 0, 0, 0);
-                        t0.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t0.a1, t0.b1, t0.c, 0, 0, 0);
-                        t1.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t1.a1, t1.b1, t1.c, 0, 0, 0);
-                        store_tile(t0);
-                        if (two) store_tile(t1);
-                    }
-                }
-                __syncthreads();
-                PROF_MARK(1);                             // 1: trailing updates of the factorization
-            }
         }
         __syncthreads();
         PROF_MARK(1);
         bool valid = sh.flag == 0;
         if (valid) {
-            if constexpr (!GLOBAL_MATRIX) {
+            {
                 // Back substitution by ONE wave with the vector in registers (n <= 192: three values per lane): a step is a
                 // v_readlane broadcast and one multiply-add per register - ~50 cycles against the ~270 of a step that crosses a
                 // workgroup barrier and an LDS round trip, and there are 2 n steps per solve.  The matrix entries do not depend
@@ -1612,20 +1470,6 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     for (int r = 0; r < kR; ++r) if (tid + 64 * r < n) vstep[tid + 64 * r] = yo[r];
                 }
                 __syncthreads();
-            } else {
-                // one column per step (a step is one barrier + one memory round trip)
-                for (int k = 0; k < n; ++k) {                                 // forward: L z = rhs
-                    const double t = vstep[k] * vinv[k];
-                    for (int i = k + 1 + tid; i < n; i += kBlockThreads) vstep[i] -= Mat[tri(i, k)] * t;
-                    __syncthreads();
-                }
-                for (int i = tid; i < n; i += kBlockThreads) vstep[i] *= vinv[i];
-                __syncthreads();
-                for (int k = n - 1; k > 0; --k) {                             // backward: L^T y = w
-                    const double yk = vstep[k];
-                    for (int j = tid; j < k; j += kBlockThreads) vstep[j] -= Mat[tri(k, j)] * vinv[j] * yk;
-                    __syncthreads();
-                }
             }
         }
         PROF_MARK(6);                                 // 6: triangular solves
@@ -2286,7 +2130,7 @@ __global__ void k_wg_order_keys(const CompDesc *descs, int n, int b1, int b2, in
 // order to the hardware dispatcher, which deals workgroups to the XCDs round-robin whatever they cost: a CU sat idle 0.16 ms on
 // average (up to 1.3 ms) before its next 160-KB workgroup while the queue was still full, and CUs ended up with one to seven
 // components each (`scripts/c5_timeline.py`).  Here a free CU always takes the largest component left.
-template <bool GLOBAL_MATRIX, int kBlockThreads>
+template <int kBlockThreads>
 __device__ __forceinline__ void block_kernel_body(const KernelArgs &a, int max_rows) {
     extern __shared__ double dyn[];
     __shared__ BlockShared sh;
@@ -2302,19 +2146,13 @@ __device__ __forceinline__ void block_kernel_body(const KernelArgs &a, int max_r
         const int ci = __builtin_amdgcn_readfirstlane(next_ci);
         __syncthreads();                              // everyone has read it before the next round overwrites it
         if (ci < 0) break;
-        solve_component<GLOBAL_MATRIX, kBlockThreads>(a, max_rows, ci, dyn, sh);
+        solve_component<kBlockThreads>(a, max_rows, ci, dyn, sh);
         __syncthreads();                              // the component's last LDS reads are done
     }
 }
-template <bool GLOBAL_MATRIX, int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
-    block_kernel_body<GLOBAL_MATRIX, kBlockThreads>(a, max_rows);
-}
-// the same with ONE wave per SIMD (a 256-thread workgroup that owns its CU): 512 registers per wave - 256 VGPRs and the accumulation
-// registers as spill space (v_accvgpr moves) instead of scratch memory
 template <int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_block_kernel_w1(const KernelArgs a, int max_rows) {
-    block_kernel_body<false, kBlockThreads>(a, max_rows);
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+    block_kernel_body<kBlockThreads>(a, max_rows);
 }
 
 #ifndef LFR_THREADS_S
@@ -2971,14 +2809,11 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
         const int lds_m = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_M], 2), false);
         const int lds_l = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_L], 2), false);
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s));
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<false, kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<kThreadsS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_s));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
+        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     std::max(lds_l, std::max(kThreadsL == kThreadsM ? lds_m : 0, kThreadsL == kThreadsS ? lds_s : 0))));
         HIP_TRY(hipFuncSetAttribute((const void *)solve_sky_kernel<kThreadsG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(b->sky_lds_doubles * sizeof(double))));
-#ifdef LFR_L_W1
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel_w1<kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_l));
-#endif
     }
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
@@ -3042,13 +2877,9 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         const int by_waves = std::max(1, 512 / threads), by_lds = lds ? std::max(1, (int)((size_t)160 * 1024 / (lds + 256))) : by_waves;
         const int wgs = std::min(n, b->ctx->n_cu * std::min(by_waves, by_lds));
         switch (cls) {
-            case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<false, kThreadsS>), dim3(wgs), dim3(kThreadsS), lds, cs, a, rows); break;
-            case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
-#ifdef LFR_L_W1
-            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel_w1<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
-#else
-            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<false, kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
-#endif
+            case lfr::KC_BLOCK:   hipLaunchKernelGGL((solve_block_kernel<kThreadsS>), dim3(wgs), dim3(kThreadsS), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
+            case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
             default: {
                 // block-envelope kernel: LDS = the back-substitution vector (the workspace copy when it does not fit); two workgroups per CU
                 const size_t sky_lds = (size_t)b->sky_lds_doubles * sizeof(double);
