@@ -11,10 +11,12 @@
 //                              of a match sit in neighbouring lanes and exchange their terms through DPP before
 //                              7 ds_add_f64 per edge assemble J^T J in LDS, the damped system is eliminated in
 //                              registers (lane = row) with ds_swizzle broadcasts, sized per wave.
-//   solve_block_kernel         one persistent 128/256/512-thread workgroup per larger component; packed J^T J in LDS
-//                              (<=192 rows, three LDS-footprint classes) or in an HBM workspace (GLOBAL variant),
-//                              owner-computes assembly, blocked LDL^T (16-column panels, fp64 MFMA trailing update);
-//                              edges re-streamed from L2/HBM per pass.
+//   solve_block_kernel         persistent 128/256/512-thread workgroups over the components of up to 192 rows (three LDS-footprint
+//                              classes): packed J^T J in LDS, fused evaluate-and-assemble sweep (four to eight lanes per node, the
+//                              records re-streamed from HBM and nothing else), blocked LDL^T with 16-column panels - the diagonal
+//                              tiles on a wave that runs ahead of the others, trailing updates on the fp64 matrix cores.
+//   solve_sky_kernel           one 256-thread workgroup per component above 192 rows: block-envelope LDL^T (16x16 tiles inside the
+//                              envelope of a fill-reducing node order, lfr_order.cpp) in an HBM workspace.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
