@@ -680,6 +680,8 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 // Cycles per panel of the 190-row class: 14.3 k with one workgroup barrier per panel and the rows' substitution after the diagonal
 // tile (round 3, first half), 12.6 k now (wave 0: update 1.8 k, waiting for wave 1 3.7 k, elimination + loads/stores 7.0 k) - wave 1's
 // substitution of ONE tile plus its update is what wave 0 still waits for; the other workers are as loaded as wave 0 (11-12 k per phase).
+// (Wave 1 running its OWN copy of the elimination with its tiles carried along - so that its first tile is final when wave 0 publishes -
+// was built too: wave 0 waits 2.4 k instead of 3.7 k per panel, and its elimination takes 8.6 k instead of 7.0 k; no gain, removed.)
 // (The pivot column through LDS instead of v_readlane - 3.8 k against 4.8 k cycles per tile in the isolated probe - DOUBLES the elimination here:
 // 14 k cycles per panel with seven other waves loading and storing tiles through the same LDS.)
 // scripts/emul_factor_v2.py is a lane-level CPU model of the FIRST round-3 schedule (one barrier per panel; random wave order + a race
