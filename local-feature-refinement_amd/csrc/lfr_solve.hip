@@ -979,7 +979,6 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
 // LDS classes need; without the attribute the allocator takes 264)
 template <int kBlockThreads>
 __device__ __forceinline__ void solve_component(const KernelArgs &a, const int max_rows, const int ci, double *dyn, BlockShared &sh) {
-    constexpr int kTileRows = kBlockThreads / 16;      // (kTileRows x 16) thread tiling of the matrix loops
 #ifdef LFR_PROFILE_WGTIME
     const unsigned long long wg_t0_ = __builtin_amdgcn_s_memtime();
     const unsigned long long wg_r0_ = wall_clock64();          // 100 MHz, the same counter on every XCD
@@ -1373,27 +1372,21 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
             matrix_valid = true;
             PROF_MARK(0);
         }
-        // ---- H = S A S + D^2 in place, rhs = S g ----
+        // ---- the damped system.  Ceres solves (S A S + D^2) y = S g with the Jacobi scaling S; that is (A + S^-1 D^2 S^-1) (S y) = g: the
+        // UNSCALED matrix with the same scaled LM diagonal gives the step S y directly - n diagonal entries to touch instead of n^2 / 2
+        // (the packed kernel has always done this; rounds 1-2 scaled every entry here: 3 % of a 190-row component, 19 % of a sparse
+        // 1000-row one whose tiles live in HBM) ----
         for (int i = tid; i < n; i += kBlockThreads) {
             if (!reuse_diagonal) vdiag[i] = fmin(fmax(vscale[i] * vscale[i] * vadiag[i], kMinLmDiag), kMaxLmDiag);
-            vD[i] = sqrt(vdiag[i] / radius);
-            vstep[i] = vscale[i] * vg[i];
+            const double di = sqrt(vdiag[i] / radius) / vscale[i];           // D / s
+            vD[i] = di;
+            vstep[i] = vg[i];
+            Mat[tri(i, i)] += di * di;
         }
         reuse_diagonal = true;
-        __syncthreads();
-        // (kTileRows x 16) thread tiling over (row, column): no index inversion, balanced trailing updates
-        const int ti = tid >> 4, tj = tid & 15;
-        for (int i = ti; i < n; i += kTileRows) {
-            const double si = vscale[i];
-            for (int j = tj; j <= i; j += 16) {
-                double v = Mat[tri(i, j)] * si * vscale[j];
-                if (i == j) v += vD[i] * vD[i];
-                Mat[tri(i, j)] = v;
-            }
-        }
         matrix_valid = false;
         __syncthreads();
-        PROF_MARK(5);                                 // 5: scaling
+        PROF_MARK(5);                                 // 5: damping
         double *vinv = vgn;            // free until the line search
         {
             factor_lds<kBlockThreads>(Mat, vinv, n, sh, a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr);        // 16-column panels, one barrier per panel (see factor_lds)
@@ -1481,7 +1474,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         if (valid) {
             double part = 0.0, bad = 0.0;
             for (int i = tid; i < n; i += kBlockThreads) {
-                const double rhs0 = vscale[i] * vg[i];
+                const double rhs0 = vg[i];
                 const double st = -vstep[i];
                 if (!isfinite(st)) bad = 1.0;
                 part += -rhs0 * st + vD[i] * vD[i] * st * st;
@@ -1499,7 +1492,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         n_invalid = 0;
         double gd_part = 0.0, dm_part = 0.0;
         for (int i = tid; i < n; i += kBlockThreads) {
-            const double dl = -vstep[i] * vscale[i];
+            const double dl = -vstep[i];
             vdelta[i] = dl;
             gd_part += vg[i] * dl;
             dm_part = fmax(dm_part, fabs(dl));
@@ -1765,22 +1758,12 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
         return total;
     };
 
-    // ---- H = S A S + D^2 over the stored tiles, right-hand side S g into row n ----
+    // ---- the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the stored tiles' diagonal, g into row n (see solve_component) ----
     auto scale_matrix = [&]() {
-        for (int R = wave; R < RT; R += kWaves) {
-            for (int J = (int)fb[R]; J <= R; ++J) {
-                double *t = tile_ptr(R, J);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int idx = lane + 64 * u, i = 16 * R + (idx >> 4), j = 16 * J + (idx & 15);
-                    double v = t[idx] * vscale[i] * vscale[j];
-                    if (i == j) v += vD[i] * vD[i];
-                    t[idx] = v;
-                }
-            }
+        for (int j = tid; j < n; j += kBlockThreads) {
+            tile_ptr(j >> 4, j >> 4)[((j & 15) << 4) + (j & 15)] += vD[j] * vD[j];
+            tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)] = vg[j];
         }
-        __syncthreads();
-        for (int j = tid; j < n; j += kBlockThreads) tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)] = vscale[j] * vg[j];
         __syncthreads();
     };
 
@@ -1933,8 +1916,11 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
     };
 
     // ---- the trust-region loop of solve_component, over vectors in matrix order ----
+    // (-DLFR_PROFILE_PHASES: 0 sweeps, 1 factorization, 5 scaling, 6 back substitution, 4 everything else - the slots of the LDS kernels)
+    PROF_DECL
     int exec_passes = 1;
     double cost = sweep(vx, vg);
+    PROF_MARK(0);
     for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
     __syncthreads();
     auto grad_max = [&](const double *xv, const double *gv) {
@@ -1953,26 +1939,31 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
         if (radius <= kMinRadius) break;
         ++iteration;
         step_successful = false;
+        PROF_MARK(4);
         if (!matrix_valid) {           // the factorization of a rejected step overwrote J^T J: re-assemble
             sweep(vx, vg);
             ++exec_passes;
             matrix_valid = true;
+            PROF_MARK(0);
         }
         for (int i = tid; i < n; i += kBlockThreads) {
             if (!reuse_diagonal) vdiag[i] = fmin(fmax(vscale[i] * vscale[i] * vadiag[i], kMinLmDiag), kMaxLmDiag);
-            vD[i] = sqrt(vdiag[i] / radius);
+            vD[i] = sqrt(vdiag[i] / radius) / vscale[i];                     // D / s
         }
         reuse_diagonal = true;
         __syncthreads();
         scale_matrix();
+        PROF_MARK(5);
         matrix_valid = false;
         bool valid = factor();
+        PROF_MARK(1);
         if (valid) back_substitute();
+        PROF_MARK(6);
         double model_cost_change = 0.0;
         if (valid) {
             double part = 0.0, bad = 0.0;
             for (int i = tid; i < n; i += kBlockThreads) {
-                const double rhs0 = vscale[i] * vg[i];
+                const double rhs0 = vg[i];
                 const double st = -vstep[i];
                 if (!isfinite(st)) bad = 1.0;
                 part += -rhs0 * st + vD[i] * vD[i] * st * st;
@@ -1990,7 +1981,7 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
         n_invalid = 0;
         double gd_part = 0.0, dm_part = 0.0;
         for (int i = tid; i < n; i += kBlockThreads) {
-            const double dl = -vstep[i] * vscale[i];
+            const double dl = -vstep[i];
             vdelta[i] = dl;
             gd_part += vg[i] * dl;
             dm_part = fmax(dm_part, fabs(dl));
@@ -2006,7 +1997,9 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
             for (;;) {
                 for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
                 __syncthreads();
+                PROF_MARK(4);
                 cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
+                PROF_MARK(0);
                 ++exec_passes; ++n_ls_evals;
                 current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
                 current.gradient = 0.0; current.gradient_valid = false;
@@ -2058,6 +2051,8 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
             decrease_factor *= 2.0;
         }
     }
+    PROF_MARK(4);
+    PROF_FLUSH();
     __syncthreads();
     for (int i = tid; i < n; i += kBlockThreads)
         a.positions[2 * (size_t)a.node_ids[d.node_off + (int)ipos[i >> 1]] + (i & 1)] = term != LFR_TERM_FAILURE ? vx[i] : 0.0;
