@@ -1881,32 +1881,55 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
     // ---- L D L^T y = g with w = L^-1 g in row n: z = w; block rows upwards: y_K = solve within the diagonal tile, z_J -= tile(K, J)^T y_K ----
     auto back_substitute = [&]() {
         for (int j = tid; j < n; j += kBlockThreads) zl[j] = tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)];
+        // The factored tiles are final and live in HBM: what a step needs is loaded one step AHEAD of the dependent chain - wave 0 fetches
+        // the next diagonal tile while it solves the current one, every wave fetches its first off-diagonal tile of the block row before
+        // the barrier that releases the block's solution (a load from the workspace is ~2000 cycles, a block step was ~5000).
+        double m[16], iv = 0.0;                               // wave 0: column r16 of the rows below it in the diagonal tile, 1 / d
+        auto load_diag = [&](const int K) {
+            const double *T = tile_ptr(K, K);
+#pragma unroll
+            for (int k = 0; k < 16; ++k) m[k] = T[(k << 4) + r16];
+            iv = r16 < min(16, n - 16 * K) ? vinv[16 * K + r16] : 0.0;
+        };
+        if (wave == 0) load_diag(P - 1);
         __syncthreads();
         for (int K = P - 1; K >= 0; --K) {
             const int kb = 16 * K, nbp = min(16, n - kb);
-            if (wave == 0) {
-                const double *T = tile_ptr(K, K);
-                double m[16];                                    // column r16 of the rows below it
+            const int J0 = (int)fb[K] + wave;                  // this wave's first tile (K, J0) of the block row, if J0 < K
+            double tv[4] = {0.0, 0.0, 0.0, 0.0};
+            if (J0 < K) {
+                const double *T = tile_ptr(K, J0);
 #pragma unroll
-                for (int k = 0; k < 16; ++k) m[k] = T[(k << 4) + r16];
+                for (int r = 0; r < 4; ++r) tv[r] = T[((kq + 4 * r) << 4) + r16];
+            }
+            if (wave == 0) {
+                double mc[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) mc[k] = m[k];
+                const double ivc = iv;
+                if (K > 0) load_diag(K - 1);                   // (in flight during the solve below)
                 double z = r16 < nbp ? zl[kb + r16] : 0.0;
-                const double iv = r16 < nbp ? vinv[kb + r16] : 0.0;
                 double yo = 0.0;
 #pragma unroll
                 for (int k = 15; k >= 0; --k) {
-                    const double yv = z * iv;
+                    const double yv = z * ivc;
                     const double yk = readlane_f64(yv, k);
                     yo = (r16 == k) ? yv : yo;
-                    z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
+                    z = fma(-((r16 < k) ? mc[k] : 0.0), yk, z);
                 }
                 if (lane < 16) { ss.y[r16] = yo; if (r16 < nbp) vstep[kb + r16] = yo; }
             }
             __syncthreads();
-            for (int J = (int)fb[K] + wave; J < K; J += kWaves) {
-                const double *T = tile_ptr(K, J);
+            for (int J = J0; J < K; J += kWaves) {
                 double part = 0.0;
+                if (J == J0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) part = fma(T[((kq + 4 * r) << 4) + r16], ss.y[kq + 4 * r], part);
+                    for (int r = 0; r < 4; ++r) part = fma(tv[r], ss.y[kq + 4 * r], part);
+                } else {
+                    const double *T = tile_ptr(K, J);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part = fma(T[((kq + 4 * r) << 4) + r16], ss.y[kq + 4 * r], part);
+                }
                 part += __shfl_xor(part, 16, 64);
                 part += __shfl_xor(part, 32, 64);
                 if (kq == 0) zl[16 * J + r16] -= part;
