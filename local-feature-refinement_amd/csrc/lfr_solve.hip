@@ -1799,18 +1799,20 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                     av[j] = below ? (on ? v : 0.0) : (j <= r16 ? v : 0.0);
                 }
                 bool bad = false;
+                double my_inv = 0.0;                          // lane kk keeps 1 / d_kk: one store after the loop instead of a masked one per step
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     if (kk < nbp) {
                         const double dk = readlane_f64(av[kk], kk);
                         bad = bad || !(dk > 0.0);
                         const double ik = fast_rcp(dk);
-                        if (lane == kk) { ss.inv[kk] = ik; vinv[kb + kk] = ik; }
+                        my_inv = lane == kk ? ik : my_inv;
                         const double lik = av[kk] * ik;
 #pragma unroll
                         for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
-                    } else if (lane == kk) ss.inv[kk] = 0.0;
+                    }
                 }
+                if (lane < 16) { ss.inv[lane] = my_inv; if (lane < nbp) vinv[kb + lane] = my_inv; }
                 if (lane < 16) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) { ss.diag[(r16 << 4) + j] = av[j]; if (j <= r16) T[(r16 << 4) + j] = av[j]; }
