@@ -734,18 +734,20 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             a[j] = kq == 0 ? ((rv && j <= r16) ? v : (j == r16 ? 1.0 : 0.0)) : (rv ? v : 0.0);
         }
         bool bad = false;
+        double my_inv = 0.0;                                        // lane k keeps 1 / d_k: one store after the loop instead of a masked one per step
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
             if (k < nbp) {                                          // wave-uniform
                 const double dk = readlane_f64(a[k], k);
                 bad = bad || !(dk > 0.0);
                 const double ik = fast_rcp(dk);
-                if (lane == k) vinv[kb + k] = ik;
+                my_inv = lane == k ? ik : my_inv;
                 const double lik = a[k] * ik;                       // rows below the pivot (the others only touch their padding)
 #pragma unroll
                 for (int j = k + 1; j < 16; ++j) a[j] = fma(-lik, readlane_f64(a[k], j), a[j]);
             }
         }
+        if (lane < nbp) vinv[kb + lane] = my_inv;
         if (rv) {
 #pragma unroll
             for (int c = 0; c < 16; ++c) if (kq == 0 ? c <= r16 : c >= 1) Mat[base + c] = a[c];
