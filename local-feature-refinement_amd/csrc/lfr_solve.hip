@@ -1795,10 +1795,12 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                 double *T = below ? tile_ptr((int)act_list[on ? li : 0], k) : tile_ptr(k, k);
                 if (!on && below) T = tile_ptr(k, k);
                 double av[16];
+                {   // the lane's whole row (contiguous: wide loads), the part it does not own masked afterwards
+                    const double2 *rowp = reinterpret_cast<const double2 *>(T + (r16 << 4));
 #pragma unroll
-                for (int j = 0; j < 16; ++j) {
-                    const double v = T[(r16 << 4) + (below ? j : min(j, r16))];
-                    av[j] = below ? (on ? v : 0.0) : (j <= r16 ? v : 0.0);
+                    for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; av[2 * j] = v.x; av[2 * j + 1] = v.y; }
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) av[j] = below ? (on ? av[j] : 0.0) : (j <= r16 ? av[j] : 0.0);
                 }
                 bool bad = false;
                 double my_inv = 0.0;                          // lane kk keeps 1 / d_kk: one store after the loop instead of a masked one per step
@@ -1815,12 +1817,16 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                     }
                 }
                 if (lane < 16) { ss.inv[lane] = my_inv; if (lane < nbp) vinv[kb + lane] = my_inv; }
+                // whole rows go back (wide stores).  Above the diagonal the tile then holds elimination leftovers: nobody reads them - the
+                // factorization, the back substitution and the damping use the lower triangle, a sweep zeroes whole tiles first.
+                if (lane < 16 || on) {
+                    double2 *rowp = reinterpret_cast<double2 *>(T + (r16 << 4));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) rowp[j] = make_double2(av[2 * j], av[2 * j + 1]);
+                }
                 if (lane < 16) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) { ss.diag[(r16 << 4) + j] = av[j]; if (j <= r16) T[(r16 << 4) + j] = av[j]; }
-                } else if (on) {
-#pragma unroll
-                    for (int c = 1; c < 16; ++c) T[(r16 << 4) + c] = av[c];
+                    for (int j = 0; j < 16; ++j) ss.diag[(r16 << 4) + j] = av[j];
                 }
                 if (bad && lane == 0) sh.flag = 1;
             }
