@@ -1620,6 +1620,7 @@ struct SkyShared {
     double diag[256];           // the factored diagonal tile of the current panel (unscaled columns, d on the diagonal)
     double inv[16];             // 1 / d of the panel's pivots
     double y[16];               // back substitution: the block's solution
+    double fin[3][256];         // the rows wave 0 carried through the panel's elimination (tiles act[0 .. 2], k): operands of the pair updates
     unsigned short act[2][4096];   // active block rows of the current / the next panel (a component has at most 4096 block rows)
     int n_act[2];
 };
@@ -1771,6 +1772,9 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
 
     // ---- block-envelope LDL^T in place.  Column k keeps the unscaled entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1/d_k in vinv ----
     auto factor = [&]() -> bool {
+        unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
+        (void)fprof;
+        FPROF_DECL
         // the active block rows of panel k (fb[R] <= k < R) are listed while panel k - 1 runs its updates (two lists)
         auto list_active = [&](const int k, const int buf) {
             for (int R = k + 1 + tid; R < RT; R += kBlockThreads)
@@ -1824,14 +1828,21 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
 #pragma unroll
                     for (int j = 0; j < 8; ++j) rowp[j] = make_double2(av[2 * j], av[2 * j + 1]);
                 }
+                if (on) {                                     // ... and stay in LDS for the pair updates of this panel (a load from the workspace: ~2000 cycles)
+                    double2 *f = reinterpret_cast<double2 *>(ss.fin[li] + (r16 << 4));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) f[j] = make_double2(av[2 * j], av[2 * j + 1]);
+                }
                 if (lane < 16) {
 #pragma unroll
                     for (int j = 0; j < 16; ++j) ss.diag[(r16 << 4) + j] = av[j];
                 }
                 if (bad && lane == 0) sh.flag = 1;
             }
+            FPROF_MARK(0);                                // 0: elimination (wave 0) / idle (the others)
             if (tid == 0) ss.n_act[cur ^ 1] = 0;          // (the other list was last read in panel k - 1)
             __syncthreads();
+            FPROF_MARK(5);                                // 5: barriers
             // (b) rows of the remaining active tiles (R, k): a_ic -= sum_{j<c} (a_ij / d_j) a_cj, four tiles per wave and pass
             if (n_act > kOwn) {                           // (uniform)
                 for (int g4 = wave; kOwn + 4 * g4 < n_act; g4 += kWaves) {
@@ -1853,11 +1864,14 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                         for (int c = 1; c < 16; ++c) rowp[c] = r[c];
                     }
                 }
+                FPROF_MARK(4);                            // 4: rows of the remaining active tiles
                 __syncthreads();
+                FPROF_MARK(5);
             }
             // (c) tiles (R_i, R_j) of every pair of active block rows -= U(R_i, k) (U(R_j, k) / d)^T  (fp64 MFMA, K = 16); the next
             // panel's list meanwhile
             if (k + 1 < P) list_active(k + 1, cur ^ 1);
+            FPROF_MARK(3);                                // 3: the next panel's list
             {
                 double ninv[4];
 #pragma unroll
@@ -1869,7 +1883,9 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                     while (J > I) { J -= I + 1; ++I; }
                     const int Ra = (int)act_list[I], Rb = (int)act_list[J];
                     const int Rhi = max(Ra, Rb), Rlo = min(Ra, Rb);
-                    const double *ta = tile_ptr(Rhi, k) + (r16 << 4) + kq, *tb = tile_ptr(Rlo, k) + (r16 << 4) + kq;
+                    const int Ihi = Ra >= Rb ? I : J, Ilo = Ra >= Rb ? J : I;                // list positions: the first kOwn were carried
+                    const double *ta = (Ihi < kOwn ? ss.fin[Ihi] : tile_ptr(Rhi, k)) + (r16 << 4) + kq;
+                    const double *tb = (Ilo < kOwn ? ss.fin[Ilo] : tile_ptr(Rlo, k)) + (r16 << 4) + kq;
                     double *tc = tile_ptr(Rhi, Rlo) + (kq << 4) + r16;
                     f64x4 c;
 #pragma unroll
@@ -1883,8 +1899,11 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                     for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
                 }
             }
+            FPROF_MARK(1);                                // 1: pair updates
             __syncthreads();
+            FPROF_MARK(5);
         }
+        FPROF_FLUSH();
         return sh.flag == 0;
     };
 
@@ -2513,7 +2532,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         b->sky_tiles += plans[i].tilebase[plans[i].RT];
         b->sky_dense_tiles += (int64_t)plans[i].RT * (plans[i].RT + 1) / 2;
     }
-    b->sky_lds_doubles = (size_t)max_pad * sizeof(double) <= (size_t)140 * 1024 ? max_pad : 0;
+    b->sky_lds_doubles = (size_t)max_pad * sizeof(double) <= (size_t)132 * 1024 ? max_pad : 0;      // (160 KB - 25 KB of static LDS in the kernel)
     if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
     b->d_workspace = (double *)b->ws_slab.base;
     // headers: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
