@@ -1659,8 +1659,10 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
     // One sweep over the edges at xv (matrix order): the cost, gout = J^T r and the unscaled J^T J in the tiles.  Evaluation: one
     // thread per edge, 64 B of corrected jacobian / residual to the scratch.  Assembly: every matrix row belongs to ONE thread that
     // walks its node's out-edges, then its in-edges, in a fixed order (bitwise reproducible).
+    PROF_DECL
     auto sweep = [&](const double *xv, double *gout) -> double {
         double cost = 0.0;
+        PROF_SWEEP_MARK(4);
         for (size_t i = tid; i < ((size_t)n_tiles << 8); i += kBlockThreads) tiles[i] = 0.0;
         for (int e = tid; e < E; e += kBlockThreads) {
             const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
@@ -1685,7 +1687,9 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
             w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
             w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
         }
+        PROF_SWEEP_MARK(3);                               // (-DLFR_PROFILE_SWEEP) 3: zeroing + edge evaluation
         const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch complete, tiles zero)
+        PROF_SWEEP_MARK(2);                               // 2: the reduction's barriers (waiting for the slowest thread)
         for (int row = tid; row < n; row += kBlockThreads) {
             const int p = row >> 1, c = row & 1, v = (int)ipos[p], R = row >> 4;
             const lfr::NodeInc ni = inc[v];
@@ -1969,7 +1973,6 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
 
     // ---- the trust-region loop of solve_component, over vectors in matrix order ----
     // (-DLFR_PROFILE_PHASES: 0 sweeps, 1 factorization, 5 scaling, 6 back substitution, 4 everything else - the slots of the LDS kernels)
-    PROF_DECL
     int exec_passes = 1;
     double cost = sweep(vx, vg);
     PROF_MARK(0);
