@@ -452,7 +452,9 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // Fused gather: a whole batch over flows that live in HBM lets the packed kernel read its edges from the graph's own arrays
     // (72-byte flow rows, 8-byte aligned) - the 400 MB of records for config 4 are neither written nor re-read.  Shards gather zero-copy
     // from pinned host memory (once, into records); LFR_FUSED_GATHER=0 switches the path off.
-    bool fused = shard_world == 1 && !dg.flows_zero_copy && aligned8 && dg.disp1 && dg.disp2;
+    // Caller-owned device flows (lfr_graph_from_arrays_device_flows) are only promised to live until the batch exists (lfr.h): such a
+    // batch gathers its records now and never looks at the caller's memory again.
+    bool fused = shard_world == 1 && !dg.flows_zero_copy && !dg.flows_external && aligned8 && dg.disp1 && dg.disp2;
     if (const char *e = getenv("LFR_FUSED_GATHER")) fused = fused && e[0] != '0';
     out.fused = fused;
     if (fused) { TAKE_OUT(out.d_edge_ref, uint32_t, E2); TAKE_OUT(out.d_edge_word, uint32_t, E2); }

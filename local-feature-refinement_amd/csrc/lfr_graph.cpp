@@ -92,6 +92,12 @@ struct SubGraph {
 
 // Scratch of bisect_core, one per thread, grown and kept: a cut recursion calls it thousands of times, and fresh multi-megabyte vectors
 // (mapped, faulted in, unmapped every call) cost more than the arithmetic on them.
+#ifndef LFR_CUT_LOPSIDED_GAIN
+#define LFR_CUT_LOPSIDED_GAIN 0.6
+#endif
+#ifndef LFR_CUT_SPAWN_MIN
+#define LFR_CUT_SPAWN_MIN 16384
+#endif
 struct BisectScratch {
     struct Nb { int node, w; };                                   // (integer weights: every sum below is exact in doubles)
     std::vector<uint32_t> off, fill;
@@ -99,14 +105,16 @@ struct BisectScratch {
     std::vector<double> deg, attach, ext;
     std::vector<char> in;
     std::vector<int> heap, pos, order;
+    void release() { *this = BisectScratch(); }
 };
+BisectScratch &bisect_scratch() { static thread_local BisectScratch ws; return ws; }
 
 void bisect_core(const SubGraph &g, std::vector<char> &side) {
     const int n = (int)g.ids.size();
     side.assign(n, 1);
     if (n == 0) return;
     const size_t E = g.ea.size();
-    static thread_local BisectScratch ws;
+    BisectScratch &ws = bisect_scratch();
     using Nb = BisectScratch::Nb;
     std::vector<uint32_t> &off = ws.off, &fill = ws.fill;
     off.assign(n + 1, 0);                                         // CSR adjacency, neighbours in edge order
@@ -193,7 +201,9 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
         // a lopsided prefix has to EARN its place: unless its normalized cut beats the balanced (half-volume) prefix by the factor
         // below, the balanced one wins - a graph without a bottleneck (config 5's meta graph: random wrong matches between dense tracks)
         // otherwise recursed 27 levels deep for 4 % less dropped similarity
-        static const double need = [] { const char *e = getenv("LFR_CUT_LOPSIDED_GAIN"); return e ? atof(e) : 0.6; }();
+        // (a build-time constant, -DLFR_CUT_LOPSIDED_GAIN=x for experiments: the partition - and with it labels and positions - is a pure
+        // function of the input, not of the process environment)
+        constexpr double need = LFR_CUT_LOPSIDED_GAIN;
         const double half_val = ncut(half_cut, half_vol);
         if (!(best_val < need * half_val)) { best_len = half_len; best_cut = half_cut; best_vol = half_vol; }
     }
@@ -290,8 +300,8 @@ void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_
     std::vector<int> sub[2];
     std::future<void> second;
     bool spawned = false;
-    // (a thread costs 0.1-1 ms to start: only halves whose own bisection takes longer than that; LFR_CUT_SPAWN_MIN overrides)
-    static const size_t spawn_min = getenv("LFR_CUT_SPAWN_MIN") ? (size_t)atoll(getenv("LFR_CUT_SPAWN_MIN")) : 16384;
+    // (a thread costs 0.1-1 ms to start: only halves whose own bisection takes longer than that: -DLFR_CUT_SPAWN_MIN; the labels do not depend on it)
+    constexpr size_t spawn_min = LFR_CUT_SPAWN_MIN;
     if (!child[0].ea.empty() && child[1].ea.size() >= spawn_min) {
         if (g_cut_tasks.fetch_add(1) < 64) {
             second = std::async(std::launch::async, [&] { cut_rec(child[1], node_weights, max_weight, sub[1]); });
@@ -334,6 +344,7 @@ std::unordered_map<int, int> recursive_cut(const std::vector<std::pair<int, int>
     const SubGraph g = compact(edges, weights);
     std::vector<int> out;
     cut_rec(g, node_weights, max_weight, out);
+    bisect_scratch().release();                                   // (the calling thread would otherwise keep multi-megabyte vectors for the life of the process)
     std::unordered_map<int, int> final_map;
     final_map.reserve(g.ids.size() * 2);
     for (size_t i = 0; i < g.ids.size(); ++i) final_map.emplace(g.ids[i], out[i]);

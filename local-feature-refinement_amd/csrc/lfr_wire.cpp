@@ -112,6 +112,19 @@ void Graph::finish() {
             else if (e != 0u || (bits & 0x7fffffu)) { emin = std::min(emin, e); emax = std::max(emax, e); }   // (zeros add nothing)
         }
         sims_sum_exactly = !odd && (emax < emin || emax - emin <= 10u);
+        // ... and the NUMBER of terms of one sum: n float32 values whose exponents span s binades add exactly in fp64 while
+        // 24 + s + log2(n) <= 53.  A root score sums one node's matches (<= max degree), a meta-edge weight the matches between two
+        // tracks (<= #images nodes per track, each with <= max degree matches).  The reference keeps duplicated matches
+        // (solve.cc:476-478), so the degree is unbounded in principle: count it.
+        if (sims_sum_exactly && M > 0) {
+            std::vector<uint32_t> deg(node_image.size(), 0);
+            for (size_t m = 0; m < M; ++m) { ++deg[m_node1[m]]; ++deg[m_node2[m]]; }
+            uint64_t dmax = 0;
+            for (uint32_t d : deg) dmax = std::max<uint64_t>(dmax, d);
+            const uint32_t spread = emax < emin ? 0u : emax - emin;
+            const uint64_t terms = dmax * std::max<uint64_t>(1, image_names.size());
+            sims_sum_exactly = terms <= ((uint64_t)1 << (29u - spread));
+        }
     }
 }
 
@@ -689,7 +702,7 @@ static int parse_all(const std::vector<std::string> &paths, Graph &g, const std:
             }
         });
         // ingest straight to a device: 144 of the 164 bytes per match are final now; they travel while the nodes are numbered
-        if (g.prefetch_device >= 0 && M0 == 0) prestage_flows(g, g.prefetch_device, g.n_nodes() + 2 * M);
+        if (g.prefetch_device >= 0 && M0 == 0) prestage_flows(g, g.prefetch_device, 2 * M);      // (M0 == 0: no nodes yet; this thread must not look at g.node_image, the main thread is resizing it)
     });
     const int64_t n_new = M - M0;
     const int64_t N0 = g.n_nodes();

@@ -158,7 +158,8 @@ def test_small_image_count_standins(lfr_lib, maker, tmp_path):
     ma = getattr(synthetic, maker)()
     g, p, b, st, pos, ref = solve_both(ma)
     assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
-    assert p.stats()["max_component_size"] <= g.n_images or p.stats()["n_cut_components"] >= 0
+    assert p.stats()["max_component_size"] <= g.n_images          # solve.cc:205-238: every part ends at or below the cap
+    assert p.stats()["n_cut_components"] > 0                      # ... and these stand-ins do go through the cut
     pb, out, side = str(tmp_path / "m.pb"), str(tmp_path / "s.pb"), str(tmp_path / "comp.i64")
     capi.write_matching_file(pb, ma)
     p.labels()[2].astype("<i8").tofile(side)
@@ -322,6 +323,19 @@ def test_device_resident_flows_producer_contract(lfr_lib):
         assert (want == got).all()
         with pytest.raises(capi.LfrError):
             capi.Problem(g_dev)          # host assembly needs host flows
+    # the contract of lfr.h: the caller's flows only have to live until the batch exists (the fused gather
+    # read them during the first solve).  Overwrite them between Batch() and solve(): the result must not change.
+    g_dev = capi.Graph.from_device_flows(ma, d1.data_ptr(), d2.data_ptr(), 0, ())
+    want, _ = capi.Problem(capi.Graph.from_arrays(ma)).solve_hip(0)
+    b = capi.Batch(capi.Problem(g_dev, device_graph_stage=0), 0)
+    for p_ in ptrs:
+        assert hip.hipMemset(p_, 0x7f, ctypes.c_size_t(ma.disp1.size * 4)) == 0
+    assert hip.hipDeviceSynchronize() == 0
+    b.solve()
+    assert (want == b.download()).all()
+    b.solve()                               # (a second solve takes the record path of a fused batch)
+    assert (want == b.download()).all()
+    b.close()
     for p_ in ptrs:
         hip.hipFree(p_)
 
