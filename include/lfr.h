@@ -175,14 +175,13 @@ int64_t lfr_bisect_graph(int64_t n_edges, const int32_t *edge_a, const int32_t *
  * own literal recursion around lfr_bisect_graph; the two must agree) and for timing the host part of the cut.  Returns the node count. */
 int64_t lfr_debug_recursive_cut(int64_t n_edges, const int32_t *edge_a, const int32_t *edge_b, const int32_t *weights,
                                 int64_t n_node_weights, const int64_t *node_weights, int64_t max_weight, int32_t *nodes, int32_t *subset);
-/* The fill-reducing order + block envelope the solver gives a component whose normal matrix does not fit LDS (the
- * reference hands such systems to Ceres' SPARSE_NORMAL_CHOLESKY, solve.cc:147): exposed so that a checker can measure the
- * envelope.  src_dst_kind[e] = src | (dst | kind << 15) << 16 over the component's directed edges (local node indices,
- * variable nodes first).  Writes pos[n_var] (position of every variable node), first_block[RT] (first 16-column block of
- * every 16-row block, RT = (2 n_var + 16) / 16) and info[6] = {RT, tiles, tiles of the track order, tiles of reverse
- * Cuthill-McKee, order chosen, workspace doubles}; returns the number of 16x16 tiles stored (< 0: error). */
-int64_t lfr_debug_sky_plan(int32_t n_var, int64_t n_edges, const uint32_t *src_dst_kind, uint16_t *pos, uint16_t *first_block,
-                           int64_t *info);
+/* The elimination-tree plan the solver gives a component whose normal matrix does not fit LDS (the reference hands such systems to
+ * Ceres' SPARSE_NORMAL_CHOLESKY, solve.cc:147): nested dissection of the tracks, 16-row blocks, block-level symbolic factorization,
+ * columns by level of the elimination tree, left-looking update lists and the sweep's (node, neighbour) items - exactly the words
+ * the kernel reads, so that a checker can execute the plan on the CPU (tests/test_tree_plan.py).  words[e] as above.  Returns the
+ * number of 32-bit words of the plan (copied to `blob` if cap is large enough; < 0: error); info[8] = {blocks, tiles, levels,
+ * items, updates, tracks, segments, column rounds}. */
+int64_t lfr_debug_tree_plan(int32_t n_var, int64_t n_edges, const uint32_t *words, uint32_t *blob, int64_t cap, int64_t *info);
 int lfr_problem_get_stats(const lfr_problem *p, lfr_problem_stats *stats);
 /* per node: track_idx_container, is_root, component_idx_container of solve.cc:526,570,586 */
 int lfr_problem_get_labels(const lfr_problem *p, int64_t *track, uint8_t *is_root, int64_t *component);

@@ -187,22 +187,24 @@ void prestage_flows(const Graph &g, int device, int64_t n_bound);   // scanner: 
 int graph_make_resident(const Graph &g, int device);                // = lfr_graph_to_device
 
 // ------------------------------------------------------------------------------------------
-// Block-envelope plan of a KC_GLOBAL component (lfr_order.cpp): the variable nodes renumbered so that the
-// normal matrix has a small envelope; the kernel stores the 16x16 tiles [fb[R], R] of every block row R.
+// Elimination-tree plan of a KC_GLOBAL component (lfr_treeplan.cpp): nested dissection of the tracks, blocks of <= 8 nodes,
+// block-level symbolic factorization, columns by level of the elimination tree, left-looking update lists, sweep items.
+// `blob` is what the kernel reads (u32 words): hdr[32] = {NB, tiles, offset of the tiles (doubles from the base), offset of the
+// vectors, n_pad = 16 NB, levels, items, phase-1 tasks, then the word offsets of colptr[NB+1], rowsof[tiles], nreal[NB],
+// level_ptr[levels+1], level_cols[NB], p1_ptr[levels+1], p1_tasks[][4], upd[][3], x_ptr[levels+1], x_tasks[][3], ncarry[NB],
+// items[items+1][4], item_edges[], node_items[8 NB + 1], ipos[8 NB]; [23] = offset of the items' partial sums, [24] = vector stride}.
 // ------------------------------------------------------------------------------------------
-constexpr int kSkyVectors = 12;              // vectors of n_pad doubles behind the tiles (x, trial x, g, trial g, scale, diag, step, D, diag(A), delta, 1/d, spare)
-struct SkyPlan {
-    int n_var = 0, n = 0, RT = 0;            // variable nodes, rows (2 n_var), 16-row blocks of the n + 1 rows carried (row n = right-hand side)
-    std::vector<uint16_t> pos, ipos;         // position of local node v / node at position p
-    std::vector<uint16_t> fb;                // first block column of block row R
-    std::vector<uint32_t> tilebase;          // RT + 1: index of the first tile of block row R
-    int order_used = 0;                      // 0: tracks in heavy-first postorder, 1: reverse Cuthill-McKee
-    uint64_t tiles_by_tracks = 0, tiles_rcm = 0;
-    uint64_t header_doubles() const, n_pad() const, doubles() const;
-    void write_header(void *dst) const;      // header_doubles() * 8 bytes
+constexpr int kTreeHdrWords = 32;
+constexpr int kTreeVectors = 12;             // x, trial x, g, trial g, scale, diag, step, D, diag(A), delta, 1/d, w (the right-hand side riding through the factorization)
+struct TreePlan {
+    int n_var = 0, NB = 0, n_levels = 0, n_tracks = 0, n_segments = 0, max_front = 0;
+    uint32_t n_tiles = 0, n_items = 0;
+    uint64_t n_updates = 0, column_rounds = 0;
+    std::vector<uint32_t> blob;              // empty: the component is beyond the plan's 32-bit offsets
+    uint64_t vec_stride() const, header_doubles() const, doubles() const;
 };
-// src_dst_kind[e] = src | (dst | kind << 15) << 16 of the component's records (the last word of EdgeRec)
-void sky_plan(int n_var, int64_t n_edges, const uint32_t *src_dst_kind, SkyPlan &out);
+// words[e] = src | (dst | kind << 15) << 16 of the component's records (the last word of EdgeRec)
+void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out);
 
 }  // namespace lfr
 

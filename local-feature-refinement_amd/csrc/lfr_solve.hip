@@ -15,8 +15,9 @@
 //                              classes): packed J^T J in LDS, fused evaluate-and-assemble sweep (four to eight lanes per node, the
 //                              records re-streamed from HBM and nothing else), blocked LDL^T with 16-column panels - the diagonal
 //                              tiles on a wave that runs ahead of the others, trailing updates on the fp64 matrix cores.
-//   solve_sky_kernel           one 256-thread workgroup per component above 192 rows: block-envelope LDL^T (16x16 tiles inside the
-//                              envelope of a fill-reducing node order, lfr_order.cpp) in an HBM workspace.
+//   solve_tree_kernel          one 512-thread workgroup per component above 192 rows: sparse LDL^T along the elimination tree of a
+//                              nested-dissection order (lfr_treeplan.cpp), 16x16 tiles in an HBM workspace, columns of one tree level
+//                              factored side by side by the workgroup's waves.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -68,7 +69,6 @@ struct KernelArgs {
     int tukey_variant;
     int scratch_sweep;         // 1: the workgroup kernels use the scratch sweep of rounds 1-2 (LFR_SCRATCH_SWEEP=1 at batch creation; A/B and tests)
     int cls;
-    int sky_lds;                // KC_GLOBAL: the back-substitution vector lives in dynamic LDS
     // fused gather (packed classes of a device-assembled whole batch): record p is directed edge edge_ref[p] of the graph - flow row
     // (f_row ? f_row[m] : m) of f_disp2 (even ids) / f_disp1 (odd ids), similarity f_sim[m], m = id >> 1 - with local indices edge_word[p]
     const uint32_t *edge_ref, *edge_word, *f_row;
@@ -1597,221 +1597,204 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 }
 
 // =============================================================================================
-// Components whose normal matrix does not fit LDS (> 192 rows): BLOCK-ENVELOPE LDL^T in an HBM workspace
+// Components whose normal matrix does not fit LDS (> 192 rows): LEVEL-SCHEDULED sparse LDL^T along the elimination tree
 // =============================================================================================
-// The reference gives these systems to Ceres' SPARSE_NORMAL_CHOLESKY (solve.cc:147).  The variable nodes are renumbered on the
-// host when the batch is created (lfr_order.cpp: tracks in heavy-first postorder of their meta forest or reverse Cuthill-McKee,
-// whichever stores fewer tiles) so that every row's nonzeros start close to the diagonal; the matrix lives as row-major 16x16
-// tiles, block row R holding the block columns fb[R] .. R (an LDL^T without pivoting never fills outside that envelope), the
-// right-hand side riding as row n (its block row spans every column).  A cap-sized component of config-4-scale data
-// (1344 nodes, 2688 rows) keeps ~3 tiles per block row where the dense packed matrix of round 2 had 14 k.
+// The reference gives these systems to Ceres' SPARSE_NORMAL_CHOLESKY (solve.cc:147).  The plan (lfr_treeplan.cpp, made when the batch
+// is created) renumbers the variable nodes by nested dissection, packs them into blocks of <= 8 nodes = 16 rows, factors the block
+// structure symbolically and lists the columns by LEVEL of the block elimination tree.  Columns of one level are independent, so the
+// factorization is a handful of levels (6-8 for a 2.5 k-row cap-sized component) whose column tasks the workgroup's waves take side by
+// side - round 3's block-envelope kernel walked ~170 dependent panels with one wave working and three waiting.
 //
-// Workspace of a component (a.workspace + a.ws_off[ci], written by lfr_batch_create): u32 hdr[8] = {RT, tiles, offset of the
-// tiles, offset of the vectors (doubles), n_pad}, u32 tilebase[RT + 1], u16 fb[RT], u16 pos[n_var], u16 ipos[n_var]; the tiles;
-// kSkyVectors vectors of n_pad doubles.  Everything the solver touches is in MATRIX order (vector index 2 pos[v] + c).
+// Workspace of a component (a.workspace + a.ws_off[ci]): the plan's words (TreePlan::blob), the 16x16 tiles column by column (the
+// diagonal tile first), 6 doubles of partial sums per sweep item, kTreeVectors vectors of 16 NB + 16 doubles in MATRIX order (row of
+// node at position p, coordinate c: 2 p + c; index 16 NB is a zero slot the constants read).
 //
-// Right-looking over the 16-column panels: (a) wave 0 factors the diagonal tile (lane = row, v_readlane broadcasts) and leaves
-// it in LDS, (b) every active block row (fb[R] <= k < R) finishes its tile of the panel against it with lane = row (four tiles =
-// 64 rows per wave and pass), (c) the tiles (R, J) of every pair of active block rows take the rank-16 update on the fp64
-// matrix cores.  With a tree-like envelope two or three block rows are active per panel: the factorization is ~170 short
-// dependent panels (latency bound, ~10 k cycles each), not 6.5 GFLOP.  Back substitution walks the block rows upwards with
-// the vector in LDS.
-struct SkyShared {
-    double diag[256];           // the factored diagonal tile of the current panel (unscaled columns, d on the diagonal)
-    double inv[16];             // 1 / d of the panel's pivots
-    double y[16];               // back substitution: the block's solution
-    double fin[3][256];         // the rows wave 0 carried through the panel's elimination (tiles act[0 .. 2], k): operands of the pair updates
-    unsigned short act[2][4096];   // active block rows of the current / the next panel (a component has at most 4096 block rows)
-    int n_act[2];
+//   sweep      one lane per (node, neighbour) ITEM: it evaluates the records between the two nodes (both directions, duplicates) and
+//              STORES the pair's 2x2 cross block; the node's diagonal block and gradient are summed over its items in list order by
+//              one lane.  No atomics, no scratch per edge: bitwise reproducible whatever the input (a record is evaluated by the
+//              owner of either end: two evaluations per record, nothing else to exchange).
+//   factor     per level: (1) every tile of the level's columns takes its left-looking update sum_k U(I,k) D_k^-1 U(J,k)^T on the
+//              fp64 matrix cores, one wave per tile, the list of (tile (I,k), tile (J,k), k) precomputed; the right-hand side w_J
+//              rides along in the diagonal tile's task; (2) one wave per column factors the diagonal tile with lane = row in lanes
+//              0-15 (v_readlane broadcasts) while lane 16 carries w_J and lanes 17-63 the rows of the first three tiles below it
+//              through the same steps - a_ic -= (a_ik / d_k) a_ck IS their substitution; (3) columns with more rows than that
+//              substitute the rest four tiles per wave.  A barrier after each phase that had work.
+//   substitute levels top down, one wave per column: z_J = w_J - sum_I U(I,J)^T y_I, then the 16 steps inside the diagonal tile.
+// Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1 / d_k in vinv.
+#ifndef LFR_THREADS_G
+#define LFR_THREADS_G 512
+#endif
+struct TreeShared {
+    double diag[LFR_THREADS_G / 64][272];      // per wave: the diagonal tile + 1/d of a column whose extra rows the wave substitutes
 };
 
 template <int kBlockThreads>
-__device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const int ci, double *zl_lds, BlockShared &sh, SkyShared &ss) {
+__device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const int ci, BlockShared &sh, TreeShared &ts) {
     constexpr int kWaves = kBlockThreads / 64;
+    constexpr uint32_t kNone = 0xffffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const CompDesc d = a.descs[ci];
-    const int n_var = d.n_var, n = 2 * n_var, E = (int)d.n_edges;
     const int tv = a.tukey_variant;
     const EdgeRec *edges = a.edges + d.edge_off;
     double *wsb = a.workspace + a.ws_off[ci];
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(wsb);
-    const int RT = (int)hdr[0], n_tiles = (int)hdr[1], n_pad = (int)hdr[4];
-    const uint32_t *tilebase = hdr + 8;
-    const uint16_t *fb = reinterpret_cast<const uint16_t *>(tilebase + RT + 1);
-    const uint16_t *pos = fb + RT, *ipos = pos + n_var;
-    double *tiles = wsb + hdr[2];
-    double *vec = wsb + hdr[3];
-    double *vx = vec, *vxc = vec + n_pad, *vg = vec + 2 * (size_t)n_pad, *vgn = vec + 3 * (size_t)n_pad, *vscale = vec + 4 * (size_t)n_pad,
-           *vdiag = vec + 5 * (size_t)n_pad, *vstep = vec + 6 * (size_t)n_pad, *vD = vec + 7 * (size_t)n_pad, *vadiag = vec + 8 * (size_t)n_pad,
-           *vdelta = vec + 9 * (size_t)n_pad, *vinv = vec + 10 * (size_t)n_pad;
-    double *zl = zl_lds ? zl_lds : vec + 11 * (size_t)n_pad;      // back-substitution vector: LDS, or the spare workspace vector for huge components
-    const int P = (n + 15) >> 4;                         // pivot panels
-    const int Rn = n >> 4;                               // block row of the right-hand side (row n)
-    auto tile_ptr = [&](const int R, const int J) -> double * { return tiles + ((size_t)(tilebase[R] + (uint32_t)(J - (int)fb[R])) << 8); };
+    const int NB = (int)hdr[0], n_tiles = (int)hdr[1], n_pad = (int)hdr[4], n_levels = (int)hdr[5], n_items = (int)hdr[6];
+    const uint32_t *colptr = hdr + hdr[8], *rowsof = hdr + hdr[9], *nreal = hdr + hdr[10], *level_ptr = hdr + hdr[11], *level_cols = hdr + hdr[12],
+                   *p1_ptr = hdr + hdr[13], *p1_tasks = hdr + hdr[14], *upd = hdr + hdr[15], *x_ptr = hdr + hdr[16], *x_tasks = hdr + hdr[17],
+                   *ncarry = hdr + hdr[18], *items = hdr + hdr[19], *item_edges = hdr + hdr[20], *node_items = hdr + hdr[21], *ipos = hdr + hdr[22];
+    double *tiles = wsb + hdr[2], *part = wsb + hdr[23], *vec = wsb + hdr[3];
+    const size_t vs = hdr[24];
+    double *vx = vec, *vxc = vec + vs, *vg = vec + 2 * vs, *vgn = vec + 3 * vs, *vscale = vec + 4 * vs, *vdiag = vec + 5 * vs, *vstep = vec + 6 * vs,
+           *vD = vec + 7 * vs, *vadiag = vec + 8 * vs, *vdelta = vec + 9 * vs, *vinv = vec + 10 * vs, *vw = vec + 11 * vs;
+    const int n = n_pad;                                 // rows incl. padding (inert: x = g = step = 0)
+    auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
-    for (int i = tid; i < n_pad; i += kBlockThreads) { vx[i] = 0.0; vxc[i] = 0.0; vscale[i] = 1.0; vD[i] = 0.0; vg[i] = 0.0; vgn[i] = 0.0; }
+    for (int i = tid; i < (int)vs; i += kBlockThreads) {
+        vx[i] = 0.0; vxc[i] = 0.0; vscale[i] = 1.0; vD[i] = 0.0; vg[i] = 0.0; vgn[i] = 0.0; vstep[i] = 0.0; vinv[i] = 0.0; vw[i] = 0.0;
+        vadiag[i] = 0.0; vdiag[i] = 0.0; vdelta[i] = 0.0;
+    }
     __syncthreads();
 
-    const lfr::NodeInc *inc = a.node_inc + d.node_off;
-    const uint32_t *in_idx = a.in_idx + d.edge_off;
-    double *es = a.workspace + a.es_off[ci];
-    // One sweep over the edges at xv (matrix order): the cost, gout = J^T r and the unscaled J^T J in the tiles.  Evaluation: one
-    // thread per edge, 64 B of corrected jacobian / residual to the scratch.  Assembly: every matrix row belongs to ONE thread that
-    // walks its node's out-edges, then its in-edges, in a fixed order (bitwise reproducible).
     PROF_DECL
+    // ---- one sweep at xv: the cost, gout = J^T r and the unscaled J^T J in the tiles ----
     auto sweep = [&](const double *xv, double *gout) -> double {
-        double cost = 0.0;
-        PROF_SWEEP_MARK(4);
-        for (size_t i = tid; i < ((size_t)n_tiles << 8); i += kBlockThreads) tiles[i] = 0.0;
-        for (int e = tid; e < E; e += kBlockThreads) {
-            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + e);
-            uint4 q[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) q[i] = rp[i];
-            float flow[18];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                flow[4 * i] = __uint_as_float(q[i].x); flow[4 * i + 1] = __uint_as_float(q[i].y);
-                flow[4 * i + 2] = __uint_as_float(q[i].z); flow[4 * i + 3] = __uint_as_float(q[i].w);
-            }
-            flow[16] = __uint_as_float(q[4].x); flow[17] = __uint_as_float(q[4].y);
-            const float sim = __uint_as_float(q[4].z);
-            const int s = (int)(q[4].w & 0xffffu), dk = (int)(q[4].w >> 16);
-            const int dn = dk & 0x7fff, kind = dk >> 15;
-            const int xa = s < n_var ? 2 * (int)pos[s] : n, xb = dn < n_var ? 2 * (int)pos[dn] : n;     // constants read the zero slot
-            EdgeOut o;
-            eval_edge<true>(flow, sim, kind, tv, xv[xa], xv[xa + 1], xv[xb], xv[xb + 1], o);
-            cost += o.cost;
-            double2 *w = reinterpret_cast<double2 *>(es + 8 * (size_t)e);
-            w[0] = make_double2(o.j00, o.j01); w[1] = make_double2(o.j10, o.j11);
-            w[2] = make_double2(o.sq, o.r0);   w[3] = make_double2(o.r1, 0.0);
+        {
+            double2 *t2 = reinterpret_cast<double2 *>(tiles);
+            const double2 z = make_double2(0.0, 0.0);
+            for (size_t i = tid; i < ((size_t)n_tiles << 7); i += kBlockThreads) t2[i] = z;
         }
-        PROF_SWEEP_MARK(3);                               // (-DLFR_PROFILE_SWEEP) 3: zeroing + edge evaluation
-        const double total = block_sum<kBlockThreads>(cost, sh);          // (barriers inside: scratch complete, tiles zero)
-        PROF_SWEEP_MARK(2);                               // 2: the reduction's barriers (waiting for the slowest thread)
-        for (int row = tid; row < n; row += kBlockThreads) {
-            const int p = row >> 1, c = row & 1, v = (int)ipos[p], R = row >> 4;
-            const lfr::NodeInc ni = inc[v];
-            double *rowbase = tiles + ((size_t)(tilebase[R] - (uint32_t)fb[R]) << 8) + ((row & 15) << 4);   // + (block column << 8) + (column & 15)
-            double gacc = 0.0, dsame = 0.0, dlow = 0.0;
-            constexpr int kAhead = 4;
-            for (uint32_t k0 = 0; k0 < ni.out_count; k0 += kAhead) {   // edges v -> w : J1 = d r / d x_v
-                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
-                int wn_[kAhead];
+        __syncthreads();
+        double cost = 0.0;
+        for (int i = tid; i < n_items; i += kBlockThreads) {
+            const uint4 it = reinterpret_cast<const uint4 *>(items)[i];          // {row of the node, row of the neighbour (or the zero slot), cross block, first edge}
+            const uint32_t e_end = items[4 * (i + 1) + 3];
+            const double xv0 = xv[it.x], xv1 = xv[it.x + 1], xu0 = xv[it.y], xu1 = xv[it.y + 1];
+            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0, d00 = 0.0, d10 = 0.0, d11 = 0.0, g0 = 0.0, g1 = 0.0;
+            for (uint32_t q = it.w; q < e_end; ++q) {
+                const uint32_t ew = item_edges[q];                               // record << 2 | direction << 1 | count the cost here
+                const uint4 *rp = reinterpret_cast<const uint4 *>(edges + (ew >> 2));
+                uint4 qv[5];
 #pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    const uint32_t e = ni.out_begin + min(k0 + u, ni.out_count - 1);
-                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e);
-                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
-                    wn_[u] = (int)(edges[e].dst_kind & 0x7fff);
+                for (int k = 0; k < 5; ++k) qv[k] = rp[k];
+                float flow[18];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    flow[4 * k] = __uint_as_float(qv[k].x); flow[4 * k + 1] = __uint_as_float(qv[k].y);
+                    flow[4 * k + 2] = __uint_as_float(qv[k].z); flow[4 * k + 3] = __uint_as_float(qv[k].w);
                 }
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    if (k0 + u >= ni.out_count) break;
-                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
-                    const double jc0 = c ? a0.y : a0.x, jc1 = c ? a1.y : a1.x;    // column c of J1
-                    gacc += jc0 * a2.y + jc1 * a3.x;
-                    dsame += jc0 * jc0 + jc1 * jc1;
-                    if (c) dlow += a0.y * a0.x + a1.y * a1.x;
-                    const int wn = wn_[u];
-                    if (wn < n_var) {
-                        const int pw = (int)pos[wn];
-                        if (pw < p) {                           // block (v, w) += J1^T * sq
-                            double *t = rowbase + ((size_t)(pw >> 3) << 8) + ((2 * pw) & 15);
-                            mat_add(t, jc0 * a2.x);
-                            mat_add(t + 1, jc1 * a2.x);
-                        }
-                    }
+                flow[16] = __uint_as_float(qv[4].x); flow[17] = __uint_as_float(qv[4].y);
+                const float sim = __uint_as_float(qv[4].z);
+                const int kind = (int)(qv[4].w >> 31);
+                const bool rev = (ew & 2u) != 0u;                                // the record runs neighbour -> node
+                EdgeOut o;
+                eval_edge<true>(flow, sim, kind, tv, rev ? xu0 : xv0, rev ? xu1 : xv1, rev ? xv0 : xu0, rev ? xv1 : xu1, o);
+                if (ew & 1u) cost += o.cost;
+                if (!rev) {                                                      // d r / d x_node = J1, d r / d x_neighbour = sq I
+                    d00 += o.j00 * o.j00 + o.j10 * o.j10; d10 += o.j01 * o.j00 + o.j11 * o.j10; d11 += o.j01 * o.j01 + o.j11 * o.j11;
+                    g0 += o.j00 * o.r0 + o.j10 * o.r1; g1 += o.j01 * o.r0 + o.j11 * o.r1;
+                    c00 += o.j00 * o.sq; c01 += o.j10 * o.sq; c10 += o.j01 * o.sq; c11 += o.j11 * o.sq;       // J1^T (sq I)
+                } else {                                                         // d r / d x_node = sq I, d r / d x_neighbour = J1
+                    d00 += o.sq * o.sq; d11 += o.sq * o.sq;
+                    g0 += o.sq * o.r0; g1 += o.sq * o.r1;
+                    c00 += o.sq * o.j00; c01 += o.sq * o.j01; c10 += o.sq * o.j10; c11 += o.sq * o.j11;       // (sq I) J1
                 }
             }
-            for (uint32_t k0 = 0; k0 < ni.in_count; k0 += kAhead) {    // edges w -> v : d r / d x_v = sq * I
-                double2 q0[kAhead], q1[kAhead], q2[kAhead], q3[kAhead];
-                int wn_[kAhead];
-                uint32_t e_[kAhead];
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) e_[u] = in_idx[ni.in_begin + min(k0 + u, ni.in_count - 1)];
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    const double2 *w = reinterpret_cast<const double2 *>(es + 8 * (size_t)e_[u]);
-                    q0[u] = w[0]; q1[u] = w[1]; q2[u] = w[2]; q3[u] = w[3];
-                    wn_[u] = (int)edges[e_[u]].src;
-                }
-#pragma unroll
-                for (int u = 0; u < kAhead; ++u) {
-                    if (k0 + u >= ni.in_count) break;
-                    const double2 a0 = q0[u], a1 = q1[u], a2 = q2[u], a3 = q3[u];
-                    const double sq = a2.x, rc = c ? a3.x : a2.y;
-                    gacc += sq * rc;
-                    dsame += sq * sq;
-                    const int wn = wn_[u];
-                    if (wn < n_var) {
-                        const int pw = (int)pos[wn];
-                        if (pw < p) {                           // block (v, w) += sq * J1'
-                            double *t = rowbase + ((size_t)(pw >> 3) << 8) + ((2 * pw) & 15);
-                            mat_add(t, sq * (c ? a1.x : a0.x));
-                            mat_add(t + 1, sq * (c ? a1.y : a0.y));
-                        }
-                    }
-                }
+            if (it.z != kNone) {                                                 // the neighbour sits earlier in the order: the pair's block is stored here
+                double2 *t = reinterpret_cast<double2 *>(tiles + it.z);
+                t[0] = make_double2(c00, c01); t[8] = make_double2(c10, c11);
             }
-            gout[row] = gacc;
-            double *dg = rowbase + ((size_t)R << 8) + (row & 15);
-            dg[0] = dsame;
-            if (c) dg[-1] = dlow;
-            vadiag[row] = dsame;
+            double2 *pp = reinterpret_cast<double2 *>(part + 6 * (size_t)i);
+            pp[0] = make_double2(d00, d10); pp[1] = make_double2(d11, g0); pp[2] = make_double2(g1, 0.0);
+        }
+        const double total = block_sum<kBlockThreads>(cost, sh);           // (barriers inside: cross blocks and partial sums are out)
+        for (int p = tid; p < 8 * NB; p += kBlockThreads) {
+            if (ipos[p] == kNone) continue;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
+            for (uint32_t i = node_items[p]; i < node_items[p + 1]; ++i) {
+                const double2 *pp = reinterpret_cast<const double2 *>(part + 6 * (size_t)i);
+                const double2 u0 = pp[0], u1 = pp[1], u2 = pp[2];
+                s0 += u0.x; s1 += u0.y; s2 += u1.x; s3 += u1.y; s4 += u2.x;
+            }
+            double *T = tiles + ((size_t)colptr[p >> 3] << 8) + 34 * (p & 7);         // entry (2 slot, 2 slot) of the diagonal tile
+            T[0] = s0; T[16] = s1; T[17] = s2;
+            gout[2 * p] = s3; gout[2 * p + 1] = s4;
+            vadiag[2 * p] = s0; vadiag[2 * p + 1] = s2;
         }
         __syncthreads();
         return total;
     };
 
-    // ---- the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the stored tiles' diagonal, g into row n (see solve_component) ----
+    // ---- the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the diagonal tiles, g into w ----
     auto scale_matrix = [&]() {
         for (int j = tid; j < n; j += kBlockThreads) {
-            tile_ptr(j >> 4, j >> 4)[((j & 15) << 4) + (j & 15)] += vD[j] * vD[j];
-            tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)] = vg[j];
+            tiles[((size_t)colptr[j >> 4] << 8) + 17 * (j & 15)] += vD[j] * vD[j];
+            vw[j] = vg[j];
         }
         __syncthreads();
     };
 
-    // ---- block-envelope LDL^T in place.  Column k keeps the unscaled entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1/d_k in vinv ----
     auto factor = [&]() -> bool {
-        unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
-        (void)fprof;
-        FPROF_DECL
-        // the active block rows of panel k (fb[R] <= k < R) are listed while panel k - 1 runs its updates (two lists)
-        auto list_active = [&](const int k, const int buf) {
-            for (int R = k + 1 + tid; R < RT; R += kBlockThreads)
-                if ((int)fb[R] <= k) ss.act[buf][atomicAdd(&ss.n_act[buf], 1)] = (unsigned short)R;
-        };
-        if (tid == 0) { sh.flag = 0; ss.n_act[0] = 0; ss.n_act[1] = 0; }
+        if (tid == 0) sh.flag = 0;
         __syncthreads();
-        list_active(0, 0);
-        __syncthreads();
-        for (int k = 0; k < P; ++k) {
-            const int kb = 16 * k, nbp = min(16, n - kb), cur = k & 1;
-            const int n_act = ss.n_act[cur];
-            const unsigned short *act_list = ss.act[cur];
-            constexpr int kOwn = 3;                       // active tiles wave 0 finishes inside the diagonal tile's elimination
-            if (wave == 0) {
-                // (a) the diagonal tile: lane = row in lanes 0-15.  Lanes 16-63 carry the rows of the first three active tiles (R, k)
-                // through the same elimination steps - a_ic -= (a_ij / d_j) a_cj with a_cj read from lane c IS their substitution - so a
-                // narrow envelope (<= 3 active block rows: the usual case after the fill-reducing order) needs no substitution pass
-                // and one barrier less per panel.
-                const int li = kq - 1;
-                const bool below = kq > 0, on = below && li < n_act;
-                double *T = below ? tile_ptr((int)act_list[on ? li : 0], k) : tile_ptr(k, k);
-                if (!on && below) T = tile_ptr(k, k);
+        for (int l = 0; l < n_levels; ++l) {
+            // (1) left-looking updates of the level's tiles
+            const int u0 = (int)rfl(p1_ptr[l]), u1 = (int)rfl(p1_ptr[l + 1]);
+            if (u1 > u0) {
+                for (int t = u0 + wave; t < u1; t += kWaves) {
+                    const uint4 task = reinterpret_cast<const uint4 *>(p1_tasks)[t];
+                    const uint32_t tt = rfl(task.x), ub = rfl(task.y), ue = rfl(task.z), jd = rfl(task.w);
+                    const int J = (int)(jd & 0x7fffffffu);
+                    const bool dg = (jd >> 31) != 0u;                            // the diagonal tile: w_J rides along
+                    double *tc = tiles + ((size_t)tt << 8) + (kq << 4) + r16;
+                    f64x4 c, cw = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = tc[r << 6];
+                    for (uint32_t u = ub; u < ue; ++u) {
+                        const uint32_t ia = rfl(upd[3 * u]), ib = rfl(upd[3 * u + 1]), k = rfl(upd[3 * u + 2]);
+                        const double *ta = tiles + ((size_t)ia << 8) + (r16 << 4) + kq;
+                        const double *tb = tiles + ((size_t)ib << 8) + (r16 << 4) + kq;
+                        const double *iv = vinv + 16 * (size_t)k + kq, *wk = vw + 16 * (size_t)k + kq;
+                        double av[4], bv[4], aw[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            av[kk] = ta[4 * kk]; bv[kk] = -(tb[4 * kk] * iv[4 * kk]);
+                            aw[kk] = (dg && r16 == 0) ? wk[4 * kk] : 0.0;
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
+                        if (dg) {
+#pragma unroll
+                            for (int kk = 0; kk < 4; ++kk) cw = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], bv[kk], cw, 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
+                    if (dg && kq == 0) vw[16 * (size_t)J + r16] += cw[0];
+                }
+                __syncthreads();
+            }
+            // (2) the level's columns: diagonal tile (lanes 0-15), w_J (lane 16), rows of the first tiles below (lanes 17-63)
+            const int q0 = (int)rfl(level_ptr[l]), q1 = (int)rfl(level_ptr[l + 1]);
+            for (int q = q0 + wave; q < q1; q += kWaves) {
+                const int J = (int)rfl(level_cols[q]);
+                const uint32_t t0 = rfl(colptr[J]);
+                const int nc = (int)rfl(ncarry[J]), nbp = 2 * (int)rfl(nreal[J]);
+                const int s = lane - 17;
+                const bool is_diag = lane < 16, is_rhs = lane == 16, on = lane >= 17 && (s >> 4) < nc;
+                double *src = is_diag ? tiles + ((size_t)t0 << 8) + (r16 << 4)
+                            : is_rhs  ? vw + 16 * (size_t)J
+                                      : tiles + ((size_t)(t0 + 1u + (uint32_t)(on ? (s >> 4) : 0)) << 8) + ((s & 15) << 4);
                 double av[16];
-                {   // the lane's whole row (contiguous: wide loads), the part it does not own masked afterwards
-                    const double2 *rowp = reinterpret_cast<const double2 *>(T + (r16 << 4));
+                {
+                    const double2 *rowp = reinterpret_cast<const double2 *>(src);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; av[2 * j] = v.x; av[2 * j + 1] = v.y; }
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) av[j] = below ? (on ? av[j] : 0.0) : (j <= r16 ? av[j] : 0.0);
+                    for (int j = 0; j < 16; ++j) av[j] = is_diag ? (j <= r16 ? av[j] : 0.0) : ((is_rhs || on) ? av[j] : 0.0);
                 }
                 bool bad = false;
-                double my_inv = 0.0;                          // lane kk keeps 1 / d_kk: one store after the loop instead of a masked one per step
+                double my_inv = 0.0;
 #pragma unroll
                 for (int kk = 0; kk < 16; ++kk) {
                     if (kk < nbp) {
@@ -1824,148 +1807,86 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
                         for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
                     }
                 }
-                if (lane < 16) { ss.inv[lane] = my_inv; if (lane < nbp) vinv[kb + lane] = my_inv; }
-                // whole rows go back (wide stores).  Above the diagonal the tile then holds elimination leftovers: nobody reads them - the
-                // factorization, the back substitution and the damping use the lower triangle, a sweep zeroes whole tiles first.
-                if (lane < 16 || on) {
-                    double2 *rowp = reinterpret_cast<double2 *>(T + (r16 << 4));
+                if (lane < nbp) vinv[16 * (size_t)J + lane] = my_inv;
+                if (is_diag || is_rhs || on) {
+                    double2 *rowp = reinterpret_cast<double2 *>(src);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) rowp[j] = make_double2(av[2 * j], av[2 * j + 1]);
                 }
-                if (on) {                                     // ... and stay in LDS for the pair updates of this panel (a load from the workspace: ~2000 cycles)
-                    double2 *f = reinterpret_cast<double2 *>(ss.fin[li] + (r16 << 4));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) f[j] = make_double2(av[2 * j], av[2 * j + 1]);
-                }
-                if (lane < 16) {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) ss.diag[(r16 << 4) + j] = av[j];
-                }
                 if (bad && lane == 0) sh.flag = 1;
             }
-            FPROF_MARK(0);                                // 0: elimination (wave 0) / idle (the others)
-            if (tid == 0) ss.n_act[cur ^ 1] = 0;          // (the other list was last read in panel k - 1)
             __syncthreads();
-            FPROF_MARK(5);                                // 5: barriers
-            // (b) rows of the remaining active tiles (R, k): a_ic -= sum_{j<c} (a_ij / d_j) a_cj, four tiles per wave and pass
-            if (n_act > kOwn) {                           // (uniform)
-                for (int g4 = wave; kOwn + 4 * g4 < n_act; g4 += kWaves) {
-                    const int li = kOwn + 4 * g4 + kq;
-                    const bool act = li < n_act;
-                    const int R = (int)act_list[act ? li : 0];
-                    double *rowp = tile_ptr(R, k) + (r16 << 4);
+            // (3) rows the column tasks did not carry (columns with more than three tiles below the diagonal): four tiles per wave
+            const int x0 = (int)rfl(x_ptr[l]), x1 = (int)rfl(x_ptr[l + 1]);
+            if (x1 > x0) {
+                double *xd = ts.diag[wave];
+                for (int t = x0 + wave; t < x1; t += kWaves) {
+                    const int J = (int)rfl(x_tasks[3 * t]), i0 = (int)rfl(x_tasks[3 * t + 1]), cnt = (int)rfl(x_tasks[3 * t + 2]);
+                    const uint32_t t0 = rfl(colptr[J]);
+                    const double *Td = tiles + ((size_t)t0 << 8);
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) xd[lane + 64 * i] = Td[lane + 64 * i];
+                    if (lane < 16) xd[256 + lane] = vinv[16 * (size_t)J + lane];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const bool act = kq < cnt;
+                    double *rowp = tiles + ((size_t)(t0 + 1u + (uint32_t)i0 + (uint32_t)(act ? kq : 0)) << 8) + (r16 << 4);
                     double r[16];
 #pragma unroll
                     for (int c = 0; c < 16; ++c) r[c] = rowp[c];
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
-                        const double tj = r[j] * ss.inv[j];
+                        const double tj = r[j] * xd[256 + j];
 #pragma unroll
-                        for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, ss.diag[(c << 4) + j], r[c]);
+                        for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, xd[(c << 4) + j], r[c]);
                     }
                     if (act) {
 #pragma unroll
                         for (int c = 1; c < 16; ++c) rowp[c] = r[c];
                     }
                 }
-                FPROF_MARK(4);                            // 4: rows of the remaining active tiles
                 __syncthreads();
-                FPROF_MARK(5);
             }
-            // (c) tiles (R_i, R_j) of every pair of active block rows -= U(R_i, k) (U(R_j, k) / d)^T  (fp64 MFMA, K = 16); the next
-            // panel's list meanwhile
-            if (k + 1 < P) list_active(k + 1, cur ^ 1);
-            FPROF_MARK(3);                                // 3: the next panel's list
-            {
-                double ninv[4];
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) ninv[kk] = -ss.inv[4 * kk + kq];
-                const int T = (n_act * (n_act + 1)) >> 1;
-                int I = 0, J = 0, tcur = 0;
-                for (int t = wave; t < T; t += kWaves) {
-                    J += t - tcur; tcur = t;
-                    while (J > I) { J -= I + 1; ++I; }
-                    const int Ra = (int)act_list[I], Rb = (int)act_list[J];
-                    const int Rhi = max(Ra, Rb), Rlo = min(Ra, Rb);
-                    const int Ihi = Ra >= Rb ? I : J, Ilo = Ra >= Rb ? J : I;                // list positions: the first kOwn were carried
-                    const double *ta = (Ihi < kOwn ? ss.fin[Ihi] : tile_ptr(Rhi, k)) + (r16 << 4) + kq;
-                    const double *tb = (Ilo < kOwn ? ss.fin[Ilo] : tile_ptr(Rlo, k)) + (r16 << 4) + kq;
-                    double *tc = tile_ptr(Rhi, Rlo) + (kq << 4) + r16;
-                    f64x4 c;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) c[r] = tc[r << 6];
-                    double av[4], bv[4];
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) { av[kk] = ta[4 * kk]; bv[kk] = tb[4 * kk] * ninv[kk]; }
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
-                }
-            }
-            FPROF_MARK(1);                                // 1: pair updates
-            __syncthreads();
-            FPROF_MARK(5);
         }
-        FPROF_FLUSH();
         return sh.flag == 0;
     };
 
-    // ---- L D L^T y = g with w = L^-1 g in row n: z = w; block rows upwards: y_K = solve within the diagonal tile, z_J -= tile(K, J)^T y_K ----
+    // ---- L D L^T y = g with w = L^-1 g: levels top down; y_J = D^-1 (w_J - sum_I U(I,J)^T y_I) through the diagonal tile ----
     auto back_substitute = [&]() {
-        for (int j = tid; j < n; j += kBlockThreads) zl[j] = tile_ptr(Rn, j >> 4)[((n & 15) << 4) + (j & 15)];
-        // The factored tiles are final and live in HBM: what a step needs is loaded one step AHEAD of the dependent chain - wave 0 fetches
-        // the next diagonal tile while it solves the current one, every wave fetches its first off-diagonal tile of the block row before
-        // the barrier that releases the block's solution (a load from the workspace is ~2000 cycles, a block step was ~5000).
-        double m[16], iv = 0.0;                               // wave 0: column r16 of the rows below it in the diagonal tile, 1 / d
-        auto load_diag = [&](const int K) {
-            const double *T = tile_ptr(K, K);
+        for (int l = n_levels - 1; l >= 0; --l) {
+            const int q0 = (int)rfl(level_ptr[l]), q1 = (int)rfl(level_ptr[l + 1]);
+            for (int q = q0 + wave; q < q1; q += kWaves) {
+                const int J = (int)rfl(level_cols[q]);
+                const uint32_t t0 = rfl(colptr[J]), t1 = rfl(colptr[J + 1]);
+                const int nbp = 2 * (int)rfl(nreal[J]);
+                const double *Td = tiles + ((size_t)t0 << 8);
+                double m[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) m[k] = T[(k << 4) + r16];
-            iv = r16 < min(16, n - 16 * K) ? vinv[16 * K + r16] : 0.0;
-        };
-        if (wave == 0) load_diag(P - 1);
-        __syncthreads();
-        for (int K = P - 1; K >= 0; --K) {
-            const int kb = 16 * K, nbp = min(16, n - kb);
-            const int J0 = (int)fb[K] + wave;                  // this wave's first tile (K, J0) of the block row, if J0 < K
-            double tv[4] = {0.0, 0.0, 0.0, 0.0};
-            if (J0 < K) {
-                const double *T = tile_ptr(K, J0);
+                for (int k = 0; k < 16; ++k) m[k] = Td[(k << 4) + r16];
+                const double iv = r16 < nbp ? vinv[16 * (size_t)J + r16] : 0.0;
+                double z = vw[16 * (size_t)J + r16];
+                double acc = 0.0;
+                for (uint32_t t = t0 + 1u; t < t1; ++t) {
+                    const int I = (int)rfl(rowsof[t]);
+                    const double *T = tiles + ((size_t)t << 8) + (kq << 4) + r16;
+                    const double *yI = vstep + 16 * (size_t)I + kq;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tv[r] = T[((kq + 4 * r) << 4) + r16];
-            }
-            if (wave == 0) {
-                double mc[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) mc[k] = m[k];
-                const double ivc = iv;
-                if (K > 0) load_diag(K - 1);                   // (in flight during the solve below)
-                double z = r16 < nbp ? zl[kb + r16] : 0.0;
+                    for (int r = 0; r < 4; ++r) acc = fma(T[r << 6], yI[4 * r], acc);
+                }
+                acc += __shfl_xor(acc, 16, 64);
+                acc += __shfl_xor(acc, 32, 64);
+                z -= acc;
                 double yo = 0.0;
 #pragma unroll
                 for (int k = 15; k >= 0; --k) {
-                    const double yv = z * ivc;
+                    const double yv = z * iv;
                     const double yk = readlane_f64(yv, k);
                     yo = (r16 == k) ? yv : yo;
-                    z = fma(-((r16 < k) ? mc[k] : 0.0), yk, z);
+                    z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
                 }
-                if (lane < 16) { ss.y[r16] = yo; if (r16 < nbp) vstep[kb + r16] = yo; }
-            }
-            __syncthreads();
-            for (int J = J0; J < K; J += kWaves) {
-                double part = 0.0;
-                if (J == J0) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) part = fma(tv[r], ss.y[kq + 4 * r], part);
-                } else {
-                    const double *T = tile_ptr(K, J);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) part = fma(T[((kq + 4 * r) << 4) + r16], ss.y[kq + 4 * r], part);
-                }
-                part += __shfl_xor(part, 16, 64);
-                part += __shfl_xor(part, 32, 64);
-                if (kq == 0) zl[16 * J + r16] -= part;
+                if (lane < 16) vstep[16 * (size_t)J + r16] = yo;
             }
             __syncthreads();
         }
@@ -2016,14 +1937,14 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
         PROF_MARK(6);
         double model_cost_change = 0.0;
         if (valid) {
-            double part = 0.0, bad = 0.0;
+            double partial = 0.0, bad = 0.0;
             for (int i = tid; i < n; i += kBlockThreads) {
                 const double rhs0 = vg[i];
                 const double st = -vstep[i];
                 if (!isfinite(st)) bad = 1.0;
-                part += -rhs0 * st + vD[i] * vD[i] * st * st;
+                partial += -rhs0 * st + vD[i] * vD[i] * st * st;
             }
-            model_cost_change = 0.5 * block_sum<kBlockThreads>(part, sh);
+            model_cost_change = 0.5 * block_sum<kBlockThreads>(partial, sh);
             bad = block_max<kBlockThreads>(bad, sh);
             valid = bad == 0.0 && model_cost_change > 0.0;
         }
@@ -2109,8 +2030,13 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
     PROF_MARK(4);
     PROF_FLUSH();
     __syncthreads();
-    for (int i = tid; i < n; i += kBlockThreads)
-        a.positions[2 * (size_t)a.node_ids[d.node_off + (int)ipos[i >> 1]] + (i & 1)] = term != LFR_TERM_FAILURE ? vx[i] : 0.0;
+    for (int p = tid; p < 8 * NB; p += kBlockThreads) {
+        const uint32_t v = ipos[p];
+        if (v == kNone) continue;
+        double *out = a.positions + 2 * (size_t)a.node_ids[d.node_off + v];
+        out[0] = term != LFR_TERM_FAILURE ? vx[2 * p] : 0.0;
+        out[1] = term != LFR_TERM_FAILURE ? vx[2 * p + 1] : 0.0;
+    }
     if (tid == 0) {
         CompInfoDev inf;
         inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
@@ -2122,10 +2048,9 @@ __device__ __forceinline__ void solve_sky_component(const KernelArgs &a, const i
 
 // persistent workgroups over the class's queue, like solve_block_kernel
 template <int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(1, 1))) void solve_sky_kernel(const KernelArgs a) {
-    extern __shared__ double dyn[];
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_tree_kernel(const KernelArgs a) {
     __shared__ BlockShared sh;
-    __shared__ SkyShared ss;
+    __shared__ TreeShared ts;
     __shared__ int next_ci;
     for (;;) {
         if (threadIdx.x == 0) {
@@ -2136,7 +2061,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(1
         const int ci = __builtin_amdgcn_readfirstlane(next_ci);
         __syncthreads();
         if (ci < 0) break;
-        solve_sky_component<kBlockThreads>(a, ci, a.sky_lds ? dyn : nullptr, sh, ss);
+        solve_tree_component<kBlockThreads>(a, ci, sh, ts);
         __syncthreads();
     }
 }
@@ -2218,9 +2143,6 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2
 #ifndef LFR_THREADS_L
 #define LFR_THREADS_L 512
 #endif
-#ifndef LFR_THREADS_G
-#define LFR_THREADS_G 256
-#endif
 constexpr int kThreadsS = LFR_THREADS_S, kThreadsM = LFR_THREADS_M, kThreadsL = LFR_THREADS_L, kThreadsG = LFR_THREADS_G;
 
 size_t block_vector_doubles(int max_rows) { return 2 * (size_t)(max_rows + 2) + 8 * (size_t)max_rows; }
@@ -2267,7 +2189,8 @@ struct lfr_batch {
     CompInfoDev *d_infos = nullptr;
     double *d_workspace = nullptr;
     uint64_t es_doubles = 0;                             // per-edge scratch of the workgroup classes (8 doubles per edge), the head of the workspace
-    int sky_lds_doubles = 0;                             // KC_GLOBAL: back-substitution vector of the largest component (0: does not fit LDS, the kernel uses its workspace copy)
+    int tree_levels_max = 0;                             // KC_GLOBAL: levels of the deepest elimination tree
+    int64_t tree_blocks = 0, tree_updates = 0;           // KC_GLOBAL: 16-row columns / left-looking tile updates per factorization, summed over the class
     int64_t sky_tiles = 0, sky_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
     // fused gather: the packed kernel reads the graph's own flow arrays (kept alive through dev_hold)
@@ -2506,7 +2429,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         HIP_TRY(hipMemcpy2DAsync(words.data(), 4, reinterpret_cast<const char *>(b->d_edges + e0) + 76, sizeof(EdgeRec), 4, ne, hipMemcpyDeviceToHost, st));
         HIP_TRY(lfr::stream_wait(st));
     }
-    std::vector<lfr::SkyPlan> plans(ng);
+    std::vector<lfr::TreePlan> plans(ng);
     {
         std::atomic<int> next{0};
         const int T = std::max(1, std::min(ng, (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
@@ -2515,7 +2438,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
                 const int i = next.fetch_add(1);
                 if (i >= ng) break;
                 const CompDesc &d = b->descs[g0 + i];
-                lfr::sky_plan(d.n_var, d.n_edges, words.data() + (d.edge_off - e0), plans[i]);
+                lfr::tree_plan(d.n_var, d.n_edges, words.data() + (d.edge_off - e0), plans[i]);
             }
         };
         std::vector<std::thread> th;
@@ -2525,26 +2448,27 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     }
     std::vector<uint64_t> off(ng);
     uint64_t ws = (b->es_doubles + 31) / 32 * 32, hdr_total = 0;
-    int max_pad = 0;
     b->sky_tiles = b->sky_dense_tiles = 0;
+    b->tree_levels_max = 0; b->tree_blocks = 0; b->tree_updates = 0;
     for (int i = 0; i < ng; ++i) {
+        if (plans[i].blob.empty()) { lfr::set_error("a component is too large for the elimination-tree plan's 32-bit offsets"); return LFR_ERR_UNSUPPORTED; }
         off[i] = ws;
         ws += (plans[i].doubles() + 31) / 32 * 32;
         hdr_total += plans[i].header_doubles();
-        max_pad = std::max(max_pad, (int)plans[i].n_pad());
-        b->sky_tiles += plans[i].tilebase[plans[i].RT];
-        b->sky_dense_tiles += (int64_t)plans[i].RT * (plans[i].RT + 1) / 2;
+        b->sky_tiles += plans[i].n_tiles;
+        b->sky_dense_tiles += (int64_t)plans[i].NB * (plans[i].NB + 1) / 2;
+        b->tree_levels_max = std::max(b->tree_levels_max, plans[i].n_levels);
+        b->tree_blocks += plans[i].NB; b->tree_updates += (int64_t)plans[i].n_updates;
     }
-    b->sky_lds_doubles = (size_t)max_pad * sizeof(double) <= (size_t)132 * 1024 ? max_pad : 0;      // (160 KB - 25 KB of static LDS in the kernel)
     if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
     b->d_workspace = (double *)b->ws_slab.base;
-    // headers: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
+    // the plans' words: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
     size_t got = 0;
     double *stage = (double *)b->ctx->pinned_acquire(std::max<uint64_t>(hdr_total, 1) * sizeof(double), &got);
     if (!stage) return LFR_ERR_NOMEM;
     uint64_t so = 0;
     for (int i = 0; i < ng; ++i) {
-        plans[i].write_header(stage + so);
+        memcpy(stage + so, plans[i].blob.data(), plans[i].blob.size() * 4);
         if (hipMemcpyAsync(b->d_workspace + off[i], stage + so, plans[i].header_doubles() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
             b->ctx->pinned_release(stage, got); lfr::set_error("hipMemcpyAsync of a plan failed"); return LFR_ERR_HIP;
         }
@@ -2553,11 +2477,11 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     hipError_t e1 = hipMemcpyAsync(b->d_ws_off + g0, off.data(), ng * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     hipError_t e2 = hipStreamSynchronize(st);
     b->ctx->pinned_release(stage, got);
-    if (e1 != hipSuccess || e2 != hipSuccess) { lfr::set_error("upload of the block-envelope plans failed"); return LFR_ERR_HIP; }
+    if (e1 != hipSuccess || e2 != hipSuccess) { lfr::set_error("upload of the elimination-tree plans failed"); return LFR_ERR_HIP; }
     if (getenv("LFR_VERBOSE"))
-        fprintf(stderr, "lfr: %d component(s) above %d rows: block-envelope plans keep %lld of %lld tiles (%.1f %%), workspace %.1f MB\n", ng,
+        fprintf(stderr, "lfr: %d component(s) above %d rows: elimination-tree plans keep %lld of %lld tiles (%.1f %%) in %lld columns, at most %d levels, workspace %.1f MB\n", ng,
                 lfr::block_max_rows(), (long long)b->sky_tiles, (long long)b->sky_dense_tiles, 100.0 * b->sky_tiles / std::max<int64_t>(1, b->sky_dense_tiles),
-                ws * 8e-6);
+                (long long)b->tree_blocks, b->tree_levels_max, ws * 8e-6);
     return LFR_OK;
 }
 
@@ -2867,7 +2791,6 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<kThreadsM>, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(lds_m, kThreadsM == kThreadsS ? lds_s : 0)));
         HIP_TRY(hipFuncSetAttribute((const void *)solve_block_kernel<kThreadsL>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                     std::max(lds_l, std::max(kThreadsL == kThreadsM ? lds_m : 0, kThreadsL == kThreadsS ? lds_s : 0))));
-        HIP_TRY(hipFuncSetAttribute((const void *)solve_sky_kernel<kThreadsG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(b->sky_lds_doubles * sizeof(double))));
     }
     {   // the packed launch is reported in the slot of its largest class (by edges)
         int64_t best = -1;
@@ -2888,7 +2811,6 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     { const char *e = getenv("LFR_SCRATCH_SWEEP"); a.scratch_sweep = (e && e[0] == '1') ? 1 : 0; }
     a.queue = reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT);
     a.wg_order = b->d_wg_order; a.wg_begin = b->class_begin[lfr::KC_BLOCK];
-    a.sky_lds = b->sky_lds_doubles > 0;
     a.edge_ref = b->d_edge_ref; a.edge_word = b->d_edge_word;
     a.f_row = nullptr; a.f_disp1 = a.f_disp2 = a.f_sim = nullptr;
     if (b->fused) {
@@ -2935,10 +2857,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
             case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
             default: {
-                // block-envelope kernel: LDS = the back-substitution vector (the workspace copy when it does not fit); two workgroups per CU
-                const size_t sky_lds = (size_t)b->sky_lds_doubles * sizeof(double);
-                const int per_cu = 1;                       // (built for one wave per SIMD: 512 registers, its spills live in the accumulation registers)
-                hipLaunchKernelGGL((solve_sky_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu * per_cu)), dim3(kThreadsG), sky_lds, cs, a);
+                // elimination-tree kernel: one 512-thread workgroup per CU (two waves per SIMD), static LDS only
+                hipLaunchKernelGGL((solve_tree_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu)), dim3(kThreadsG), 0, cs, a);
                 break;
             }
         }

@@ -105,7 +105,7 @@ def lib():
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
         "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, C.c_int, vp]),
-        "lfr_debug_sky_plan": (i64, [i32, i64, vp, vp, vp, vp]),
+        "lfr_debug_tree_plan": (i64, [i32, i64, vp, vp, i64, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
@@ -121,7 +121,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_sky_plan", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -478,15 +478,14 @@ class Batch:
                 "n_var_nodes": nvar, "n_edges": ne}
 
 
-def sky_plan(n_var, src_dst_kind):
-    """Fill-reducing order + block envelope of one large component (lfr_debug_sky_plan): pos[n_var], first_block[RT], info dict."""
-    w = np.ascontiguousarray(src_dst_kind, np.uint32)
-    rt = (2 * int(n_var) + 16) // 16
-    pos = np.zeros(max(int(n_var), 1), np.uint16)
-    fb = np.zeros(max(rt, 1), np.uint16)
-    info = np.zeros(6, np.int64)
-    n = lib().lfr_debug_sky_plan(int(n_var), int(w.shape[0]), _ptr(w), _ptr(pos), _ptr(fb), _ptr(info))
+def tree_plan(n_var, words):
+    """Elimination-tree plan of one large component (lfr_debug_tree_plan): (blob of uint32 words as the kernel reads it, info dict)."""
+    w = np.ascontiguousarray(words, np.uint32)
+    info = np.zeros(8, np.int64)
+    n = lib().lfr_debug_tree_plan(int(n_var), int(w.shape[0]), _ptr(w), None, 0, _ptr(info))
     if n < 0:
         _check(int(n))
-    return pos[:n_var], fb[:rt], {"RT": int(info[0]), "tiles": int(info[1]), "tiles_by_tracks": int(info[2]), "tiles_rcm": int(info[3]),
-                                 "order": "tracks" if info[4] == 0 else "rcm", "workspace_doubles": int(info[5])}
+    blob = np.zeros(int(n), np.uint32)
+    lib().lfr_debug_tree_plan(int(n_var), int(w.shape[0]), _ptr(w), _ptr(blob), int(n), _ptr(info))
+    keys = ("blocks", "tiles", "levels", "items", "updates", "tracks", "segments", "column_rounds")
+    return blob, {k: int(v) for k, v in zip(keys, info)}

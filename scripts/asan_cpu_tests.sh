@@ -5,7 +5,7 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/local-feature-refinement_amd/csrc; O=/tmp/asan; mkdir -p $O
 H=/opt/rocm/bin/hipcc
-for f in lfr_wire.cpp lfr_graph.cpp lfr_order.cpp lfr_devctx.cpp; do
+for f in lfr_wire.cpp lfr_graph.cpp lfr_treeplan.cpp lfr_devctx.cpp; do
   $H --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-omit-frame-pointer -I $R/include -I $C -c $C/$f -o $O/$f.o
 done
 $H --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan $O/*.o $C/_obj/lfr_solve.hip.o $C/_obj/lfr_assemble.hip.o $C/_obj/lfr_graphstage.hip.o -o $O/liblfr_asan.so

@@ -6,11 +6,11 @@
 set -e
 R=$(cd $(dirname $0)/.. && pwd); C=$R/local-feature-refinement_amd/csrc; O=/tmp/tsan; mkdir -p $O
 H=/opt/rocm/bin/hipcc
-for f in lfr_wire.cpp lfr_graph.cpp lfr_order.cpp lfr_devctx.cpp; do
+for f in lfr_wire.cpp lfr_graph.cpp lfr_treeplan.cpp lfr_devctx.cpp; do
   $H --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=thread -I $R/include -I $C -c $C/$f -o $O/$f.o
 done
 /opt/rocm/lib/llvm/bin/clang++ -O1 -g -fsanitize=thread -I $R/include -c $R/scripts/probes/host_harness.cpp -o $O/harness.o
-$H --offload-arch=gfx950 -fsanitize=thread $O/harness.o $O/lfr_wire.cpp.o $O/lfr_graph.cpp.o $O/lfr_order.cpp.o $O/lfr_devctx.cpp.o $C/_obj/lfr_solve.hip.o $C/_obj/lfr_assemble.hip.o $C/_obj/lfr_graphstage.hip.o -o $O/harness
+$H --offload-arch=gfx950 -fsanitize=thread $O/harness.o $O/lfr_wire.cpp.o $O/lfr_graph.cpp.o $O/lfr_treeplan.cpp.o $O/lfr_devctx.cpp.o $C/_obj/lfr_solve.hip.o $C/_obj/lfr_assemble.hip.o $C/_obj/lfr_graphstage.hip.o -o $O/harness
 python - <<PY
 import sys
 sys.path.insert(0, "$R/local-feature-refinement_amd")
