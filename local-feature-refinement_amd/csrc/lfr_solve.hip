@@ -624,7 +624,7 @@ __device__ __forceinline__ void mat_add(double *p, double v) { __hip_atomic_fetc
 __device__ __forceinline__ uint32_t tri(int i, int j) { return (__umul24((unsigned)i, (unsigned)i + 1u) >> 1) + (unsigned)j; }
 
 struct BlockShared {
-    double red[8];
+    double red[16];
     double bcast[4];
     int flag;
     int ready;               // factor_lds: last panel whose diagonal block wave 0 has factored and published
@@ -1624,9 +1624,38 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #ifndef LFR_THREADS_G
 #define LFR_THREADS_G 512
 #endif
+// -DLFR_PROFILE_PHASES -DLFR_PROFILE_TREE: the slots of the phase profile split the tree kernel's sweep and factorization -
+// 0 node pass + reductions of the sweeps, 1 column tasks (+ extra rows), 2 zeroing the tiles, 3 sweep items, 4 bookkeeping and the LM
+// diagonal, 5 left-looking updates, 6 back substitution
+#if defined(LFR_PROFILE_PHASES) && defined(LFR_PROFILE_TREE)
+#define TPROF_MARK(i) PROF_MARK(i)
+#define LFR_TREE_SLOT_SCALE 4
+#else
+#define TPROF_MARK(i)
+#define LFR_TREE_SLOT_SCALE 5
+#endif
 struct TreeShared {
-    double diag[LFR_THREADS_G / 64][272];      // per wave: the diagonal tile + 1/d of a column whose extra rows the wave substitutes
+    // per wave: four tiles in rows of 18 doubles (the column task turns its accumulators from the matrix cores' layout into
+    // lane = row through them; the extra-row tasks stage a diagonal tile there) + 16 doubles (the right-hand side / 1/d)
+    double x[LFR_THREADS_G / 64][4 * 288 + 16];
+    double red3[LFR_THREADS_G / 64][3];
 };
+// The plan's words are written by the host before the launch and never by the kernel: read through the constant address space they
+// are scalar loads (s_load, one per wave, through the scalar cache) instead of vector loads + v_readfirstlane behind ~1 us of latency.
+typedef const __attribute__((address_space(4))) uint32_t *PlanWords;
+
+// two sums and a maximum over the workgroup with one pair of barriers
+template <int kBlockThreads>
+__device__ __forceinline__ void block_reduce3(double &s0, double &s1, double &m0, TreeShared &ts) {
+    s0 = wave_sum(s0); s1 = wave_sum(s1); m0 = wave_max(m0);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { double *r = ts.red3[threadIdx.x >> 6]; r[0] = s0; r[1] = s1; r[2] = m0; }
+    __syncthreads();
+    double a = 0.0, b = 0.0, c = ts.red3[0][2];
+#pragma unroll
+    for (int w = 0; w < kBlockThreads / 64; ++w) { a += ts.red3[w][0]; b += ts.red3[w][1]; c = fmax(c, ts.red3[w][2]); }
+    s0 = a; s1 = b; m0 = c;
+}
 
 template <int kBlockThreads>
 __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const int ci, BlockShared &sh, TreeShared &ts) {
@@ -1638,33 +1667,39 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     const int tv = a.tukey_variant;
     const EdgeRec *edges = a.edges + d.edge_off;
     double *wsb = a.workspace + a.ws_off[ci];
-    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(wsb);
-    const int NB = (int)hdr[0], n_tiles = (int)hdr[1], n_pad = (int)hdr[4], n_levels = (int)hdr[5], n_items = (int)hdr[6];
-    const uint32_t *colptr = hdr + hdr[8], *rowsof = hdr + hdr[9], *nreal = hdr + hdr[10], *level_ptr = hdr + hdr[11], *level_cols = hdr + hdr[12],
-                   *p1_ptr = hdr + hdr[13], *p1_tasks = hdr + hdr[14], *upd = hdr + hdr[15], *x_ptr = hdr + hdr[16], *x_tasks = hdr + hdr[17],
-                   *ncarry = hdr + hdr[18], *items = hdr + hdr[19], *item_edges = hdr + hdr[20], *node_items = hdr + hdr[21], *ipos = hdr + hdr[22];
-    double *tiles = wsb + hdr[2], *part = wsb + hdr[23], *vec = wsb + hdr[3];
-    const size_t vs = hdr[24];
+    const PlanWords pl = (PlanWords)(uintptr_t)wsb;
+    const int NB = (int)pl[0], n_tiles = (int)pl[1], n_pad = (int)pl[4], n_levels = (int)pl[5], n_items = (int)pl[6];
+    const PlanWords colptr = pl + pl[8], rowsof = pl + pl[9], nreal = pl + pl[10], level_ptr = pl + pl[11], level_cols = pl + pl[12],
+                    p1_ptr = pl + pl[13], p1_tasks = pl + pl[14], upd = pl + pl[15], x_ptr = pl + pl[16], x_tasks = pl + pl[17],
+                    ncarry = pl + pl[18], col_upd_ptr = pl + pl[25], col_upd = pl + pl[26];
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(wsb);            // (per-lane reads: vector loads)
+    const uint32_t *items = hdr + pl[19], *item_edges = hdr + pl[20], *node_items = hdr + pl[21], *ipos = hdr + pl[22];
+    const PlanWords col_desc = pl + pl[27];
+    double *atiles = wsb + pl[2], *tiles = atiles + ((size_t)n_tiles << 8), *part = wsb + pl[23], *vec = wsb + pl[3];     // A (the sweeps' J^T J), the factor
+    const size_t vs = pl[24];
     double *vx = vec, *vxc = vec + vs, *vg = vec + 2 * vs, *vgn = vec + 3 * vs, *vscale = vec + 4 * vs, *vdiag = vec + 5 * vs, *vstep = vec + 6 * vs,
            *vD = vec + 7 * vs, *vadiag = vec + 8 * vs, *vdelta = vec + 9 * vs, *vinv = vec + 10 * vs, *vw = vec + 11 * vs;
     const int n = n_pad;                                 // rows incl. padding (inert: x = g = step = 0)
-    auto rfl = [](uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
 
     for (int i = tid; i < (int)vs; i += kBlockThreads) {
         vx[i] = 0.0; vxc[i] = 0.0; vscale[i] = 1.0; vD[i] = 0.0; vg[i] = 0.0; vgn[i] = 0.0; vstep[i] = 0.0; vinv[i] = 0.0; vw[i] = 0.0;
         vadiag[i] = 0.0; vdiag[i] = 0.0; vdelta[i] = 0.0;
     }
+    {   // A's tiles: zero once per solve - a sweep stores the same entries every time (one 2x2 block per matched pair, one per node).
+        // The factor's tiles too: the column task writes rows 0-14 of the third tile it carries, and row 15 (a padding row) must not
+        // hold whatever the workspace held before (a NaN times the zero of a padding row's solution is a NaN).
+        double2 *t2 = reinterpret_cast<double2 *>(atiles);
+        const double2 z = make_double2(0.0, 0.0);
+        for (size_t i = tid; i < ((size_t)n_tiles << 8); i += kBlockThreads) t2[i] = z;
+    }
     __syncthreads();
 
     PROF_DECL
-    // ---- one sweep at xv: the cost, gout = J^T r and the unscaled J^T J in the tiles ----
+    // ---- one sweep at xv: the cost, gout = J^T r and the unscaled J^T J in the tiles.  (Starts with a barrier of its own: whatever
+    //      the caller wrote to xv before is visible to the items.) ----
     auto sweep = [&](const double *xv, double *gout) -> double {
-        {
-            double2 *t2 = reinterpret_cast<double2 *>(tiles);
-            const double2 z = make_double2(0.0, 0.0);
-            for (size_t i = tid; i < ((size_t)n_tiles << 7); i += kBlockThreads) t2[i] = z;
-        }
         __syncthreads();
+        TPROF_MARK(2);
         double cost = 0.0;
         for (int i = tid; i < n_items; i += kBlockThreads) {
             const uint4 it = reinterpret_cast<const uint4 *>(items)[i];          // {row of the node, row of the neighbour (or the zero slot), cross block, first edge}
@@ -1701,12 +1736,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 }
             }
             if (it.z != kNone) {                                                 // the neighbour sits earlier in the order: the pair's block is stored here
-                double2 *t = reinterpret_cast<double2 *>(tiles + it.z);
+                double2 *t = reinterpret_cast<double2 *>(atiles + it.z);
                 t[0] = make_double2(c00, c01); t[8] = make_double2(c10, c11);
             }
             double2 *pp = reinterpret_cast<double2 *>(part + 6 * (size_t)i);
             pp[0] = make_double2(d00, d10); pp[1] = make_double2(d11, g0); pp[2] = make_double2(g1, 0.0);
         }
+        TPROF_MARK(3);
         const double total = block_sum<kBlockThreads>(cost, sh);           // (barriers inside: cross blocks and partial sums are out)
         for (int p = tid; p < 8 * NB; p += kBlockThreads) {
             if (ipos[p] == kNone) continue;
@@ -1716,7 +1752,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 const double2 u0 = pp[0], u1 = pp[1], u2 = pp[2];
                 s0 += u0.x; s1 += u0.y; s2 += u1.x; s3 += u1.y; s4 += u2.x;
             }
-            double *T = tiles + ((size_t)colptr[p >> 3] << 8) + 34 * (p & 7);         // entry (2 slot, 2 slot) of the diagonal tile
+            double *T = atiles + ((size_t)hdr[pl[8] + (p >> 3)] << 8) + 34 * (p & 7);  // entry (2 slot, 2 slot) of the diagonal tile
             T[0] = s0; T[16] = s1; T[17] = s2;
             gout[2 * p] = s3; gout[2 * p + 1] = s4;
             vadiag[2 * p] = s0; vadiag[2 * p + 1] = s2;
@@ -1725,74 +1761,181 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         return total;
     };
 
-    // ---- the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the diagonal tiles, g into w ----
-    auto scale_matrix = [&]() {
-        for (int j = tid; j < n; j += kBlockThreads) {
-            tiles[((size_t)colptr[j >> 4] << 8) + 17 * (j & 15)] += vD[j] * vD[j];
-            vw[j] = vg[j];
+    // descriptor of a column task (lfr_treeplan.cpp: col_desc, columns in level order): one pair of scalar loads
+    struct ColDesc { uint32_t J, t0, nc, nbp, ne, e_rest, k0, tb0, a00, a01, a02, k1, tb1, a10, a11, a12, nsub, i0, i1, i2, i3; };
+    auto load_desc = [&](const int q) -> ColDesc {
+        const PlanWords w = col_desc + 32 * (size_t)q;
+        ColDesc c;
+        c.J = w[0]; c.t0 = w[1]; c.nc = w[2]; c.nbp = w[3]; c.ne = w[4]; c.e_rest = w[5];
+        c.k0 = w[6]; c.tb0 = w[7]; c.a00 = w[8]; c.a01 = w[9]; c.a02 = w[10];
+        c.k1 = w[11]; c.tb1 = w[12]; c.a10 = w[13]; c.a11 = w[14]; c.a12 = w[15];
+        c.nsub = w[16]; c.i0 = w[17]; c.i1 = w[18]; c.i2 = w[19]; c.i3 = w[20];
+        return c;
+    };
+    // operands of one update entry in the matrix cores' layouts: B = U(J,k) (also the A operand of the diagonal tile), 1/d, w_k and
+    // the tiles (I_i, k) of the carried rows
+    struct UpdB { double raw[4], iv[4], wk[4]; };
+    struct UpdY { double y0[4], y1[4], y2[4]; };
+    auto load_b = [&](const uint32_t k, const uint32_t tb, UpdB &o) {
+        const double *tbp = tiles + ((size_t)tb << 8) + (r16 << 4) + kq;
+        const double *ivp = vinv + 16 * (size_t)k + kq, *wkp = vw + 16 * (size_t)k + kq;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { o.raw[kk] = tbp[4 * kk]; o.iv[kk] = ivp[4 * kk]; o.wk[kk] = wkp[4 * kk]; }
+    };
+    auto load_y = [&](const uint32_t a0, const uint32_t a1, const uint32_t a2, UpdY &o) {
+        if (a0 != kNone) { const double *ap = tiles + ((size_t)a0 << 8) + (r16 << 4) + kq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) o.y0[kk] = ap[4 * kk]; }
+        if (a1 != kNone) { const double *ap = tiles + ((size_t)a1 << 8) + (r16 << 4) + kq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) o.y1[kk] = ap[4 * kk]; }
+        if (a2 != kNone) { const double *ap = tiles + ((size_t)a2 << 8) + (r16 << 4) + kq;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) o.y2[kk] = ap[4 * kk]; }
+    };
+    struct ColAcc { f64x4 cD, cS0, cS1, cS2; double wacc; };
+    auto apply_ops = [&](const uint32_t a0, const uint32_t a1, const uint32_t a2, const UpdB &o, const UpdY &y, ColAcc &c) {
+        double bv[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) { bv[kk] = -(o.raw[kk] * o.iv[kk]); c.wacc = fma(bv[kk], o.wk[kk], c.wacc); }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) c.cD = __builtin_amdgcn_mfma_f64_16x16x4f64(o.raw[kk], bv[kk], c.cD, 0, 0, 0);
+        if (a0 != kNone) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c.cS0 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y0[kk], bv[kk], c.cS0, 0, 0, 0);
         }
-        __syncthreads();
+        if (a1 != kNone) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c.cS1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y1[kk], bv[kk], c.cS1, 0, 0, 0);
+        }
+        if (a2 != kNone) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) c.cS2 = __builtin_amdgcn_mfma_f64_16x16x4f64(y.y2[kk], bv[kk], c.cS2, 0, 0, 0);
+        }
+    };
+    // what a column task loads before it can start: A's tiles of the column (accumulator layout: row 4 r + kq, column r16), w_J, the
+    // LM diagonal of this lane's row, the operands of its first two update entries
+    struct ColPre { f64x4 cD, cS0, cS1, cS2; double wj, dd; UpdB o0; };
+    auto issue_column = [&](const ColDesc &c, ColPre &p) {
+        const double *p0 = atiles + ((size_t)c.t0 << 8) + (kq << 4) + r16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p.cD[r] = p0[r << 6];
+        p.cS0 = f64x4{0.0, 0.0, 0.0, 0.0}; p.cS1 = p.cS0; p.cS2 = p.cS0;
+        if (c.nc > 0u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.cS0[r] = p0[256 + (r << 6)];
+        }
+        if (c.nc > 1u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.cS1[r] = p0[512 + (r << 6)];
+        }
+        if (c.nc > 2u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p.cS2[r] = p0[768 + (r << 6)];
+        }
+        p.wj = vw[16 * (size_t)c.J + r16];
+        p.dd = vD[16 * (size_t)c.J + r16];
+        if (c.ne > 0u) load_b(c.k0, c.tb0, p.o0);
     };
 
     auto factor = [&]() -> bool {
-        if (tid == 0) sh.flag = 0;
-        __syncthreads();
+        double *xd = ts.x[wave];                          // (sh.flag was reset before the caller's last barrier)
+        unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
+        (void)fprof;
+        FPROF_DECL
         for (int l = 0; l < n_levels; ++l) {
-            // (1) left-looking updates of the level's tiles
-            const int u0 = (int)rfl(p1_ptr[l]), u1 = (int)rfl(p1_ptr[l + 1]);
-            if (u1 > u0) {
-                for (int t = u0 + wave; t < u1; t += kWaves) {
-                    const uint4 task = reinterpret_cast<const uint4 *>(p1_tasks)[t];
-                    const uint32_t tt = rfl(task.x), ub = rfl(task.y), ue = rfl(task.z), jd = rfl(task.w);
-                    const int J = (int)(jd & 0x7fffffffu);
-                    const bool dg = (jd >> 31) != 0u;                            // the diagonal tile: w_J rides along
-                    double *tc = tiles + ((size_t)tt << 8) + (kq << 4) + r16;
-                    f64x4 c, cw = {0.0, 0.0, 0.0, 0.0};
+            // (a) tiles their columns do not carry (columns with more than three tiles below the diagonal): left-looking update by
+            // one wave per tile, A(I,J) - sum_k U(I,k) D_k^-1 U(J,k)^T on the fp64 matrix cores
+            const int u0 = (int)p1_ptr[l], u1 = (int)p1_ptr[l + 1];
+            for (int t = u0 + wave; t < u1; t += kWaves) {
+                const uint32_t tt = p1_tasks[4 * t], ub = p1_tasks[4 * t + 1], ue = p1_tasks[4 * t + 2];
+                const double *tsrc = atiles + ((size_t)tt << 8) + (kq << 4) + r16;
+                f64x4 c;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) c[r] = tc[r << 6];
-                    for (uint32_t u = ub; u < ue; ++u) {
-                        const uint32_t ia = rfl(upd[3 * u]), ib = rfl(upd[3 * u + 1]), k = rfl(upd[3 * u + 2]);
-                        const double *ta = tiles + ((size_t)ia << 8) + (r16 << 4) + kq;
-                        const double *tb = tiles + ((size_t)ib << 8) + (r16 << 4) + kq;
-                        const double *iv = vinv + 16 * (size_t)k + kq, *wk = vw + 16 * (size_t)k + kq;
-                        double av[4], bv[4], aw[4];
+                for (int r = 0; r < 4; ++r) c[r] = tsrc[r << 6];
+                for (uint32_t u = ub; u < ue; ++u) {
+                    const uint32_t ia = upd[3 * u], ib = upd[3 * u + 1], k = upd[3 * u + 2];
+                    const double *ta = tiles + ((size_t)ia << 8) + (r16 << 4) + kq;
+                    const double *tb = tiles + ((size_t)ib << 8) + (r16 << 4) + kq;
+                    const double *iv = vinv + 16 * (size_t)k + kq;
+                    double av[4], bv[4];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            av[kk] = ta[4 * kk]; bv[kk] = -(tb[4 * kk] * iv[4 * kk]);
-                            aw[kk] = (dg && r16 == 0) ? wk[4 * kk] : 0.0;
-                        }
+                    for (int kk = 0; kk < 4; ++kk) { av[kk] = ta[4 * kk]; bv[kk] = -(tb[4 * kk] * iv[4 * kk]); }
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
-                        if (dg) {
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk) cw = __builtin_amdgcn_mfma_f64_16x16x4f64(aw[kk], bv[kk], cw, 0, 0, 0);
-                        }
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
-                    if (dg && kq == 0) vw[16 * (size_t)J + r16] += cw[0];
+                    for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
                 }
-                __syncthreads();
+                double *tc = tiles + ((size_t)tt << 8) + (kq << 4) + r16;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
             }
-            // (2) the level's columns: diagonal tile (lanes 0-15), w_J (lane 16), rows of the first tiles below (lanes 17-63)
-            const int q0 = (int)rfl(level_ptr[l]), q1 = (int)rfl(level_ptr[l + 1]);
-            for (int q = q0 + wave; q < q1; q += kWaves) {
-                const int J = (int)rfl(level_cols[q]);
-                const uint32_t t0 = rfl(colptr[J]);
-                const int nc = (int)rfl(ncarry[J]), nbp = 2 * (int)rfl(nreal[J]);
+            FPROF_MARK(4);                                // 4: tile tasks
+            // (b) the level's columns, one wave each, software pipelined: while a column is turned and eliminated the loads of the
+            // wave's NEXT column are in flight (a load from the workspace is ~1000-2000 cycles: the components of a launch do not fit L2).
+            //   the updates of the diagonal tile, of w_J and of the carried tiles (accumulators in the matrix cores' layout), a turn
+            //   through LDS into lane = row, the elimination, whole rows back to the workspace
+            const int q1 = (int)level_ptr[l + 1];
+            int q = (int)level_ptr[l] + wave;
+            ColDesc dn;
+            ColPre pn;
+            if (q < q1) { dn = load_desc(q); issue_column(dn, pn); }
+            while (q < q1) {
+                const ColDesc dc = dn;
+                const int qn = q + kWaves;
+                if (qn < q1) dn = load_desc(qn);          // (scalar loads: on their way during the updates below)
+                ColAcc acc;
+                acc.cD = pn.cD; acc.cS0 = pn.cS0; acc.cS1 = pn.cS1; acc.cS2 = pn.cS2; acc.wacc = 0.0;
+                const double wj = pn.wj;
+                {   // the scaled LM diagonal (A + S^-1 D^2 S^-1): this lane holds the diagonal entry of row r16 if r16 = 4 r + kq
+                    const double dd2 = (r16 & 3) == kq ? pn.dd * pn.dd : 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
+                }
+                {   // the tiles of the carried rows and the second entry come now (their addresses came with the descriptor)
+                    UpdY y0, y1;
+                    UpdB o1;
+                    if (dc.ne > 0u) load_y(dc.a00, dc.a01, dc.a02, y0);
+                    if (dc.ne > 1u) { load_b(dc.k1, dc.tb1, o1); load_y(dc.a10, dc.a11, dc.a12, y1); }
+                    if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, y0, acc);
+                    if (dc.ne > 1u) apply_ops(dc.a10, dc.a11, dc.a12, o1, y1, acc);
+                }
+                for (uint32_t e = dc.e_rest; e < dc.e_rest + dc.ne - 2u && dc.ne > 2u; ++e) {          // further entries (a column with more than two children)
+                    const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
+                    UpdB o;
+                    UpdY y;
+                    load_b(k, tb, o);
+                    load_y(a0, a1, a2, y);
+                    apply_ops(a0, a1, a2, o, y, acc);
+                }
+                double wacc = acc.wacc;
+                wacc += __shfl_xor(wacc, 16, 64);
+                wacc += __shfl_xor(wacc, 32, 64);
+                FPROF_MARK(0);                            // 0: loads + left-looking updates
+                // matrix-core layout (row 4 r + kq, column r16) -> lane = row
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    double *o = xd + (4 * r + kq) * 18 + r16;
+                    o[0] = acc.cD[r]; o[288] = acc.cS0[r]; o[576] = acc.cS1[r]; o[864] = acc.cS2[r];
+                }
+                if (kq == 0) xd[1152 + r16] = wj + wacc;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (qn < q1) issue_column(dn, pn);        // the next column's loads (the accumulators' registers are free now): in flight during the elimination
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int J = (int)dc.J, nc = (int)dc.nc, nbp = (int)dc.nbp;
+                double *tD = tiles + ((size_t)dc.t0 << 8);
                 const int s = lane - 17;
                 const bool is_diag = lane < 16, is_rhs = lane == 16, on = lane >= 17 && (s >> 4) < nc;
-                double *src = is_diag ? tiles + ((size_t)t0 << 8) + (r16 << 4)
-                            : is_rhs  ? vw + 16 * (size_t)J
-                                      : tiles + ((size_t)(t0 + 1u + (uint32_t)(on ? (s >> 4) : 0)) << 8) + ((s & 15) << 4);
                 double av[16];
                 {
-                    const double2 *rowp = reinterpret_cast<const double2 *>(src);
+                    const double *rs = is_diag ? xd + r16 * 18 : is_rhs ? xd + 1152 : xd + 288 * (1 + (s >> 4)) + (s & 15) * 18;
+                    const double2 *rowp = reinterpret_cast<const double2 *>(rs);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; av[2 * j] = v.x; av[2 * j + 1] = v.y; }
 #pragma unroll
                     for (int j = 0; j < 16; ++j) av[j] = is_diag ? (j <= r16 ? av[j] : 0.0) : ((is_rhs || on) ? av[j] : 0.0);
                 }
+                FPROF_MARK(1);                            // 1: the turn through LDS
                 bool bad = false;
                 double my_inv = 0.0;
 #pragma unroll
@@ -1807,27 +1950,32 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                         for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
                     }
                 }
+                FPROF_MARK(2);                            // 2: elimination
                 if (lane < nbp) vinv[16 * (size_t)J + lane] = my_inv;
                 if (is_diag || is_rhs || on) {
-                    double2 *rowp = reinterpret_cast<double2 *>(src);
+                    double *dst = is_diag ? tD + (r16 << 4) : is_rhs ? vw + 16 * (size_t)J : tD + ((size_t)(1 + (s >> 4)) << 8) + ((s & 15) << 4);
+                    double2 *rowp = reinterpret_cast<double2 *>(dst);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) rowp[j] = make_double2(av[2 * j], av[2 * j + 1]);
                 }
                 if (bad && lane == 0) sh.flag = 1;
+                FPROF_MARK(3);                            // 3: stores
+                q = qn;
             }
             __syncthreads();
-            // (3) rows the column tasks did not carry (columns with more than three tiles below the diagonal): four tiles per wave
-            const int x0 = (int)rfl(x_ptr[l]), x1 = (int)rfl(x_ptr[l + 1]);
+            FPROF_MARK(5);                                // 5: waiting at the level's barrier
+            TPROF_MARK(1);
+            // (c) rows the column tasks did not carry: substituted against the finished diagonal tile, four tiles per wave
+            const int x0 = (int)x_ptr[l], x1 = (int)x_ptr[l + 1];
             if (x1 > x0) {
-                double *xd = ts.diag[wave];
                 for (int t = x0 + wave; t < x1; t += kWaves) {
-                    const int J = (int)rfl(x_tasks[3 * t]), i0 = (int)rfl(x_tasks[3 * t + 1]), cnt = (int)rfl(x_tasks[3 * t + 2]);
-                    const uint32_t t0 = rfl(colptr[J]);
+                    const int J = (int)x_tasks[3 * t], i0 = (int)x_tasks[3 * t + 1], cnt = (int)x_tasks[3 * t + 2];
+                    const uint32_t t0 = colptr[J];
                     const double *Td = tiles + ((size_t)t0 << 8);
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
                     for (int i = 0; i < 4; ++i) xd[lane + 64 * i] = Td[lane + 64 * i];
-                    if (lane < 16) xd[256 + lane] = vinv[16 * (size_t)J + lane];
+                    if (lane < 16) xd[1152 + lane] = vinv[16 * (size_t)J + lane];
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1838,7 +1986,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     for (int c = 0; c < 16; ++c) r[c] = rowp[c];
 #pragma unroll
                     for (int j = 0; j < 15; ++j) {
-                        const double tj = r[j] * xd[256 + j];
+                        const double tj = r[j] * xd[1152 + j];
 #pragma unroll
                         for (int c = j + 1; c < 16; ++c) r[c] = fma(-tj, xd[(c << 4) + j], r[c]);
                     }
@@ -1848,63 +1996,98 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     }
                 }
                 __syncthreads();
+                TPROF_MARK(5);
             }
         }
+        FPROF_FLUSH();
         return sh.flag == 0;
     };
 
-    // ---- L D L^T y = g with w = L^-1 g: levels top down; y_J = D^-1 (w_J - sum_I U(I,J)^T y_I) through the diagonal tile ----
+    // ---- L D L^T y = g with w = L^-1 g: levels top down; y_J = D^-1 (w_J - sum_I U(I,J)^T y_I) through the diagonal tile.  Pipelined
+    //      like the factorization: the next column's tiles are on their way while the 16 dependent steps of this one run. ----
+    struct BackPre { double m[16], iv, z, tvv[4][4], yv[4][4]; };
+    auto issue_back = [&](const ColDesc &c, BackPre &p) {
+        const double *Td = tiles + ((size_t)c.t0 << 8);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) p.m[k] = Td[(k << 4) + r16];
+        p.iv = r16 < (int)c.nbp ? vinv[16 * (size_t)c.J + r16] : 0.0;
+        p.z = vw[16 * (size_t)c.J + r16];
+        const uint32_t rows[4] = {c.i0, c.i1, c.i2, c.i3};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i < c.nsub) {
+                const double *T = Td + ((size_t)(1 + i) << 8) + (kq << 4) + r16;
+                const double *yI = vstep + 16 * (size_t)rows[i] + kq;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { p.tvv[i][r] = T[r << 6]; p.yv[i][r] = yI[4 * r]; }
+            }
+        }
+    };
     auto back_substitute = [&]() {
         for (int l = n_levels - 1; l >= 0; --l) {
-            const int q0 = (int)rfl(level_ptr[l]), q1 = (int)rfl(level_ptr[l + 1]);
-            for (int q = q0 + wave; q < q1; q += kWaves) {
-                const int J = (int)rfl(level_cols[q]);
-                const uint32_t t0 = rfl(colptr[J]), t1 = rfl(colptr[J + 1]);
-                const int nbp = 2 * (int)rfl(nreal[J]);
-                const double *Td = tiles + ((size_t)t0 << 8);
-                double m[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) m[k] = Td[(k << 4) + r16];
-                const double iv = r16 < nbp ? vinv[16 * (size_t)J + r16] : 0.0;
-                double z = vw[16 * (size_t)J + r16];
+            const int q1 = (int)level_ptr[l + 1];
+            int q = (int)level_ptr[l] + wave;
+            ColDesc dn;
+            BackPre pn;
+            if (q < q1) { dn = load_desc(q); issue_back(dn, pn); }
+            while (q < q1) {
+                const ColDesc dc = dn;
+                const int qn = q + kWaves;
+                if (qn < q1) dn = load_desc(qn);
                 double acc = 0.0;
-                for (uint32_t t = t0 + 1u; t < t1; ++t) {
-                    const int I = (int)rfl(rowsof[t]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if ((uint32_t)i < dc.nsub) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc = fma(pn.tvv[i][r], pn.yv[i][r], acc);
+                    }
+                }
+                for (uint32_t t = dc.t0 + 5u; t < dc.t0 + 1u + dc.nsub; ++t) {          // further tiles (a column with more than four rows below the diagonal)
+                    const int I = (int)rowsof[t];
                     const double *T = tiles + ((size_t)t << 8) + (kq << 4) + r16;
                     const double *yI = vstep + 16 * (size_t)I + kq;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc = fma(T[r << 6], yI[4 * r], acc);
                 }
+                double m[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) m[k] = pn.m[k];
+                const double iv = pn.iv;
+                double z = pn.z;
+                if (qn < q1) issue_back(dn, pn);
                 acc += __shfl_xor(acc, 16, 64);
                 acc += __shfl_xor(acc, 32, 64);
                 z -= acc;
                 double yo = 0.0;
 #pragma unroll
                 for (int k = 15; k >= 0; --k) {
-                    const double yv = z * iv;
-                    const double yk = readlane_f64(yv, k);
-                    yo = (r16 == k) ? yv : yo;
+                    const double yvk = z * iv;
+                    const double yk = readlane_f64(yvk, k);
+                    yo = (r16 == k) ? yvk : yo;
                     z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
                 }
-                if (lane < 16) vstep[16 * (size_t)J + r16] = yo;
+                if (lane < 16) vstep[16 * (size_t)dc.J + r16] = yo;
+                q = qn;
             }
             __syncthreads();
         }
     };
 
-    // ---- the trust-region loop of solve_component, over vectors in matrix order ----
+    // ---- the trust-region loop of solve_component, over vectors in matrix order; the vector passes are fused so that an iteration
+    //      has three reductions beside the sweeps' ----
     // (-DLFR_PROFILE_PHASES: 0 sweeps, 1 factorization, 5 scaling, 6 back substitution, 4 everything else - the slots of the LDS kernels)
     int exec_passes = 1;
     double cost = sweep(vx, vg);
     PROF_MARK(0);
-    for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
-    __syncthreads();
-    auto grad_max = [&](const double *xv, const double *gv) {
+    double gmax = 0.0;
+    {
         double m = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) m = fmax(m, fabs(xv[i] - clampb(xv[i] - gv[i])));
-        return block_max<kBlockThreads>(m, sh);
-    };
-    double gmax = grad_max(vx, vg);
+        for (int i = tid; i < n; i += kBlockThreads) {
+            vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
+            m = fmax(m, fabs(vx[i] - clampb(vx[i] - vg[i])));
+        }
+        gmax = block_max<kBlockThreads>(m, sh);
+    }
     double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
     bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
@@ -1916,37 +2099,43 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         ++iteration;
         step_successful = false;
         PROF_MARK(4);
-        if (!matrix_valid) {           // the factorization of a rejected step overwrote J^T J: re-assemble
+        if (!matrix_valid) {           // A holds J^T J of a rejected trial point: re-assemble at x
             sweep(vx, vg);
             ++exec_passes;
             matrix_valid = true;
             PROF_MARK(0);
         }
+        // the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the diagonal tiles, g into w
         for (int i = tid; i < n; i += kBlockThreads) {
-            if (!reuse_diagonal) vdiag[i] = fmin(fmax(vscale[i] * vscale[i] * vadiag[i], kMinLmDiag), kMaxLmDiag);
-            vD[i] = sqrt(vdiag[i] / radius) / vscale[i];                     // D / s
+            const double sc = vscale[i];
+            double dg = vdiag[i];
+            if (!reuse_diagonal) { dg = fmin(fmax(sc * sc * vadiag[i], kMinLmDiag), kMaxLmDiag); vdiag[i] = dg; }
+            const double Di = sqrt(dg / radius) / sc;                        // D / s
+            vD[i] = Di;                                                      // (the column tasks add D^2 to their diagonal tiles)
+            vw[i] = vg[i];
         }
         reuse_diagonal = true;
+        if (tid == 0) sh.flag = 0;                        // raised by a non-positive pivot
         __syncthreads();
-        scale_matrix();
-        PROF_MARK(5);
-        matrix_valid = false;
-        bool valid = factor();
+        PROF_MARK(LFR_TREE_SLOT_SCALE);
+        bool valid = factor();                            // (reads A, writes the factor: J^T J at x stays in A until a trial point is swept)
         PROF_MARK(1);
         if (valid) back_substitute();
         PROF_MARK(6);
-        double model_cost_change = 0.0;
+        double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
-            double partial = 0.0, bad = 0.0;
+            double partial = 0.0, gd_part = 0.0, dm_part = 0.0;
             for (int i = tid; i < n; i += kBlockThreads) {
-                const double rhs0 = vg[i];
-                const double st = -vstep[i];
-                if (!isfinite(st)) bad = 1.0;
-                partial += -rhs0 * st + vD[i] * vD[i] * st * st;
+                const double gi = vg[i], Di = vD[i];
+                const double dl = -vstep[i];
+                vdelta[i] = dl;
+                partial += -gi * dl + Di * Di * dl * dl;
+                gd_part += gi * dl;
+                dm_part = isfinite(dl) ? fmax(dm_part, fabs(dl)) : INFINITY;
             }
-            model_cost_change = 0.5 * block_sum<kBlockThreads>(partial, sh);
-            bad = block_max<kBlockThreads>(bad, sh);
-            valid = bad == 0.0 && model_cost_change > 0.0;
+            block_reduce3<kBlockThreads>(partial, gd_part, dm_part, ts);
+            model_cost_change = 0.5 * partial; g_dot_delta = gd_part; dir_max = dm_part;
+            valid = isfinite(dir_max) && model_cost_change > 0.0;
         }
         if (!valid) {
             if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
@@ -1955,15 +2144,6 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             continue;
         }
         n_invalid = 0;
-        double gd_part = 0.0, dm_part = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) {
-            const double dl = -vstep[i];
-            vdelta[i] = dl;
-            gd_part += vg[i] * dl;
-            dm_part = fmax(dm_part, fabs(dl));
-        }
-        const double g_dot_delta = block_sum<kBlockThreads>(gd_part, sh);
-        const double dir_max = block_max<kBlockThreads>(dm_part, sh);
         // ---- projected Armijo line search ----
         double alpha = 1.0, cost_c = 0.0;
         bool ls_ok = false;
@@ -1972,9 +2152,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             int n_iter = 0;
             for (;;) {
                 for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
-                __syncthreads();
                 PROF_MARK(4);
                 cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
+                matrix_valid = false;
                 PROF_MARK(0);
                 ++exec_passes; ++n_ls_evals;
                 current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
@@ -1994,28 +2174,33 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         }
         if (!ls_ok) {
             for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
-            __syncthreads();
             cost_c = sweep(vxc, vgn);
+            matrix_valid = false;
             ++exec_passes;
         }
         ++n_cand;
         const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
-        double sn = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) sn += (vx[i] - vxc[i]) * (vx[i] - vxc[i]);
-        const double step_norm = sqrt(block_sum<kBlockThreads>(sn, sh));
+        // step norm, and - should the candidate be accepted - its norm and projected gradient, in one pass
+        double sn = 0.0, xn = 0.0, gm = 0.0;
+        for (int i = tid; i < n; i += kBlockThreads) {
+            const double xo = vx[i], xc = vxc[i];
+            sn += (xo - xc) * (xo - xc);
+            xn += xc * xc;
+            gm = fmax(gm, fabs(xc - clampb(xc - vgn[i])));
+        }
+        block_reduce3<kBlockThreads>(sn, xn, gm, ts);
+        const double step_norm = sqrt(sn);
         if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
         const double cost_change = cost - cost_cand;
         if (fabs(cost_change) <= kFunctionTol * cost) break;
         const double rel = cost_change / model_cost_change;
         if (rel > kMinRelDecrease) {
-            double xn = 0.0;
+            for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; vg[i] = vgn[i]; }
             __syncthreads();
-            for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; vg[i] = vgn[i]; }
-            x_norm = sqrt(block_sum<kBlockThreads>(xn, sh));
-            __syncthreads();
+            x_norm = sqrt(xn);
             cost = cost_cand;
             matrix_valid = true;              // the accepted candidate is the last evaluated point: its J^T J is in the tiles
-            gmax = grad_max(vx, vg);
+            gmax = gm;
             step_successful = true;
             ++n_successful;
             const double t = 2.0 * rel - 1.0;
@@ -2048,7 +2233,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
 
 // persistent workgroups over the class's queue, like solve_block_kernel
 template <int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void solve_tree_kernel(const KernelArgs a) {
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((kBlockThreads + 255) / 256, (kBlockThreads + 255) / 256))) void solve_tree_kernel(const KernelArgs a) {
     __shared__ BlockShared sh;
     __shared__ TreeShared ts;
     __shared__ int next_ci;

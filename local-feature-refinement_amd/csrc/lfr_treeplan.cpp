@@ -358,47 +358,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // rows of every block row: rowlist[I] = columns k < I with a tile (I, k), ascending, with the tile's id
     std::vector<std::vector<std::pair<int32_t, uint32_t>>> rowlist(NB);
     for (int k = 0; k < NB; ++k) for (size_t i = 0; i < st[k].size(); ++i) rowlist[st[k][i]].push_back({k, colptr[k] + 1u + (uint32_t)i});
-    // ---- update lists (left-looking) and the phase-1 tasks per level ----
-    std::vector<uint32_t> upd;                                   // triples (tile (I, k), tile (J, k), k)
-    std::vector<uint32_t> p1_tasks;                              // quadruples (target tile, first update, end, J | diag << 31)
-    std::vector<uint32_t> p1_ptr(n_levels + 1, 0);
-    uint64_t n_upd = 0;
-    {
-        std::vector<std::vector<uint32_t>> per_target;
-        for (int l = 0; l < n_levels; ++l) {
-            for (uint32_t q = level_ptr[l]; q < level_ptr[l + 1]; ++q) {
-                const int J = (int)level_cols[q];
-                const std::vector<int32_t> &sJ = st[J];
-                per_target.assign(1 + sJ.size(), {});
-                for (auto &rk : rowlist[J]) {
-                    const int k = rk.first;
-                    const uint32_t tJk = rk.second;
-                    const std::vector<int32_t> &sk = st[k];
-                    // the rows of column k at or below J: J itself (-> the diagonal tile) and rows I > J (all in struct(J): fill closure)
-                    size_t i = std::lower_bound(sk.begin(), sk.end(), J) - sk.begin();
-                    size_t j = 0;
-                    for (; i < sk.size(); ++i) {
-                        const int I = sk[i];
-                        const uint32_t tIk = colptr[k] + 1u + (uint32_t)i;
-                        size_t target;
-                        if (I == J) target = 0;
-                        else { while (j < sJ.size() && sJ[j] < I) ++j; target = 1 + j; }     // (sJ[j] == I by closure)
-                        per_target[target].push_back(tIk); per_target[target].push_back(tJk); per_target[target].push_back((uint32_t)k);
-                    }
-                }
-                for (size_t t = 0; t < per_target.size(); ++t) {
-                    if (per_target[t].empty()) continue;
-                    const uint32_t b0 = (uint32_t)(upd.size() / 3);
-                    upd.insert(upd.end(), per_target[t].begin(), per_target[t].end());
-                    p1_tasks.push_back(colptr[J] + (uint32_t)t); p1_tasks.push_back(b0); p1_tasks.push_back((uint32_t)(upd.size() / 3));
-                    p1_tasks.push_back((uint32_t)J | (t == 0 ? 0x80000000u : 0u));
-                }
-            }
-            p1_ptr[l + 1] = (uint32_t)(p1_tasks.size() / 4);
-        }
-        n_upd = upd.size() / 3;
-    }
-    // ---- rows the column task carries through the diagonal tile's elimination; the rest are "extra row" tasks (phase 2b) ----
+    // ---- rows the column task carries through the diagonal tile's elimination; the rest are "extra row" tasks ----
     // lanes 16 = right-hand side, 17 .. 63 = rows 0-15 of the first two tiles below the diagonal and rows 0-14 of the third
     std::vector<uint32_t> ncarry(NB), x_ptr(n_levels + 1, 0), x_tasks;
     for (int l = 0; l < n_levels; ++l) {
@@ -411,6 +371,72 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
             for (int i = nc; i < ns; i += 4) { x_tasks.push_back((uint32_t)J); x_tasks.push_back((uint32_t)i); x_tasks.push_back((uint32_t)std::min(4, ns - i)); }
         }
         x_ptr[l + 1] = (uint32_t)(x_tasks.size() / 3);
+    }
+    // ---- left-looking update lists ----
+    // The column task of J applies the updates of its diagonal tile, of the right-hand side and of the tiles it carries itself:
+    // col_upd[J] = per column k of row J (ascending) the quintuple (k, tile (J, k), tile (I_0, k), tile (I_1, k), tile (I_2, k)) with
+    // I_i the carried rows (none: 0xffffffff).  The other tiles of a column (rows beyond the carried ones) are separate tile tasks:
+    // (target tile, first update, end, J) over triples (tile (I, k), tile (J, k), k).
+    constexpr uint32_t kNone = 0xffffffffu;
+    std::vector<uint32_t> col_upd_ptr(NB + 1, 0), col_upd;
+    std::vector<uint32_t> upd, p1_tasks, p1_ptr(n_levels + 1, 0);
+    uint64_t n_upd = 0;
+    {
+        std::vector<std::vector<uint32_t>> col_entries(NB);
+        std::vector<std::vector<uint32_t>> per_target;
+        for (int l = 0; l < n_levels; ++l) {
+            for (uint32_t q = level_ptr[l]; q < level_ptr[l + 1]; ++q) {
+                const int J = (int)level_cols[q];
+                const std::vector<int32_t> &sJ = st[J];
+                const size_t nc = ncarry[J];
+                per_target.assign(sJ.size(), {});
+                std::vector<uint32_t> &ce = col_entries[J];
+                for (auto &rk : rowlist[J]) {
+                    const int k = rk.first;
+                    const uint32_t tJk = rk.second;
+                    const std::vector<int32_t> &sk = st[k];
+                    uint32_t carried[3] = {kNone, kNone, kNone};
+                    // the rows of column k below J are rows of column J as well (fill closure): walk both lists
+                    size_t i = std::lower_bound(sk.begin(), sk.end(), J) - sk.begin() + 1, j = 0;
+                    for (; i < sk.size(); ++i) {
+                        const int I = sk[i];
+                        const uint32_t tIk = colptr[k] + 1u + (uint32_t)i;
+                        while (j < sJ.size() && sJ[j] < I) ++j;              // (sJ[j] == I)
+                        if (j < nc) carried[j] = tIk;
+                        else { per_target[j].push_back(tIk); per_target[j].push_back(tJk); per_target[j].push_back((uint32_t)k); }
+                        ++n_upd;
+                    }
+                    ce.push_back((uint32_t)k); ce.push_back(tJk); ce.push_back(carried[0]); ce.push_back(carried[1]); ce.push_back(carried[2]);
+                    ++n_upd;
+                }
+                for (size_t t = nc; t < per_target.size(); ++t) {      // (also without updates: the task moves the tile from A to the factor)
+                    const uint32_t b0 = (uint32_t)(upd.size() / 3);
+                    upd.insert(upd.end(), per_target[t].begin(), per_target[t].end());
+                    p1_tasks.push_back(colptr[J] + 1u + (uint32_t)t); p1_tasks.push_back(b0); p1_tasks.push_back((uint32_t)(upd.size() / 3));
+                    p1_tasks.push_back((uint32_t)J);
+                }
+            }
+            p1_ptr[l + 1] = (uint32_t)(p1_tasks.size() / 4);
+        }
+        for (int J = 0; J < NB; ++J) {
+            col_upd_ptr[J] = (uint32_t)(col_upd.size() / 5);
+            col_upd.insert(col_upd.end(), col_entries[J].begin(), col_entries[J].end());
+        }
+        col_upd_ptr[NB] = (uint32_t)(col_upd.size() / 5);
+    }
+    // ---- column descriptors in execution order (level by level): everything a column task needs to start its loads comes with ONE
+    //      pair of scalar loads - {J, diagonal tile, carried tiles, pivots, update entries, first further entry, entry 0 (5 words), entry 1,
+    //      tiles below the diagonal, rows of the first four of them} - instead of a chain of dependent lookups ----
+    std::vector<uint32_t> col_desc(32 * (size_t)NB, 0);
+    for (int q = 0; q < NB; ++q) {
+        const int J = (int)level_cols[q];
+        uint32_t *dsc = &col_desc[32 * (size_t)q];
+        const uint32_t e0 = col_upd_ptr[J], ne = col_upd_ptr[J + 1] - e0;
+        dsc[0] = (uint32_t)J; dsc[1] = colptr[J]; dsc[2] = ncarry[J]; dsc[3] = 2u * nreal[J]; dsc[4] = ne; dsc[5] = e0 + 2u;
+        for (uint32_t i = 0; i < 2; ++i)
+            for (int w5 = 0; w5 < 5; ++w5) dsc[6 + 5 * i + w5] = i < ne ? col_upd[5 * (size_t)(e0 + i) + w5] : (w5 == 0 ? (uint32_t)J : w5 == 1 ? colptr[J] : kNone);
+        dsc[16] = (uint32_t)st[J].size();
+        for (size_t i = 0; i < 4; ++i) dsc[17 + i] = i < st[J].size() ? (uint32_t)st[J][i] : (uint32_t)J;
     }
     // ---- sweep items ----
     const uint32_t n_pad = 16u * (uint32_t)NB;
@@ -470,13 +496,15 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     put(blob, 8, colptr); put(blob, 9, rowsof); put(blob, 10, nreal); put(blob, 11, level_ptr); put(blob, 12, level_cols);
     put(blob, 13, p1_ptr); put(blob, 14, p1_tasks); put(blob, 15, upd); put(blob, 16, x_ptr); put(blob, 17, x_tasks); put(blob, 18, ncarry);
     put(blob, 19, items); put(blob, 20, item_edges); put(blob, 21, node_items); put(blob, 22, ipos);
+    put(blob, 25, col_upd_ptr); put(blob, 26, col_upd); put(blob, 27, col_desc);
     while (blob.size() % 64) blob.push_back(0);                  // the tiles start at a multiple of 32 doubles
     out.n_var = n_var; out.NB = NB; out.n_levels = n_levels; out.n_tiles = n_tiles; out.n_items = n_items; out.n_updates = n_upd;
     out.n_tracks = T; out.n_segments = S;
     blob[0] = (uint32_t)NB; blob[1] = n_tiles; blob[2] = (uint32_t)(blob.size() / 2); blob[4] = n_pad; blob[5] = (uint32_t)n_levels;
     blob[6] = n_items; blob[7] = (uint32_t)(p1_tasks.size() / 4);
-    // behind the tiles: 6 doubles of partial sums per item, then the vectors
-    const uint64_t off_part = (uint64_t)blob[2] + 256ull * n_tiles;
+    // two sets of tiles - A (the sweep stores J^T J there, always the same entries: zeroed once per solve, never by a sweep) and U (the
+    // factor) -, then 6 doubles of partial sums per item, then the vectors
+    const uint64_t off_part = (uint64_t)blob[2] + 512ull * n_tiles;
     const uint64_t off_vec = (off_part + 6ull * n_items + 31) / 32 * 32;
     if (off_vec + (uint64_t)kTreeVectors * out.vec_stride() >= (1ull << 32)) { out.blob.clear(); return; }     // (32-bit offsets: a 30-GB workspace is not a component)
     blob[3] = (uint32_t)off_vec; blob[23] = (uint32_t)off_part; blob[24] = (uint32_t)out.vec_stride();

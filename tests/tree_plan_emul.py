@@ -11,7 +11,7 @@ class Plan:
         b = np.asarray(blob, np.uint32)
         self.blob = b
         self.NB, self.n_tiles, self.off_tiles, self.off_vec, self.n_pad, self.n_levels, self.n_items, self.n_p1 = (int(x) for x in b[:8])
-        o = [int(x) for x in b[8:23]]
+        o = [int(x) for x in b[8:23]] + [int(b[25]), int(b[26]), int(b[27])]
         NB, L = self.NB, self.n_levels
 
         def arr(i, n):
@@ -33,13 +33,16 @@ class Plan:
         self.node_items = arr(13, 8 * NB + 1)
         self.ipos = arr(14, 8 * NB)
         self.off_part, self.vec_stride = int(b[23]), int(b[24])
+        self.col_upd_ptr = arr(15, NB + 1)
+        self.col_upd = arr(16, 5 * int(self.col_upd_ptr[-1])).reshape(-1, 5)
+        self.col_desc = arr(17, 32 * NB).reshape(-1, 32)
 
     # ---- structural invariants ----
     def check(self, n_var):
         NB = self.NB
         assert self.n_pad == 16 * NB and self.vec_stride == 16 * NB + 16
         assert self.off_tiles % 32 == 0 and self.off_vec % 32 == 0 and self.off_tiles * 2 >= 32
-        assert self.off_part == self.off_tiles + 256 * self.n_tiles and self.off_vec >= self.off_part + 6 * self.n_items
+        assert self.off_part == self.off_tiles + 512 * self.n_tiles and self.off_vec >= self.off_part + 6 * self.n_items
         real = self.ipos[self.ipos != NONE]
         assert sorted(real.tolist()) == list(range(n_var))                       # every variable node has exactly one position
         for J in range(NB):                                                      # real slots first, padding behind
@@ -58,21 +61,41 @@ class Plan:
             assert (lvl[rows[1:]] > lvl[J]).all()                                # a column's rows are its ancestors
             if len(rows) > 1:
                 assert lvl[rows[1]] >= lvl[J] + 1
-        # update lists: one task per target tile, sources at lower levels, tiles of the right rows / columns
+        # update lists: every tile below a diagonal is updated by exactly one party (its column's task if carried, a tile task
+        # otherwise), sources at lower levels, tiles of the right rows / columns, ascending k = a fixed summation order
         colof = np.repeat(np.arange(NB), np.diff(self.colptr))
         seen = set()
         for l in range(self.n_levels):
             for t in range(self.p1_ptr[l], self.p1_ptr[l + 1]):
-                tt, ub, ue, jd = self.p1_tasks[t]
-                J, diag = int(jd) & 0x7FFFFFFF, int(jd) >> 31
-                assert tt not in seen and ue > ub
-                seen.add(int(tt))
-                assert colof[tt] == J and lvl[J] == l and (diag == 1) == (self.rowsof[tt] == J)
+                tt, ub, ue, J = (int(x) for x in self.p1_tasks[t])
+                assert tt not in seen and ue >= ub
+                seen.add(tt)
+                assert colof[tt] == J and lvl[J] == l and tt - self.colptr[J] - 1 >= self.ncarry[J]
                 u = self.upd[ub:ue]
-                assert (np.diff(u[:, 2]) > 0).all()                              # ascending k: a fixed summation order
+                assert (np.diff(u[:, 2]) > 0).all()
                 assert (colof[u[:, 0]] == u[:, 2]).all() and (colof[u[:, 1]] == u[:, 2]).all()
                 assert (self.rowsof[u[:, 0]] == self.rowsof[tt]).all() and (self.rowsof[u[:, 1]] == J).all()
                 assert (lvl[u[:, 2]] < l).all()
+        for J in range(NB):
+            ce = self.col_upd[self.col_upd_ptr[J]:self.col_upd_ptr[J + 1]]
+            assert (np.diff(ce[:, 0]) > 0).all() and (lvl[ce[:, 0]] < lvl[J]).all()
+            assert (colof[ce[:, 1]] == ce[:, 0]).all() and (self.rowsof[ce[:, 1]] == J).all()
+            for i in range(3):
+                m = ce[:, 2 + i] != NONE
+                assert not m.any() or i < self.ncarry[J]
+                if m.any():
+                    assert (colof[ce[m, 2 + i]] == ce[m, 0]).all() and (self.rowsof[ce[m, 2 + i]] == self.rowsof[self.colptr[J] + 1 + i]).all()
+        for q in range(NB):                                                      # the descriptors restate the tables, column by column in level order
+            dsc = self.col_desc[q]
+            J = int(self.level_cols[q])
+            e0, e1 = self.col_upd_ptr[J], self.col_upd_ptr[J + 1]
+            ns = self.colptr[J + 1] - self.colptr[J] - 1
+            assert dsc[0] == J and dsc[1] == self.colptr[J] and dsc[2] == self.ncarry[J] and dsc[3] == 2 * self.nreal[J]
+            assert dsc[4] == e1 - e0 and dsc[5] == e0 + 2 and dsc[16] == ns
+            for i in range(min(2, e1 - e0)):
+                assert (dsc[6 + 5 * i:11 + 5 * i] == self.col_upd[e0 + i]).all()
+            for i in range(min(4, ns)):
+                assert dsc[17 + i] == self.rowsof[self.colptr[J] + 1 + i]
         for l in range(self.n_levels):
             for t in range(self.x_ptr[l], self.x_ptr[l + 1]):
                 J, i0, cnt = self.x_tasks[t]
@@ -85,6 +108,8 @@ class Plan:
                 assert self.nreal[self.rowsof[self.colptr[J] + 3]] <= 7          # lanes 49-63 hold rows 0-14 of the third tile
             covered = nc + sum(int(c) for (j, i0, c) in self.x_tasks if j == J)
             assert covered == ns
+            for i in range(nc, ns):                                                # every tile its column does not carry has a tile task
+                assert int(self.colptr[J] + 1 + i) in seen
         return lvl
 
     # ---- the sweep: per-record quantities -> tiles, gradient, diagonal ----
@@ -135,24 +160,20 @@ class Plan:
         w = w.copy().reshape(self.NB, 16)
         inv = np.zeros((self.NB, 16))
         for l in range(self.n_levels):
-            new = {}
-            for t in range(self.p1_ptr[l], self.p1_ptr[l + 1]):      # phase 1: reads only tiles of lower levels
-                tt, ub, ue, jd = self.p1_tasks[t]
-                J, diag = int(jd) & 0x7FFFFFFF, int(jd) >> 31
-                acc = tiles[tt].copy()
-                wj = w[J].copy()
+            for t in range(self.p1_ptr[l], self.p1_ptr[l + 1]):      # tile tasks: the tiles their columns do not carry
+                tt, ub, ue, J = self.p1_tasks[t]
                 for (ta, tb, k) in self.upd[ub:ue]:
-                    acc -= tiles[ta] @ np.diag(inv[k]) @ tiles[tb].T
-                    if diag:
-                        wj -= tiles[tb] @ (inv[k] * w[k])
-                new[int(tt)] = (acc, wj if diag else None, J)
-            for tt, (acc, wj, J) in new.items():
-                tiles[tt] = acc
-                if wj is not None:
-                    w[J] = wj
-            for J in self.level_cols[self.level_ptr[l]:self.level_ptr[l + 1]]:      # phase 2: the column tasks
+                    tiles[tt] -= tiles[ta] @ np.diag(inv[k]) @ tiles[tb].T
+            for J in self.level_cols[self.level_ptr[l]:self.level_ptr[l + 1]]:      # column tasks: updates, then the elimination
                 t0 = self.colptr[J]
                 nbp = 2 * self.nreal[J]
+                for (k, tb, c0, c1, c2) in self.col_upd[self.col_upd_ptr[J]:self.col_upd_ptr[J + 1]]:
+                    B = np.diag(inv[k]) @ tiles[tb].T
+                    tiles[t0] -= tiles[tb] @ B
+                    w[J] -= tiles[tb] @ (inv[k] * w[k])
+                    for i, c in enumerate((c0, c1, c2)):
+                        if c != NONE:
+                            tiles[t0 + 1 + i] -= tiles[c] @ B
                 D = np.tril(tiles[t0])
                 rows = [tiles[t0 + 1 + i] for i in range(self.ncarry[J])] + [w[J][None, :]]
                 for kk in range(nbp):
