@@ -1524,7 +1524,11 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
+#ifdef LFR_EXP_NOLS
+                const double nstep = -1.0;
+#else
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
+#endif
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;
@@ -1634,6 +1638,9 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #define TPROF_MARK(i)
 #define LFR_TREE_SLOT_SCALE 5
 #endif
+#ifndef LFR_TREE_PINGPONG
+#define LFR_TREE_PINGPONG 0      // 1: two operand sets alternate over a column's further update entries (measured: the extra registers make the column loop spill)
+#endif
 struct TreeShared {
     // per wave: four tiles in rows of 18 doubles (the column task turns its accumulators from the matrix cores' layout into
     // lane = row through them; the extra-row tasks stage a diagonal tile there) + 16 doubles (the right-hand side / 1/d)
@@ -1643,6 +1650,8 @@ struct TreeShared {
 // The plan's words are written by the host before the launch and never by the kernel: read through the constant address space they
 // are scalar loads (s_load, one per wave, through the scalar cache) instead of vector loads + v_readfirstlane behind ~1 us of latency.
 typedef const __attribute__((address_space(4))) uint32_t *PlanWords;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // two sums and a maximum over the workgroup with one pair of barriers
 template <int kBlockThreads>
@@ -1723,7 +1732,11 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 const int kind = (int)(qv[4].w >> 31);
                 const bool rev = (ew & 2u) != 0u;                                // the record runs neighbour -> node
                 EdgeOut o;
+#ifdef LFR_EXP_NOEVAL
+                o.cost = flow[0]; o.r0 = flow[1]; o.r1 = flow[2]; o.j00 = flow[3]; o.j01 = flow[4]; o.j10 = flow[5]; o.j11 = flow[6]; o.sq = sim + kind + tv + xu0 + xv0 + xu1 + xv1;
+#else
                 eval_edge<true>(flow, sim, kind, tv, rev ? xu0 : xv0, rev ? xu1 : xv1, rev ? xv0 : xu0, rev ? xv1 : xu1, o);
+#endif
                 if (ew & 1u) cost += o.cost;
                 if (!rev) {                                                      // d r / d x_node = J1, d r / d x_neighbour = sq I
                     d00 += o.j00 * o.j00 + o.j10 * o.j10; d10 += o.j01 * o.j00 + o.j11 * o.j10; d11 += o.j01 * o.j01 + o.j11 * o.j11;
@@ -1772,26 +1785,48 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         c.nsub = w[16]; c.i0 = w[17]; c.i1 = w[18]; c.i2 = w[19]; c.i3 = w[20];
         return c;
     };
+    // The factorization reads and writes the workspace through BUFFER instructions: a resource descriptor per array (four SGPRs), a
+    // scalar byte offset per tile / vector block and ONE 32-bit VGPR offset per lane layout - instead of a 64-bit VGPR address per
+    // access.  (With flat addresses the column loop ran out of registers, and a single address spilled and reloaded between the
+    // prefetch and the elimination made the wave wait for the prefetch it was meant to overlap.)
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(atiles, 0, (int)0xfffffffe, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(tiles, 0, (int)0xfffffffe, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vec, 0, (int)0xfffffffe, 0x00020000);
+    auto bld = [](const __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff) -> double {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    };
+    auto bst = [](const double x, const __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff) {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, voff, soff, 0);
+    };
+    const unsigned bo_ab = 8u * (unsigned)((r16 << 4) + kq);   // bytes: operand layout of the matrix cores, element kk at + 32 kk
+    const unsigned bo_c = 8u * (unsigned)((kq << 4) + r16);    // accumulator layout: element r at + 512 r
+    const unsigned bo_k = 8u * (unsigned)kq, bo_r = 8u * (unsigned)r16;
+    const unsigned so_inv = (unsigned)(10 * vs) * 8u, so_w = (unsigned)(11 * vs) * 8u, so_D = (unsigned)(7 * vs) * 8u, so_step = (unsigned)(6 * vs) * 8u;   // byte offsets of the vectors in rV
     // operands of one update entry in the matrix cores' layouts: B = U(J,k) (also the A operand of the diagonal tile), 1/d, w_k and
     // the tiles (I_i, k) of the carried rows
     struct UpdB { double raw[4], iv[4], wk[4]; };
     struct UpdY { double y0[4], y1[4], y2[4]; };
     auto load_b = [&](const uint32_t k, const uint32_t tb, UpdB &o) {
-        const double *tbp = tiles + ((size_t)tb << 8) + (r16 << 4) + kq;
-        const double *ivp = vinv + 16 * (size_t)k + kq, *wkp = vw + 16 * (size_t)k + kq;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) { o.raw[kk] = tbp[4 * kk]; o.iv[kk] = ivp[4 * kk]; o.wk[kk] = wkp[4 * kk]; }
+        for (int kk = 0; kk < 4; ++kk) {
+            o.raw[kk] = bld(rU, bo_ab + 32u * kk, tb << 11);
+            o.iv[kk] = bld(rV, bo_k + 32u * kk, so_inv + (k << 7));
+            o.wk[kk] = bld(rV, bo_k + 32u * kk, so_w + (k << 7));
+        }
     };
     auto load_y = [&](const uint32_t a0, const uint32_t a1, const uint32_t a2, UpdY &o) {
-        if (a0 != kNone) { const double *ap = tiles + ((size_t)a0 << 8) + (r16 << 4) + kq;
+        if (a0 != kNone) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) o.y0[kk] = ap[4 * kk]; }
-        if (a1 != kNone) { const double *ap = tiles + ((size_t)a1 << 8) + (r16 << 4) + kq;
+            for (int kk = 0; kk < 4; ++kk) o.y0[kk] = bld(rU, bo_ab + 32u * kk, a0 << 11);
+        }
+        if (a1 != kNone) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) o.y1[kk] = ap[4 * kk]; }
-        if (a2 != kNone) { const double *ap = tiles + ((size_t)a2 << 8) + (r16 << 4) + kq;
+            for (int kk = 0; kk < 4; ++kk) o.y1[kk] = bld(rU, bo_ab + 32u * kk, a1 << 11);
+        }
+        if (a2 != kNone) {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) o.y2[kk] = ap[4 * kk]; }
+            for (int kk = 0; kk < 4; ++kk) o.y2[kk] = bld(rU, bo_ab + 32u * kk, a2 << 11);
+        }
     };
     struct ColAcc { f64x4 cD, cS0, cS1, cS2; double wacc; };
     auto apply_ops = [&](const uint32_t a0, const uint32_t a1, const uint32_t a2, const UpdB &o, const UpdY &y, ColAcc &c) {
@@ -1814,28 +1849,28 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         }
     };
     // what a column task loads before it can start: A's tiles of the column (accumulator layout: row 4 r + kq, column r16), w_J, the
-    // LM diagonal of this lane's row, the operands of its first two update entries
-    struct ColPre { f64x4 cD, cS0, cS1, cS2; double wj, dd; UpdB o0; };
+    // LM diagonal of this lane's row, the operands of its first update entry
+    struct ColPre { f64x4 cD, cS0, cS1, cS2; double wj, dd; UpdB o0; UpdY y0; };
     auto issue_column = [&](const ColDesc &c, ColPre &p) {
-        const double *p0 = atiles + ((size_t)c.t0 << 8) + (kq << 4) + r16;
+        const unsigned so = c.t0 << 11;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p.cD[r] = p0[r << 6];
+        for (int r = 0; r < 4; ++r) p.cD[r] = bld(rA, bo_c + 512u * r, so);
         p.cS0 = f64x4{0.0, 0.0, 0.0, 0.0}; p.cS1 = p.cS0; p.cS2 = p.cS0;
         if (c.nc > 0u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p.cS0[r] = p0[256 + (r << 6)];
+            for (int r = 0; r < 4; ++r) p.cS0[r] = bld(rA, bo_c + 512u * r, so + 2048u);
         }
         if (c.nc > 1u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p.cS1[r] = p0[512 + (r << 6)];
+            for (int r = 0; r < 4; ++r) p.cS1[r] = bld(rA, bo_c + 512u * r, so + 4096u);
         }
         if (c.nc > 2u) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) p.cS2[r] = p0[768 + (r << 6)];
+            for (int r = 0; r < 4; ++r) p.cS2[r] = bld(rA, bo_c + 512u * r, so + 6144u);
         }
-        p.wj = vw[16 * (size_t)c.J + r16];
-        p.dd = vD[16 * (size_t)c.J + r16];
-        if (c.ne > 0u) load_b(c.k0, c.tb0, p.o0);
+        p.wj = bld(rV, bo_r, so_w + (c.J << 7));
+        p.dd = bld(rV, bo_r, so_D + (c.J << 7));
+        if (c.ne > 0u) { load_b(c.k0, c.tb0, p.o0); load_y(c.a00, c.a01, c.a02, p.y0); }
     };
 
     auto factor = [&]() -> bool {
@@ -1849,24 +1884,22 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             const int u0 = (int)p1_ptr[l], u1 = (int)p1_ptr[l + 1];
             for (int t = u0 + wave; t < u1; t += kWaves) {
                 const uint32_t tt = p1_tasks[4 * t], ub = p1_tasks[4 * t + 1], ue = p1_tasks[4 * t + 2];
-                const double *tsrc = atiles + ((size_t)tt << 8) + (kq << 4) + r16;
                 f64x4 c;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) c[r] = tsrc[r << 6];
+                for (int r = 0; r < 4; ++r) c[r] = bld(rA, bo_c + 512u * r, tt << 11);
                 for (uint32_t u = ub; u < ue; ++u) {
                     const uint32_t ia = upd[3 * u], ib = upd[3 * u + 1], k = upd[3 * u + 2];
-                    const double *ta = tiles + ((size_t)ia << 8) + (r16 << 4) + kq;
-                    const double *tb = tiles + ((size_t)ib << 8) + (r16 << 4) + kq;
-                    const double *iv = vinv + 16 * (size_t)k + kq;
                     double av[4], bv[4];
 #pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) { av[kk] = ta[4 * kk]; bv[kk] = -(tb[4 * kk] * iv[4 * kk]); }
+                    for (int kk = 0; kk < 4; ++kk) {
+                        av[kk] = bld(rU, bo_ab + 32u * kk, ia << 11);
+                        bv[kk] = -(bld(rU, bo_ab + 32u * kk, ib << 11) * bld(rV, bo_k + 32u * kk, so_inv + (k << 7)));
+                    }
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kk], bv[kk], c, 0, 0, 0);
                 }
-                double *tc = tiles + ((size_t)tt << 8) + (kq << 4) + r16;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) tc[r << 6] = c[r];
+                for (int r = 0; r < 4; ++r) bst(c[r], rU, bo_c + 512u * r, tt << 11);
             }
             FPROF_MARK(4);                                // 4: tile tasks
             // (b) the level's columns, one wave each, software pipelined: while a column is turned and eliminated the loads of the
@@ -1890,15 +1923,36 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
                 }
-                {   // the tiles of the carried rows and the second entry come now (their addresses came with the descriptor)
-                    UpdY y0, y1;
-                    UpdB o1;
-                    if (dc.ne > 0u) load_y(dc.a00, dc.a01, dc.a02, y0);
-                    if (dc.ne > 1u) { load_b(dc.k1, dc.tb1, o1); load_y(dc.a10, dc.a11, dc.a12, y1); }
-                    if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, y0, acc);
-                    if (dc.ne > 1u) apply_ops(dc.a10, dc.a11, dc.a12, o1, y1, acc);
+                if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
+#if LFR_TREE_PINGPONG
+                if (dc.ne > 1u) {
+                    // further entries (a separator's column has one per child, up to ~16): two operand sets alternate, the loads of entry
+                    // e + 1 in flight while entry e runs on the matrix cores
+                    uint32_t e = dc.e_rest - 1u;
+                    const uint32_t e_end = dc.e_rest - 2u + dc.ne;
+                    UpdB oa, ob;
+                    UpdY ya, yb;
+                    uint32_t a0a = dc.a10, a1a = dc.a11, a2a = dc.a12, a0b = kNone, a1b = kNone, a2b = kNone;
+                    load_b(dc.k1, dc.tb1, oa); load_y(a0a, a1a, a2a, ya);
+                    for (;;) {
+                        if (e + 1u < e_end) {
+                            const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                            a0b = col_upd[5 * (e + 1u) + 2]; a1b = col_upd[5 * (e + 1u) + 3]; a2b = col_upd[5 * (e + 1u) + 4];
+                            load_b(k, tb, ob); load_y(a0b, a1b, a2b, yb);
+                        }
+                        apply_ops(a0a, a1a, a2a, oa, ya, acc);
+                        if (++e >= e_end) break;
+                        if (e + 1u < e_end) {
+                            const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                            a0a = col_upd[5 * (e + 1u) + 2]; a1a = col_upd[5 * (e + 1u) + 3]; a2a = col_upd[5 * (e + 1u) + 4];
+                            load_b(k, tb, oa); load_y(a0a, a1a, a2a, ya);
+                        }
+                        apply_ops(a0b, a1b, a2b, ob, yb, acc);
+                        if (++e >= e_end) break;
+                    }
                 }
-                for (uint32_t e = dc.e_rest; e < dc.e_rest + dc.ne - 2u && dc.ne > 2u; ++e) {          // further entries (a column with more than two children)
+#else
+                for (uint32_t e = dc.e_rest - 1u; e < dc.e_rest - 2u + dc.ne && dc.ne > 1u; ++e) {    // further entries (a separator's column has one per child)
                     const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
                     UpdB o;
                     UpdY y;
@@ -1906,6 +1960,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     load_y(a0, a1, a2, y);
                     apply_ops(a0, a1, a2, o, y, acc);
                 }
+#endif
                 double wacc = acc.wacc;
                 wacc += __shfl_xor(wacc, 16, 64);
                 wacc += __shfl_xor(wacc, 32, 64);
@@ -1922,8 +1977,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 __builtin_amdgcn_wave_barrier();
                 if (qn < q1) issue_column(dn, pn);        // the next column's loads (the accumulators' registers are free now): in flight during the elimination
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int J = (int)dc.J, nc = (int)dc.nc, nbp = (int)dc.nbp;
-                double *tD = tiles + ((size_t)dc.t0 << 8);
+                const int nc = (int)dc.nc, nbp = (int)dc.nbp;
                 const int s = lane - 17;
                 const bool is_diag = lane < 16, is_rhs = lane == 16, on = lane >= 17 && (s >> 4) < nc;
                 double av[16];
@@ -1951,12 +2005,21 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     }
                 }
                 FPROF_MARK(2);                            // 2: elimination
-                if (lane < nbp) vinv[16 * (size_t)J + lane] = my_inv;
-                if (is_diag || is_rhs || on) {
-                    double *dst = is_diag ? tD + (r16 << 4) : is_rhs ? vw + 16 * (size_t)J : tD + ((size_t)(1 + (s >> 4)) << 8) + ((s & 15) << 4);
-                    double2 *rowp = reinterpret_cast<double2 *>(dst);
+                if (lane < nbp) bst(my_inv, rV, 8u * (unsigned)lane, so_inv + (dc.J << 7));
+                if (is_diag || on) {                      // rows of the diagonal tile and of the carried tiles: whole rows, 16 bytes per store
+                    const unsigned ro = is_diag ? 8u * (unsigned)(r16 << 4) : 8u * (unsigned)(((1 + (s >> 4)) << 8) + ((s & 15) << 4));
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) rowp[j] = make_double2(av[2 * j], av[2 * j + 1]);
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
+                                                                        __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
+                                                               rU, ro + 16u * j, dc.t0 << 11, 0);
+                }
+                if (is_rhs) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
+                                                                        __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
+                                                               rV, 16u * j, so_w + (dc.J << 7), 0);
                 }
                 if (bad && lane == 0) sh.flag = 1;
                 FPROF_MARK(3);                            // 3: stores
@@ -2007,19 +2070,20 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     //      like the factorization: the next column's tiles are on their way while the 16 dependent steps of this one run. ----
     struct BackPre { double m[16], iv, z, tvv[4][4], yv[4][4]; };
     auto issue_back = [&](const ColDesc &c, BackPre &p) {
-        const double *Td = tiles + ((size_t)c.t0 << 8);
+        const unsigned so = c.t0 << 11;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) p.m[k] = Td[(k << 4) + r16];
-        p.iv = r16 < (int)c.nbp ? vinv[16 * (size_t)c.J + r16] : 0.0;
-        p.z = vw[16 * (size_t)c.J + r16];
+        for (int k = 0; k < 16; ++k) p.m[k] = bld(rU, bo_r + 128u * k, so);
+        p.iv = r16 < (int)c.nbp ? bld(rV, bo_r, so_inv + (c.J << 7)) : 0.0;
+        p.z = bld(rV, bo_r, so_w + (c.J << 7));
         const uint32_t rows[4] = {c.i0, c.i1, c.i2, c.i3};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if ((uint32_t)i < c.nsub) {
-                const double *T = Td + ((size_t)(1 + i) << 8) + (kq << 4) + r16;
-                const double *yI = vstep + 16 * (size_t)rows[i] + kq;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { p.tvv[i][r] = T[r << 6]; p.yv[i][r] = yI[4 * r]; }
+                for (int r = 0; r < 4; ++r) {
+                    p.tvv[i][r] = bld(rU, bo_c + 512u * r, so + 2048u * (1 + i));
+                    p.yv[i][r] = bld(rV, bo_k + 32u * r, so_step + (rows[i] << 7));
+                }
             }
         }
     };
@@ -2043,11 +2107,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     }
                 }
                 for (uint32_t t = dc.t0 + 5u; t < dc.t0 + 1u + dc.nsub; ++t) {          // further tiles (a column with more than four rows below the diagonal)
-                    const int I = (int)rowsof[t];
-                    const double *T = tiles + ((size_t)t << 8) + (kq << 4) + r16;
-                    const double *yI = vstep + 16 * (size_t)I + kq;
+                    const uint32_t I = rowsof[t];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = fma(T[r << 6], yI[4 * r], acc);
+                    for (int r = 0; r < 4; ++r) acc = fma(bld(rU, bo_c + 512u * r, t << 11), bld(rV, bo_k + 32u * r, so_step + (I << 7)), acc);
                 }
                 double m[16];
 #pragma unroll
@@ -2066,7 +2128,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     yo = (r16 == k) ? yvk : yo;
                     z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
                 }
-                if (lane < 16) vstep[16 * (size_t)dc.J + r16] = yo;
+                if (lane < 16) bst(yo, rV, bo_r, so_step + (dc.J << 7));
                 q = qn;
             }
             __syncthreads();
@@ -2120,7 +2182,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         PROF_MARK(LFR_TREE_SLOT_SCALE);
         bool valid = factor();                            // (reads A, writes the factor: J^T J at x stays in A until a trial point is swept)
         PROF_MARK(1);
+#ifndef LFR_EXP_NOBACK
         if (valid) back_substitute();
+#endif
         PROF_MARK(6);
         double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
@@ -2166,7 +2230,11 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
+#ifdef LFR_EXP_NOLS
+                const double nstep = -1.0;
+#else
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
+#endif
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;

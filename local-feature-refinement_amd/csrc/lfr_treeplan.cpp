@@ -285,6 +285,8 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     std::vector<std::vector<int32_t>> unit(S);                 // nodes of a collapsed subtree (<= 8), handed to the parent
     std::vector<std::vector<int32_t>> pending(S);              // collapsed children of a segment, in the order they finish
     std::vector<std::vector<int32_t>> blocks;
+    std::vector<int> last_block(S, -1);                        // the last block a (non-collapsed) segment emitted: the top of its chain
+    std::vector<std::vector<int>> kids(S);                     // non-collapsed children
     for (int s = S - 1; s >= 0; --s) {
         sub_weight[s] += (int64_t)segs[s].tracks.size();
         const int par = segs[s].parent;
@@ -303,12 +305,32 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
             if (cur.size() + unit[c].size() > 8) close();
             cur.insert(cur.end(), unit[c].begin(), unit[c].end());
         }
+        // A small separator would be a column of its own with one to three pivots (every column costs the factorization the same
+        // latencies).  If it fits, it takes in the TOP blocks of its children instead - their last, often half-empty blocks move up
+        // into the separator's block (amalgamation of a parent with the tops of its children: no new coupling between blocks, the
+        // children's other blocks still come first).
+        if (cur.size() + segs[s].tracks.size() <= 8 && !kids[s].empty()) {
+            size_t room = 8 - cur.size() - segs[s].tracks.size();
+            std::vector<int> cand;
+            for (int c : kids[s]) if (last_block[c] >= 0 && !blocks[last_block[c]].empty() && blocks[last_block[c]].size() <= room) cand.push_back(c);
+            std::stable_sort(cand.begin(), cand.end(), [&](int a, int b) { return blocks[last_block[a]].size() > blocks[last_block[b]].size(); });
+            for (int c : cand) {
+                std::vector<int32_t> &top = blocks[last_block[c]];
+                if (top.size() > room) continue;
+                room -= top.size();
+                cur.insert(cur.end(), top.begin(), top.end());
+                top.clear();                                   // (empty blocks are dropped below)
+            }
+        }
         for (int v : segs[s].tracks) {                         // ... and the last of them may take in the segment's first nodes
             if (cur.size() == 8) close();
             cur.push_back(v);
         }
         close();
+        last_block[s] = (int)blocks.size() - 1;
+        if (par >= 0) kids[par].push_back(s);
     }
+    blocks.erase(std::remove_if(blocks.begin(), blocks.end(), [](const std::vector<int32_t> &b) { return b.empty(); }), blocks.end());
     const int NB = (int)blocks.size();
     std::vector<int32_t> blk(n_var, -1), slot(n_var, 0);
     for (int b = 0; b < NB; ++b) for (size_t i = 0; i < blocks[b].size(); ++i) { blk[blocks[b][i]] = b; slot[blocks[b][i]] = (int32_t)i; }
