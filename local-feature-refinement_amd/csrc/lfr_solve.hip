@@ -695,7 +695,7 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 #define FPROF_RESET() do { ft0_ = __builtin_amdgcn_s_memtime(); } while (0)
 #define FPROF_FLUSH() do { if (lane == 0 && wave < 2 && fprof) { for (int i_ = 0; i_ < 6; ++i_) atomicAdd(&fprof[wave * 8 + i_], ft_[i_]); atomicAdd(&fprof[wave * 8 + 7], 1ull); } } while (0)
 #else
-#define FPROF_DECL
+#define FPROF_DECL unsigned long long ft_[6] = {0, 0, 0, 0, 0, 0}; unsigned long long ft0_ = 0; (void)ft_; (void)ft0_;
 #define FPROF_MARK(i)
 #define FPROF_RESET()
 #define FPROF_FLUSH()
@@ -1646,6 +1646,7 @@ struct TreeShared {
     // lane = row through them; the extra-row tasks stage a diagonal tile there) + 16 doubles (the right-hand side / 1/d)
     double x[LFR_THREADS_G / 64][4 * 288 + 16];
     double red3[LFR_THREADS_G / 64][3];
+    int pend[lfr::kTreeMaxFlagColumns];        // "thin" plans: children a column still waits for (factorization) / column solved (back substitution)
 };
 // The plan's words are written by the host before the launch and never by the kernel: read through the constant address space they
 // are scalar loads (s_load, one per wave, through the scalar cache) instead of vector loads + v_readfirstlane behind ~1 us of latency.
@@ -1775,14 +1776,14 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     };
 
     // descriptor of a column task (lfr_treeplan.cpp: col_desc, columns in level order): one pair of scalar loads
-    struct ColDesc { uint32_t J, t0, nc, nbp, ne, e_rest, k0, tb0, a00, a01, a02, k1, tb1, a10, a11, a12, nsub, i0, i1, i2, i3; };
+    struct ColDesc { uint32_t J, t0, nc, nbp, ne, e_rest, k0, tb0, a00, a01, a02, k1, tb1, a10, a11, a12, nsub, i0, i1, i2, i3, parent, p1_first; };
     auto load_desc = [&](const int q) -> ColDesc {
         const PlanWords w = col_desc + 32 * (size_t)q;
         ColDesc c;
         c.J = w[0]; c.t0 = w[1]; c.nc = w[2]; c.nbp = w[3]; c.ne = w[4]; c.e_rest = w[5];
         c.k0 = w[6]; c.tb0 = w[7]; c.a00 = w[8]; c.a01 = w[9]; c.a02 = w[10];
         c.k1 = w[11]; c.tb1 = w[12]; c.a10 = w[13]; c.a11 = w[14]; c.a12 = w[15];
-        c.nsub = w[16]; c.i0 = w[17]; c.i1 = w[18]; c.i2 = w[19]; c.i3 = w[20];
+        c.nsub = w[16]; c.i0 = w[17]; c.i1 = w[18]; c.i2 = w[19]; c.i3 = w[20]; c.parent = w[21]; c.p1_first = w[23];
         return c;
     };
     // The factorization reads and writes the workspace through BUFFER instructions: a resource descriptor per array (four SGPRs), a
@@ -1873,7 +1874,241 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (c.ne > 0u) { load_b(c.k0, c.tb0, p.o0); load_y(c.a00, c.a01, c.a02, p.y0); }
     };
 
+    // One column task: the updates of the diagonal tile, of w_J and of the carried tiles with the operands in `pn` (accumulators in the
+    // matrix cores' layout), a turn through LDS into lane = row, the elimination, whole rows back to the workspace.  `next_ready`: the
+    // loads of the wave's next column (descriptor `dn`) go out into `pn` once the accumulators have left their registers.
+    auto run_column = [&](const ColDesc &dc, ColPre &pn, const bool next_ready, const ColDesc &dn, const bool finish_extra, double *xd, unsigned long long *fprof, unsigned long long (&ft_)[6], unsigned long long &ft0_) {
+        (void)fprof; (void)ft_; (void)ft0_;
+        ColAcc acc;
+        acc.cD = pn.cD; acc.cS0 = pn.cS0; acc.cS1 = pn.cS1; acc.cS2 = pn.cS2; acc.wacc = 0.0;
+        const double wj = pn.wj;
+        {   // the scaled LM diagonal (A + S^-1 D^2 S^-1): this lane holds the diagonal entry of row r16 if r16 = 4 r + kq
+            const double dd2 = (r16 & 3) == kq ? pn.dd * pn.dd : 0.0;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
+        }
+        if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
+#if LFR_TREE_PINGPONG
+        if (dc.ne > 1u) {
+            // further entries (a separator's column has one per child, up to ~16): two operand sets alternate, the loads of entry
+            // e + 1 in flight while entry e runs on the matrix cores
+            uint32_t e = dc.e_rest - 1u;
+            const uint32_t e_end = dc.e_rest - 2u + dc.ne;
+            UpdB oa, ob;
+            UpdY ya, yb;
+            uint32_t a0a = dc.a10, a1a = dc.a11, a2a = dc.a12, a0b = kNone, a1b = kNone, a2b = kNone;
+            load_b(dc.k1, dc.tb1, oa); load_y(a0a, a1a, a2a, ya);
+            for (;;) {
+                if (e + 1u < e_end) {
+                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                    a0b = col_upd[5 * (e + 1u) + 2]; a1b = col_upd[5 * (e + 1u) + 3]; a2b = col_upd[5 * (e + 1u) + 4];
+                    load_b(k, tb, ob); load_y(a0b, a1b, a2b, yb);
+                }
+                apply_ops(a0a, a1a, a2a, oa, ya, acc);
+                if (++e >= e_end) break;
+                if (e + 1u < e_end) {
+                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                    a0a = col_upd[5 * (e + 1u) + 2]; a1a = col_upd[5 * (e + 1u) + 3]; a2a = col_upd[5 * (e + 1u) + 4];
+                    load_b(k, tb, oa); load_y(a0a, a1a, a2a, ya);
+                }
+                apply_ops(a0b, a1b, a2b, ob, yb, acc);
+                if (++e >= e_end) break;
+            }
+        }
+#else
+        for (uint32_t e = dc.e_rest - 1u; e < dc.e_rest - 2u + dc.ne && dc.ne > 1u; ++e) {    // further entries (a separator's column has one per child)
+            const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
+            UpdB o;
+            UpdY y;
+            load_b(k, tb, o);
+            load_y(a0, a1, a2, y);
+            apply_ops(a0, a1, a2, o, y, acc);
+        }
+#endif
+        double wacc = acc.wacc;
+        wacc += __shfl_xor(wacc, 16, 64);
+        wacc += __shfl_xor(wacc, 32, 64);
+        FPROF_MARK(0);                            // 0: loads + left-looking updates
+        // matrix-core layout (row 4 r + kq, column r16) -> lane = row
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            double *o = xd + (4 * r + kq) * 18 + r16;
+            o[0] = acc.cD[r]; o[288] = acc.cS0[r]; o[576] = acc.cS1[r]; o[864] = acc.cS2[r];
+        }
+        if (kq == 0) xd[1152 + r16] = wj + wacc;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (next_ready) issue_column(dn, pn);     // the next column's loads (the accumulators' registers are free now): in flight during the elimination
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const int nc = (int)dc.nc, nbp = (int)dc.nbp;
+        const int s = lane - 17;
+        const bool is_diag = lane < 16, is_rhs = lane == 16, on = lane >= 17 && (s >> 4) < nc;
+        double av[16];
+        {
+            const double *rs = is_diag ? xd + r16 * 18 : is_rhs ? xd + 1152 : xd + 288 * (1 + (s >> 4)) + (s & 15) * 18;
+            const double2 *rowp = reinterpret_cast<const double2 *>(rs);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; av[2 * j] = v.x; av[2 * j + 1] = v.y; }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) av[j] = is_diag ? (j <= r16 ? av[j] : 0.0) : ((is_rhs || on) ? av[j] : 0.0);
+        }
+        FPROF_MARK(1);                            // 1: the turn through LDS
+        bool bad = false;
+        double my_inv = 0.0;
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            if (kk < nbp) {
+                const double dk = readlane_f64(av[kk], kk);
+                bad = bad || !(dk > 0.0);
+                const double ik = fast_rcp(dk);
+                my_inv = lane == kk ? ik : my_inv;
+                const double lik = av[kk] * ik;
+#pragma unroll
+                for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
+            }
+        }
+        FPROF_MARK(2);                            // 2: elimination
+        if (lane < nbp) bst(my_inv, rV, 8u * (unsigned)lane, so_inv + (dc.J << 7));
+        if (is_diag || on) {                      // rows of the diagonal tile and of the carried tiles: whole rows, 16 bytes per store
+            const unsigned ro = is_diag ? 8u * (unsigned)(r16 << 4) : 8u * (unsigned)(((1 + (s >> 4)) << 8) + ((s & 15) << 4));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
+                                                                __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
+                                                       rU, ro + 16u * j, dc.t0 << 11, 0);
+        }
+        if (is_rhs) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
+                                                                __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
+                                                       rV, 16u * j, so_w + (dc.J << 7), 0);
+        }
+        if (bad && lane == 0) sh.flag = 1;
+        FPROF_MARK(3);                            // 3: stores
+        if (finish_extra && dc.nsub > dc.nc) {
+            // Tiles below the diagonal beyond the carried ones (thin plans: a few per component): this wave finishes them itself, three at
+            // a time - left-looking updates on the matrix cores, a turn through LDS, then the substitution against the factored diagonal
+            // tile (staged in LDS with 1 / d), lane = row in lanes 16-63.
+            __builtin_amdgcn_wave_barrier();
+            if (is_diag) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) xd[(r16 << 4) + j] = av[j];
+            }
+            if (lane < 16) xd[1152 + lane] = my_inv;
+            for (uint32_t i = dc.nc; i < dc.nsub; i += 3u) {
+                const uint32_t cnt = min(3u, dc.nsub - i);
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t u = 0; u < cnt; ++u) {
+                    const uint32_t tk = dc.p1_first + (i - dc.nc) + u;
+                    const uint32_t tt = p1_tasks[4 * tk], ub = p1_tasks[4 * tk + 1], ue = p1_tasks[4 * tk + 2];
+                    f64x4 c;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) c[r] = bld(rA, bo_c + 512u * r, tt << 11);
+                    for (uint32_t e = ub; e < ue; ++e) {
+                        const uint32_t ia = upd[3 * e], ib = upd[3 * e + 1], k = upd[3 * e + 2];
+                        double aa[4], bb[4];
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            aa[kk] = bld(rU, bo_ab + 32u * kk, ia << 11);
+                            bb[kk] = -(bld(rU, bo_ab + 32u * kk, ib << 11) * bld(rV, bo_k + 32u * kk, so_inv + (k << 7)));
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) c = __builtin_amdgcn_mfma_f64_16x16x4f64(aa[kk], bb[kk], c, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xd[288 * (1 + u) + (4 * r + kq) * 18 + r16] = c[r];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const int s2 = lane - 16;
+                const bool act = lane >= 16 && (uint32_t)(s2 >> 4) < cnt;
+                double rr[16];
+                {
+                    const double2 *rowp = reinterpret_cast<const double2 *>(xd + 288 * (1 + (act ? (s2 >> 4) : 0)) + (s2 & 15) * 18);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; rr[2 * j] = v.x; rr[2 * j + 1] = v.y; }
+                }
+#pragma unroll
+                for (int j = 0; j < 15; ++j) {
+                    const double tj = rr[j] * xd[1152 + j];
+#pragma unroll
+                    for (int c = j + 1; c < 16; ++c) rr[c] = fma(-tj, xd[(c << 4) + j], rr[c]);
+                }
+                if (act) {
+                    const unsigned ro = 8u * (unsigned)((s2 & 15) << 4);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j)
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, rr[2 * j])[0], __builtin_bit_cast(u32x2_t, rr[2 * j])[1],
+                                                                        __builtin_bit_cast(u32x2_t, rr[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, rr[2 * j + 1])[1]},
+                                                               rU, ro + 16u * j, (dc.t0 + 1u + i + (uint32_t)(s2 >> 4)) << 11, 0);
+                }
+            }
+        }
+    };
+
+    // ---- "thin" plans (every column carries all its tiles): no barrier per level.  A column starts when its children in the elimination
+    //      tree are done (ts.pend[J], an LDS counter its children decrement; a child's completion implies its whole subtree's), the waves
+    //      walk their columns in level order - dependencies always point to lower levels, so some wave can always proceed - and the loads
+    //      of a wave's next column go out early whenever that column is already ready, across level boundaries too. ----
+    const bool thin = pl[28] != 0u;
+    auto spin_timeout = [&]() { if (lane == 0) { sh.flag = 1; atomicAdd(a.queue + 15, 1u); } };      // (a miscount must not hang the GPU: the step is rejected, the counter says so)
+    auto pend_load = [&](const uint32_t J) -> int {
+        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ts.pend[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
+    // this wave's next column after position q of level l (levels ascending / descending); false: none left
+    auto next_up = [&](int &l, int &q) -> bool {
+        q += kWaves;
+        while (q >= (int)level_ptr[l + 1]) { if (++l >= n_levels) return false; q = (int)level_ptr[l] + wave; }
+        return true;
+    };
+    auto next_down = [&](int &l, int &q) -> bool {
+        q += kWaves;
+        while (q >= (int)level_ptr[l + 1]) { if (--l < 0) return false; q = (int)level_ptr[l] + wave; }
+        return true;
+    };
+    auto factor_thin = [&]() -> bool {
+        double *xd = ts.x[wave];
+        unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
+        (void)fprof;
+        FPROF_DECL
+        for (int q = tid; q < NB; q += kBlockThreads) ts.pend[hdr[pl[27] + 32 * q]] = (int)hdr[pl[27] + 32 * q + 22];       // children per column
+        __syncthreads();
+        int l = 0, q = (int)level_ptr[0] + wave - kWaves;
+        bool have = next_up(l, q), pre = false;
+        ColDesc dn;
+        ColPre pn;
+        if (have) dn = load_desc(q);
+        while (have) {
+            const ColDesc dc = dn;
+            if (!pre) {                                   // not prefetched: wait for the children, then load
+                int spins = 0;
+                while (pend_load(dc.J) != 0) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 22)) { spin_timeout(); break; } }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                issue_column(dc, pn);
+            }
+            FPROF_MARK(5);                                // 5: waiting for children
+            have = next_up(l, q);
+            bool next_ready = false;
+            if (have) {
+                dn = load_desc(q);
+                next_ready = pend_load(dn.J) == 0;
+                if (next_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            run_column(dc, pn, next_ready, dn, true, xd, fprof, ft_, ft0_);
+            pre = next_ready;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the column's rows are out before its parent hears of it
+            if (lane == 0 && dc.parent != kNone) __hip_atomic_fetch_sub(&ts.pend[dc.parent], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        __syncthreads();
+        FPROF_FLUSH();
+        return sh.flag == 0;
+    };
+
     auto factor = [&]() -> bool {
+        if (thin) return factor_thin();
         double *xd = ts.x[wave];                          // (sh.flag was reset before the caller's last barrier)
         unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
         (void)fprof;
@@ -1915,114 +2150,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 const ColDesc dc = dn;
                 const int qn = q + kWaves;
                 if (qn < q1) dn = load_desc(qn);          // (scalar loads: on their way during the updates below)
-                ColAcc acc;
-                acc.cD = pn.cD; acc.cS0 = pn.cS0; acc.cS1 = pn.cS1; acc.cS2 = pn.cS2; acc.wacc = 0.0;
-                const double wj = pn.wj;
-                {   // the scaled LM diagonal (A + S^-1 D^2 S^-1): this lane holds the diagonal entry of row r16 if r16 = 4 r + kq
-                    const double dd2 = (r16 & 3) == kq ? pn.dd * pn.dd : 0.0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
-                }
-                if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
-#if LFR_TREE_PINGPONG
-                if (dc.ne > 1u) {
-                    // further entries (a separator's column has one per child, up to ~16): two operand sets alternate, the loads of entry
-                    // e + 1 in flight while entry e runs on the matrix cores
-                    uint32_t e = dc.e_rest - 1u;
-                    const uint32_t e_end = dc.e_rest - 2u + dc.ne;
-                    UpdB oa, ob;
-                    UpdY ya, yb;
-                    uint32_t a0a = dc.a10, a1a = dc.a11, a2a = dc.a12, a0b = kNone, a1b = kNone, a2b = kNone;
-                    load_b(dc.k1, dc.tb1, oa); load_y(a0a, a1a, a2a, ya);
-                    for (;;) {
-                        if (e + 1u < e_end) {
-                            const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
-                            a0b = col_upd[5 * (e + 1u) + 2]; a1b = col_upd[5 * (e + 1u) + 3]; a2b = col_upd[5 * (e + 1u) + 4];
-                            load_b(k, tb, ob); load_y(a0b, a1b, a2b, yb);
-                        }
-                        apply_ops(a0a, a1a, a2a, oa, ya, acc);
-                        if (++e >= e_end) break;
-                        if (e + 1u < e_end) {
-                            const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
-                            a0a = col_upd[5 * (e + 1u) + 2]; a1a = col_upd[5 * (e + 1u) + 3]; a2a = col_upd[5 * (e + 1u) + 4];
-                            load_b(k, tb, oa); load_y(a0a, a1a, a2a, ya);
-                        }
-                        apply_ops(a0b, a1b, a2b, ob, yb, acc);
-                        if (++e >= e_end) break;
-                    }
-                }
-#else
-                for (uint32_t e = dc.e_rest - 1u; e < dc.e_rest - 2u + dc.ne && dc.ne > 1u; ++e) {    // further entries (a separator's column has one per child)
-                    const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
-                    UpdB o;
-                    UpdY y;
-                    load_b(k, tb, o);
-                    load_y(a0, a1, a2, y);
-                    apply_ops(a0, a1, a2, o, y, acc);
-                }
-#endif
-                double wacc = acc.wacc;
-                wacc += __shfl_xor(wacc, 16, 64);
-                wacc += __shfl_xor(wacc, 32, 64);
-                FPROF_MARK(0);                            // 0: loads + left-looking updates
-                // matrix-core layout (row 4 r + kq, column r16) -> lane = row
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    double *o = xd + (4 * r + kq) * 18 + r16;
-                    o[0] = acc.cD[r]; o[288] = acc.cS0[r]; o[576] = acc.cS1[r]; o[864] = acc.cS2[r];
-                }
-                if (kq == 0) xd[1152 + r16] = wj + wacc;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                if (qn < q1) issue_column(dn, pn);        // the next column's loads (the accumulators' registers are free now): in flight during the elimination
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const int nc = (int)dc.nc, nbp = (int)dc.nbp;
-                const int s = lane - 17;
-                const bool is_diag = lane < 16, is_rhs = lane == 16, on = lane >= 17 && (s >> 4) < nc;
-                double av[16];
-                {
-                    const double *rs = is_diag ? xd + r16 * 18 : is_rhs ? xd + 1152 : xd + 288 * (1 + (s >> 4)) + (s & 15) * 18;
-                    const double2 *rowp = reinterpret_cast<const double2 *>(rs);
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { const double2 v = rowp[j]; av[2 * j] = v.x; av[2 * j + 1] = v.y; }
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) av[j] = is_diag ? (j <= r16 ? av[j] : 0.0) : ((is_rhs || on) ? av[j] : 0.0);
-                }
-                FPROF_MARK(1);                            // 1: the turn through LDS
-                bool bad = false;
-                double my_inv = 0.0;
-#pragma unroll
-                for (int kk = 0; kk < 16; ++kk) {
-                    if (kk < nbp) {
-                        const double dk = readlane_f64(av[kk], kk);
-                        bad = bad || !(dk > 0.0);
-                        const double ik = fast_rcp(dk);
-                        my_inv = lane == kk ? ik : my_inv;
-                        const double lik = av[kk] * ik;
-#pragma unroll
-                        for (int j = kk + 1; j < 16; ++j) av[j] = fma(-lik, readlane_f64(av[kk], j), av[j]);
-                    }
-                }
-                FPROF_MARK(2);                            // 2: elimination
-                if (lane < nbp) bst(my_inv, rV, 8u * (unsigned)lane, so_inv + (dc.J << 7));
-                if (is_diag || on) {                      // rows of the diagonal tile and of the carried tiles: whole rows, 16 bytes per store
-                    const unsigned ro = is_diag ? 8u * (unsigned)(r16 << 4) : 8u * (unsigned)(((1 + (s >> 4)) << 8) + ((s & 15) << 4));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
-                                                                        __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
-                                                               rU, ro + 16u * j, dc.t0 << 11, 0);
-                }
-                if (is_rhs) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__builtin_bit_cast(u32x2_t, av[2 * j])[0], __builtin_bit_cast(u32x2_t, av[2 * j])[1],
-                                                                        __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
-                                                               rV, 16u * j, so_w + (dc.J << 7), 0);
-                }
-                if (bad && lane == 0) sh.flag = 1;
-                FPROF_MARK(3);                            // 3: stores
+                run_column(dc, pn, qn < q1, dn, false, xd, fprof, ft_, ft0_);
                 q = qn;
             }
             __syncthreads();
@@ -2087,7 +2215,70 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
         }
     };
+    // one column of the back substitution with its operands in `pn`; the next column's loads go out before the 16 dependent steps
+    auto run_back = [&](const ColDesc &dc, BackPre &pn, const bool next_ready, const ColDesc &dn) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i < dc.nsub) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc = fma(pn.tvv[i][r], pn.yv[i][r], acc);
+            }
+        }
+        for (uint32_t t = dc.t0 + 5u; t < dc.t0 + 1u + dc.nsub; ++t) {          // further tiles (a column with more than four rows below the diagonal)
+            const uint32_t I = rowsof[t];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc = fma(bld(rU, bo_c + 512u * r, t << 11), bld(rV, bo_k + 32u * r, so_step + (I << 7)), acc);
+        }
+        double m[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) m[k] = pn.m[k];
+        const double iv = pn.iv;
+        double z = pn.z;
+        if (next_ready) issue_back(dn, pn);
+        acc += __shfl_xor(acc, 16, 64);
+        acc += __shfl_xor(acc, 32, 64);
+        z -= acc;
+        double yo = 0.0;
+#pragma unroll
+        for (int k = 15; k >= 0; --k) {
+            const double yvk = z * iv;
+            const double yk = readlane_f64(yvk, k);
+            yo = (r16 == k) ? yvk : yo;
+            z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
+        }
+        if (lane < 16) bst(yo, rV, bo_r, so_step + (dc.J << 7));
+    };
     auto back_substitute = [&]() {
+        if (thin) {       // no barrier per level: a column starts when its parent is solved (ts.pend[parent] == 1; all counters are 0 after the factorization)
+            int l = n_levels - 1, q = (int)level_ptr[l] + wave - kWaves;
+            bool have = next_down(l, q), pre = false;
+            ColDesc dn;
+            BackPre pn;
+            if (have) dn = load_desc(q);
+            while (have) {
+                const ColDesc dc = dn;
+                if (!pre) {
+                    int spins = 0;
+                    while (dc.parent != kNone && pend_load(dc.parent) == 0) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 22)) { spin_timeout(); break; } }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    issue_back(dc, pn);
+                }
+                have = next_down(l, q);
+                bool next_ready = false;
+                if (have) {
+                    dn = load_desc(q);
+                    next_ready = dn.parent == kNone || pend_load(dn.parent) != 0;
+                    if (next_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                run_back(dc, pn, next_ready, dn);
+                pre = next_ready;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) __hip_atomic_store(&ts.pend[dc.J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __syncthreads();
+            return;
+        }
         for (int l = n_levels - 1; l >= 0; --l) {
             const int q1 = (int)level_ptr[l + 1];
             int q = (int)level_ptr[l] + wave;
@@ -2098,37 +2289,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 const ColDesc dc = dn;
                 const int qn = q + kWaves;
                 if (qn < q1) dn = load_desc(qn);
-                double acc = 0.0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if ((uint32_t)i < dc.nsub) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) acc = fma(pn.tvv[i][r], pn.yv[i][r], acc);
-                    }
-                }
-                for (uint32_t t = dc.t0 + 5u; t < dc.t0 + 1u + dc.nsub; ++t) {          // further tiles (a column with more than four rows below the diagonal)
-                    const uint32_t I = rowsof[t];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc = fma(bld(rU, bo_c + 512u * r, t << 11), bld(rV, bo_k + 32u * r, so_step + (I << 7)), acc);
-                }
-                double m[16];
-#pragma unroll
-                for (int k = 0; k < 16; ++k) m[k] = pn.m[k];
-                const double iv = pn.iv;
-                double z = pn.z;
-                if (qn < q1) issue_back(dn, pn);
-                acc += __shfl_xor(acc, 16, 64);
-                acc += __shfl_xor(acc, 32, 64);
-                z -= acc;
-                double yo = 0.0;
-#pragma unroll
-                for (int k = 15; k >= 0; --k) {
-                    const double yvk = z * iv;
-                    const double yk = readlane_f64(yvk, k);
-                    yo = (r16 == k) ? yvk : yo;
-                    z = fma(-((r16 < k) ? m[k] : 0.0), yk, z);
-                }
-                if (lane < 16) bst(yo, rV, bo_r, so_step + (dc.J << 7));
+                run_back(dc, pn, qn < q1, dn);
                 q = qn;
             }
             __syncthreads();

@@ -400,7 +400,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // I_i the carried rows (none: 0xffffffff).  The other tiles of a column (rows beyond the carried ones) are separate tile tasks:
     // (target tile, first update, end, J) over triples (tile (I, k), tile (J, k), k).
     constexpr uint32_t kNone = 0xffffffffu;
-    std::vector<uint32_t> col_upd_ptr(NB + 1, 0), col_upd;
+    std::vector<uint32_t> col_upd_ptr(NB + 1, 0), col_upd, p1_first(NB, 0);
     std::vector<uint32_t> upd, p1_tasks, p1_ptr(n_levels + 1, 0);
     uint64_t n_upd = 0;
     {
@@ -431,6 +431,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
                     ce.push_back((uint32_t)k); ce.push_back(tJk); ce.push_back(carried[0]); ce.push_back(carried[1]); ce.push_back(carried[2]);
                     ++n_upd;
                 }
+                p1_first[J] = (uint32_t)(p1_tasks.size() / 4);
                 for (size_t t = nc; t < per_target.size(); ++t) {      // (also without updates: the task moves the tile from A to the factor)
                     const uint32_t b0 = (uint32_t)(upd.size() / 3);
                     upd.insert(upd.end(), per_target[t].begin(), per_target[t].end());
@@ -449,6 +450,8 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // ---- column descriptors in execution order (level by level): everything a column task needs to start its loads comes with ONE
     //      pair of scalar loads - {J, diagonal tile, carried tiles, pivots, update entries, first further entry, entry 0 (5 words), entry 1,
     //      tiles below the diagonal, rows of the first four of them} - instead of a chain of dependent lookups ----
+    std::vector<uint32_t> n_children(NB, 0);
+    for (int J = 0; J < NB; ++J) if (!st[J].empty()) ++n_children[st[J][0]];
     std::vector<uint32_t> col_desc(32 * (size_t)NB, 0);
     for (int q = 0; q < NB; ++q) {
         const int J = (int)level_cols[q];
@@ -459,6 +462,9 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
             for (int w5 = 0; w5 < 5; ++w5) dsc[6 + 5 * i + w5] = i < ne ? col_upd[5 * (size_t)(e0 + i) + w5] : (w5 == 0 ? (uint32_t)J : w5 == 1 ? colptr[J] : kNone);
         dsc[16] = (uint32_t)st[J].size();
         for (size_t i = 0; i < 4; ++i) dsc[17 + i] = i < st[J].size() ? (uint32_t)st[J][i] : (uint32_t)J;
+        dsc[21] = st[J].empty() ? kNone : (uint32_t)st[J][0];          // parent in the elimination tree
+        dsc[22] = n_children[J];
+        dsc[23] = p1_first[J];                                         // the tile tasks of the tiles this column does not carry: p1_first .. + (tiles below - carried)
     }
     // ---- sweep items ----
     const uint32_t n_pad = 16u * (uint32_t)NB;
@@ -524,6 +530,15 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     out.n_tracks = T; out.n_segments = S;
     blob[0] = (uint32_t)NB; blob[1] = n_tiles; blob[2] = (uint32_t)(blob.size() / 2); blob[4] = n_pad; blob[5] = (uint32_t)n_levels;
     blob[6] = n_items; blob[7] = (uint32_t)(p1_tasks.size() / 4);
+    // "thin" plan: the kernel runs the columns on dependency counters (a column starts when its children are done) instead of a barrier
+    // per level.
+    // (A column with a few tiles beyond the three it carries finishes them itself, behind its elimination; plans with many such tiles -
+    // dense components - keep the barrier schedule, where tile tasks are dealt to all waves.)
+    {
+        uint32_t max_extra = 0;
+        for (int J = 0; J < NB; ++J) max_extra = std::max<uint32_t>(max_extra, (uint32_t)st[J].size() - ncarry[J]);
+        blob[28] = (NB <= kTreeMaxFlagColumns && max_extra <= 6u && p1_tasks.size() / 4 <= (size_t)NB / 8 + 4) ? 1u : 0u;
+    }
     // two sets of tiles - A (the sweep stores J^T J there, always the same entries: zeroed once per solve, never by a sweep) and U (the
     // factor) -, then 6 doubles of partial sums per item, then the vectors
     const uint64_t off_part = (uint64_t)blob[2] + 512ull * n_tiles;

@@ -96,6 +96,13 @@ class Plan:
                 assert (dsc[6 + 5 * i:11 + 5 * i] == self.col_upd[e0 + i]).all()
             for i in range(min(4, ns)):
                 assert dsc[17 + i] == self.rowsof[self.colptr[J] + 1 + i]
+            assert dsc[21] == (self.rowsof[self.colptr[J] + 1] if ns else NONE)      # parent in the elimination tree
+            assert dsc[22] == sum(1 for K in range(NB) if self.colptr[K + 1] - self.colptr[K] > 1 and self.rowsof[self.colptr[K] + 1] == J)
+            if ns > self.ncarry[J]:                                                # its tile tasks: one per tile it does not carry, in tile order
+                for i in range(self.ncarry[J], ns):
+                    assert self.p1_tasks[dsc[23] + i - self.ncarry[J], 0] == self.colptr[J] + 1 + i
+        max_extra = max(int(self.colptr[J + 1] - self.colptr[J] - 1 - self.ncarry[J]) for J in range(NB))
+        assert int(self.blob[28]) == (1 if NB <= 4096 and max_extra <= 6 and self.n_p1 <= NB // 8 + 4 else 0)
         for l in range(self.n_levels):
             for t in range(self.x_ptr[l], self.x_ptr[l + 1]):
                 J, i0, cnt = self.x_tasks[t]
