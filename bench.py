@@ -35,6 +35,40 @@ EDGE_BYTES = 84                 # u32 src + u32 dst + f32 sim + 1
 NODE_BYTES = 32                 # 16 B position read + 16 B written per variable node per pass
 
 
+def kernel_source_sha256():
+    """sha256 over the kernel sources a PMC profile depends on: a committed counter file carries the hash of the
+    sources it was collected with; when they differ from the tree this run was built from, its numbers are not reported."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("lfr_solve.hip", "lfr_device.hpp"):
+        with open(os.path.join(ROOT, "local-feature-refinement_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def fresh(d):
+    """the committed PMC summary `d` was collected with the kernel sources of this tree"""
+    return bool(d) and d.get("kernel_source_sha256") == kernel_source_sha256()
+
+
+def cpu_leg(ma, comp_override, n_threads, n_edges):
+    """The C restatement (oracle/lfr_oracle.c, -O3 -march=native, built on this box; envelope Cholesky above 192 rows) on one of the
+    secondary workloads at `n_threads` threads, components taken from the product (the Graclus cut cannot be restated): Solver span only."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import lfr_oracle
+    best = None
+    for _ in range(2):
+        r = lfr_oracle.run(ma, n_threads=n_threads, native=True, comp_override=comp_override)
+        if r["rc"] != 0:
+            return {"error": "oracle rc %d" % r["rc"]}
+        if best is None or r["solver_ms"] < best["solver_ms"]:
+            best = r
+    return {"threads": n_threads, "kind": "port", "solver_span_ms": best["solver_ms"], "edges_per_s": n_edges / (best["solver_ms"] * 1e-3),
+            "what": "C restatement of the Ceres path (not Ceres), assembly + solve of all components (solve.cc:615-638), best of two runs; "
+                    "systems above 192 rows are factored inside the envelope of a reverse Cuthill-McKee order (a sparse direct solver, "
+                    "like the reference's SPARSE_NORMAL_CHOLESKY), smaller ones dense"}, best
+
+
 def profile_numbers(kernel, n_edges):
     """HBM bytes per launch and VALU busy of the dominant kernel FROM THE COMMITTED rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE / WRITE_SIZE / SQ counters collected in separate --pmc runs of this same
@@ -230,7 +264,7 @@ def main():
         serial = os.environ.get("LFR_SERIAL_CLASSES") == "1"
         kernel_names = ["solve_group_kernel<8,1,3>", "solve_group_kernel<16,1,6>", "(retired)",
                         "solve_group_kernel<32,1,6>", "solve_group_kernel<32,2,5>", "solve_block_kernel<lds,rows<=88>",
-                        "solve_block_kernel<lds,rows<=130>", "solve_block_kernel<lds,rows<=192>", "solve_sky_kernel<block envelope,hbm>"]
+                        "solve_block_kernel<lds,rows<=130>", "solve_block_kernel<lds,rows<=192>", "solve_tree_kernel<elimination tree,hbm>"]
         if not serial:      # one launch for all packed classes; its events sit in the slot of the largest class
             kernel_names[dom if dom < 5 else 0] = "solve_packed_kernel"
         dur_s = cls_ms[dom] * 1e-3
@@ -240,6 +274,9 @@ def main():
         exec_evals = st["exec_passes_edges"] * (st["dominant_kernel_edges"] / max(1, st["n_edges"]))   # edge evaluations executed by that launch
         flops = exec_evals * FLOP_PER_EDGE_EVAL
         prof = profile_numbers(kernel_names[dom], int(st["dominant_kernel_edges"]))
+        prof_stale = bool(prof) and not fresh(prof)
+        if prof_stale:
+            prof = None                                   # counters of other kernel sources: not this build's
         traffic = prof.get("hbm_bytes_per_launch") if prof else None
         hbm_bytes = max(b_once, traffic or 0)
         b_stream = st["dominant_ref_passes_edges"] * EDGE_BYTES + st["dominant_ref_passes_nodes"] * NODE_BYTES
@@ -252,7 +289,11 @@ def main():
             "launch_ms": cls_ms[dom], "launch_edges": int(st["dominant_kernel_edges"]),
             "hbm": {"achieved": hbm_bytes / dur_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_bytes / dur_s / 1e9 / HBM_PEAK_GBPS,
                     "bytes_per_launch": int(hbm_bytes), "read_once_bytes": int(b_once)},
-            "traffic": traffic, "traffic_source": "profiles/pmc_traffic.json (committed rocprofv3 PMC passes of this command; not measured in this run)" if traffic else None,
+            "traffic": traffic,
+            "traffic_source": ("profiles/pmc_traffic.json (committed rocprofv3 PMC passes of this command with these kernel sources - kernel_source_sha256 matches; "
+                               "not measured in this run)" if traffic else
+                               "none: profiles/pmc_traffic.json was collected with other kernel sources (kernel_source_sha256 differs)" if prof_stale else None),
+            "kernel_source_sha256": kernel_source_sha256(),
             "valu_busy": (prof or {}).get("valu_busy"),
             "streaming_equiv": {"bytes": int(b_stream), "GBps": b_stream / dur_s / 1e9,
                                 "passes_per_edge_reference": st["dominant_ref_passes_edges"] / max(1, st["dominant_kernel_edges"]),
@@ -378,8 +419,14 @@ def main():
             wg5 = rows5 > 32                                      # the workgroup classes (a dense LDL^T per LM iteration)
             fact_flops = float((rows5[wg5] ** 3 / 3.0 * info5["iterations"][wg5]).sum())
             eval_flops = float(st5["exec_passes_edges"]) * FLOP_PER_EDGE_EVAL
-            prof5 = pmc_numbers("r03_pmc_config5.json")
+            prof5 = pmc_numbers("r04_pmc_config5.json")
+            stale5 = bool(prof5) and not fresh(prof5)
+            if stale5:
+                prof5 = None
             traffic5 = (prof5 or {}).get("hbm_bytes_per_solve")
+            cpu5 = None
+            if not args.no_cpu_baseline:
+                cpu5, _ = cpu_leg(ma5, p5.labels()[2], min(8, os.cpu_count() or 1), st5["n_edges"])
             alg_bytes5 = float(st5["exec_passes_edges"]) * 80
             res["long_tracks_workload"] = {
                 # Two roofs of the solve as a whole (the three LDS classes run concurrently).  HBM: every sweep re-streams the 80-byte
@@ -389,10 +436,14 @@ def main():
                 # executed edge evaluation on the fp64 VALU, both 78.6 TFLOP/s peak.
                 "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                              "traffic": traffic5,
-                             "achieved": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9, "frac": (traffic5 or alg_bytes5) / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "achieved": alg_bytes5 / (ms5 * 1e-3) / 1e9, "frac": alg_bytes5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "frac_what": "ALGORITHMIC bytes (below) over the step time; traffic_ratio = counter traffic / algorithmic bytes",
+                             "traffic_ratio": (traffic5 / alg_bytes5) if traffic5 else None,
                              "algorithmic_bytes": alg_bytes5,
                              "algorithmic_bytes_what": "per executed sweep and edge: the 80 B record (nothing else leaves the CU)",
-                             "traffic_source": "profiles/r03_pmc_config5.json (committed rocprofv3 PMC passes over this workload, 2*FETCH_SIZE + WRITE_SIZE; not measured in this run)" if traffic5 else None,
+                             "traffic_source": ("profiles/r04_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
+                                                "not measured in this run)" if traffic5 else
+                                                "none: the committed counters were collected with other kernel sources (kernel_source_sha256 differs)" if stale5 else None),
                              "fp64": {"achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                                       "factorization_flops": fact_flops, "edge_evaluation_flops": eval_flops,
@@ -406,12 +457,13 @@ def main():
                 "total_span_resident_graph_ms": sp5["ms"], "graph_stage": {k: p5.stats()[k] for k in ("tracks_ms", "roots_ms", "graph_cut_ms", "kruskal_rounds", "n_cut_components")},
                 "mean_iterations": st5["sum_iterations"] / max(1, st5["n_components"]), "failed": st5["n_failed"], "no_convergence": st5["n_no_convergence"],
                 "setup_s": t_prep5,
+                "cpu_baseline": cpu5,
             }
             del b5, p5, g5, ma5
         if not args.no_sparse and world == 1:
             # cap-sized SPARSE components - 1344 images, short tracks matched along a ring lattice, chained by wrong
             # matches; the size cap leaves components of up to 1344 nodes (2.7 k-row systems, tree-plus-few-cycles sparse): the
-            # block-envelope kernel of the HBM class (round 2: a dense packed matrix, 83x slower on these - profiles/r03_sparse_vs_dense.txt)
+            # elimination-tree kernel of the HBM class (round 2: a dense packed matrix; round 3: a block envelope factored as one chain of panels)
             t0 = time.perf_counter()
             mas = synthetic.capsized_sparse(n_tracks=args.sparse_tracks)
             gs = capi.Graph.from_arrays(mas)
@@ -435,7 +487,52 @@ def main():
             rowss = 2 * infos["n_var_nodes"]
             bigs = rowss > 192
             _, cs, es_ = bs.timing(0)
+            # What the launch executed, counted from the elimination-tree plans (lfr_batch_tree_stats) and the solver's own
+            # counters: per factorization of a component 8192 flop per 16x16x16 left-looking update on the fp64 matrix cores, 3840 per
+            # stored tile for the elimination / substitution of its 16 rows (240 multiply-adds each) and 512 per tile in the back
+            # substitution; 200 flop per edge evaluation, every record evaluated by the owner of either end (2 x).  HBM bytes per
+            # factorization + solve: each tile of A read once, each tile of the factor written once, read once by the back substitution
+            # and ~1.5 times as an operand of an update (6 KB per tile + 3 KB per update); per sweep 2 x 80 B per record + ~150 B per
+            # sweep item (item words, partial sums, the pair's 2x2 block).
+            ts_ = bs.tree_stats()
+            its = infos["iterations"].astype(np.float64)
+            fact_flops_s = float(((ts_["updates"] * 8192.0 + ts_["tiles"] * (3840.0 + 512.0)) * its).sum())
+            eval_flops_s = float(sts["exec_passes_edges"]) * 2.0 * FLOP_PER_EDGE_EVAL
+            fact_bytes_s = float(((ts_["tiles"] * 6144.0 + ts_["updates"] * 3072.0) * its).sum())
+            sweeps_per_edge = float(sts["exec_passes_edges"]) / max(1, sts["n_edges"])
+            sweep_bytes_s = float(sts["exec_passes_edges"]) * 160.0 + float(ts_["items"].sum()) * 150.0 * sweeps_per_edge
+            prof_s = pmc_numbers("r04_pmc_sparse.json")
+            stale_s = bool(prof_s) and not fresh(prof_s)
+            if stale_s:
+                prof_s = None
+            traffic_s = (prof_s or {}).get("hbm_bytes_per_solve")
+            cpu_s = None
+            if not args.no_cpu_baseline:
+                cpu_s, _ = cpu_leg(mas, ps.labels()[2], min(8, os.cpu_count() or 1), sts["n_edges"])
+            big_i = int(np.argmax(np.where(bigs, its * ts_["columns"], 0))) if bigs.any() else 0
             res["sparse_capsized_workload"] = {
+                "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
+                             "achieved": (fact_bytes_s + sweep_bytes_s) / (mss * 1e-3) / 1e9,
+                             "frac": (fact_bytes_s + sweep_bytes_s) / (mss * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "frac_what": "ALGORITHMIC bytes over the step time.  Neither roof binds: the launch lasts as long as its slowest component - "
+                                          "iterations x (levels of dependent column tasks + sweeps) on ONE workgroup, the other CUs done or idle",
+                             "algorithmic_bytes": fact_bytes_s + sweep_bytes_s, "factorization_bytes": fact_bytes_s, "sweep_bytes": sweep_bytes_s,
+                             "traffic": traffic_s, "traffic_ratio": (traffic_s / (fact_bytes_s + sweep_bytes_s)) if traffic_s else None,
+                             "traffic_source": ("profiles/r04_pmc_sparse.json (committed rocprofv3 PMC passes over this workload with these kernel sources; not measured in this run)"
+                                                if traffic_s else "none: the committed counters were collected with other kernel sources" if stale_s else None),
+                             "fp64": {"achieved": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                                      "factorization_flops": fact_flops_s, "edge_evaluation_flops": eval_flops_s,
+                                      "factorizations": int(its[bigs].sum()), "tile_updates_per_solve": float((ts_["updates"] * its).sum())},
+                             "pmc": {k: prof_s[k] for k in prof_s if k.startswith("SQ_") or k in ("valu_busy", "wait_fraction")} if prof_s else None},
+                "plans": {"columns": int(ts_["columns"].sum()), "tiles": int(ts_["tiles"].sum()), "updates_per_factorization": int(ts_["updates"].sum()),
+                          "levels_max": int(ts_["levels"].max()), "levels_mean": float(ts_["levels"][bigs].mean()) if bigs.any() else 0.0,
+                          "dense_tiles": float((np.ceil(rowss[bigs] / 16.0) * (np.ceil(rowss[bigs] / 16.0) + 1) / 2).sum())},
+                "critical_component": {"rows": int(rowss[big_i]), "iterations": int(infos["iterations"][big_i]), "columns": int(ts_["columns"][big_i]),
+                                       "levels": int(ts_["levels"][big_i])},
+                "cpu_baseline": cpu_s,
+                "speedup_vs_cpu_baseline_8_threads": (cpu_s["solver_span_ms"] / mss) if cpu_s and "solver_span_ms" in cpu_s else None,
+                "spin_timeouts": bs.spin_timeouts(),
                 "workload": "capsized_sparse: synthetic match graph, 1344 images, %d tracks (mean length 6) matched along ring lattices of degree 4 and chained "
                             "by wrong matches, ratio-test similarities; %d directed edges, %d components, %d of them above 192 rows (max %d rows)"
                             % (args.sparse_tracks, sts["n_edges"], sts["n_components"], int(bigs.sum()), int(rowss.max())),
@@ -446,8 +543,8 @@ def main():
                 "max_iterations_large": int(infos["iterations"][bigs].max()) if bigs.any() else 0,
                 "dense_factorization_flops_equivalent": float((rowss[bigs].astype(np.float64) ** 3 / 3.0 * infos["iterations"][bigs]).sum()),
                 "batch_creation_ms": t_batch * 1e3, "failed": sts["n_failed"], "no_convergence": sts["n_no_convergence"], "setup_s": t_preps,
-                "note": "latency bound: a 2.5 k-row component is ~160 dependent 16-column panels per factorization; the launch lasts as long as "
-                        "its slowest component (one workgroup per component, one component per CU at a time)",
+                "note": "round 3 (block-envelope kernel: ~160 dependent 16-column panels per factorization on one wave): 35 ms; round 4: nested "
+                        "dissection + columns by level of the elimination tree, the workgroup's eight waves take independent columns side by side",
             }
             del bs, ps, gs, mas
         ref_bin = os.environ.get("LFR_REFERENCE_SOLVE")

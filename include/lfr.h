@@ -244,6 +244,13 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats);
  * in LDS: <= 88 rows, <= 130 rows, <= 192 rows; workgroup per component with the matrix in HBM). */
 #define LFR_NUM_KERNEL_CLASSES 9
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges);
+/* Per component (order of lfr_batch_component_info): columns, tiles, 16x16x16 updates per factorization, levels and sweep items of the
+ * elimination-tree plan a component above 192 rows is solved with (the reference: Ceres SPARSE_NORMAL_CHOLESKY, solve.cc:147); zeros
+ * for the other components.  Any pointer may be NULL.  Returns the number of components (< 0: error). */
+int64_t lfr_batch_tree_stats(lfr_batch *b, int64_t *columns, int64_t *tiles, int64_t *updates, int64_t *levels, int64_t *items);
+/* Diagnostics: bounded spin-waits inside the workgroup kernels (wave hand-offs of the factorizations) that ran out during the
+ * latest solve of the batch - each one rejected an LM step instead of hanging the GPU.  0 on a healthy run; < 0: error. */
+int64_t lfr_batch_spin_timeouts(lfr_batch *b);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written.  Waits for the
  * latest lfr_batch_solve of this batch, whatever stream it was issued on. */
 int lfr_batch_download(lfr_batch *b, double *positions);

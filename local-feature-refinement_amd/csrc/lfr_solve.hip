@@ -705,7 +705,7 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
                               // unrolled substitution costs registers (g = 1: 414 spilled VGPRs, g = 4: 396, g = 8: 297, one wait up front: 67)
 #endif
 template <int kBlockThreads>
-__device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int n, BlockShared &sh, unsigned long long *fprof) {
+__device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int n, BlockShared &sh, unsigned long long *fprof, unsigned int *spin_timeouts) {
     constexpr int kWaves = kBlockThreads / 64;
     static_assert(kWaves >= 2, "factor_lds needs a wave beside the one that factors the diagonal blocks");
     constexpr int kWorkers = kWaves - 1;        // waves 1.. : everything but the diagonal blocks
@@ -893,7 +893,7 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
         int spins = 0;
         while (__builtin_amdgcn_readfirstlane(__hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) < need) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 22)) { if (lane == 0) sh.flag = 1; break; }
+            if (++spins > (1 << 22)) { if (lane == 0) { sh.flag = 1; atomicAdd(spin_timeouts, 1u); } break; }     // (counted: lfr_batch_spin_timeouts; the GPU tests assert 0)
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
@@ -1391,7 +1391,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         PROF_MARK(5);                                 // 5: damping
         double *vinv = vgn;            // free until the line search
         {
-            factor_lds<kBlockThreads>(Mat, vinv, n, sh, a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr);        // 16-column panels, one barrier per panel (see factor_lds)
+            factor_lds<kBlockThreads>(Mat, vinv, n, sh, a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr, a.queue + 15);        // 16-column panels, one barrier per panel (see factor_lds)
         }
         __syncthreads();
         PROF_MARK(1);
@@ -2605,6 +2605,8 @@ struct lfr_batch {
     uint64_t es_doubles = 0;                             // per-edge scratch of the workgroup classes (8 doubles per edge), the head of the workspace
     int tree_levels_max = 0;                             // KC_GLOBAL: levels of the deepest elimination tree
     int64_t tree_blocks = 0, tree_updates = 0;           // KC_GLOBAL: 16-row columns / left-looking tile updates per factorization, summed over the class
+    int tree_begin = 0;                                  // first descriptor of the class; per component of the class: columns, tiles, 16x16x16 updates, levels, sweep items
+    std::vector<int64_t> tree_comp_stats;                // 5 per component
     int64_t sky_tiles = 0, sky_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
     // fused gather: the packed kernel reads the graph's own flow arrays (kept alive through dev_hold)
@@ -2873,7 +2875,10 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         b->sky_dense_tiles += (int64_t)plans[i].NB * (plans[i].NB + 1) / 2;
         b->tree_levels_max = std::max(b->tree_levels_max, plans[i].n_levels);
         b->tree_blocks += plans[i].NB; b->tree_updates += (int64_t)plans[i].n_updates;
+        const int64_t cs[5] = {plans[i].NB, plans[i].n_tiles, (int64_t)plans[i].n_updates, plans[i].n_levels, plans[i].n_items};
+        b->tree_comp_stats.insert(b->tree_comp_stats.end(), cs, cs + 5);
     }
+    b->tree_begin = g0;
     if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
     b->d_workspace = (double *)b->ws_slab.base;
     // the plans' words: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
@@ -3461,6 +3466,18 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     return LFR_OK;
 }
 
+// Bounded spins that ran out during the batch's latest solve (the hand-off flags of the LDS factorization, the dependency counters of
+// the elimination-tree kernel): a timeout rejects an LM step instead of hanging the GPU, so it must be visible - 0 in every test.
+int64_t lfr_batch_spin_timeouts(lfr_batch *b) {
+    if (!b) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (b->n_solves == 0 || !b->d_prof) return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    unsigned int v = 0;
+    HIP_TRY(hipMemcpy(&v, reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT) + 15, sizeof v, hipMemcpyDeviceToHost));
+    return (int64_t)v;
+}
+
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges) {
     if (!b || solves_back < 0 || solves_back >= lfr_batch::kSlots || solves_back >= b->n_solves) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     HIP_TRY(hipSetDevice(b->device));
@@ -3553,6 +3570,26 @@ int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iter
         if (n_edges) n_edges[i] = (int32_t)b->descs[i].n_edges;
     }
     return (int64_t)b->descs.size();
+}
+
+// Per component (the order of lfr_batch_component_info): what the elimination-tree plan of a component above 192 rows holds - 16-row
+// columns, 16x16 tiles of the factor, 16x16x16 left-looking updates per factorization, levels of the elimination tree, sweep items; zeros
+// for the components of the other kernel classes.  Lets a checker count the flops and bytes a solve executed (bench.py's roofline).
+int64_t lfr_batch_tree_stats(lfr_batch *b, int64_t *columns, int64_t *tiles, int64_t *updates, int64_t *levels, int64_t *items) {
+    if (!b) return LFR_ERR_ARG;
+    if (ensure_mirrors(b) != LFR_OK) return LFR_ERR_HIP;
+    const size_t n = b->descs.size();
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t k = (int64_t)i - b->tree_begin;
+        const bool in = k >= 0 && (size_t)(5 * k + 4) < b->tree_comp_stats.size();
+        const int64_t *cs = in ? &b->tree_comp_stats[5 * k] : nullptr;
+        if (columns) columns[i] = in ? cs[0] : 0;
+        if (tiles) tiles[i] = in ? cs[1] : 0;
+        if (updates) updates[i] = in ? cs[2] : 0;
+        if (levels) levels[i] = in ? cs[3] : 0;
+        if (items) items[i] = in ? cs[4] : 0;
+    }
+    return (int64_t)n;
 }
 
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions, lfr_solve_stats *stats) {

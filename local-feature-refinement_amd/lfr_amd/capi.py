@@ -103,6 +103,8 @@ def lib():
         "lfr_batch_positions_view": (C.c_int, [vp, pp]),
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
+        "lfr_batch_spin_timeouts": (i64, [vp]),
+        "lfr_batch_tree_stats": (i64, [vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
         "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, C.c_int, vp]),
         "lfr_debug_tree_plan": (i64, [i32, i64, vp, vp, i64, vp]),
@@ -125,7 +127,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -462,6 +464,23 @@ class Batch:
             return np.zeros((0, 2), np.float64)
         buf = (C.c_double * (2 * n)).from_address(p.value)
         return np.frombuffer(buf, dtype=np.float64).reshape(n, 2)
+
+    def tree_stats(self):
+        """Per component (order of component_info): columns / tiles / 16x16x16 updates per factorization / levels / sweep items of the
+        elimination-tree plan (zeros for components of the other kernel classes)."""
+        n = lib().lfr_batch_tree_stats(self._h, None, None, None, None, None)
+        if n < 0:
+            _check(int(n))
+        out = {k: np.zeros(n, np.int64) for k in ("columns", "tiles", "updates", "levels", "items")}
+        lib().lfr_batch_tree_stats(self._h, _ptr(out["columns"]), _ptr(out["tiles"]), _ptr(out["updates"]), _ptr(out["levels"]), _ptr(out["items"]))
+        return out
+
+    def spin_timeouts(self):
+        """Bounded spin-waits of the workgroup kernels that ran out during the latest solve (0 on a healthy run)."""
+        n = lib().lfr_batch_spin_timeouts(self._h)
+        if n < 0:
+            _check(int(n))
+        return int(n)
 
     def component_info(self):
         n = lib().lfr_batch_component_info(self._h, None, None, None, None, None, None)

@@ -415,6 +415,61 @@ static int cholesky(double *A, int n) {
     return 0;
 }
 
+/* Systems above ENVELOPE_MIN_ROWS rows: the reference asks Ceres for SPARSE_NORMAL_CHOLESKY (solve.cc:147).  A dense n^3/3
+ * factorization would make this restatement a straw man as a timed CPU baseline for large sparse components, so they are factored
+ * inside the ENVELOPE (profile) of a reverse Cuthill-McKee order of the variable nodes: row i keeps columns first[i] .. i, an
+ * LL^T without pivoting never fills outside.  Same arithmetic up to the summation order; used for every purpose (parity and timing).
+ * set LFRO_DENSE_ONLY=1 in the environment to force the dense path (A/B). */
+#define ENVELOPE_MIN_ROWS 193
+static int cholesky_profile(double *A, int n, const int *first) {
+    for (int i = 0; i < n; ++i) {
+        double *Ai = A + (size_t)i * n;
+        for (int j = first[i]; j <= i; ++j) {
+            const double *Aj = A + (size_t)j * n;
+            double s = Ai[j];
+            const int k0 = first[i] > first[j] ? first[i] : first[j];
+            for (int k = k0; k < j; ++k) s -= Ai[k] * Aj[k];
+            if (j < i) Ai[j] = s / Aj[j];
+            else { if (!(s > 0.0)) return -1; Ai[i] = sqrt(s); }
+        }
+    }
+    return 0;
+}
+typedef struct { int deg, node; } DegNode;
+static int degnode_cmp(const void *a, const void *b) {
+    const DegNode *x = (const DegNode *)a, *y = (const DegNode *)b;
+    return x->deg != y->deg ? (x->deg < y->deg ? -1 : 1) : (x->node < y->node ? -1 : (x->node > y->node ? 1 : 0));
+}
+/* reverse Cuthill-McKee over the variable nodes: pos[node] = position; scratch allocated here (once per large component) */
+static void rcm_order(int nv, int ne, const int *esrc, const int *edst, int *pos) {
+    int *off = (int *)calloc((size_t)nv + 1, sizeof(int));
+    for (int e = 0; e < ne; ++e) if (esrc[e] >= 0 && edst[e] >= 0 && esrc[e] != edst[e]) { ++off[esrc[e] + 1]; ++off[edst[e] + 1]; }
+    for (int i = 0; i < nv; ++i) off[i + 1] += off[i];
+    int *adj = (int *)malloc(sizeof(int) * (size_t)(off[nv] > 0 ? off[nv] : 1)), *cur = (int *)malloc(sizeof(int) * (size_t)(nv + 1));
+    memcpy(cur, off, sizeof(int) * (size_t)nv);
+    for (int e = 0; e < ne; ++e) if (esrc[e] >= 0 && edst[e] >= 0 && esrc[e] != edst[e]) { adj[cur[esrc[e]]++] = edst[e]; adj[cur[edst[e]]++] = esrc[e]; }
+    int *order = (int *)malloc(sizeof(int) * (size_t)(nv > 0 ? nv : 1)), n_ord = 0;
+    char *seen = (char *)calloc((size_t)nv + 1, 1);
+    DegNode *nb = (DegNode *)malloc(sizeof(DegNode) * (size_t)(nv > 0 ? nv : 1));
+    for (;;) {
+        int start = -1;                                     /* the unvisited node of the smallest degree starts the next piece */
+        for (int v = 0; v < nv; ++v) if (!seen[v] && (start < 0 || off[v + 1] - off[v] < off[start + 1] - off[start])) start = v;
+        if (start < 0) break;
+        const int piece0 = n_ord;
+        order[n_ord++] = start; seen[start] = 1;
+        for (int h = piece0; h < n_ord; ++h) {
+            const int v = order[h];
+            int m = 0;
+            for (int k = off[v]; k < off[v + 1]; ++k) { const int u = adj[k]; if (!seen[u]) { seen[u] = 1; nb[m].deg = off[u + 1] - off[u]; nb[m].node = u; ++m; } }
+            qsort(nb, (size_t)m, sizeof(DegNode), degnode_cmp);
+            for (int i = 0; i < m; ++i) order[n_ord++] = nb[i].node;
+        }
+        for (int i = piece0, j = n_ord - 1; i < j; ++i, --j) { const int t = order[i]; order[i] = order[j]; order[j] = t; }
+    }
+    for (int i = 0; i < nv; ++i) pos[order[i]] = i;
+    free(off); free(adj); free(cur); free(order); free(seen); free(nb);
+}
+
 /* Per-thread scratch that survives from one component to the next (the timed CPU baseline solves ~150 k small components:
  * a calloc/free pair per buffer and component was a visible part of its time).  Slots grow, never shrink. */
 enum { TL_BUF = 0, TL_EJ, TL_VIDX, TL_EDGES, TL_X, TL_SLOTS };
@@ -446,6 +501,30 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
     p->ej2 = p->eJ1 + 4 * (size_t)p->ne;
     p->er = p->ej2 + p->ne;
 
+    /* large systems: envelope order (perm[node] = position; prow(i) = row of variable i in the permuted matrix) */
+    int *perm = NULL, *first = NULL;
+    double *rhs_p = NULL;
+    {
+        const char *dense_only = getenv("LFRO_DENSE_ONLY");
+        if (n >= ENVELOPE_MIN_ROWS && !(dense_only && dense_only[0] == '1')) {
+            perm = (int *)malloc(sizeof(int) * (size_t)p->nv);
+            first = (int *)malloc(sizeof(int) * (size_t)n);
+            rhs_p = (double *)malloc(sizeof(double) * (size_t)n);
+            int *es = (int *)malloc(sizeof(int) * (size_t)(p->ne > 0 ? p->ne : 1)), *ed = (int *)malloc(sizeof(int) * (size_t)(p->ne > 0 ? p->ne : 1));
+            for (int e = 0; e < p->ne; ++e) { es[e] = p->edges[e].src; ed[e] = p->edges[e].dst; }
+            rcm_order(p->nv, p->ne, es, ed, perm);
+            for (int i = 0; i < n; ++i) first[i] = i & ~1;               /* the node's own 2x2 block */
+            for (int e = 0; e < p->ne; ++e) {
+                if (es[e] < 0 || ed[e] < 0) continue;
+                const int pa = perm[es[e]], pb = perm[ed[e]], hi = pa > pb ? pa : pb, lo = pa > pb ? pb : pa;
+                if (2 * lo < first[2 * hi]) first[2 * hi] = 2 * lo;
+                if (2 * lo < first[2 * hi + 1]) first[2 * hi + 1] = 2 * lo;
+            }
+            free(es); free(ed);
+        }
+    }
+#define PNODE(a) (perm ? perm[(a)] : (a))
+#define PROW(i) (perm ? 2 * perm[(i) >> 1] + ((i) & 1) : (i))
     for (int i = 0; i < n; ++i) x[i] = clampb(0.0);
     double x_norm = 0.0;
     double cost = problem_eval(p, x, 1, g);
@@ -475,7 +554,8 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
         step_successful = 0;
 
         /* H = Js^T Js (lower), rhs = Js^T r, column norms of Js */
-        memset(H, 0, sizeof(double) * (size_t)n * n);
+        if (first) { for (int i = 0; i < n; ++i) memset(H + (size_t)i * n + first[i], 0, sizeof(double) * (size_t)(i - first[i] + 1)); }
+        else memset(H, 0, sizeof(double) * (size_t)n * n);
         memset(rhs, 0, sizeof(double) * n);
         for (int e = 0; e < p->ne; ++e) {
             const OEdge *ed = &p->edges[e];
@@ -485,7 +565,8 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
             if (a >= 0) {
                 A[0] = J1[0] * scale[2 * a]; A[1] = J1[1] * scale[2 * a + 1];
                 A[2] = J1[2] * scale[2 * a]; A[3] = J1[3] * scale[2 * a + 1];
-                double *Haa = H + (size_t)(2 * a) * n + 2 * a;
+                const int pa = PNODE(a);
+                double *Haa = H + (size_t)(2 * pa) * n + 2 * pa;
                 Haa[0] += A[0] * A[0] + A[2] * A[2];
                 Haa[n] += A[1] * A[0] + A[3] * A[2];
                 Haa[n + 1] += A[1] * A[1] + A[3] * A[3];
@@ -494,7 +575,8 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
             }
             if (b >= 0) {
                 bs[0] = p->ej2[e] * scale[2 * b]; bs[1] = p->ej2[e] * scale[2 * b + 1];
-                double *Hbb = H + (size_t)(2 * b) * n + 2 * b;
+                const int pb = PNODE(b);
+                double *Hbb = H + (size_t)(2 * pb) * n + 2 * pb;
                 Hbb[0] += bs[0] * bs[0];
                 Hbb[n + 1] += bs[1] * bs[1];
                 rhs[2 * b] += bs[0] * r[0];
@@ -502,25 +584,39 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
             }
             if (a >= 0 && b >= 0) {
                 /* cross block (rows of the larger index): B^T A or A^T B */
-                if (b > a) {
-                    double *Hba = H + (size_t)(2 * b) * n + 2 * a;
+                const int pa = PNODE(a), pb = PNODE(b);
+                if (pb > pa) {
+                    double *Hba = H + (size_t)(2 * pb) * n + 2 * pa;
                     Hba[0] += bs[0] * A[0]; Hba[1] += bs[0] * A[1];
                     Hba[n] += bs[1] * A[2]; Hba[n + 1] += bs[1] * A[3];
                 } else {
-                    double *Hab = H + (size_t)(2 * a) * n + 2 * b;
+                    double *Hab = H + (size_t)(2 * pa) * n + 2 * pb;
                     Hab[0] += A[0] * bs[0]; Hab[1] += A[2] * bs[1];
                     Hab[n] += A[1] * bs[0]; Hab[n + 1] += A[3] * bs[1];
                 }
             }
         }
         if (!reuse_diagonal)
-            for (int i = 0; i < n; ++i) diagonal[i] = fmin(fmax(H[(size_t)i * n + i], MIN_LM_DIAGONAL), MAX_LM_DIAGONAL);
-        for (int i = 0; i < n; ++i) { D[i] = sqrt(diagonal[i] / radius); H[(size_t)i * n + i] += D[i] * D[i]; }
+            for (int i = 0; i < n; ++i) { const int r = PROW(i); diagonal[i] = fmin(fmax(H[(size_t)r * n + r], MIN_LM_DIAGONAL), MAX_LM_DIAGONAL); }
+        for (int i = 0; i < n; ++i) { const int r = PROW(i); D[i] = sqrt(diagonal[i] / radius); H[(size_t)r * n + r] += D[i] * D[i]; }
         reuse_diagonal = 1;
 
-        int valid = cholesky(H, n) == 0;
+        int valid = (first ? cholesky_profile(H, n, first) : cholesky(H, n)) == 0;
         double model_cost_change = 0.0;
-        if (valid) {
+        if (valid && first) {                      /* the same two triangular solves inside the envelope, in the permuted order */
+            for (int i = 0; i < n; ++i) rhs_p[PROW(i)] = rhs[i];
+            for (int i = 0; i < n; ++i) {
+                double sacc = rhs_p[i];
+                for (int k = first[i]; k < i; ++k) sacc -= H[(size_t)i * n + k] * rhs_p[k];
+                rhs_p[i] = sacc / H[(size_t)i * n + i];
+            }
+            for (int i = n - 1; i >= 0; --i) {
+                const double y = rhs_p[i] / H[(size_t)i * n + i];
+                rhs_p[i] = y;
+                for (int k = first[i]; k < i; ++k) rhs_p[k] -= H[(size_t)i * n + k] * y;
+            }
+            for (int i = 0; i < n; ++i) { step[i] = -rhs_p[PROW(i)]; if (!isfinite(step[i])) valid = 0; }
+        } else if (valid) {
             for (int i = 0; i < n; ++i) {          /* L z = rhs */
                 double s = rhs[i];
                 for (int k = 0; k < i; ++k) s -= H[(size_t)i * n + k] * step[k];
@@ -615,6 +711,9 @@ static void solve_problem(Problem *p, double *x_out, CompInfo *info, Trace *tr) 
     info->n_jac_evals = p->n_jac_evals;
     if (term == TERM_FAILURE) memset(x_out, 0, sizeof(double) * n);
     else memcpy(x_out, best, sizeof(double) * n);
+    free(perm); free(first); free(rhs_p);
+#undef PNODE
+#undef PROW
 }
 
 

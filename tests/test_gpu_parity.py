@@ -348,9 +348,10 @@ def test_workgroup_classes_bitwise_repeatable(lfr_lib):
     p = capi.Problem(capi.Graph.from_arrays(ma))
     b = capi.Batch(p, 0)
     xs = []
-    for _ in range(4):
-        b.solve()
+    for _ in range(12):                      # (a stress on the factorization's hand-rolled wave hand-offs: a lost or late flag would show as a
+        b.solve()                            # timing-dependent result or as a spin that ran out - ADVICE r3)
         xs.append(b.download().copy())
+        assert b.spin_timeouts() == 0
     b2 = capi.Batch(p, 0)
     b2.solve()
     xs.append(b2.download().copy())

@@ -1,4 +1,4 @@
-"""Components above 192 rows (kernel class KC_GLOBAL): the block-envelope LDL^T in the HBM workspace against the C oracle's dense
+"""Components above 192 rows (kernel class KC_GLOBAL): the level-scheduled sparse LDL^T along the elimination tree against the C oracle's dense
 solver (the reference: Ceres SPARSE_NORMAL_CHOLESKY, solve.cc:147).  Tolerance 1e-4 px = 6.25e-6 units, same trajectory."""
 import numpy as np
 import pytest
@@ -22,6 +22,7 @@ def _check(ma, min_rows, oracle_threads=8):
     rows = 2 * info["n_var_nodes"]
     assert rows.max() >= min_rows and (rows > 192).sum() >= 3
     assert st["n_failed"] == 0
+    assert b.spin_timeouts() == 0                                            # no wave gave up waiting for a dependency
     err = np.abs(pos - ref["positions"]).max(axis=1)
     assert err.max() <= TOL_UNITS, "max |dx| = %.3e units on %d nodes" % (err.max(), (err > TOL_UNITS).sum())
     oi = ref["infos"][info["component"]]
@@ -46,5 +47,6 @@ def test_cap_sized_sparse_components_at_full_size(lfr_lib):
     """config-4-scale image count: components at the 1344-node cap, ~2.5 k-row systems (VERDICT r2 #2)."""
     g, p, b, st = _check(synthetic.capsized_sparse(n_tracks=2500, seed=7), 2000, oracle_threads=40)
     x1 = b.download().copy()
-    b.solve()
-    assert (b.download() == x1).all()                                             # bitwise repeatable
+    for _ in range(5):                                                            # the dependency-counter schedule hands columns to whichever wave is ready:
+        b.solve()                                                                 # every tile is still written by one wave in a fixed order
+        assert (b.download() == x1).all() and b.spin_timeouts() == 0             # bitwise repeatable
