@@ -91,10 +91,21 @@ struct KernelArgs {
 #define PROF_DECL unsigned long long pt_[7] = {0, 0, 0, 0, 0, 0, 0}; unsigned long long pt0_ = __builtin_amdgcn_s_memtime();
 #define PROF_MARK(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt_[i] += t_ - pt0_; pt0_ = t_; } while (0)
 #define PROF_FLUSH() do { if (lane == 0) for (int i_ = 0; i_ < 7; ++i_) atomicAdd(&a.prof[a.cls * 8 + i_], pt_[i_]); if (lane == 0) atomicAdd(&a.prof[a.cls * 8 + 7], 1ull); } while (0)
+#elif defined(LFR_ISA_MARKS)
+// -DLFR_ISA_MARKS (scripts/isa_account.py, compile only): comments in the ISA that delimit the phases of the packed kernel, so that the
+// instructions of each phase can be counted by kind
+#define PROF_DECL
+#define PROF_MARK(i) asm volatile("; LFR_MARK " #i)
+#define PROF_FLUSH()
 #else
 #define PROF_DECL
 #define PROF_MARK(i)
 #define PROF_FLUSH()
+#endif
+#ifdef LFR_ISA_MARKS
+#define ISA_MARK(name) asm volatile("; LFR_MARK " name)
+#else
+#define ISA_MARK(name)
 #endif
 // -DLFR_PROFILE_SWEEP (with LFR_PROFILE_PHASES): slot 3 = edge evaluation of the workgroup kernel's sweeps, slots 0/2 keep their
 // assembly walks, the factorization reports as one number in slot 1
@@ -206,6 +217,9 @@ template <int NV, int LPR, int EPL, bool FUSED>
 __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int block_in_class, unsigned char *lds_raw) {
     constexpr int S = NV * LPR, G = 64 / S, CPL = NV / LPR, LD = NV + 1;
     static_assert(S <= 64 && (LPR == 1 || LPR == 2), "group geometry");
+#ifdef LFR_ISA_MARKS
+    asm volatile("; LFR_CLASS %0 %1 %2" :: "n"(NV), "n"(LPR), "n"(EPL));
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int gid = lane / S, sl = lane % S;
     const int row = sl % NV, part = sl / NV;
@@ -273,6 +287,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     PROF_DECL
     PROF_MARK(0);                                     // 0: prologue (edge load)
     for (;;) {
+        ISA_MARK("loop_top");
         if (!__any(phase != PH_DONE)) break;
 
         // ======================= A: iteration entry + LM step =======================
@@ -312,6 +327,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                         h[c] = v;
                     }
                     PROF_MARK(5);                     // 5: step setup (diagonal, h build)
+                    ISA_MARK("gauss_jordan");
                     GaussJordan<NV, LPR, 0, CL>::run(h, rhs, piv_own, minpiv, row, part, nv2_max);
                 };
                 const int c_hi = (nv2_max + LPR - 1) / LPR;          // wave-uniform
@@ -329,6 +345,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                     if (c_hi <= 10) LFR_CL(10); else if (c_hi <= 12) LFR_CL(12); else if (c_hi <= 14) LFR_CL(14); else LFR_CL(16);
                 }
 #undef LFR_CL
+                ISA_MARK("step_reductions");
                 fail = !(minpiv > 0.0);
                 const double step = is_row ? -(rhs * fast_rcp(piv_own)) : 0.0;
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
@@ -374,6 +391,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         PROF_MARK(6);                                 // 6: zero J^T J
         double cost_l = 0.0;
         if (__any(pe && jac)) {
+            ISA_MARK("sweep_setup");
             // full sweep (a cost-only group riding in this wave evaluates in full too, but assembles nothing)
 #pragma unroll
             for (int k = 0; k < EPL; ++k) {
@@ -391,7 +409,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const int xa = 2 * min(es, n_var), xb = 2 * min(ed, n_var);      // constants read the zero slot
                 const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
                 EdgeOut o;
+                ISA_MARK("eval");
                 eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                ISA_MARK("assemble");
                 cost_l += o.cost;
                 if (!jac) continue;
                 double *A = L.A, *g = L.g;
@@ -440,7 +460,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
                 EdgeOut o;
                 (void)ra; (void)rb;
+                ISA_MARK("eval_cost_only");
                 eval_edge<false>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                ISA_MARK("cost_only_loop");
                 cost_l += o.cost;
             }
         }
@@ -3047,7 +3069,7 @@ int lfr_hip_reserve(int device, int64_t n_nodes, int64_t n_matches) {
     const size_t want[5] = {
         (size_t)16 * M + (size_t)4 * N + (size_t)144 * M + ((size_t)1 << 16),                              // DevGraph with staged flows
         (size_t)9 * N + 4096,                                                                             // DevProblem
-        (size_t)96 * M + (size_t)96 * N + ((size_t)32 << 20),                                             // graph-stage temporaries
+        (size_t)96 * M + (size_t)112 * N + ((size_t)32 << 20),                                            // graph-stage temporaries
         (size_t)96 * M + (size_t)48 * N + (size_t)128 * (N + 1) + ((size_t)32 << 20),                     // assembly temporaries (C <= N)
         lfr::assembly_output_bytes(N, M, N) + (size_t)(16 + 32) * (size_t)(N + 1) + ((size_t)1 << 17)};   // batch slab
     void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
