@@ -192,7 +192,7 @@ int graph_make_resident(const Graph &g, int device);                // = lfr_gra
 // `blob` is what the kernel reads (u32 words): hdr[32] = {NB, tiles, offset of the tiles (doubles from the base), offset of the
 // vectors, n_pad = 16 NB, levels, items, phase-1 tasks, then the word offsets of colptr[NB+1], rowsof[tiles], nreal[NB],
 // level_ptr[levels+1], level_cols[NB], p1_ptr[levels+1], p1_tasks[][4], upd[][3], x_ptr[levels+1], x_tasks[][3], ncarry[NB],
-// items[items+1][4], item_edges[], node_items[8 NB + 1], ipos[8 NB]; [23] = offset of the items' partial sums, [24] = vector stride,
+// items[items+1][8], item_edges[], node_items[8 NB + 1], ipos[8 NB]; [23] = offset of the items' partial sums, [24] = vector stride,
 // [28] = 1: every column carries all its tiles (dependency-counter schedule), [25] [26] [27] = word offsets of col_upd_ptr[NB+1], col_upd[][5], col_desc[NB][32] (columns in level order)}.  Behind the words: the
 // tiles of A, the tiles of the factor, the items' partial sums, the vectors.
 // ------------------------------------------------------------------------------------------

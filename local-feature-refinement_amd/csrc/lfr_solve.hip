@@ -1733,17 +1733,27 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         __syncthreads();
         TPROF_MARK(2);
         double cost = 0.0;
-        for (int i = tid; i < n_items; i += kBlockThreads) {
-            const uint4 it = reinterpret_cast<const uint4 *>(items)[i];          // {row of the node, row of the neighbour (or the zero slot), cross block, first edge}
-            const uint32_t e_end = items[4 * (i + 1) + 3];
-            const double xv0 = xv[it.x], xv1 = xv[it.x + 1], xu0 = xv[it.y], xu1 = xv[it.y + 1];
-            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0, d00 = 0.0, d10 = 0.0, d11 = 0.0, g0 = 0.0, g1 = 0.0;
-            for (uint32_t q = it.w; q < e_end; ++q) {
-                const uint32_t ew = item_edges[q];                               // record << 2 | direction << 1 | count the cost here
-                const uint4 *rp = reinterpret_cast<const uint4 *>(edges + (ew >> 2));
-                uint4 qv[5];
+        // One item = 8 words (lfr_treeplan.cpp): rows of the node and of the neighbour, the pair's block in A, the record count, the first
+        // two records inline.  The item of the NEXT pass is fetched before this one is evaluated, and both records of the usual pair
+        // are loaded before the first evaluation: one exposed round trip per pass instead of three dependent ones.
+        auto load_record = [&](const uint32_t ew, uint4 (&qv)[5]) {
+            const uint4 *rp = reinterpret_cast<const uint4 *>(edges + (ew >> 2));
 #pragma unroll
-                for (int k = 0; k < 5; ++k) qv[k] = rp[k];
+            for (int k = 0; k < 5; ++k) qv[k] = rp[k];
+        };
+        int i = tid;
+        uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
+        if (i < n_items) { ia = reinterpret_cast<const uint4 *>(items)[2 * i]; ib = reinterpret_cast<const uint4 *>(items)[2 * i + 1]; }
+        while (i < n_items) {
+            const uint4 it = ia, it2 = ib;                                       // {row, row of the neighbour, cross block, records} {record 0, record 1, further, -}
+            const int in = i + kBlockThreads;
+            if (in < n_items) { ia = reinterpret_cast<const uint4 *>(items)[2 * in]; ib = reinterpret_cast<const uint4 *>(items)[2 * in + 1]; }
+            const double xv0 = xv[it.x], xv1 = xv[it.x + 1], xu0 = xv[it.y], xu1 = xv[it.y + 1];
+            uint4 q0[5], q1[5];
+            load_record(it2.x, q0);
+            load_record(it.w > 1u ? it2.y : it2.x, q1);
+            double c00 = 0.0, c01 = 0.0, c10 = 0.0, c11 = 0.0, d00 = 0.0, d10 = 0.0, d11 = 0.0, g0 = 0.0, g1 = 0.0;
+            auto one = [&](const uint32_t ew, const uint4 (&qv)[5]) {
                 float flow[18];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -1755,11 +1765,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 const int kind = (int)(qv[4].w >> 31);
                 const bool rev = (ew & 2u) != 0u;                                // the record runs neighbour -> node
                 EdgeOut o;
-#ifdef LFR_EXP_NOEVAL
-                o.cost = flow[0]; o.r0 = flow[1]; o.r1 = flow[2]; o.j00 = flow[3]; o.j01 = flow[4]; o.j10 = flow[5]; o.j11 = flow[6]; o.sq = sim + kind + tv + xu0 + xv0 + xu1 + xv1;
-#else
                 eval_edge<true>(flow, sim, kind, tv, rev ? xu0 : xv0, rev ? xu1 : xv1, rev ? xv0 : xu0, rev ? xv1 : xu1, o);
-#endif
                 if (ew & 1u) cost += o.cost;
                 if (!rev) {                                                      // d r / d x_node = J1, d r / d x_neighbour = sq I
                     d00 += o.j00 * o.j00 + o.j10 * o.j10; d10 += o.j01 * o.j00 + o.j11 * o.j10; d11 += o.j01 * o.j01 + o.j11 * o.j11;
@@ -1770,6 +1776,14 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     g0 += o.sq * o.r0; g1 += o.sq * o.r1;
                     c00 += o.sq * o.j00; c01 += o.sq * o.j01; c10 += o.sq * o.j10; c11 += o.sq * o.j11;       // (sq I) J1
                 }
+            };
+            if (it.w > 0u) one(it2.x, q0);
+            if (it.w > 1u) one(it2.y, q1);
+            for (uint32_t q = 2u; q < it.w; ++q) {                               // duplicated matches
+                const uint32_t ew = item_edges[it2.z + q - 2u];
+                uint4 qx[5];
+                load_record(ew, qx);
+                one(ew, qx);
             }
             if (it.z != kNone) {                                                 // the neighbour sits earlier in the order: the pair's block is stored here
                 double2 *t = reinterpret_cast<double2 *>(atiles + it.z);
@@ -1777,6 +1791,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
             double2 *pp = reinterpret_cast<double2 *>(part + 6 * (size_t)i);
             pp[0] = make_double2(d00, d10); pp[1] = make_double2(d11, g0); pp[2] = make_double2(g1, 0.0);
+            i = in;
         }
         TPROF_MARK(3);
         const double total = block_sum<kBlockThreads>(cost, sh);           // (barriers inside: cross blocks and partial sums are out)
@@ -2350,14 +2365,22 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             matrix_valid = true;
             PROF_MARK(0);
         }
-        // the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the diagonal tiles, g into w
-        for (int i = tid; i < n; i += kBlockThreads) {
-            const double sc = vscale[i];
-            double dg = vdiag[i];
-            if (!reuse_diagonal) { dg = fmin(fmax(sc * sc * vadiag[i], kMinLmDiag), kMaxLmDiag); vdiag[i] = dg; }
-            const double Di = sqrt(dg / radius) / sc;                        // D / s
-            vD[i] = Di;                                                      // (the column tasks add D^2 to their diagonal tiles)
-            vw[i] = vg[i];
+        // the damped system (A + S^-1 D^2 S^-1) (S y) = g: the scaled LM diagonal onto the diagonal tiles, g into w.
+        // (The vector passes of this loop take FOUR elements per thread and step, every load of the step issued before the first use: a
+        // load from the workspace is ~1-2 k cycles, and an element at a time each pass paid that once per element - index n is the
+        // vectors' zero slot, so an index past the end reads zeros and stores nothing.)
+        for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+            double sc[4], dg[4], ad[4], gg[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); sc[u] = vscale[i]; dg[u] = vdiag[i]; ad[u] = vadiag[i]; gg[u] = vg[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * kBlockThreads;
+                if (i >= n) break;
+                if (!reuse_diagonal) { dg[u] = fmin(fmax(sc[u] * sc[u] * ad[u], kMinLmDiag), kMaxLmDiag); vdiag[i] = dg[u]; }
+                vD[i] = sqrt(dg[u] / radius) / sc[u];                        // D / s (the column tasks add D^2 to their diagonal tiles)
+                vw[i] = gg[u];
+            }
         }
         reuse_diagonal = true;
         if (tid == 0) sh.flag = 0;                        // raised by a non-positive pivot
@@ -2372,13 +2395,20 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
             double partial = 0.0, gd_part = 0.0, dm_part = 0.0;
-            for (int i = tid; i < n; i += kBlockThreads) {
-                const double gi = vg[i], Di = vD[i];
-                const double dl = -vstep[i];
-                vdelta[i] = dl;
-                partial += -gi * dl + Di * Di * dl * dl;
-                gd_part += gi * dl;
-                dm_part = isfinite(dl) ? fmax(dm_part, fabs(dl)) : INFINITY;
+            for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+                double gi[4], Di[4], st[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); gi[u] = vg[i]; Di[u] = vD[i]; st[u] = vstep[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * kBlockThreads;
+                    if (i >= n) break;
+                    const double dl = -st[u];
+                    vdelta[i] = dl;
+                    partial += -gi[u] * dl + Di[u] * Di[u] * dl * dl;
+                    gd_part += gi[u] * dl;
+                    dm_part = isfinite(dl) ? fmax(dm_part, fabs(dl)) : INFINITY;
+                }
             }
             block_reduce3<kBlockThreads>(partial, gd_part, dm_part, ts);
             model_cost_change = 0.5 * partial; g_dot_delta = gd_part; dir_max = dm_part;
@@ -2398,7 +2428,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
             int n_iter = 0;
             for (;;) {
-                for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
+                for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+                    double xo[4], dl[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xo[u] = vx[i]; dl[u] = vdelta[i]; }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlockThreads; if (i < n) vxc[i] = clampb(__dadd_rn(xo[u], __dmul_rn(alpha, dl[u]))); }
+                }
                 PROF_MARK(4);
                 cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
                 matrix_valid = false;
@@ -2433,11 +2469,16 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
         // step norm, and - should the candidate be accepted - its norm and projected gradient, in one pass
         double sn = 0.0, xn = 0.0, gm = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) {
-            const double xo = vx[i], xc = vxc[i];
-            sn += (xo - xc) * (xo - xc);
-            xn += xc * xc;
-            gm = fmax(gm, fabs(xc - clampb(xc - vgn[i])));
+        for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+            double xo[4], xc[4], gn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xo[u] = vx[i]; xc[u] = vxc[i]; gn[u] = vgn[i]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {            // (past the end: zeros, which add nothing)
+                sn += (xo[u] - xc[u]) * (xo[u] - xc[u]);
+                xn += xc[u] * xc[u];
+                gm = fmax(gm, fabs(xc[u] - clampb(xc[u] - gn[u])));
+            }
         }
         block_reduce3<kBlockThreads>(sn, xn, gm, ts);
         const double step_norm = sqrt(sn);
@@ -2446,7 +2487,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (fabs(cost_change) <= kFunctionTol * cost) break;
         const double rel = cost_change / model_cost_change;
         if (rel > kMinRelDecrease) {
-            for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; vg[i] = vgn[i]; }
+            for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+                double xc[4], gn[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xc[u] = vxc[i]; gn[u] = vgn[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlockThreads; if (i < n) { vx[i] = xc[u]; vg[i] = gn[u]; } }
+            }
             __syncthreads();
             x_norm = sqrt(xn);
             cost = cost_cand;

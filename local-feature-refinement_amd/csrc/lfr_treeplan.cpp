@@ -494,7 +494,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
             return colptr[J] + 1u + (uint32_t)(it - st[J].begin());
         };
         for (size_t p = 0; p < ipos.size(); ++p) {
-            node_items[p] = (uint32_t)(items.size() / 4);
+            node_items[p] = (uint32_t)(items.size() / 8);
             if (ipos[p] == 0xffffffffu) continue;
             const int v = (int)ipos[p];
             std::sort(inc.begin() + inc_off[v], inc.begin() + inc_off[v + 1], [](const Inc &a, const Inc &b) {
@@ -507,17 +507,24 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
                     if (blk[u] < blk[v] || (blk[u] == blk[v] && slot[u] < slot[v]))
                         cross = tile_of(blk[v], blk[u]) * 256u + (2u * (uint32_t)slot[v]) * 16u + 2u * (uint32_t)slot[u];
                 }
-                items.push_back(2u * (uint32_t)p); items.push_back(xu); items.push_back(cross); items.push_back((uint32_t)item_edges.size());
-                for (; i < inc_off[v + 1] && inc[i].nbr == u; ++i) {
+                // an item = 8 words: {row of the node, row of the neighbour (or the zero slot), offset of the pair's 2x2 block in A (or none),
+                // records, the first two records inline (record << 2 | direction << 1 | count the cost here), first further record in
+                // item_edges, 0} - the usual pair (one record per direction) needs no second lookup
+                uint32_t ew[2] = {0u, 0u}, n_e = 0;
+                const uint32_t ext = (uint32_t)item_edges.size();
+                for (; i < inc_off[v + 1] && inc[i].nbr == u; ++i, ++n_e) {
                     const uint32_t cost_flag = inc[i].dir == 0 ? 1u : (u >= n_var ? 1u : 0u);   // every record's cost is counted once
-                    item_edges.push_back(inc[i].rec << 2 | (uint32_t)inc[i].dir << 1 | cost_flag);
+                    const uint32_t w = inc[i].rec << 2 | (uint32_t)inc[i].dir << 1 | cost_flag;
+                    if (n_e < 2) ew[n_e] = w; else item_edges.push_back(w);
                 }
+                items.push_back(2u * (uint32_t)p); items.push_back(xu); items.push_back(cross); items.push_back(n_e);
+                items.push_back(ew[0]); items.push_back(ew[1]); items.push_back(ext); items.push_back(0u);
             }
         }
-        node_items[ipos.size()] = (uint32_t)(items.size() / 4);
-        items.push_back(0); items.push_back(0); items.push_back(0xffffffffu); items.push_back((uint32_t)item_edges.size());    // sentinel: the end of the last list
+        node_items[ipos.size()] = (uint32_t)(items.size() / 8);
+        for (int pad = 0; pad < 8; ++pad) items.push_back(pad == 2 ? 0xffffffffu : 0u);        // one item past the end (the sweep reads one ahead)
     }
-    const uint32_t n_items = (uint32_t)(items.size() / 4) - 1;
+    const uint32_t n_items = (uint32_t)(items.size() / 8) - 1;
     // ---- the blob ----
     std::vector<uint32_t> &blob = out.blob;
     blob.assign(kTreeHdrWords, 0);

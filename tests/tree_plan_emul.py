@@ -28,8 +28,9 @@ class Plan:
         self.x_ptr = arr(8, L + 1)
         self.x_tasks = arr(9, 3 * int(self.x_ptr[-1])).reshape(-1, 3)
         self.ncarry = arr(10, NB)
-        self.items = arr(11, 4 * (self.n_items + 1)).reshape(-1, 4)
-        self.item_edges = arr(12, int(self.items[-1, 3]))
+        self.items = arr(11, 8 * (self.n_items + 1)).reshape(-1, 8)
+        n_ext = int(np.maximum(self.items[:-1, 3] - 2, 0).sum())
+        self.item_edges = arr(12, n_ext)
         self.node_items = arr(13, 8 * NB + 1)
         self.ipos = arr(14, 8 * NB)
         self.off_part, self.vec_stride = int(b[23]), int(b[24])
@@ -128,12 +129,11 @@ class Plan:
         counted = np.zeros(len(words), np.int64)
         part = np.zeros((self.n_items, 5))
         for i in range(self.n_items):
-            xv, xu, cross, eb = self.items[i]
-            ee = self.items[i + 1, 3]
+            xv, xu, cross, ne, ew0, ew1, ext, _ = self.items[i]
             cb = np.zeros((2, 2))
             d = np.zeros((2, 2))
             gg = np.zeros(2)
-            for q in self.item_edges[eb:ee]:
+            for q in [ew0, ew1][:min(ne, 2)] + self.item_edges[ext:ext + max(ne - 2, 0)].tolist():
                 e, dr, cf = int(q) >> 2, (int(q) >> 1) & 1, int(q) & 1
                 counted[e] += cf
                 if dr == 0:            # record v -> u : d r / d x_v = J1, d r / d x_u = sq I
