@@ -32,7 +32,14 @@ CASES = {
     "sparse_ratio": dict(seed=511, n_images=120, n_tracks=10, track_degree=4, ratio_sims=True, dup_frac=0.05, eps_out=0.02),
     "sparse_long": dict(seed=512, n_images=160, n_tracks=4, len_dist="uniform", len_lo=20, len_hi=40, track_degree=5, eps_out=0.004,
                         ratio_sims=True, dup_frac=0.03),        # long sparse tracks (workgroup classes), a few joined by wrong matches; no component above the cap
+    # round 4: the control flow of the large-component paths, iteration by iteration -
+    # three ~105-node ring-lattice tracks: ~208-row sparse systems, the elimination-tree kernel (> 192 rows; the C oracle's envelope path)
+    "sparse_tree": dict(seed=613, n_images=120, n_tracks=3, len_dist="uniform", len_lo=100, len_hi=110, track_degree=4, ratio_sims=True, dup_frac=0.02),
+    # 14 images: multi-track components above the size cap, cut by the reference's recursion (solve.cc:185-250, 311-364) around the
+    # product's two-way primitive (lfr_bisect_graph - Graclus cannot be restated); the pieces are then solved like any component
+    "cut": dict(seed=612, n_images=14, n_tracks=40, eps_out=0.04),
 }
+NEEDS_BISECT = {"cut"}
 
 
 def main():
@@ -42,10 +49,14 @@ def main():
             continue
         ma = synthetic.generate(**kw)
         pairs = ma.to_pairs()
+        bisect = None
+        if name in NEEDS_BISECT:
+            from lfr_amd import capi
+            bisect = capi.bisect_graph
         open(os.path.join(HERE, name + ".pb"), "wb").write(wire.encode_matching_file(pairs))
         out = {}
         for variant in ("ceres1", "ceres2"):
-            res = lfr_ref.solve_pairs(pairs, tukey_variant=variant, want_trace=True)
+            res = lfr_ref.solve_pairs(pairs, tukey_variant=variant, want_trace=True, bisect_fn=bisect)
             nc = res["n_components"]
             its = np.zeros(nc, np.int32)
             term = np.zeros(nc, np.int32)
@@ -65,7 +76,7 @@ def main():
                    node_feat=np.asarray([k[1] for k in res["node_key"]], np.int64),
                    node_image=np.asarray([k[0] for k in res["node_key"]]))
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
-        sol = lfr_ref.solution_images(lfr_ref.solve_pairs(pairs))
+        sol = lfr_ref.solution_images(lfr_ref.solve_pairs(pairs, bisect_fn=bisect))
         open(os.path.join(HERE, name + ".solution.pb"), "wb").write(wire.encode_solution_file(sol))
         print(name, "nodes", res["n_nodes"], "comps", res["n_components"], "max iters", int(out["iterations_ceres1"].max()),
               "ls evals > iters:", int((out["n_ls_evals_ceres1"] > out["iterations_ceres1"]).sum()))

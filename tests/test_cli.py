@@ -51,3 +51,21 @@ def test_parse_failure_exit_code(lfr_lib, tmp_path):
     r = subprocess.run([sys.executable, SOLVE, "--matches_file", str(bad), "--output_file", str(tmp_path / "o.pb")],
                        capture_output=True, text=True)
     assert r.returncode == 255 and "Failed to parse proto object." in r.stderr      # solve.cc:433-436
+
+
+@pytest.mark.gpu
+def test_compare_with_reference_dry_run(lfr_lib, tmp_path):
+    """scripts/compare_with_reference.py is the way from "parity unpinned" to "green" for whoever has a reference build of `solve`.
+    Nobody here has one, so the script is kept runnable with the product's own launcher standing in for the reference binary: same
+    stdout lines parsed, both SolutionFiles decoded, the default Tukey flavour must match itself exactly (VERDICT r3 #8)."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import compare_with_reference as cwr
+    pb = os.path.join(ROOT, "tests", "golden", "outliers.pb")
+    res = cwr.compare(SOLVE, pb, str(tmp_path), variants=("ceres1", "ceres2"))
+    assert res.get("error") is None and res["reference"]["rc"] == 0
+    assert res["best_variant"] == "ceres1" and res["parity"] == "green"
+    assert res["variants"]["ceres1"]["max_abs_diff_px"] == 0.0
+    assert res["variants"]["ceres2"]["max_abs_diff_px"] > 0.0            # inter-track (Tukey) edges exist: the flavours differ
+    assert "stdout_mismatch" not in res
+    for k in ("n_nodes", "n_edges", "n_tracks", "n_components"):
+        assert res["reference"][k] == res["variants"]["ceres1"][k]

@@ -1,5 +1,6 @@
 """Committed golden vectors (tests/golden/, produced by oracle/lfr_ref.py — see make_golden.py).
 CPU: the C oracle and the native graph stage reproduce them.  GPU: the HIP path does."""
+import ctypes
 import os
 import subprocess
 import sys
@@ -12,7 +13,7 @@ from lfr_amd import capi, synthetic, wire
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 GOLD = os.path.join(HERE, "golden")
-NAMES = ["clean", "outliers", "noisy", "bounds", "linesearch", "linesearch2", "sparse_ratio", "sparse_long"]
+NAMES = ["clean", "outliers", "noisy", "bounds", "linesearch", "linesearch2", "sparse_ratio", "sparse_long", "sparse_tree", "cut"]
 TOL_UNITS = 6.25e-6          # 1e-4 px at fact = 1 (colmap_utils.py:135-136); north_star tolerance
 
 
@@ -27,7 +28,9 @@ def test_c_oracle_reproduces_golden(name, variant):
     pairs, z = load(name)
     ma = synthetic.pairs_to_arrays(pairs)
     worst = int(z["trace_component_" + variant])
-    o = O.run(ma, tukey_variant=variant, trace_comp=worst)
+    # ("cut": components above the size cap - the reference's recursion around the product's two-way primitive, as in make_golden.py)
+    bisect = ctypes.cast(capi.lib().lfr_bisect_graph, ctypes.c_void_p).value if name == "cut" else None
+    o = O.run(ma, tukey_variant=variant, trace_comp=worst, bisect=bisect)
     assert (o["track"] == z["track"]).all() and (o["is_root"] == z["is_root"]).all() and (o["comp"] == z["comp"]).all()
     # 1e-9: the quintic line-search interpolation uses different (equally valid) root finders /
     # linear solvers in the two restatements; everything else agrees to ~1e-16
