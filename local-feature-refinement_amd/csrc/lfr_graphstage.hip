@@ -655,7 +655,24 @@ int upload_labels(const Problem &p, int device, bool stage_flows, std::shared_pt
     dp->ctx = ctx; dp->graph = dg; dp->N = N;
     if (!dp->slab.init(ctx, (size_t)9 * N + 4096)) return LFR_ERR_NOMEM;
     dp->track = dp->slab.take_n<int32_t>(N); dp->comp = dp->slab.take_n<int32_t>(N); dp->is_root = dp->slab.take_n<uint8_t>(N);
+    // Labels that already live on ANOTHER GPU (the device graph stage ran there) come over the GPU-GPU link - xGMI on an 8-GPU node -
+    // instead of through the host: 9 bytes per node, no D2H, no widening to the host's 64-bit labels and back.
+    std::shared_ptr<DevProblem> peer;
+    {
+        std::lock_guard<std::mutex> lk(p.label_mu);
+        for (auto &d : p.devs) if (d && d->track && d->N == N && d->ctx->device != device) { peer = d; break; }
+    }
+    if (peer && N > 0) {
+        const int src = peer->ctx->device;
+        LFR_HIP_TRY(hipMemcpyPeerAsync(dp->track, device, peer->track, src, (size_t)4 * N, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyPeerAsync(dp->comp, device, peer->comp, src, (size_t)4 * N, ctx->s_main));
+        LFR_HIP_TRY(hipMemcpyPeerAsync(dp->is_root, device, peer->is_root, src, (size_t)N, ctx->s_main));
+        LFR_HIP_TRY(hipStreamSynchronize(ctx->s_main));
+        out = dp;
+        return LFR_OK;
+    }
     if (N > 0) {
+        if (!p.host_labels_valid) { const int rc2 = p.ensure_host_labels(); if (rc2 != LFR_OK) return rc2; }
         std::vector<int32_t> t32(N), c32(N);
         for (int64_t i = 0; i < N; ++i) { t32[i] = (int32_t)p.track[i]; c32[i] = (int32_t)p.comp[i]; }
         LFR_HIP_TRY(hipMemcpyAsync(dp->track, t32.data(), (size_t)4 * N, hipMemcpyHostToDevice, ctx->s_main));

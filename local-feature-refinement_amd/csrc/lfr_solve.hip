@@ -3692,7 +3692,13 @@ int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices,
     std::vector<std::string> errs(n_devices);
     const size_t n = (size_t)p->p.g->n_nodes();
     memset(positions, 0, sizeof(double) * 2 * n);
-    if (!p->p.host_batch) { const int rc = p->p.ensure_host_labels(); if (rc != LFR_OK) return rc; }   // once, before the threads fork
+    // labels-only problems: the labels of the other GPUs come from the GPU that ran the graph stage (peer copies in upload_labels);
+    // without such a GPU the host copies are fetched once, before the threads fork
+    {
+        bool on_a_device = false;
+        { std::lock_guard<std::mutex> lk(p->p.label_mu); for (auto &d : p->p.devs) on_a_device = on_a_device || (d && d->track); }
+        if (!p->p.host_batch && !on_a_device) { const int rc = p->p.ensure_host_labels(); if (rc != LFR_OK) return rc; }
+    }
     auto work = [&](int k) {
         lfr_batch *bt = nullptr;
         rcs[k] = lfr_batch_create(p, devices[k], k, n_devices, tukey_variant, &bt);

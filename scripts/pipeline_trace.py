@@ -1,5 +1,5 @@
 """One-shot pipeline (graph stage -> assembly -> solve -> positions) of config 4 or config 5, a few repetitions: run it under
-`rocprofv3 --kernel-trace` (scripts/r3_trace.sh) to see what the Total span is made of.  usage: pipeline_trace.py [c4|c5] [reps]"""
+`rocprofv3 --kernel-trace` (scripts/pipeline_trace.sh) to see what the Total span is made of.  usage: pipeline_trace.py [c4|c5] [reps]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "local-feature-refinement_amd"))

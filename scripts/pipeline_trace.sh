@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: scripts/r3_trace.sh c4|c5  -> kernels of the LAST pipeline repetition, in launch order, with durations and gaps
+# usage: scripts/pipeline_trace.sh c4|c5  -> kernels of the LAST pipeline repetition, in launch order, with durations and gaps
 which=${1:-c4}
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/trace_$which; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp

@@ -1,4 +1,5 @@
-"""Large sparse components (block-envelope kernel): timing on the GPU box.  usage: python scripts/sky_check.py [n_tracks] [n_images]"""
+"""Cap-sized sparse components (solve_tree_kernel): timing on the GPU box; with LFR_LIB_OVERRIDE=<-DLFR_PROFILE_PHASES -DLFR_PROFILE_TREE / -DLFR_PROFILE_FACTOR build> the phase profiles.
+usage: python scripts/prof_sparse.py [n_tracks] [n_images]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "local-feature-refinement_amd"))

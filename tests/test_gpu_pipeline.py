@@ -251,6 +251,30 @@ def test_bench_two_ranks_on_one_gpu(lfr_lib, scaling):
         assert out[k]["ms"] > 0
 
 
+def test_bench_four_ranks_on_one_gpu_at_full_size(lfr_lib):
+    """Readiness for the first 8-GPU lease: four ranks (gloo) on GPU 0 at the HEADLINE size - every rank holds a 5 M-edge
+    graph, the strong-scaling leg shards ONE config-4 graph four ways on the device (snake deal, zero-copy gather of each shard's flows)
+    and the edges of the shards add up to the graph."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LFR_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--devices", "0,0,0,0", "--steps", "2", "--warmup", "1",
+                        "--span-reps", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=1200)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["scaling"] == "weak" and out["solve"]["failed"] == 0
+    one = out["config"]["edges_per_gpu"]
+    assert 4.9e6 < one < 5.1e6
+    assert abs(out["value"] * out["ms_per_step"] * 1e-3 - 4 * one) / (4 * one) < 0.02           # four graphs per step
+    ss = out["strong_scaling"]
+    assert abs(ss["edges"] - one) / one < 0.02 and ss["total_span_ms"] > 0                        # one graph, four shards
+
+
 def test_bench_two_gpus_over_rccl(lfr_lib):
     """The first multi-GPU lease should exercise RCCL, not discover it: bench.py --gpus 2 with the default backend (nccl = RCCL on
     ROCm), one rank per GPU.  Skipped on one-GPU boxes."""
