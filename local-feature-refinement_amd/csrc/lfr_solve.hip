@@ -1546,11 +1546,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                     current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
-#ifdef LFR_EXP_NOLS
-                const double nstep = -1.0;
-#else
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
-#endif
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;
@@ -1659,9 +1655,6 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 #else
 #define TPROF_MARK(i)
 #define LFR_TREE_SLOT_SCALE 5
-#endif
-#ifndef LFR_TREE_PINGPONG
-#define LFR_TREE_PINGPONG 0      // 1: two operand sets alternate over a column's further update entries (measured: the extra registers make the column loop spill)
 #endif
 struct TreeShared {
     // per wave: four tiles in rows of 18 doubles (the column task turns its accumulators from the matrix cores' layout into
@@ -1925,34 +1918,6 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
         }
         if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
-#if LFR_TREE_PINGPONG
-        if (dc.ne > 1u) {
-            // further entries (a separator's column has one per child, up to ~16): two operand sets alternate, the loads of entry
-            // e + 1 in flight while entry e runs on the matrix cores
-            uint32_t e = dc.e_rest - 1u;
-            const uint32_t e_end = dc.e_rest - 2u + dc.ne;
-            UpdB oa, ob;
-            UpdY ya, yb;
-            uint32_t a0a = dc.a10, a1a = dc.a11, a2a = dc.a12, a0b = kNone, a1b = kNone, a2b = kNone;
-            load_b(dc.k1, dc.tb1, oa); load_y(a0a, a1a, a2a, ya);
-            for (;;) {
-                if (e + 1u < e_end) {
-                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
-                    a0b = col_upd[5 * (e + 1u) + 2]; a1b = col_upd[5 * (e + 1u) + 3]; a2b = col_upd[5 * (e + 1u) + 4];
-                    load_b(k, tb, ob); load_y(a0b, a1b, a2b, yb);
-                }
-                apply_ops(a0a, a1a, a2a, oa, ya, acc);
-                if (++e >= e_end) break;
-                if (e + 1u < e_end) {
-                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
-                    a0a = col_upd[5 * (e + 1u) + 2]; a1a = col_upd[5 * (e + 1u) + 3]; a2a = col_upd[5 * (e + 1u) + 4];
-                    load_b(k, tb, oa); load_y(a0a, a1a, a2a, ya);
-                }
-                apply_ops(a0b, a1b, a2b, ob, yb, acc);
-                if (++e >= e_end) break;
-            }
-        }
-#else
         for (uint32_t e = dc.e_rest - 1u; e < dc.e_rest - 2u + dc.ne && dc.ne > 1u; ++e) {    // further entries (a separator's column has one per child)
             const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
             UpdB o;
@@ -1961,7 +1926,6 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             load_y(a0, a1, a2, y);
             apply_ops(a0, a1, a2, o, y, acc);
         }
-#endif
         double wacc = acc.wacc;
         wacc += __shfl_xor(wacc, 16, 64);
         wacc += __shfl_xor(wacc, 32, 64);
@@ -2388,9 +2352,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         PROF_MARK(LFR_TREE_SLOT_SCALE);
         bool valid = factor();                            // (reads A, writes the factor: J^T J at x stays in A until a trial point is swept)
         PROF_MARK(1);
-#ifndef LFR_EXP_NOBACK
         if (valid) back_substitute();
-#endif
         PROF_MARK(6);
         double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
@@ -2449,11 +2411,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     current.gradient = block_sum<kBlockThreads>(p, sh);
                     current.gradient_valid = isfinite(current.gradient);
                 }
-#ifdef LFR_EXP_NOLS
-                const double nstep = -1.0;
-#else
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
-#endif
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;
