@@ -12,10 +12,10 @@
 //
 // No host round trips: every launch is sized by an upper bound (N, 2M, C) and bounded on the device by the
 // counts the previous kernels left there; one read-back of the 160-byte summary ends the stage.
-// Everything is integer/byte work: radix sorts (hipCUB), scans, histograms with integer atomics
+// Everything is integer/byte work: radix sorts (rocPRIM), scans, histograms with integer atomics
 // (exact and order-independent), gathers.  HBM-bound; no LDS tiling to speak of.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstring>
@@ -370,22 +370,22 @@ template <class K, class V>
 int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("assembly: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     return LFR_OK;
 }
 template <class T>
 int exclusive_sum(DevArena &arena, const T *in, T *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
+    LFR_HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, std::remove_cv_t<std::remove_reference_t<decltype(*out)>>(0), (size_t)n, rocprim::plus<std::remove_cv_t<std::remove_reference_t<decltype(*out)>>>(), st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("assembly: device arena exhausted (scan of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st));
+    LFR_HIP_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, std::remove_cv_t<std::remove_reference_t<decltype(*out)>>(0), (size_t)n, rocprim::plus<std::remove_cv_t<std::remove_reference_t<decltype(*out)>>>(), st));
     return LFR_OK;
 }
 

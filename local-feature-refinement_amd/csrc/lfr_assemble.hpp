@@ -13,6 +13,14 @@
 #include "lfr_devctx.hpp"
 #include "lfr_internal.hpp"
 
+// rocPRIM directly (not through the hipCUB compatibility layer).  Radix sort: rocPRIM's default takes a merge sort (log2(n / block) launches of
+// ~6 us) up to 2^20 keys - the node order of config 4 (0.88 M keys of 19 bits) was 21 launches, 150 us; from 256 K keys the one-sweep radix
+// passes (one launch per 8 key bits) are the shorter road.  Only .hip translation units see this.
+#ifdef __HIPCC__
+#include <rocprim/rocprim.hpp>
+using LfrRadixSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)256 * 1024>;
+#endif
+
 namespace lfr {
 
 #define LFR_HIP_TRY(expr)                                                                     \

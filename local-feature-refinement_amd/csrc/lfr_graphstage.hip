@@ -5,7 +5,7 @@
 // The constrained maximum spanning forest is greedy over the globally sorted match list, i.e.
 // order dependent — but only INSIDE a connected component of the match graph: two matches of
 // different connected components never interact.  So (hard part 4):
-//   1. radix-sort the matches by (similarity, n1, n2) descending            (hipCUB)
+//   1. radix-sort the matches by (similarity, n1, n2) descending            (rocPRIM)
 //   2. plain connected components of the match graph, ignoring image conflicts (lock-free union-find)
 //   3. stable-sort the ordered matches by connected component
 //   4. small connected components: one thread each replays the reference's sequential union-find with the
@@ -27,7 +27,7 @@
 // Integer work throughout; the only floating-point accumulation (root scores, sums of float32
 // similarities in fp64) is exact for any realistic input, hence order independent.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <type_traits>
 
 #include <algorithm>
 #include <chrono>
@@ -63,32 +63,32 @@ template <class K, class V>
 int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("graph stage: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, bytes, kin, kout, vin, vout, (int)n, begin_bit, end_bit, st));
+    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
     return LFR_OK;
 }
-// sums of the values of equal adjacent keys (hipCUB ReduceByKey); *n_runs (device) = number of distinct runs
+// sums of the values of equal adjacent keys (rocPRIM reduce_by_key); *n_runs (device) = number of distinct runs
 int sum_by_key(DevArena &arena, const unsigned long long *keys, unsigned long long *unique, const double *vals, double *sums, uint32_t *n_runs,
                int64_t n, hipStream_t st) {
     size_t bytes = 0;
-    LFR_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(nullptr, bytes, keys, unique, vals, sums, n_runs, hipcub::Sum(), (int)n, st));
+    LFR_HIP_TRY(rocprim::reduce_by_key(nullptr, bytes, keys, vals, (size_t)n, unique, sums, n_runs, rocprim::plus<double>(), rocprim::equal_to<unsigned long long>(), st));
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("graph stage: device arena exhausted (reduce-by-key)"); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(hipcub::DeviceReduce::ReduceByKey(tmp, bytes, keys, unique, vals, sums, n_runs, hipcub::Sum(), (int)n, st));
+    LFR_HIP_TRY(rocprim::reduce_by_key(tmp, bytes, keys, vals, (size_t)n, unique, sums, n_runs, rocprim::plus<double>(), rocprim::equal_to<unsigned long long>(), st));
     return LFR_OK;
 }
 
 int exclusive_sum(DevArena &arena, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, in, out, (int)n, st));
+    LFR_HIP_TRY(rocprim::exclusive_scan(nullptr, bytes, in, out, std::remove_cv_t<std::remove_reference_t<decltype(*out)>>(0), (size_t)n, rocprim::plus<std::remove_cv_t<std::remove_reference_t<decltype(*out)>>>(), st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("graph stage: device arena exhausted (scan of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st));
+    LFR_HIP_TRY(rocprim::exclusive_scan(tmp, bytes, in, out, std::remove_cv_t<std::remove_reference_t<decltype(*out)>>(0), (size_t)n, rocprim::plus<std::remove_cv_t<std::remove_reference_t<decltype(*out)>>>(), st));
     return LFR_OK;
 }
 

@@ -19,7 +19,6 @@
 //                              nested-dissection order (lfr_treeplan.cpp), 16x16 tiles in an HBM workspace, columns of one tree level
 //                              factored side by side by the workgroup's waves.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <atomic>
@@ -3215,8 +3214,8 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
             const int wg_begin = b->class_begin[lfr::KC_BLOCK], n_wg = b->class_begin[lfr::KC_COUNT] - wg_begin;
             hipStream_t so = ctx->s_main;
             size_t tmp_bytes = 0;
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
-                                                       (uint32_t *)nullptr, n_wg, 0, 27, so));
+            HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, tmp_bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr, (const uint32_t *)nullptr,
+                                                                   (uint32_t *)nullptr, (size_t)n_wg, 0u, 27u, so));
             if (!b->order_slab.init(ctx, 16 * (size_t)n_wg + tmp_bytes + 4096)) return LFR_ERR_NOMEM;
             b->d_wg_order = b->order_slab.take_n<uint32_t>(n_wg);
             uint32_t *keys = b->order_slab.take_n<uint32_t>(n_wg), *keys_sorted = b->order_slab.take_n<uint32_t>(n_wg), *vals = b->order_slab.take_n<uint32_t>(n_wg);
@@ -3226,7 +3225,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
                                b->class_begin[lfr::KC_BLOCK_M] - wg_begin, b->class_begin[lfr::KC_BLOCK_L] - wg_begin, b->class_begin[lfr::KC_GLOBAL] - wg_begin,
                                keys, vals, wg_begin);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys_sorted, vals, b->d_wg_order, n_wg, 0, 27, so));
+            HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, tmp_bytes, keys, keys_sorted, vals, b->d_wg_order, (size_t)n_wg, 0u, 27u, so));
             if (!(b->ev_order = ctx->event_acquire(false))) return LFR_ERR_HIP;
             HIP_TRY(hipEventRecord(b->ev_order, so));
         }
