@@ -50,3 +50,47 @@ def test_cap_sized_sparse_components_at_full_size(lfr_lib):
     for _ in range(5):                                                            # the dependency-counter schedule hands columns to whichever wave is ready:
         b.solve()                                                                 # every tile is still written by one wave in a fixed order
         assert (b.download() == x1).all() and b.spin_timeouts() == 0             # bitwise repeatable
+
+
+def _explicit(n_images, matches, seed):
+    """MatchArrays from explicit (image a, image b) matches between feature 0 of the images (one node per image); flows = consistent
+    offsets + noise"""
+    rng = np.random.default_rng(seed)
+    p = np.clip(rng.normal(0.0, 0.15, size=(n_images, 2)), -0.45, 0.45)
+    pairs = []
+    for a, b in sorted(matches):
+        assert a < b
+
+        def flow(src, dst):
+            base = p[dst] - p[src]
+            return [(float(base[0] + rng.normal(0, 0.02)), float(base[1] + rng.normal(0, 0.02))) for _ in range(9)]
+        pairs.append({"image_name1": "%06d.png" % a, "fact1": 1.0, "image_name2": "%06d.png" % b, "fact2": 1.0,
+                      "matches": [{"feature_idx1": 0, "feature_idx2": 0, "similarity": float(rng.uniform(0.5, 1.0)),
+                                   "disp1": flow(b, a), "disp2": flow(a, b)}]})
+    return synthetic.pairs_to_arrays(pairs)
+
+
+def test_star_and_comb_shaped_tracks(lfr_lib):
+    """Shapes the synthetic generator does not make.  A STAR: one image matched against 170 others and nothing else - its centre is the track's
+    root (largest score), so the variable nodes are linked only through a constant: 170 independent one-node pieces of the elimination
+    tree.  A COMB: a 120-node path with a tooth on every node (240 nodes, a tree).  And a path with a few long-range chords (cycles)."""
+    star = [(0, i) for i in range(1, 171)]
+    comb = [(200 + i, 201 + i) for i in range(119)] + [(200 + i, 400 + i) for i in range(120)]
+    chords = [(700 + i, 701 + i) for i in range(149)] + [(700 + i, 700 + i + 37) for i in range(0, 110, 11)]
+    ma = _explicit(900, star + comb + chords, seed=5)
+    g = capi.Graph.from_arrays(ma)
+    p = capi.Problem(g)
+    b = capi.Batch(p, 0)
+    st = b.solve()
+    pos = b.download()
+    ref = O.run(ma, n_threads=8)
+    assert ref["rc"] == 0 and (ref["comp"] == p.labels()[2]).all()
+    info = b.component_info()
+    rows = 2 * info["n_var_nodes"]
+    assert sorted(rows.tolist()) == [298, 340, 478]                              # all three above 192 rows: the elimination-tree kernel
+    assert st["n_failed"] == 0 and b.spin_timeouts() == 0
+    assert np.abs(pos - ref["positions"]).max() <= TOL_UNITS
+    oi = ref["infos"][info["component"]]
+    assert (oi["termination"] == info["termination"]).all() and (oi["iterations"] == info["iterations"]).all()
+    ts = b.tree_stats()
+    assert (ts["columns"] > 0).all() and (ts["levels"] >= 1).all()
