@@ -229,7 +229,8 @@ int lfr_hip_trim(int device);
 
 /* Shard `shard_rank` of `shard_world` (see lfr_problem_shard_components) resident on HIP device `device`:
  * assembled there from the labels (lfr_problem_build_labels / _hip), or uploaded (lfr_problem_build).
- * Limits: <= 32767 nodes per component (16-bit local indices in the 80-byte edge record), < 2^30 matches. */
+ * Limits: <= 32767 nodes per component (16-bit local indices in the 80-byte edge record), < 2^30 matches; a component above 192 rows
+ * whose factor needs 2^21 or more 16x16 tiles (4 GB: a DENSE component beyond ~16 k nodes) is refused (LFR_ERR_UNSUPPORTED). */
 int lfr_batch_create(const lfr_problem *p, int device, int shard_rank, int shard_world, int tukey_variant,
                      lfr_batch **out);
 void lfr_batch_free(lfr_batch *b);

@@ -550,7 +550,10 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // factor) -, then 6 doubles of partial sums per item, then the vectors
     const uint64_t off_part = (uint64_t)blob[2] + 512ull * n_tiles;
     const uint64_t off_vec = (off_part + 6ull * n_items + 31) / 32 * 32;
-    if (off_vec + (uint64_t)kTreeVectors * out.vec_stride() >= (1ull << 32)) { out.blob.clear(); return; }     // (32-bit offsets: a 30-GB workspace is not a component)
+    // The kernel addresses A's tiles, the factor's tiles and the vectors through three buffer descriptors with 32-bit BYTE offsets
+    // (tile << 11): fewer than 2^21 tiles (4 GB per array) and 32-bit double offsets for the rest - a dense 16 k-node component
+    // still fits, a dense 32 k-node one (34 GB of tiles) is refused with an error instead of wrapping around.
+    if (n_tiles >= (1u << 21) || off_vec + (uint64_t)kTreeVectors * out.vec_stride() >= (1ull << 32)) { out.blob.clear(); return; }
     blob[3] = (uint32_t)off_vec; blob[23] = (uint32_t)off_part; blob[24] = (uint32_t)out.vec_stride();
     // a model of the factorization's critical path: per level, the column tasks dealt to 8 waves
     {
