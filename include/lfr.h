@@ -129,6 +129,8 @@ typedef struct lfr_problem_stats {
     int64_t n_solved_nodes;        /* nodes (variable + constant) inside solved components */
     double tracks_ms, roots_ms, graph_cut_ms, assemble_ms;
     double kruskal_rounds;         /* device graph stage: parallel rounds spent on large connected components (0: none) */
+    double tie_resorts;            /* device graph stage: 1 if a long run of equal similarities made it order the matches with the three
+                                      stable sorts instead of the one sort + in-place tie fix (same order either way) */
 } lfr_problem_stats;
 
 /* max_nodes_in_component <= 0: use the number of seen images (solve.cc:586).

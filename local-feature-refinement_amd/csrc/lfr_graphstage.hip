@@ -5,9 +5,11 @@
 // The constrained maximum spanning forest is greedy over the globally sorted match list, i.e.
 // order dependent — but only INSIDE a connected component of the match graph: two matches of
 // different connected components never interact.  So (hard part 4):
-//   1. radix-sort the matches by (similarity, n1, n2) descending            (rocPRIM)
-//   2. plain connected components of the match graph, ignoring image conflicts (lock-free union-find)
-//   3. stable-sort the ordered matches by connected component
+//   1. plain connected components of the match graph, ignoring image conflicts (lock-free union-find)
+//   2. ONE radix sort (rocPRIM) by (connected component, similarity descending), then the runs of equal similarities inside a
+//      component put into the reference's (n1, n2) descending order in place (k_tie_fix).  Only when such a run is longer than
+//      kMaxTieRun: the round-3 scheme, radix sorts by n2, by (similarity, n1) and - stable - by connected component.
+//   3. (the segments of that list = the connected components)
 //   4. small connected components: one thread each replays the reference's sequential union-find with the
 //      image-conflict test over its own matches, in order.  Large ones (real match graphs are typically ONE
 //      giant connected component: wrong matches link the tracks) run the same greedy rule in parallel ROUNDS:
@@ -21,7 +23,7 @@
 // The whole chain is enqueued on ONE stream without host round trips: counts that size later steps
 // (segments, tracks, components) stay on the device and bound the kernels there; every array is sized
 // by its upper bound (N or M).  One 64-byte read-back at the end delivers the counts for the stdout lines
-// (a second one, mid-way, only tells whether large connected components exist).  A component above the size cap
+// (a second one, mid-way, tells whether large connected components exist and whether a long tie asks for the three sorts).  A component above the size cap
 // needs the graph cut: the sequential priority-queue bisection stays on the host, fed with the device's tracks
 // (lfr_graph.cpp: components_from_tracks), and the labels go back to HBM.
 // Integer work throughout; the only floating-point accumulation (root scores, sums of float32
@@ -46,6 +48,7 @@ namespace {
 constexpr int kThreads = kPipeThreads;
 constexpr int64_t kSerialSegmentEdges = 2048;     // connected components up to this many matches: one thread each
                                                    // (LFR_SERIAL_SEGMENT_EDGES overrides it: tests push everything through the rounds)
+constexpr int kMaxTieRun = 64;                     // runs of equal similarities inside a connected component up to this long are ordered in place (k_tie_fix)
 constexpr int kMaxRounds = 100000;                 // larger ones: parallel rounds (a path-shaped dependency chain this long: host stage)
 constexpr size_t kMaxBitsetBytes = (size_t)24 << 30;
 inline dim3 grid_for(int64_t n) { return pipe_grid(n); }
@@ -108,6 +111,16 @@ __global__ void k_match_keys(int64_t M, uint32_t n_minus_1, int node_bits, const
     k_lo[m] = n_minus_1 - n2[m];
     ids[m] = (uint32_t)m;
 }
+// The usual case needs ONE sort: connected components are known before any order is (the union-find of step 2 does not read one), so
+// the key (component | ~similarity) groups and orders the matches in seven radix passes; the thirteen passes of the three-sort
+// scheme above (n2, then (sim, n1), then the component, each stable) only break ties between EQUAL similarities inside a component, and
+// k_tie_fix does that in place for the short runs real similarities produce.
+__global__ void k_cc_sim_keys(int64_t M, const uint32_t *n1, const float *sim, const uint32_t *cc, uint64_t *key, uint32_t *ids) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    key[m] = ((uint64_t)cc[n1[m]] << 32) | (uint64_t)(~sim_key(sim[m]));
+    ids[m] = (uint32_t)m;
+}
 __global__ void k_gather_u64(int64_t n, const uint32_t *idx, const uint64_t *src, uint64_t *dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -165,8 +178,35 @@ __global__ void k_seg_flags(int64_t M, const uint32_t *keys, uint32_t *flags) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) flags[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1u : 0u;
 }
+__global__ void k_seg_flags_hi(int64_t M, const uint64_t *keys, uint32_t *flags) {                // (component | ~similarity) keys
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) flags[i] = (i == 0 || (keys[i] >> 32) != (keys[i - 1] >> 32)) ? 1u : 0u;
+}
 // counts[] layout (device): what the host reads back at the end of the stage
-enum { CNT_SEG = 0, CNT_TRACKS, CNT_COMPS, CNT_MAX_TRACK, CNT_MAX_COMP, CNT_MAX_SEG, CNT_WORDS = 16 };
+enum { CNT_SEG = 0, CNT_TRACKS, CNT_COMPS, CNT_MAX_TRACK, CNT_MAX_COMP, CNT_MAX_SEG, CNT_LONG_TIE, CNT_WORDS = 16 };
+// Runs of equal (component, similarity) in the one-sort order: the reference's order inside a run is descending (n1, n2) (solve.cc:489,
+// std::sort + reverse of (sim, n1, n2) tuples; equal triples are the same union whichever comes first - match id ascending, as the
+// stable three-sort scheme leaves them).  The head of a run sorts it by insertion; a run above max_run (quantized similarities in a
+// giant component) sets CNT_LONG_TIE and the host orders the list with the three sorts instead.
+__global__ void k_tie_fix(int64_t M, const uint64_t *key, uint32_t *order, const uint32_t *n1, const uint32_t *n2, int max_run, uint32_t *counts) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint64_t k = key[i];
+    if ((i > 0 && key[i - 1] == k) || i + 1 >= M || key[i + 1] != k) return;      // inside a run / a run of one
+    int64_t j = i + 2;
+    while (j < M && j - i <= max_run && key[j] == k) ++j;
+    if (j - i > max_run) { counts[CNT_LONG_TIE] = 1u; return; }
+    for (int64_t a = i + 1; a < j; ++a) {
+        const uint32_t m = order[a], m1 = n1[m], m2 = n2[m];
+        int64_t b = a;
+        while (b > i) {
+            const uint32_t q = order[b - 1], q1 = n1[q], q2 = n2[q];
+            if (q1 > m1 || (q1 == m1 && (q2 > m2 || (q2 == m2 && q < m)))) break;  // q stays in front of m
+            order[b] = q; --b;
+        }
+        order[b] = m;
+    }
+}
 // seg_id[i] = exclusive count of flags; seg_id[M] = number of segments
 __global__ void k_seg_starts(int64_t M, const uint32_t *flags, const uint32_t *seg_id, uint32_t *starts, uint32_t *counts) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -798,34 +838,45 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipMemsetAsync(bnode, 0xff, 4 * (size_t)N, st));          // -1
     LFR_HIP_TRY(hipEventRecord(ev[0], st));
 
-    // 1. matches in the reference's order: descending (sim, n1, n2)
-    TAKE(khi, uint64_t, M); TAKE(khi2, uint64_t, M); TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
-    TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
-    hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, (uint32_t)(N - 1), node_bits, n1, n2, sim, khi, klo, id0);
-    if ((rc = sort_pairs(arena, klo, klo2, id0, id1, M, 0, node_bits, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, id1, khi, khi2);
-    if ((rc = sort_pairs(arena, khi2, khi, id1, id0, M, 0, 32 + node_bits, st)) != LFR_OK) return rc;
-    uint32_t *order = id0;
-
-    // 2. connected components of the match graph (conflicts ignored)
+    // 1. connected components of the match graph (conflicts ignored)
     TAKE(cc_parent, uint32_t, N); TAKE(cc, uint32_t, N);
     hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, cc_parent);
     hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, cc_parent);
     hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, cc_parent, cc);
 
-    // 3. ordered matches grouped by connected component (stable)
+    // 2. matches grouped by connected component, inside a component in the reference's order: descending (sim, n1, n2).
+    //    One sort over (component | ~sim) + the tie fix; the exact three-sort order only if a run of equal similarities is too long for it
+    TAKE(khi, uint64_t, M); TAKE(khi2, uint64_t, M); TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
+    TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
     TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(segid, uint32_t, M + 1);
     TAKE(starts, uint32_t, std::min(N, M) + 2);
-    hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, order, n1, cc, ck0);
-    if ((rc = sort_pairs(arena, ck0, ck1, order, id1, M, 0, node_bits, st)) != LFR_OK) return rc;
-    order = id1;
-    hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
+    uint32_t *const order = id1;
+    int max_tie_run = kMaxTieRun;
+    if (const char *e = getenv("LFR_MAX_TIE_RUN")) max_tie_run = std::max(0, atoi(e));     // (tests: 0 = always the three sorts)
+    auto three_sorts = [&]() -> int {
+        int r;
+        hipLaunchKernelGGL(k_match_keys, grid_for(M), dim3(kThreads), 0, st, M, (uint32_t)(N - 1), node_bits, n1, n2, sim, khi, klo, id0);
+        if ((r = sort_pairs(arena, klo, klo2, id0, id1, M, 0, node_bits, st)) != LFR_OK) return r;
+        hipLaunchKernelGGL(k_gather_u64, grid_for(M), dim3(kThreads), 0, st, M, id1, khi, khi2);
+        if ((r = sort_pairs(arena, khi2, khi, id1, id0, M, 0, 32 + node_bits, st)) != LFR_OK) return r;
+        hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, id0, n1, cc, ck0);
+        return sort_pairs(arena, ck0, ck1, id0, id1, M, 0, node_bits, st);                // stable: -> order
+    };
+    if (max_tie_run > 0) {
+        hipLaunchKernelGGL(k_cc_sim_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, sim, cc, khi, id0);
+        if ((rc = sort_pairs(arena, khi, khi2, id0, id1, M, 0, 32 + node_bits, st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_tie_fix, grid_for(M), dim3(kThreads), 0, st, M, khi2, order, n1, n2, max_tie_run, counts);
+        hipLaunchKernelGGL(k_seg_flags_hi, grid_for(M), dim3(kThreads), 0, st, M, khi2, flags);
+    } else {
+        if ((rc = three_sorts()) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
+    }
     if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc;
     const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
     hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
     hipLaunchKernelGGL(k_seg_maxlen, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
 
-    // 4. greedy constrained union-find per connected component: small ones one thread each ...
+    // 3. greedy constrained union-find per connected component: small ones one thread each ...
     TAKE(par, int32_t, N); TAKE(next, int32_t, N); TAKE(tail, int32_t, N); TAKE(cnt, int32_t, N); TAKE(sig, ulonglong2, N);
     hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, dg->node_image, par, next, tail, cnt, sig);
     int64_t serial_limit = kSerialSegmentEdges;
@@ -837,6 +888,16 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
     LFR_HIP_TRY(stream_wait(st));
     lap("first read-back");
+    if (h_counts[CNT_LONG_TIE]) {
+        // a long run of equal similarities: the exact order from the three sorts (the segments - which matches, where - are the same:
+        // flags, segment ids and starts stay), the union-find of the small components again from scratch
+        if ((rc = three_sorts()) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, dg->node_image, par, next, tail, cnt, sig);
+        hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
+                           dg->node_image, par, next, tail, cnt, sig);
+        p.stats.tie_resorts = 1.0;
+        lap("three-sort order after a long tie");
+    }
     if (trace && ev_begin) {
         float a = 0.f;
         (void)hipEventElapsedTime(&a, ev_begin, ev[0]);

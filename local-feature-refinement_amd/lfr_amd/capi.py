@@ -29,7 +29,7 @@ class ProblemStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in (
         "n_tracks", "max_track_size", "n_components", "max_component_size", "n_cut_components",
         "n_solved_components", "n_solved_tracks", "n_solved_edges", "n_solved_nodes")] + \
-        [(n, C.c_double) for n in ("tracks_ms", "roots_ms", "graph_cut_ms", "assemble_ms", "kruskal_rounds")]
+        [(n, C.c_double) for n in ("tracks_ms", "roots_ms", "graph_cut_ms", "assemble_ms", "kruskal_rounds", "tie_resorts")]
 
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_}

@@ -222,6 +222,33 @@ def test_round_based_union_find_fuzz(lfr_lib, monkeypatch, cooperative):
     assert n_ok >= 120
 
 
+@pytest.mark.parametrize("max_run", [None, "2", "0"])
+def test_equal_similarities_keep_the_reference_order(lfr_lib, monkeypatch, max_run):
+    """The device stage orders the matches with ONE sort by (connected component, similarity) and puts runs of equal similarities into the
+    reference's (n1, n2) descending order in place (solve.cc:489); a run above kMaxTieRun (LFR_MAX_TIE_RUN) sends it to the three stable
+    sorts.  Quantized similarities in small components (short runs), in a giant component (runs of thousands) and the fuzz cases (three
+    similarity values): labels bit-identical to the host stage whichever way the order was made."""
+    from test_graph_stage import fuzz_pairs
+    if max_run is not None:
+        monkeypatch.setenv("LFR_MAX_TIE_RUN", max_run)
+    small = synthetic.generate(seed=311, n_images=64, n_tracks=3000, eps_out=0.001)
+    small.sim[:] = np.round(small.sim * 64.0) / 64.0                               # ~17 matches per component over a few dozen values
+    _, pd = _labels_equal(small)
+    assert pd.stats()["tie_resorts"] == (1 if max_run == "2" else 0)               # default: fixed in place ("0": three sorts from the start)
+    giant = synthetic.generate(seed=312, n_images=40, n_tracks=3000, eps_out=0.05)
+    giant.sim[:] = np.round(giant.sim * 8.0) / 8.0
+    ph, pd = _labels_equal(giant)
+    assert pd.stats()["kruskal_rounds"] > 0
+    assert pd.stats()["tie_resorts"] == (0 if max_run == "0" else 1)               # runs of thousands: the three sorts
+    a, _ = ph.solve_hip(0)
+    b, _ = pd.solve_hip(0)
+    assert (a == b).all()
+    for seed in range(3200, 3260):
+        ma = synthetic.pairs_to_arrays(fuzz_pairs(seed))
+        if ma.n_matches:
+            _labels_equal(ma)
+
+
 @pytest.mark.parametrize("scaling", ["weak", "strong"])
 def test_bench_two_ranks_on_one_gpu(lfr_lib, scaling):
     """bench.py's N>1 path end to end: two ranks (gloo, both on GPU 0) started by bench.py itself; weak = one graph per
