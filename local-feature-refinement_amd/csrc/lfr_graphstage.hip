@@ -19,7 +19,8 @@
 //      so every union happens with exactly the operands it has in the sequential order (same roots, same sizes,
 //      same tie rule).  Image sets are per-root bitsets (#images bits).
 //   5. track ids = rank of the root nodes; roots = arg-max (score, node) per track; components =
-//      connected components of the track meta-graph, numbered by their smallest track.
+//      connected components of the track meta-graph, numbered by their smallest track - these ARE the connected components of
+//      step 1 (k_cc_min_track), a second union-find only runs after a cut (k_meta_union_cut).
 // The whole chain is enqueued on ONE stream without host round trips: counts that size later steps
 // (segments, tracks, components) stay on the device and bound the kernels there; every array is sized
 // by its upper bound (N or M).  One 64-byte read-back at the end delivers the counts for the stdout lines
@@ -131,16 +132,28 @@ __global__ void k_iota(int64_t n, uint32_t *p) {
 }
 
 // ---- lock-free union-find (hook the larger root under the smaller): labels = smallest member ----
-// Every access to parent[] is an agent-scope atomic: a plain load may be served from the CU's
-// non-coherent vector L1, and a stale "parent[a] == a" there makes the CAS loop spin forever.
+// The walks of a find read parent[] with WORKGROUP-scope atomic loads: they may be served from the CU's vector L1, i.e. be stale.  Sound:
+// every value parent[x] ever held is an ancestor of x (or x itself) and, if not x, smaller than x, so a stale walk ends at an ancestor, and
+// what decides a union is the agent-scope CAS - on a node that is no root any more it fails and hands back the current parent, from which
+// uf_union continues (strictly smaller: it terminates); on a true root `a` with a stale, former root `b` < a it hooks a under a member of
+// b's tree, which still joins the two trees, still points downwards, and leaves the root the smallest member.  Why not agent scope
+// everywhere: in a giant connected component every find ends at the same root, and a single L2 channel serves ~2 G requests/s - the
+// finds of config 5's 5.3 M matches queued on that one word (k_cc_union: 1.4 ms; the stages below and the gated halving of uf_find are the rest of that story).
 __device__ __forceinline__ uint32_t uf_load(const uint32_t *parent, uint32_t x) {
     return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+constexpr int kHalveAfterHops = 3;
+__device__ __forceinline__ uint32_t uf_load_near(const uint32_t *parent, uint32_t x) {
+    return __hip_atomic_load(&parent[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ uint32_t uf_find(uint32_t *parent, uint32_t x) {
-    uint32_t p = uf_load(parent, x);
-    while (p != x) {                                           // path halving (parents only ever decrease)
-        const uint32_t gp = uf_load(parent, p);
-        if (gp != p) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t p = uf_load_near(parent, x);
+    int hops = 0;
+    while (p != x) {
+        // path halving, but only on walks that turn out long: thousands of threads see the same short stale path below a hot root, and
+        // their (agent-scope) halving stores of the same words queued at the L2 - config 5: 1.0-1.6 ms with them, 0.15 without
+        const uint32_t gp = uf_load_near(parent, p);
+        if (gp != p && ++hops > kHalveAfterHops) __hip_atomic_store(&parent[x], gp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         x = p; p = gp;
     }
     return x;
@@ -155,9 +168,32 @@ __device__ __forceinline__ void uf_union(uint32_t *parent, uint32_t a, uint32_t 
         a = seen;                                               // a was hooked meanwhile: continue from its new parent
     }
 }
-__global__ void k_cc_union(int64_t M, const uint32_t *n1, const uint32_t *n2, uint32_t *parent) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) uf_union(parent, n1[m], n2[m]);
+// Real match graphs are ONE giant connected component: millions of unions then meet at a handful of roots.  So the unions run in
+// stages (the sampling idea of Afforest, Sutton et al. 2018): every 32nd match first, then every 4th, then the rest, the parents
+// flattened in between (k_uf_flatten).  The giant component forms in a stage with few threads, and from the second stage on a match
+// whose ends already show the same parent is skipped without touching an atomic.  That test reads parent[] with plain loads: any
+// value parent[x] ever held is an ancestor of x in the final forest (a root is hooked under another root, a halving store writes a
+// grandparent, the flattening writes the root), so equal parents - however stale - prove that the ends are connected; unequal ones fall
+// through to the lock-free union.  The labels (smallest member) do not depend on the schedule.  Config 5 (5.3 M matches, one giant
+// component): 1.4 ms as one pass with agent-scope walks, 0.15 ms now; config 4 (147 k small components): 0.14 ms either way.
+constexpr int kUnionStages = 3;
+constexpr int kUnionStrides[kUnionStages] = {32, 4, 1};
+__device__ __forceinline__ bool uf_connected_hint(const uint32_t *parent, uint32_t a, uint32_t b) { return parent[a] == parent[b]; }
+__global__ void k_uf_flatten(int64_t n, uint32_t *parent) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x = (uint32_t)i, p = uf_load(parent, x);
+    if (p == x) return;
+    while (p != x) { x = p; p = uf_load(parent, x); }
+    __hip_atomic_store(&parent[i], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // (a walker through i sees the old ancestor or the root)
+}
+// one stage: the matches 0, stride, 2 stride, ... except those an earlier stage (multiples of done_stride, 0 = none) has united already
+__global__ void k_cc_union(int64_t M, int stride, int done_stride, const uint32_t *n1, const uint32_t *n2, uint32_t *parent) {
+    const int64_t m = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * stride;
+    if (m >= M || (done_stride && m % done_stride == 0)) return;
+    const uint32_t a = n1[m], b = n2[m];
+    if (done_stride && uf_connected_hint(parent, a, b)) return;
+    uf_union(parent, a, b);
 }
 // Labels = roots, written to a SEPARATE array by a read-only walk.  (Flattening in place - parent[i] = find(i) with
 // path halving - is wrong under concurrency: another thread's halving store, computed from an older read of
@@ -213,9 +249,15 @@ __global__ void k_seg_starts(int64_t M, const uint32_t *flags, const uint32_t *s
     if (i < M && flags[i]) starts[seg_id[i]] = (uint32_t)i;
     if (i == 0) { starts[seg_id[M]] = (uint32_t)M; counts[CNT_SEG] = seg_id[M]; }
 }
+// a maximum into ONE word (v = 0 for lanes without a value): atomics on one address take their turns at the L2 (~2 ns each: 14 k waves
+// were 28 us of a 5-us kernel), so the wave reduces first and only sends its maximum if it beats what the word already holds
+__device__ __forceinline__ void wave_atomic_max(uint32_t v, uint32_t *dst) {
+    for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
+    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
+}
 __global__ void k_seg_maxlen(int64_t cap, const uint32_t *starts, uint32_t *counts) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < cap && s < (int64_t)counts[CNT_SEG]) atomicMax(&counts[CNT_MAX_SEG], starts[s + 1] - starts[s]);
+    wave_atomic_max((s < cap && s < (int64_t)counts[CNT_SEG]) ? starts[s + 1] - starts[s] : 0u, &counts[CNT_MAX_SEG]);
 }
 
 // ---- the reference's greedy constrained union-find, one thread per connected component ----
@@ -293,57 +335,111 @@ __device__ __forceinline__ uint32_t wave_append(bool keep, uint32_t *counter) {
     }
     return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
 }
+// ... and with one atomic per WORKGROUP, ITEMS candidates per thread: a returning atomic on one address costs ~10 ns at the L2 whoever
+// sends it, so a list of millions built wave by wave (83 k atomics for config 5's 5.3 M matches) spent 0.25-1 ms per pass on its counter.
+// Every thread of the (kThreads-wide) workgroup must call it.
+template <int ITEMS>
+__device__ __forceinline__ void block_append(const bool (&keep)[ITEMS], uint32_t *counter, uint32_t (&at)[ITEMS]) {
+    __shared__ uint32_t s_wave[kThreads / 64];
+    __shared__ uint32_t s_base;
+    const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const unsigned long long mask = __ballot(keep[j]);
+        at[j] = run + (uint32_t)__popcll(mask & below);
+        run += (uint32_t)__popcll(mask);
+    }
+    if (lane == 0) s_wave[w] = run;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int i = 0; i < kThreads / 64; ++i) { const uint32_t c = s_wave[i]; s_wave[i] = total; total += c; }
+        s_base = total ? atomicAdd(counter, total) : 0u;
+    }
+    __syncthreads();
+    const uint32_t base = s_base + s_wave[w];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) at[j] += base;
+}
+constexpr int kAppendItems = 8;
+inline dim3 grid_for_items(int64_t n, int items) { return grid_for((n + items - 1) / items); }
 struct Pending { uint32_t k; int32_t ra, rb; };     // position in the ordered match list, roots of n1 / n2
 // matches of large connected components -> the first pending list; bit of the own image for their nodes
 __global__ void k_large_pending(int64_t k_lo, int64_t k_hi, int64_t serial_limit, const uint32_t *flags, const uint32_t *seg_id, const uint32_t *starts, const uint32_t *order,
                                 const uint32_t *n1, const uint32_t *n2, const int32_t *node_image, int W, unsigned long long *bits,
                                 Pending *pend, uint32_t *n_pend) {
-    const int64_t k = k_lo + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // positions [k_lo, k_hi) of the ordered list
-    bool large = false;
-    uint32_t m = 0;
-    if (k < k_hi) {
-        const uint32_t s = seg_id[k] + flags[k] - 1u;           // segment of position k
-        large = (int64_t)(starts[s + 1] - starts[s]) > serial_limit;
-        m = order[k];
+    const int64_t k0 = k_lo + (int64_t)blockIdx.x * (kThreads * kAppendItems) + threadIdx.x;      // positions [k_lo, k_hi) of the ordered list
+    bool large[kAppendItems];
+    uint32_t at[kAppendItems];
+#pragma unroll
+    for (int j = 0; j < kAppendItems; ++j) {
+        const int64_t k = k0 + (int64_t)j * kThreads;
+        large[j] = false;
+        if (k < k_hi) {
+            const uint32_t s = seg_id[k] + flags[k] - 1u;           // segment of position k
+            large[j] = (int64_t)(starts[s + 1] - starts[s]) > serial_limit;
+        }
     }
-    const uint32_t at = wave_append(large, n_pend);
-    if (!large) return;
-    const uint32_t a = n1[m], b = n2[m];
-    pend[at] = Pending{(uint32_t)k, (int32_t)a, (int32_t)b};
-    if (bits) {                                                  // (idempotent: several matches set the same bit)
-        atomicOr(&bits[(size_t)a * W + (node_image[a] >> 6)], 1ull << (node_image[a] & 63));
-        atomicOr(&bits[(size_t)b * W + (node_image[b] >> 6)], 1ull << (node_image[b] & 63));
+    block_append(large, n_pend, at);
+#pragma unroll
+    for (int j = 0; j < kAppendItems; ++j) {
+        if (!large[j]) continue;
+        const int64_t k = k0 + (int64_t)j * kThreads;
+        const uint32_t m = order[k], a = n1[m], b = n2[m];
+        pend[at[j]] = Pending{(uint32_t)k, (int32_t)a, (int32_t)b};
+        if (bits) {                                                  // (idempotent: several matches set the same bit)
+            atomicOr(&bits[(size_t)a * W + (node_image[a] >> 6)], 1ull << (node_image[a] & 63));
+            atomicOr(&bits[(size_t)b * W + (node_image[b] >> 6)], 1ull << (node_image[b] & 63));
+        }
     }
 }
 // retire what can never be accepted (same root / shared image: monotone), bid for the roots with the rest
 // (one call per wave-wide slice of the pending list: every lane of the wave calls it, `valid` says whether it holds an entry)
-__device__ __forceinline__ void round_eval_one(bool valid, Pending q, int32_t *parent, const unsigned long long *bits, int W,
-                                               unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
-    bool keep = false;
-    if (valid) {
-        q.ra = par_find(parent, q.ra); q.rb = par_find(parent, q.rb);
-        if (q.ra != q.rb) {
-            const unsigned long long *A = bits + (size_t)q.ra * W, *B = bits + (size_t)q.rb * W;
-            unsigned long long any = 0ull;
-            for (int w = 0; w < W; ++w) any |= A[w] & B[w];       // solve.cc:506-511
-            keep = any == 0ull;
-        }
-    }
-    const uint32_t at = wave_append(keep, n_out);
-    if (!keep) return;
-    out[at] = q;
+__device__ __forceinline__ bool round_evaluate(bool valid, Pending &q, int32_t *parent, const unsigned long long *bits, int W) {
+    if (!valid) return false;
+    q.ra = par_find(parent, q.ra); q.rb = par_find(parent, q.rb);
+    if (q.ra == q.rb) return false;
+    const unsigned long long *A = bits + (size_t)q.ra * W, *B = bits + (size_t)q.rb * W;
+    unsigned long long any = 0ull;
+    for (int w = 0; w < W; ++w) any |= A[w] & B[w];               // solve.cc:506-511
+    return any == 0ull;
+}
+__device__ __forceinline__ void round_bid(const Pending q, unsigned long long round_hi, unsigned long long *minpos) {
     const unsigned long long key = round_hi | q.k;                // a later round's bid beats every stale entry
     // thousands of matches bid for the root of a grown track and all but one lose: look before bidding (the value only
     // decreases, so a bid that does not beat what is already there could not have won)
     if (key < __hip_atomic_load(&minpos[q.ra], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.ra], key);
     if (key < __hip_atomic_load(&minpos[q.rb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&minpos[q.rb], key);
 }
+__device__ __forceinline__ void round_eval_one(bool valid, Pending q, int32_t *parent, const unsigned long long *bits, int W,
+                                               unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
+    const bool keep = round_evaluate(valid, q, parent, bits, W);
+    const uint32_t at = wave_append(keep, n_out);
+    if (!keep) return;
+    out[at] = q;
+    round_bid(q, round_hi, minpos);
+}
+constexpr int kEvalItems = 4;
 __global__ void k_round_eval(const uint32_t *n_in_p, const Pending *in, int32_t *parent, const unsigned long long *bits, int W,
                              unsigned long long round_hi, unsigned long long *minpos, Pending *out, uint32_t *n_out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t i0 = blockIdx.x * (kThreads * kEvalItems) + threadIdx.x;
     const uint32_t n_in = *n_in_p;                                // (the launch is sized by an upper bound: the count of an earlier round)
-    const bool valid = i < n_in;
-    round_eval_one(valid, valid ? in[i] : Pending{0, 0, 0}, parent, bits, W, round_hi, minpos, out, n_out);
+    if (blockIdx.x * (kThreads * kEvalItems) >= n_in) return;     // (uniform over the workgroup)
+    Pending q[kEvalItems];
+    bool keep[kEvalItems];
+    uint32_t at[kEvalItems];
+#pragma unroll
+    for (int j = 0; j < kEvalItems; ++j) {
+        const uint32_t i = i0 + j * kThreads;
+        const bool valid = i < n_in;
+        q[j] = valid ? in[i] : Pending{0, 0, 0};
+        keep[j] = round_evaluate(valid, q[j], parent, bits, W);
+    }
+    block_append(keep, n_out, at);
+#pragma unroll
+    for (int j = 0; j < kEvalItems; ++j) if (keep[j]) { out[at[j]] = q[j]; round_bid(q[j], round_hi, minpos); }
 }
 // counters of a batch of rounds: c[j] = matches pending before round j of the batch; the last count of the previous batch moves to the front
 __global__ void k_round_counters_shift(uint32_t *c, int R) {
@@ -462,17 +558,25 @@ __global__ void k_track_comp(int64_t cap, const uint32_t *counts, const uint32_t
 }
 __global__ void k_cut_edges(int64_t M, const uint32_t *n1, const uint32_t *n2, const float *sim, const int32_t *track, const int32_t *tcomp,
                             const uint32_t *csize, uint32_t max_nodes, unsigned long long *pair_key, double *pair_sim, uint32_t *n_list) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool keep = false;
-    int32_t ta = 0, tb = 0;
-    if (m < M) {
-        ta = track[n1[m]]; tb = track[n2[m]];
-        keep = ta != tb && csize[tcomp[ta]] > max_nodes;
+    const int64_t m0 = (int64_t)blockIdx.x * (kThreads * kAppendItems) + threadIdx.x;
+    bool keep[kAppendItems];
+    uint32_t at[kAppendItems];
+    int32_t ta[kAppendItems], tb[kAppendItems];
+#pragma unroll
+    for (int j = 0; j < kAppendItems; ++j) {
+        const int64_t m = m0 + (int64_t)j * kThreads;
+        keep[j] = false; ta[j] = tb[j] = 0;
+        if (m < M) {
+            ta[j] = track[n1[m]]; tb[j] = track[n2[m]];
+            keep[j] = ta[j] != tb[j] && csize[tcomp[ta[j]]] > max_nodes;
+        }
     }
-    const uint32_t at = wave_append(keep, n_list);
-    if (keep) {
-        pair_key[at] = ((unsigned long long)(uint32_t)min(ta, tb) << 32) | (uint32_t)max(ta, tb);
-        pair_sim[at] = (double)sim[m];
+    block_append(keep, n_list, at);
+#pragma unroll
+    for (int j = 0; j < kAppendItems; ++j) {
+        if (!keep[j]) continue;
+        pair_key[at[j]] = ((unsigned long long)(uint32_t)min(ta[j], tb[j]) << 32) | (uint32_t)max(ta[j], tb[j]);
+        pair_sim[at[j]] = (double)sim[m0 + (int64_t)j * kThreads];
     }
 }
 // meta union without the cut edges (solve.cc:346-353): gc[t] = subset of track t inside its oversized component, -1 elsewhere
@@ -528,11 +632,27 @@ __global__ void k_mark_roots(int64_t cap, const uint32_t *counts, const int32_t 
 }
 
 // ---- components of the track meta-graph ----
-__global__ void k_meta_union(int64_t M, const uint32_t *n1, const uint32_t *n2, const int32_t *track, uint32_t *parent) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const int32_t ta = track[n1[m]], tb = track[n2[m]];
-    if (ta != tb) uf_union(parent, (uint32_t)ta, (uint32_t)tb);
+// Two tracks are in one component of the meta-graph iff their nodes are in one connected component of the MATCH graph (a track is
+// connected through its accepted matches; every other match joins two tracks and is a meta edge, solve.cc:262-290), and those labels exist
+// since step 1.  So no second union-find over the matches (config 5: 2.3 ms, every union at the root of the one giant component): the
+// component of track t is named by the smallest track of its connected component.
+__global__ void k_cc_min_track(int64_t n, const uint32_t *cc, const int32_t *track, uint32_t *min_track) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = i < n;
+    const uint32_t c = valid ? cc[i] : 0xffffffffu;
+    uint32_t t = valid ? (uint32_t)track[i] : 0xffffffffu;
+    // the lanes that share the first lane's component send one minimum (a giant component: the whole wave), the others their own;
+    // nobody sends what cannot lower the word (it only decreases, so a stale read errs on the side of sending)
+    const uint32_t c0 = (uint32_t)__shfl((int)c, 0, 64);
+    const bool same = c == c0;
+    uint32_t ts = same ? t : 0xffffffffu;
+    for (int o = 32; o > 0; o >>= 1) ts = min(ts, (uint32_t)__shfl_xor((int)ts, o, 64));
+    if (same) { if ((threadIdx.x & 63) != 0) return; t = ts; }
+    if (valid && t < min_track[c]) atomicMin(&min_track[c], t);
+}
+__global__ void k_track_label(int64_t n, const uint32_t *cc, const int32_t *track, const uint32_t *min_track, uint32_t *label) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) label[track[i]] = min_track[cc[i]];                // (every node of a track writes the same value)
 }
 __global__ void k_comp_flags(int64_t cap, const uint32_t *counts, const uint32_t *parent, uint32_t *flags) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,10 +662,9 @@ __global__ void k_comp_flags(int64_t cap, const uint32_t *counts, const uint32_t
 __global__ void k_comp_sizes(int64_t cap, uint32_t *counts, const uint32_t *parent, const uint32_t *rank, const uint32_t *tsize, uint32_t *csize) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) counts[CNT_COMPS] = rank[cap];
-    if (t < cap && t < (int64_t)counts[CNT_TRACKS]) {
-        atomicAdd(&csize[rank[parent[t]]], tsize[t]);
-        atomicMax(&counts[CNT_MAX_TRACK], tsize[t]);
-    }
+    const bool live = t < cap && t < (int64_t)counts[CNT_TRACKS];
+    if (live) atomicAdd(&csize[rank[parent[t]]], tsize[t]);
+    wave_atomic_max(live ? tsize[t] : 0u, &counts[CNT_MAX_TRACK]);
 }
 __global__ void k_node_comp(int64_t n, const int32_t *track, const uint32_t *parent, const uint32_t *rank, int32_t *comp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -553,7 +672,7 @@ __global__ void k_node_comp(int64_t n, const int32_t *track, const uint32_t *par
 }
 __global__ void k_max_csize(int64_t cap, uint32_t *counts, const uint32_t *csize) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < cap && c < (int64_t)counts[CNT_COMPS]) atomicMax(&counts[CNT_MAX_COMP], csize[c]);
+    wave_atomic_max((c < cap && c < (int64_t)counts[CNT_COMPS]) ? csize[c] : 0u, &counts[CNT_MAX_COMP]);
 }
 
 }  // namespace
@@ -841,7 +960,12 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     // 1. connected components of the match graph (conflicts ignored)
     TAKE(cc_parent, uint32_t, N); TAKE(cc, uint32_t, N);
     hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, cc_parent);
-    hipLaunchKernelGGL(k_cc_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, cc_parent);
+    {
+        for (int i = 0, done = 0; i < kUnionStages; done = kUnionStrides[i], ++i) {
+            if (i) hipLaunchKernelGGL(k_uf_flatten, grid_for(N), dim3(kThreads), 0, st, N, cc_parent);
+            hipLaunchKernelGGL(k_cc_union, grid_for((M + kUnionStrides[i] - 1) / kUnionStrides[i]), dim3(kThreads), 0, st, M, kUnionStrides[i], done, n1, n2, cc_parent);
+        }
+    }
     hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, cc_parent, cc);
 
     // 2. matches grouped by connected component, inside a component in the reference's order: descending (sim, n1, n2).
@@ -975,7 +1099,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         for (int64_t k_lo = 0, size = first_block; !done && k_lo < M; k_lo += size, size *= 2) {
             const int64_t k_hi = std::min(M, k_lo + size);
             LFR_HIP_TRY(hipMemsetAsync(rc_ + kRoundBatch, 0, 4, st));
-            hipLaunchKernelGGL(k_large_pending, grid_for(k_hi - k_lo), dim3(kThreads), 0, st, k_lo, k_hi, serial_limit, flags, segid, starts, order, n1, n2,
+            hipLaunchKernelGGL(k_large_pending, grid_for_items(k_hi - k_lo, kAppendItems), dim3(kThreads), 0, st, k_lo, k_hi, serial_limit, flags, segid, starts, order, n1, n2,
                                dg->node_image, W, bits, pa, rc_ + kRoundBatch);
             LFR_HIP_TRY(hipMemcpyAsync(h_ctr, rc_ + kRoundBatch, 4, hipMemcpyDeviceToHost, st));
             LFR_HIP_TRY(stream_wait(st));
@@ -985,7 +1109,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
                 for (int j = 0; j < kRoundBatch; ++j, ++launched) {
                     const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;
-                    hipLaunchKernelGGL(k_round_eval, grid_for(bound), dim3(kThreads), 0, st, rc_ + j, pa, par, bits, W, round_hi, minpos, pb, rc_ + j + 1);
+                    hipLaunchKernelGGL(k_round_eval, grid_for_items(bound, kEvalItems), dim3(kThreads), 0, st, rc_ + j, pa, par, bits, W, round_hi, minpos, pb, rc_ + j + 1);
                     hipLaunchKernelGGL(k_round_accept, grid_for(bound), dim3(kThreads), 0, st, rc_ + j + 1, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
                     std::swap(pa, pb);
                 }
@@ -1015,9 +1139,9 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
 
     // components of the track meta-graph, numbered by their smallest track (solve.cc:292-300)
     TAKE(mp_parent, uint32_t, N); TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);
-    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, mp_parent);
-    hipLaunchKernelGGL(k_meta_union, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, dp->track, mp_parent);
-    hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, mp_parent, mp);
+    LFR_HIP_TRY(hipMemsetAsync(mp_parent, 0xff, 4 * (size_t)N, st));                     // (here: smallest track per connected component)
+    hipLaunchKernelGGL(k_cc_min_track, grid_for(N), dim3(kThreads), 0, st, N, cc, dp->track, mp_parent);
+    hipLaunchKernelGGL(k_track_label, grid_for(N), dim3(kThreads), 0, st, N, cc, dp->track, mp_parent, mp);
     hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
     if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
@@ -1074,7 +1198,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         if (!pair_key || !pair_sim) { set_error("graph stage: cut arena exhausted"); return LFR_ERR_NOMEM; }
         LFR_HIP_TRY(hipMemsetAsync(cut_n, 0, 64, st));
         hipLaunchKernelGGL(k_track_comp, grid_for(T), dim3(kThreads), 0, st, T, counts, mp, crank, tcomp);
-        hipLaunchKernelGGL(k_cut_edges, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, pair_key, pair_sim, cut_n);
+        hipLaunchKernelGGL(k_cut_edges, grid_for_items(M, kAppendItems), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, tcomp, csize, (uint32_t)max_nodes, pair_key, pair_sim, cut_n);
         uint32_t *h_n = h_counts + 8;
         LFR_HIP_TRY(hipMemcpyAsync(h_n, cut_n, 4, hipMemcpyDeviceToHost, st));
         LFR_HIP_TRY(stream_wait(st));
