@@ -235,29 +235,30 @@ __global__ void k_edge_words(int64_t cap, const uint32_t *total_edges_p, const u
 // (component, destination, edge index) keys of the in-edge sort.  Packed-class edges carry their key too (the sorted
 // position of a key is its position in the batch's edge array: solve_block_kernel indexes in_idx from the
 // component's edge offset); only the padding behind total_edges gets a key that sorts last.
-__global__ void k_incidence(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
-                            const int32_t *comp, const int32_t *di_of_comp, const uint32_t *class_of_desc, const uint32_t *edge_off,
-                            const uint32_t *node_off, const uint32_t *local_of, NodeInc *inc, uint64_t *in_keys, uint32_t *in_vals) {
+__global__ void k_incidence(int64_t cap, const uint32_t *total_edges_p, const uint64_t *keys_sorted, int node_bits, const uint32_t *words,
+                            const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2, const uint32_t *class_of_desc,
+                            const uint32_t *edge_off, const uint32_t *node_off, const uint32_t *local_of, NodeInc *inc, uint64_t *in_keys, uint32_t *in_vals) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= cap) return;
     in_keys[p] = 0x0000ffffffffffffull; in_vals[p] = 0u;
-    if (p >= (int64_t)*total_edges_p) return;
-    uint32_t s, d;
-    edge_ends(node1, node2, edge_sorted[p], s, d);
-    const uint32_t di = (uint32_t)di_of_comp[comp[s]];
-    const uint32_t ls = local_of[s], ld = local_of[d];
+    const int64_t total = (int64_t)*total_edges_p;
+    if (p >= total) return;
+    // component and source node come with the sorted key (component << node_bits | source, k_edge_keys), the local ids with the record
+    // words when the fused gather wrote them: no walk back through the match arrays (six dependent gathers per edge were 0.8 ms of
+    // config 5's assembly, with or without the atomics that used to count the runs)
+    const uint64_t key = keys_sorted[p];
+    const uint32_t di = (uint32_t)(key >> node_bits);
+    uint32_t ls, ld;
+    if (words) { const uint32_t w = words[p]; ls = w & 0xffffu; ld = (w >> 16) & 0x7fffu; }
+    else { uint32_t s, d; edge_ends(node1, node2, edge_sorted[p], s, d); ls = local_of[s]; ld = local_of[d]; }
     const uint32_t eo = edge_off[di], no = node_off[di];
     const uint32_t local_edge = (uint32_t)p - eo;
     in_keys[p] = ((uint64_t)di << 16) | ld;            // in-edge lists: by component, destination, edge index
     in_vals[p] = local_edge;
     if (class_of_desc[di] < (uint32_t)KC_BLOCK) return;
-    // a node's out-edges are a run of this list (sorted by component, then source): the first of the run writes where it begins, the
-    // last where it ends - k_inc_counts turns the ends into counts.  (One atomicAdd per edge on the node's counter - 60-90 edges of
-    // a wave on one word - was 0.8 of the 1.1 ms of this kernel on config 5; the in-edge runs: k_in_begin.)
-    bool first = local_edge == 0, last = p + 1 >= (int64_t)*total_edges_p;
-    uint32_t qs, qd;
-    if (!first) { edge_ends(node1, node2, edge_sorted[p - 1], qs, qd); first = qs != s; }
-    if (!last) { edge_ends(node1, node2, edge_sorted[p + 1], qs, qd); last = qs != s; }
+    // a node's out-edges are a run of this list (workgroup classes: sorted by component, then source): the first of the run writes
+    // where it begins, the last where it ends - k_inc_counts turns the ends into counts (the in-edge runs: k_in_begin)
+    const bool first = p == 0 || keys_sorted[p - 1] != key, last = p + 1 >= total || keys_sorted[p + 1] != key;
     if (first) inc[no + ls].out_begin = local_edge;
     if (last) inc[no + ls].out_count = local_edge + 1u;
 }
@@ -546,8 +547,8 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // below has the last word (a small component with > 320 edges - duplicated matches - still lands there).
     auto build_incidence = [&]() -> int {
         LFR_HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * (size_t)N, 16), st));
-        hipLaunchKernelGGL(k_incidence, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted,
-                           eo, no, local, out.d_node_inc, ek0, ei0);                         // the key buffers are free again
+        hipLaunchKernelGGL(k_incidence, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, node_bits, fused ? out.d_edge_word : nullptr,
+                           ei1, node1, node2, class_sorted, eo, no, local, out.d_node_inc, ek0, ei0);      // (the unsorted key buffers are free again)
         const int r = sort_pairs(arena, ek0, ek1, ei0, out.d_in_idx, E2, 0, 48, st);
         if (r != LFR_OK) return r;
         hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, eo, no, out.d_node_inc);
