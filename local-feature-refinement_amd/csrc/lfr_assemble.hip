@@ -75,6 +75,23 @@ __global__ void k_count_edges(int64_t n_matches, const uint32_t *node1, const ui
     if (k1 && !(k0 && comp[b] == comp[a])) atomicAdd(&c_edges[comp[b]], 1u);
 }
 
+// Few, large components (a giant component cut into a few thousand parts: config 5, 9.3 M edges over 2152 counters - 0.6 ms of
+// atomics taking turns): the same count through per-node counters (65 per word instead of 4300), then one add per node.
+__global__ void k_count_edges_by_node(int64_t n_matches, const uint32_t *node1, const uint32_t *node2, const uint8_t *is_var, uint8_t *kept, uint32_t *n_edges) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= n_matches) return;
+    const uint32_t a = node1[m], b = node2[m];
+    const bool var = is_var[a] || is_var[b];
+    const bool k0 = kept[2 * m] && var, k1 = kept[2 * m + 1] && var;
+    kept[2 * m] = k0; kept[2 * m + 1] = k1;
+    if (k0) atomicAdd(&n_edges[a], 1u);                       // edge 2m leaves node1, edge 2m+1 leaves node2
+    if (k1) atomicAdd(&n_edges[b], 1u);
+}
+__global__ void k_sum_node_edges(int64_t n_nodes, const int32_t *comp, const uint32_t *n_edges, uint32_t *c_edges) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < n_nodes && n_edges[n]) atomicAdd(&c_edges[comp[n]], n_edges[n]);
+}
+
 __global__ void k_count_tracks(int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tracks) return;
@@ -187,7 +204,7 @@ template <bool ALIGNED8>     // flow rows are 72 bytes: 8-byte aligned when the 
 __global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
                              const float *sim, const float *disp1, const float *disp2, const int32_t *track,
                              const uint32_t *local_of, const uint32_t *flow_row, int64_t row_lo, int64_t row_hi, uint4 *records,
-                             const uint32_t *skip_below_p) {
+                             const uint32_t *skip_below_p, const uint32_t *words) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = t / 5;
     const int chunk = (int)(t - 5 * p);
@@ -208,13 +225,16 @@ __global__ void k_emit_edges(int64_t cap, const uint32_t *total_edges_p, const u
             q.z = __float_as_uint(fl[4 * chunk + 2]); q.w = __float_as_uint(fl[4 * chunk + 3]);
         }
     } else {
-        uint32_t s, d;
-        edge_ends(node1, node2, e, s, d);
-        const uint32_t ls = local_of[s], ld = local_of[d];
-        const uint32_t kind = track[s] != track[d] ? 1u : 0u;
         q.x = __float_as_uint(fl[16]); q.y = __float_as_uint(fl[17]);
         q.z = __float_as_uint(sim[m]);
-        q.w = ls | ((ld | (kind << 15)) << 16);
+        if (words) q.w = words[p];                                // (the fused gather's word array holds exactly this: k_edge_words)
+        else {
+            uint32_t s, d;
+            edge_ends(node1, node2, e, s, d);
+            const uint32_t ls = local_of[s], ld = local_of[d];
+            const uint32_t kind = track[s] != track[d] ? 1u : 0u;
+            q.w = ls | ((ld | (kind << 15)) << 16);
+        }
     }
     records[5 * p + chunk] = q;
 }
@@ -444,7 +464,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     LFR_HIP_TRY(hipSetDevice(ctx->device));
 
     DevArena arena;                                   // temporaries of this call
-    if (!arena.init(ctx, (size_t)96 * M + (size_t)48 * N + (size_t)128 * (C + 1) + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
+    if (!arena.init(ctx, (size_t)96 * M + (size_t)52 * N + (size_t)128 * (C + 1) + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
     size_t pin_bytes = 0;
     AsmSummary *h_sum = (AsmSummary *)ctx->pinned_acquire(sizeof(AsmSummary), &pin_bytes);
     if (!h_sum) return LFR_ERR_NOMEM;
@@ -482,7 +502,14 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
     hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
-    hipLaunchKernelGGL(k_count_edges, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, ce);
+    if (M > 256 * C) {                                // (see k_count_edges_by_node)
+        TAKE(ne, uint32_t, N);
+        LFR_HIP_TRY(hipMemsetAsync(ne, 0, 4 * (size_t)N, st));
+        hipLaunchKernelGGL(k_count_edges_by_node, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, is_var, kept, ne);
+        hipLaunchKernelGGL(k_sum_node_edges, grid_for(N), dim3(kThreads), 0, st, N, comp, ne, ce);
+    } else {
+        hipLaunchKernelGGL(k_count_edges, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, ce);
+    }
     hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, ts, tc, ct);
 
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
@@ -549,7 +576,8 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         LFR_HIP_TRY(hipMemsetAsync(out.d_node_inc, 0, std::max<size_t>(sizeof(NodeInc) * (size_t)N, 16), st));
         hipLaunchKernelGGL(k_incidence, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, node_bits, fused ? out.d_edge_word : nullptr,
                            ei1, node1, node2, class_sorted, eo, no, local, out.d_node_inc, ek0, ei0);      // (the unsorted key buffers are free again)
-        const int r = sort_pairs(arena, ek0, ek1, ei0, out.d_in_idx, E2, 0, 48, st);
+        // (component << 16 | destination: 16 + comp_bits bits; the padding key's ones in that range exceed every real component index)
+        const int r = sort_pairs(arena, ek0, ek1, ei0, out.d_in_idx, E2, 0, 16 + comp_bits, st);
         if (r != LFR_OK) return r;
         hipLaunchKernelGGL(k_in_begin, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ek1, eo, no, out.d_node_inc);
         hipLaunchKernelGGL(k_inc_counts, grid_for(N), dim3(kThreads), 0, st, N, out.d_node_inc);
@@ -580,10 +608,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         if (hi > lo || (c == 0 && n_chunks == 1)) {
             if (aligned8)
                 hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr);
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr, fused ? out.d_edge_word : nullptr);
             else
                 hipLaunchKernelGGL(k_emit_edges<false>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr);
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, lo, hi, reinterpret_cast<uint4 *>(out.d_edges), fused ? &sum->packed_edges : nullptr, fused ? out.d_edge_word : nullptr);
         }
         c = c2;
     }
@@ -604,10 +632,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
             if (dg.flows_staged) for (int c = 0; c < n_chunks; ++c) if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
             if (aligned8)
                 hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges);
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges, fused ? out.d_edge_word : nullptr);
             else
                 hipLaunchKernelGGL(k_emit_edges<false>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,
-                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges);
+                                   dg.sim, dg.disp1, dg.disp2, track, local, dg.flow_row, (int64_t)0, M, reinterpret_cast<uint4 *>(out.d_edges), &sum->packed_edges, fused ? out.d_edge_word : nullptr);
         }
         LFR_HIP_TRY(stream_wait(st));         // the temporaries go back to the cache at return
     }
