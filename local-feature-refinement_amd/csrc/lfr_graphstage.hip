@@ -249,15 +249,26 @@ __global__ void k_seg_starts(int64_t M, const uint32_t *flags, const uint32_t *s
     if (i < M && flags[i]) starts[seg_id[i]] = (uint32_t)i;
     if (i == 0) { starts[seg_id[M]] = (uint32_t)M; counts[CNT_SEG] = seg_id[M]; }
 }
-// a maximum into ONE word (v = 0 for lanes without a value): atomics on one address take their turns at the L2 (~2 ns each: 14 k waves
-// were 28 us of a 5-us kernel), so the wave reduces first and only sends its maximum if it beats what the word already holds
-__device__ __forceinline__ void wave_atomic_max(uint32_t v, uint32_t *dst) {
+// A maximum into ONE word: atomics on one address take their turns at the L2 (14 k waves, one atomic each, were 28 us of a 5-us kernel;
+// looking first with an agent-scope load made it 44), so these kernels run as a few hundred workgroups that stride over the items and
+// send one maximum each.
+constexpr int kFewBlocks = 512;
+inline dim3 grid_few(int64_t n) { const dim3 g = grid_for(n); return dim3(g.x < (unsigned)kFewBlocks ? g.x : (unsigned)kFewBlocks); }
+__device__ __forceinline__ void block_atomic_max(uint32_t v, uint32_t *dst) {          // every thread of the workgroup calls it
+    __shared__ uint32_t s_max[kThreads / 64];
     for (int o = 32; o > 0; o >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, o, 64));
-    if ((threadIdx.x & 63) == 0 && v > __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dst, v);
+    if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < kThreads / 64; ++i) v = max(v, s_max[i]);
+        if (v) atomicMax(dst, v);
+    }
 }
 __global__ void k_seg_maxlen(int64_t cap, const uint32_t *starts, uint32_t *counts) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    wave_atomic_max((s < cap && s < (int64_t)counts[CNT_SEG]) ? starts[s + 1] - starts[s] : 0u, &counts[CNT_MAX_SEG]);
+    const int64_t n = cap < (int64_t)counts[CNT_SEG] ? cap : (int64_t)counts[CNT_SEG];
+    uint32_t v = 0;
+    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += (int64_t)gridDim.x * blockDim.x) v = max(v, starts[s + 1] - starts[s]);
+    block_atomic_max(v, &counts[CNT_MAX_SEG]);
 }
 
 // ---- the reference's greedy constrained union-find, one thread per connected component ----
@@ -662,17 +673,23 @@ __global__ void k_comp_flags(int64_t cap, const uint32_t *counts, const uint32_t
 __global__ void k_comp_sizes(int64_t cap, uint32_t *counts, const uint32_t *parent, const uint32_t *rank, const uint32_t *tsize, uint32_t *csize) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t == 0) counts[CNT_COMPS] = rank[cap];
-    const bool live = t < cap && t < (int64_t)counts[CNT_TRACKS];
-    if (live) atomicAdd(&csize[rank[parent[t]]], tsize[t]);
-    wave_atomic_max(live ? tsize[t] : 0u, &counts[CNT_MAX_TRACK]);
+    const int64_t n = cap < (int64_t)counts[CNT_TRACKS] ? cap : (int64_t)counts[CNT_TRACKS];
+    uint32_t v = 0;
+    for (int64_t i = t; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        atomicAdd(&csize[rank[parent[i]]], tsize[i]);
+        v = max(v, tsize[i]);
+    }
+    block_atomic_max(v, &counts[CNT_MAX_TRACK]);
 }
 __global__ void k_node_comp(int64_t n, const int32_t *track, const uint32_t *parent, const uint32_t *rank, int32_t *comp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) comp[i] = (int32_t)rank[parent[track[i]]];
 }
 __global__ void k_max_csize(int64_t cap, uint32_t *counts, const uint32_t *csize) {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    wave_atomic_max((c < cap && c < (int64_t)counts[CNT_COMPS]) ? csize[c] : 0u, &counts[CNT_MAX_COMP]);
+    const int64_t n = cap < (int64_t)counts[CNT_COMPS] ? cap : (int64_t)counts[CNT_COMPS];
+    uint32_t v = 0;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n; c += (int64_t)gridDim.x * blockDim.x) v = max(v, csize[c]);
+    block_atomic_max(v, &counts[CNT_MAX_COMP]);
 }
 
 }  // namespace
@@ -998,7 +1015,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc;
     const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
     hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
-    hipLaunchKernelGGL(k_seg_maxlen, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
+    hipLaunchKernelGGL(k_seg_maxlen, grid_few(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
 
     // 3. greedy constrained union-find per connected component: small ones one thread each ...
     TAKE(par, int32_t, N); TAKE(next, int32_t, N); TAKE(tail, int32_t, N); TAKE(cnt, int32_t, N); TAKE(sig, ulonglong2, N);
@@ -1144,8 +1161,8 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipLaunchKernelGGL(k_track_label, grid_for(N), dim3(kThreads), 0, st, N, cc, dp->track, mp_parent, mp);
     hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
     if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
-    hipLaunchKernelGGL(k_max_csize, grid_for(N), dim3(kThreads), 0, st, N, counts, csize);
+    hipLaunchKernelGGL(k_comp_sizes, grid_few(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
+    hipLaunchKernelGGL(k_max_csize, grid_few(N), dim3(kThreads), 0, st, N, counts, csize);
     hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, dp->track, mp, crank, dp->comp);
     LFR_HIP_TRY(hipGetLastError());
     LFR_HIP_TRY(hipEventRecord(ev[3], st));
@@ -1273,8 +1290,8 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(hipMemsetAsync(counts + CNT_MAX_COMP, 0, 4, st));
         hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
         if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
-        hipLaunchKernelGGL(k_comp_sizes, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
-        hipLaunchKernelGGL(k_max_csize, grid_for(N), dim3(kThreads), 0, st, N, counts, csize);
+        hipLaunchKernelGGL(k_comp_sizes, grid_few(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
+        hipLaunchKernelGGL(k_max_csize, grid_few(N), dim3(kThreads), 0, st, N, counts, csize);
         hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, dp->track, mp, crank, dp->comp);
         LFR_HIP_TRY(hipGetLastError());
         LFR_HIP_TRY(hipEventRecord(c1, st));
