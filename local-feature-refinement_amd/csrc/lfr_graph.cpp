@@ -96,15 +96,17 @@ struct SubGraph {
 #define LFR_CUT_LOPSIDED_GAIN 0.6
 #endif
 #ifndef LFR_CUT_SPAWN_MIN
-#define LFR_CUT_SPAWN_MIN 16384
+#define LFR_CUT_SPAWN_MIN 2500
 #endif
 struct BisectScratch {
     struct Nb { int node, w; };                                   // (integer weights: every sum below is exact in doubles)
     std::vector<uint32_t> off, fill;
     std::vector<Nb> nbr;
-    std::vector<double> deg, attach, ext;
+    struct HeapEntry { int64_t key; int id; };
+    std::vector<double> deg, ext;
     std::vector<char> in;
-    std::vector<int> heap, pos, order;
+    std::vector<HeapEntry> heap;
+    std::vector<int> pos, order;
     void release() { *this = BisectScratch(); }
 };
 BisectScratch &bisect_scratch() { static thread_local BisectScratch ws; return ws; }
@@ -135,8 +137,6 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
             deg[a] += w; deg[b] += w; volume += 2 * w;
         }
     }
-    std::vector<double> &attach = ws.attach;
-    attach.assign(n, 0.0);
     std::vector<char> &in = ws.in;
     in.assign(n, 0);
     double vol0 = 0.0, cut = 0.0;
@@ -145,26 +145,29 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     // smallest id; a node nobody is attached to yet has attachment 0, so an emptied frontier restarts from the
     // smallest unvisited id).  Indexed binary max-heap over the n nodes keyed (attachment, -id) with increase-key:
     // O(E log n) with n entries (a lazy-deletion queue held 2 E of them; the O(n^2) arg-max scan before that).
-    std::vector<int> &heap = ws.heap, &pos = ws.pos;
+    // Round 4: the heap holds its keys (the attachments are sums of integers: exact in an int64) - every comparison of a sift read
+    // attach[heap[slot]], two dependent loads; the growing is half of a bisection's time and the bisections of a cut are a chain.
+    std::vector<BisectScratch::HeapEntry> &heap = ws.heap;
+    std::vector<int> &pos = ws.pos;
     heap.resize(n); pos.resize(n);
-    for (int i = 0; i < n; ++i) { heap[i] = i; pos[i] = i; }                  // all keys (0, -i): already a heap
+    for (int i = 0; i < n; ++i) { heap[i] = BisectScratch::HeapEntry{0, i}; pos[i] = i; }      // all keys (0, -i): already a heap
     int hn = n;
-    auto above = [&](int a, int b) { return attach[a] > attach[b] || (attach[a] == attach[b] && a < b); };
+    auto above = [](const BisectScratch::HeapEntry &a, const BisectScratch::HeapEntry &b) { return a.key > b.key || (a.key == b.key && a.id < b.id); };
     auto sift_up = [&](int i) {
-        const int v = heap[i];
-        while (i > 0) { const int p = (i - 1) >> 1; if (!above(v, heap[p])) break; heap[i] = heap[p]; pos[heap[i]] = i; i = p; }
-        heap[i] = v; pos[v] = i;
+        const BisectScratch::HeapEntry v = heap[i];
+        while (i > 0) { const int p = (i - 1) >> 1; if (!above(v, heap[p])) break; heap[i] = heap[p]; pos[heap[i].id] = i; i = p; }
+        heap[i] = v; pos[v.id] = i;
     };
     auto sift_down = [&](int i) {
-        const int v = heap[i];
+        const BisectScratch::HeapEntry v = heap[i];
         for (;;) {
             int c = 2 * i + 1;
             if (c >= hn) break;
             if (c + 1 < hn && above(heap[c + 1], heap[c])) ++c;
             if (!above(heap[c], v)) break;
-            heap[i] = heap[c]; pos[heap[i]] = i; i = c;
+            heap[i] = heap[c]; pos[heap[i].id] = i; i = c;
         }
-        heap[i] = v; pos[v] = i;
+        heap[i] = v; pos[v.id] = i;
     };
     // Round 3: the region does not stop at half of the volume - it grows on to three quarters and the prefix of the growth order
     // with the SMALLEST normalized cut between a quarter and three quarters of the volume wins (ties -> the earliest); a graph
@@ -177,16 +180,19 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
     int best_len = -1, half_len = -1;
     double best_val = 1e300, best_cut = 0.0, best_vol = 0.0, half_cut = 0.0, half_vol = 0.0;
     while (vol0 * 4 < 3 * volume && n0 < n - 1 && hn > 0) {
-        const int best = heap[0];
-        heap[0] = heap[--hn]; pos[heap[0]] = 0;
+        const int best = heap[0].id;
+        const double attach_best = (double)heap[0].key;
+        heap[0] = heap[--hn]; pos[heap[0].id] = 0;
         if (hn > 0) sift_down(0);
         in[best] = 1; vol0 += deg[best]; ++n0;
         order.push_back(best);
-        cut += deg[best] - 2.0 * attach[best];            // its edges to the outside enter the cut, those to the region leave it
+        cut += deg[best] - 2.0 * attach_best;             // its edges to the outside enter the cut, those to the region leave it
         for (uint32_t q = off[best]; q < off[best + 1]; ++q) {
             const int v = nbr[q].node;
-            attach[v] += (double)nbr[q].w;
-            if (!in[v]) sift_up(pos[v]);
+            if (in[v]) continue;                          // (nobody reads the attachment of a node inside the region again)
+            const int at = pos[v];
+            heap[at].key += nbr[q].w;
+            sift_up(at);
         }
         if (half_len < 0 && vol0 * 2 >= volume) { half_len = n0; half_cut = cut; half_vol = vol0; }
         if (vol0 * 4 >= volume && vol0 * 4 <= 3 * volume) {
@@ -218,11 +224,11 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
         const int a = g.ea[k], b = g.eb[k];
         if (side[a] != side[b]) { const double w = (double)std::max(g.w[k], 1); ext[a] += w; ext[b] += w; }
     }
+    double ncut_now = ncut(cut, vol0);                      // (a function of (cut, vol0): recomputed when a move changes them, not per node)
     for (int sweep = 0; sweep < 8; ++sweep) {
         bool moved = false;
         for (int i = 0; i < n; ++i) {
             const double to_other = ext[i], to_same = deg[i] - ext[i];
-            const double ncut_now = ncut(cut, vol0);
             const double c2 = cut + to_same - to_other;
             const double v2 = side[i] == 0 ? vol0 - deg[i] : vol0 + deg[i];
             const int cnt0 = side[i] == 0 ? n0 - 1 : n0 + 1;
@@ -230,6 +236,7 @@ void bisect_core(const SubGraph &g, std::vector<char> &side) {
             if (ncut(c2, v2) < ncut_now) {
                 const char was = side[i];
                 side[i] ^= 1; cut = c2; vol0 = v2; n0 = cnt0; moved = true;
+                ncut_now = ncut(cut, vol0);
                 ext[i] = to_same;
                 for (uint32_t q = off[i]; q < off[i + 1]; ++q) {
                     const int v = nbr[q].node;
