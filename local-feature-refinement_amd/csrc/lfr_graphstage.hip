@@ -391,6 +391,10 @@ __device__ __forceinline__ void block_append(const bool (&keep)[ITEMS], uint32_t
 constexpr int kAppendItems = 8;
 inline dim3 grid_for_items(int64_t n, int items) { return grid_for((n + items - 1) / items); }
 struct Pending { uint32_t k; int32_t ra, rb; };     // position in the ordered match list, roots of n1 / n2
+// a bit that many threads set: a plain (possibly stale) look saves the atomic once the bit is visible - a node of config 5 has ~70 matches
+__device__ __forceinline__ void set_bit(unsigned long long *word, unsigned long long mask) {
+    if (!(*word & mask)) atomicOr(word, mask);
+}
 // matches of large connected components -> the first pending list; bit of the own image for their nodes
 __global__ void k_large_pending(int64_t k_lo, int64_t k_hi, int64_t serial_limit, const uint32_t *flags, const uint32_t *seg_id, const uint32_t *starts, const uint32_t *order,
                                 const uint32_t *n1, const uint32_t *n2, const int32_t *node_image, int W, unsigned long long *bits,
@@ -414,9 +418,9 @@ __global__ void k_large_pending(int64_t k_lo, int64_t k_hi, int64_t serial_limit
         const int64_t k = k0 + (int64_t)j * kThreads;
         const uint32_t m = order[k], a = n1[m], b = n2[m];
         pend[at[j]] = Pending{(uint32_t)k, (int32_t)a, (int32_t)b};
-        if (bits) {                                                  // (idempotent: several matches set the same bit)
-            atomicOr(&bits[(size_t)a * W + (node_image[a] >> 6)], 1ull << (node_image[a] & 63));
-            atomicOr(&bits[(size_t)b * W + (node_image[b] >> 6)], 1ull << (node_image[b] & 63));
+        if (bits) {                                                  // (idempotent: every match of a node sets the same bit - look first)
+            set_bit(&bits[(size_t)a * W + (node_image[a] >> 6)], 1ull << (node_image[a] & 63));
+            set_bit(&bits[(size_t)b * W + (node_image[b] >> 6)], 1ull << (node_image[b] & 63));
         }
     }
 }
