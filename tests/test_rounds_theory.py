@@ -102,3 +102,84 @@ def test_prefix_blocks_on_long_tracks_need_only_a_few_more_rounds():
         blocks.append((lo, min(m, lo + size))); lo += size; size *= 2
     r_single, r_blocks = n_rounds([(0, m)]), n_rounds(blocks)
     assert r_blocks <= 2 * r_single + 8                                    # a few rounds more, not a different order of magnitude
+
+
+# ---- round 4: the two shortcuts of the device graph stage, restated on the CPU ----
+def _sim_key(s):
+    """order-preserving float32 -> uint32 (lfr_graphstage.hip: sim_key)"""
+    s = np.where(s == 0, np.float32(0), s).astype(np.float32)
+    b = s.view(np.uint32)
+    return np.where(b & 0x80000000, ~b, b | 0x80000000).astype(np.uint32)
+
+
+def _components(n, a, b):
+    lab = np.arange(n)
+    while True:
+        m = np.minimum(lab[a], lab[b])
+        new = lab.copy()
+        np.minimum.at(new, a, m); np.minimum.at(new, b, m)
+        new = new[new]
+        if (new == lab).all():
+            return lab
+        lab = new
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_one_sort_plus_tie_fix_equals_the_three_stable_sorts(seed):
+    """k_cc_sim_keys + one radix sort + k_tie_fix against the round-3 scheme (stable sorts by n2, by (sim, n1), by connected component),
+    which is the reference's order (descending (sim, n1, n2), solve.cc:489) inside every component: heavy ties, duplicated matches."""
+    rng = np.random.default_rng(400 + seed)
+    n, M = 60, 900
+    a = rng.integers(0, n, M).astype(np.uint32); b = rng.integers(0, n, M).astype(np.uint32)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    dup = rng.integers(0, len(a), 60)                                   # duplicated matches: equal (sim, n1, n2) triples
+    sim = rng.choice(np.array([0.25, 0.5, 0.5, 0.75, 0.9], np.float32), len(a))
+    a, b, sim = np.r_[a, a[dup]], np.r_[b, b[dup]], np.r_[sim, sim[dup]]
+    M = len(a)
+    cc = _components(n, a, b)[a]
+    ids = np.arange(M)
+    # three stable sorts (ascending complemented keys = descending order)
+    o = ids[np.argsort((n - 1 - b)[ids], kind="stable")]
+    hi = ((~_sim_key(sim)).astype(np.uint64) << 8) | (n - 1 - a).astype(np.uint64)
+    o = o[np.argsort(hi[o], kind="stable")]
+    three = o[np.argsort(cc[o], kind="stable")]
+    # one sort by (component | ~sim), then the runs of equal keys ordered by (n1 desc, n2 desc, id asc)
+    key = (cc.astype(np.uint64) << 32) | (~_sim_key(sim)).astype(np.uint64)
+    one = ids[np.argsort(key, kind="stable")]
+    ks = key[one]
+    lo = 0
+    while lo < M:
+        hi_ = lo
+        while hi_ < M and ks[hi_] == ks[lo]:
+            hi_ += 1
+        run = sorted(one[lo:hi_], key=lambda m: (-int(a[m]), -int(b[m]), int(m)))
+        one[lo:hi_] = run
+        lo = hi_
+    assert (one == three).all()
+    # and that IS the reference's order inside a component
+    ref = sorted(ids, key=lambda m: (int(cc[m]), -float(sim[m]), -int(a[m]), -int(b[m]), int(m)))
+    assert (three == np.array(ref)).all()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_meta_components_are_the_connected_components_of_the_match_graph(seed):
+    """k_cc_min_track: whatever partition of the nodes into tracks the greedy rule produces (every track is connected through its accepted
+    matches, every match joins two nodes of one connected component), the components of the track meta-graph - tracks joined by the
+    matches between them, solve.cc:262-290 - are the match graph's connected components, named by their smallest track."""
+    rng = np.random.default_rng(500 + seed)
+    n, M, n_img = 120, 260, 9
+    img = rng.integers(0, n_img, n)
+    a = rng.integers(0, n, M); b = rng.integers(0, n, M)
+    keep = a != b
+    a, b = a[keep], b[keep]
+    root = sequential(n, img, a, b)                                      # tracks of the sequential rule (roots as ids)
+    _, track = np.unique(root, return_inverse=True)
+    T = track.max() + 1
+    meta = _components(T, track[a], track[b])                            # union-find over the inter-track matches (intra-track ones are no-ops)
+    cc = _components(n, a, b)
+    min_track = np.full(n, T, np.int64)
+    np.minimum.at(min_track, cc, track)                                  # smallest track per connected component ...
+    label = np.empty(T, np.int64)
+    label[track] = min_track[cc]                                         # ... is the label of every track in it
+    assert (label == meta).all()
