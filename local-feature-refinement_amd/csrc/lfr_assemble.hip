@@ -179,6 +179,18 @@ __global__ void k_edge_keys(int64_t n_dir, const uint32_t *node1, const uint32_t
     ids[e] = (uint32_t)e;
 }
 
+// the same order when no workgroup class is expected: the key is the descriptor index alone - 32 bits, a third less to move per radix pass
+__global__ void k_edge_keys_packed(int64_t n_dir, const uint32_t *node1, const uint32_t *node2, const int32_t *comp, const int32_t *di_of_comp,
+                                   const uint8_t *kept, uint32_t dropped_key, uint32_t *keys, uint32_t *ids) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_dir) return;
+    uint32_t s, d;
+    edge_ends(node1, node2, e, s, d);
+    const int32_t di = kept[e] ? di_of_comp[comp[s]] : -1;
+    keys[e] = di < 0 ? dropped_key : (uint32_t)di;
+    ids[e] = (uint32_t)e;
+}
+
 // packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
 // kernel's pair exchange relies on it)
 __global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
@@ -556,15 +568,21 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 
     // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
     TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);
-    hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
-                       (uint64_t)C << node_bits, ek0, ei0);
     if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
     // Packed classes carry zeros in the source-node bits (their order is component, then edge id - the sort is stable): when the graph
     // stage's largest component says that no workgroup class can exist, only the component bits are sorted - three radix passes over the
     // 5 M keys of config 4 instead of five.  A small component with > 320 edges still lands in a workgroup class: the summary below has
     // the last word and the full sort is redone then.
     const bool expect_workgroup_classes = p.stats.max_component_size > 17;
-    if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, expect_workgroup_classes ? 0 : node_bits, node_bits + comp_bits, st)) != LFR_OK) return rc;
+    if (expect_workgroup_classes) {
+        hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
+                           (uint64_t)C << node_bits, ek0, ei0);
+        if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
+    } else {                                          // (32-bit keys in the front halves of the 64-bit key buffers)
+        uint32_t *k32a = reinterpret_cast<uint32_t *>(ek0), *k32b = reinterpret_cast<uint32_t *>(ek1);
+        hipLaunchKernelGGL(k_edge_keys_packed, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, kept, (uint32_t)C, k32a, ei0);
+        if ((rc = sort_pairs(arena, k32a, k32b, ei0, ei1, E2, 0, comp_bits, st)) != LFR_OK) return rc;
+    }
     // (both directions of a match are kept or dropped together by construction - k_count_edges - and the sort is stable on the edge
     // id, so the pair check only runs on request or on the path that materialises records)
     if (!fused || getenv("LFR_CHECK_PAIRS"))
@@ -631,7 +649,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (out.summary.too_big) { set_error("a component exceeds the 32767-node batch limit"); return LFR_ERR_UNSUPPORTED; }
     if (out.summary.unpaired) { set_error("internal: a kept edge without its opposite direction"); return LFR_ERR_UNSUPPORTED; }
     if (!expect_workgroup_classes && out.summary.class_begin[KC_BLOCK] < out.summary.n_desc) {
-        // the unexpected workgroup classes need their edges by source node: the full sort (packed classes keep their order), the words again
+        // the unexpected workgroup classes need their edges by source node: the 64-bit keys and the full sort (packed classes keep their
+        // order), the words again
+        hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
+                           (uint64_t)C << node_bits, ek0, ei0);
         if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
         if (fused) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
         if ((rc = build_incidence()) != LFR_OK) return rc;
