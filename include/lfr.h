@@ -232,7 +232,8 @@ int lfr_hip_trim(int device);
 /* Shard `shard_rank` of `shard_world` (see lfr_problem_shard_components) resident on HIP device `device`:
  * assembled there from the labels (lfr_problem_build_labels / _hip), or uploaded (lfr_problem_build).
  * Limits: <= 32767 nodes per component (16-bit local indices in the 80-byte edge record), < 2^30 matches; a component above 192 rows
- * whose factor needs 2^21 or more 16x16 tiles (4 GB: a DENSE component beyond ~16 k nodes) is refused (LFR_ERR_UNSUPPORTED). */
+ * whose factor needs 2^21 or more 16x16 tiles (4 GB: a DENSE component beyond ~16 k nodes) or that holds 2^30 or more records (the
+ * plan's sweep items pack record << 2 | direction << 1 | flag into 32 bits) is refused (LFR_ERR_UNSUPPORTED). */
 int lfr_batch_create(const lfr_problem *p, int device, int shard_rank, int shard_world, int tukey_variant,
                      lfr_batch **out);
 void lfr_batch_free(lfr_batch *b);
@@ -254,6 +255,11 @@ int64_t lfr_batch_tree_stats(lfr_batch *b, int64_t *columns, int64_t *tiles, int
 /* Diagnostics: bounded spin-waits inside the workgroup kernels (wave hand-offs of the factorizations) that ran out during the
  * latest solve of the batch - each one rejected an LM step instead of hanging the GPU.  0 on a healthy run; < 0: error. */
 int64_t lfr_batch_spin_timeouts(lfr_batch *b);
+/* Components above 192 rows whose expected work reaches a threshold (LFR_TREE_TEAM="w2,w4": rows x [joins several tracks]; "0" = off)
+ * are solved by a TEAM of 2 or 4 workgroups on one XCD (the reference: one Ceres SPARSE_NORMAL_CHOLESKY problem per pool thread,
+ * solve.cc:147,617-635 - here the elimination tree's columns, the sweeps and the vector passes of ONE problem are spread over several
+ * CUs).  Returns how many components the latest solve of the batch handed to a team (< 0: error). */
+int64_t lfr_batch_team_runs(lfr_batch *b);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written.  Waits for the
  * latest lfr_batch_solve of this batch, whatever stream it was issued on. */
 int lfr_batch_download(lfr_batch *b, double *positions);

@@ -204,7 +204,7 @@ struct TreePlan {
     uint32_t n_tiles = 0, n_items = 0;
     uint64_t n_updates = 0, column_rounds = 0;
     std::vector<uint32_t> blob;              // empty: the component is beyond the plan's 32-bit offsets
-    uint64_t vec_stride() const, header_doubles() const, doubles() const;
+    uint64_t vec_stride() const, header_doubles() const, team_doubles() const, doubles() const;
 };
 // words[e] = src | (dst | kind << 15) << 16 of the component's records (the last word of EdgeRec)
 void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out);

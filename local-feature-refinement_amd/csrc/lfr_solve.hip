@@ -72,6 +72,11 @@ struct KernelArgs {
     // (f_row ? f_row[m] : m) of f_disp2 (even ids) / f_disp1 (odd ids), similarity f_sim[m], m = id >> 1 - with local indices edge_word[p]
     const uint32_t *edge_ref, *edge_word, *f_row;
     const float *f_disp1, *f_disp2, *f_sim;
+    // elimination-tree class: teams of workgroups per component (nullptr: one workgroup per component); team_work[k]: smallest
+    // hand-out key (k_wg_order_keys' `work`) solved by 2 << k workgroups
+    unsigned int *team_ctl;
+    double *team_red;
+    uint32_t team_work[3];
 };
 
 // =============================================================================================
@@ -1662,6 +1667,60 @@ struct TreeShared {
     double red3[LFR_THREADS_G / 64][3];
     int pend[lfr::kTreeMaxFlagColumns];        // "thin" plans: children a column still waits for (factorization) / column solved (back substitution)
 };
+// ---- TEAMS: several workgroups on ONE component (round 5) ----
+// A launch of this class lasts as long as its slowest component, and a component used to be one workgroup on one CU whatever its size
+// (130 components on 256 CUs: half the chip idle while a 2258-row component ran its 36 LM iterations of ~250 us alone).  A component whose
+// expected work (the hand-out key of k_wg_order_keys) is above a threshold is now solved by a TEAM of 2, 4 or 8 workgroups: the sweep's
+// items, the node pass and the vector passes are split over the team's threads, the column tasks of the factorization and of the back
+// substitution over the team's waves (same dependency counters, in HBM instead of LDS), the reductions meet in a fixed order (every
+// member computes the same bits, so the replicated trust-region state stays identical) - results are a function of the team size, which
+// is a function of the component, hence bitwise repeatable.
+//
+// Visibility (MI355X: per-CU vector L1 never refreshed by other CUs' stores, one L2 per XCD): a team is formed from workgroups that
+// registered with the SAME XCC id, so its members share one L2.  Payload (tiles, vectors, partial sums): plain stores, `s_waitcnt
+// vmcnt(0)` before the hand-off (the store has reached L2), and every load of mutable workspace data with `sc1` (bypasses L1, served
+// by the shared L2).  Synchronisation words (barrier counters, dependency counters, mailboxes, flags): agent-scope atomics only.
+// No `buffer_wbl2` / `buffer_inv` anywhere: nothing has to leave or re-enter the XCD.  Teams never span XCDs by construction
+// (registration below); workgroups that cannot complete a unit of their XCD work alone.
+//
+// Control words of a launch (KernelArgs::team_ctl, zeroed per solve): [0..7] workgroups registered per XCC, [8] registered in total,
+// [9] abort (a bounded spin ran out somewhere: every wait gives up, the components involved fail), [16 + 16 u + m] mailbox of member m
+// of unit u (a one-slot channel: the leader stores when it reads 0, the member clears), [16 + 16 u + 8 + L] arrival counter of the team
+// led by rank L.  Reduction slots (KernelArgs::team_red): per unit and leader, two parities x members x 4 doubles.
+#ifndef LFR_TEAM_MAX
+#define LFR_TEAM_MAX 4
+#endif
+constexpr int kTeamMax = LFR_TEAM_MAX;                     // workgroups per unit (a power of two <= 8)
+constexpr int kTeamUnitsPerXcc = 256 / kTeamMax;           // a launch has at most 256 workgroups
+constexpr int kTeamCtlWords = 16 + 16 * 8 * kTeamUnitsPerXcc;
+constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 4;
+constexpr unsigned kTeamMsgEnd = 0xf0000000u;
+static_assert(kTeamMax == 2 || kTeamMax == 4 || kTeamMax == 8, "team size");
+struct TeamCtx {
+    int S = 1, r = 0;                 // workgroups in the team, this workgroup's index in it
+    unsigned int *bar = nullptr;      // arrival counter of the team (monotonic)
+    unsigned int target = 0;          // its value when everyone has arrived at the latest barrier
+    double *red = nullptr;            // reduction slots [2][kTeamMax][4]
+    int par = 0;
+    unsigned int *ctl = nullptr;      // control words of the launch ([9] = abort)
+    bool dead = false;                // this workgroup has seen the abort word: waits return at once
+};
+__device__ __forceinline__ unsigned team_ld(const unsigned int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void team_st(unsigned int *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one thread: spin until *p - target >= 0 (monotonic counters) / until pred; false = gave up (abort raised)
+__device__ __noinline__ bool team_wait_counter(unsigned int *p, unsigned target, unsigned int *ctl, unsigned int *timeouts, int limit_log2) {
+    int spins = 0;
+    while ((int)(team_ld(p) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 255) == 0 && (team_ld(ctl + 9) != 0u || (spins >> limit_log2) != 0)) {
+            if (team_ld(ctl + 9) == 0u) atomicAdd(timeouts, 1u);
+            team_st(ctl + 9, 1u);
+            return false;
+        }
+    }
+    return true;
+}
+
 // The plan's words are written by the host before the launch and never by the kernel: read through the constant address space they
 // are scalar loads (s_load, one per wave, through the scalar cache) instead of vector loads + v_readfirstlane behind ~1 us of latency.
 typedef const __attribute__((address_space(4))) uint32_t *PlanWords;
@@ -1681,12 +1740,35 @@ __device__ __forceinline__ void block_reduce3(double &s0, double &s1, double &m0
     s0 = a; s1 = b; m0 = c;
 }
 
-template <int kBlockThreads>
-__device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const int ci, BlockShared &sh, TreeShared &ts) {
+template <int kBlockThreads, bool TEAM>
+__device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const int ci, BlockShared &sh, TreeShared &ts, TeamCtx &tm) {
     constexpr int kWaves = kBlockThreads / 64;
     constexpr uint32_t kNone = 0xffffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
+    // the team's threads / waves (TEAM = false: this workgroup alone, and every helper below is what it was before teams existed)
+    const int tS = TEAM ? tm.S : 1;
+    const int gt = TEAM ? tm.r * kBlockThreads + tid : tid, GT = tS * kBlockThreads;
+    const int gw = TEAM ? tm.r * kWaves + wave : wave, GW = tS * kWaves;
+    constexpr int kAux = TEAM ? 16 : 0;                   // cache policy of the workspace loads: sc1 = past this CU's L1
+    auto ldd = [](const double *p) -> double {
+        if constexpr (TEAM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
+    };
+    // barrier over the team: every wave's stores have reached L2 before its workgroup arrives
+    auto tsync = [&]() {
+        if constexpr (TEAM) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            tm.target += (unsigned)tS;
+            if (tid == 0 && !tm.dead) {
+                __hip_atomic_fetch_add(tm.bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!team_wait_counter(tm.bar, tm.target, tm.ctl, a.queue + 15, 22)) tm.dead = true;
+            }
+            __syncthreads();
+        } else {
+            __syncthreads();
+        }
+    };
     const CompDesc d = a.descs[ci];
     const int tv = a.tukey_variant;
     const EdgeRec *edges = a.edges + d.edge_off;
@@ -1705,7 +1787,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
            *vD = vec + 7 * vs, *vadiag = vec + 8 * vs, *vdelta = vec + 9 * vs, *vinv = vec + 10 * vs, *vw = vec + 11 * vs;
     const int n = n_pad;                                 // rows incl. padding (inert: x = g = step = 0)
 
-    for (int i = tid; i < (int)vs; i += kBlockThreads) {
+    unsigned int *gteam = reinterpret_cast<unsigned int *>(wsb + pl[29]);      // TEAM: [0] bad-pivot flag, [16 + J] dependency counter of column J
+    for (int i = gt; i < (int)vs; i += GT) {
         vx[i] = 0.0; vxc[i] = 0.0; vscale[i] = 1.0; vD[i] = 0.0; vg[i] = 0.0; vgn[i] = 0.0; vstep[i] = 0.0; vinv[i] = 0.0; vw[i] = 0.0;
         vadiag[i] = 0.0; vdiag[i] = 0.0; vdelta[i] = 0.0;
     }
@@ -1714,15 +1797,38 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         // hold whatever the workspace held before (a NaN times the zero of a padding row's solution is a NaN).
         double2 *t2 = reinterpret_cast<double2 *>(atiles);
         const double2 z = make_double2(0.0, 0.0);
-        for (size_t i = tid; i < ((size_t)n_tiles << 8); i += kBlockThreads) t2[i] = z;
+        for (size_t i = gt; i < ((size_t)n_tiles << 8); i += GT) t2[i] = z;
     }
-    __syncthreads();
+    tsync();
+    // sums and maxima over the team: the workgroup's value first (every thread holds it), then the members' values in a fixed order
+    auto treduce3 = [&](double &s0, double &s1, double &m0) {
+        block_reduce3<kBlockThreads>(s0, s1, m0, ts);
+        if constexpr (TEAM) {
+            double *slot = tm.red + tm.par * (kTeamMax * 4);
+            if (tid == 0) { slot[4 * tm.r] = s0; slot[4 * tm.r + 1] = s1; slot[4 * tm.r + 2] = m0; }
+            tsync();
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            for (int w = 0; w < tS; ++w) {
+                x0 += ldd(slot + 4 * w); x1 += ldd(slot + 4 * w + 1);
+                const double mw = ldd(slot + 4 * w + 2);
+                x2 = w == 0 ? mw : fmax(x2, mw);
+            }
+            s0 = x0; s1 = x1; m0 = x2;
+            tm.par ^= 1;
+        }
+    };
+    auto tsum = [&](double v) -> double {
+        if constexpr (TEAM) { double z = 0.0, m = 0.0; treduce3(v, z, m); return v; } else return block_sum<kBlockThreads>(v, sh);
+    };
+    auto tmax = [&](double v) -> double {
+        if constexpr (TEAM) { double z0 = 0.0, z1 = 0.0; treduce3(z0, z1, v); return v; } else return block_max<kBlockThreads>(v, sh);
+    };
 
     PROF_DECL
     // ---- one sweep at xv: the cost, gout = J^T r and the unscaled J^T J in the tiles.  (Starts with a barrier of its own: whatever
     //      the caller wrote to xv before is visible to the items.) ----
     auto sweep = [&](const double *xv, double *gout) -> double {
-        __syncthreads();
+        tsync();
         TPROF_MARK(2);
         double cost = 0.0;
         // One item = 8 words (lfr_treeplan.cpp): rows of the node and of the neighbour, the pair's block in A, the record count, the first
@@ -1733,14 +1839,14 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
 #pragma unroll
             for (int k = 0; k < 5; ++k) qv[k] = rp[k];
         };
-        int i = tid;
+        int i = gt;
         uint4 ia = make_uint4(0u, 0u, 0u, 0u), ib = ia;
         if (i < n_items) { ia = reinterpret_cast<const uint4 *>(items)[2 * i]; ib = reinterpret_cast<const uint4 *>(items)[2 * i + 1]; }
         while (i < n_items) {
             const uint4 it = ia, it2 = ib;                                       // {row, row of the neighbour, cross block, records} {record 0, record 1, further, -}
-            const int in = i + kBlockThreads;
+            const int in = i + GT;
             if (in < n_items) { ia = reinterpret_cast<const uint4 *>(items)[2 * in]; ib = reinterpret_cast<const uint4 *>(items)[2 * in + 1]; }
-            const double xv0 = xv[it.x], xv1 = xv[it.x + 1], xu0 = xv[it.y], xu1 = xv[it.y + 1];
+            const double xv0 = ldd(xv + it.x), xv1 = ldd(xv + it.x + 1), xu0 = ldd(xv + it.y), xu1 = ldd(xv + it.y + 1);
             uint4 q0[5], q1[5];
             load_record(it2.x, q0);
             load_record(it.w > 1u ? it2.y : it2.x, q1);
@@ -1786,21 +1892,26 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             i = in;
         }
         TPROF_MARK(3);
-        const double total = block_sum<kBlockThreads>(cost, sh);           // (barriers inside: cross blocks and partial sums are out)
-        for (int p = tid; p < 8 * NB; p += kBlockThreads) {
+        const double total = tsum(cost);                                    // (barriers inside: cross blocks and partial sums are out)
+        for (int p = gt; p < 8 * NB; p += GT) {
             if (ipos[p] == kNone) continue;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
             for (uint32_t i = node_items[p]; i < node_items[p + 1]; ++i) {
-                const double2 *pp = reinterpret_cast<const double2 *>(part + 6 * (size_t)i);
-                const double2 u0 = pp[0], u1 = pp[1], u2 = pp[2];
-                s0 += u0.x; s1 += u0.y; s2 += u1.x; s3 += u1.y; s4 += u2.x;
+                if constexpr (TEAM) {
+                    const double *pp = part + 6 * (size_t)i;
+                    s0 += ldd(pp); s1 += ldd(pp + 1); s2 += ldd(pp + 2); s3 += ldd(pp + 3); s4 += ldd(pp + 4);
+                } else {
+                    const double2 *pp = reinterpret_cast<const double2 *>(part + 6 * (size_t)i);
+                    const double2 u0 = pp[0], u1 = pp[1], u2 = pp[2];
+                    s0 += u0.x; s1 += u0.y; s2 += u1.x; s3 += u1.y; s4 += u2.x;
+                }
             }
             double *T = atiles + ((size_t)hdr[pl[8] + (p >> 3)] << 8) + 34 * (p & 7);  // entry (2 slot, 2 slot) of the diagonal tile
             T[0] = s0; T[16] = s1; T[17] = s2;
             gout[2 * p] = s3; gout[2 * p + 1] = s4;
             vadiag[2 * p] = s0; vadiag[2 * p + 1] = s2;
         }
-        __syncthreads();
+        tsync();
         return total;
     };
 
@@ -1823,7 +1934,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     const __amdgpu_buffer_rsrc_t rU = __builtin_amdgcn_make_buffer_rsrc(tiles, 0, (int)0xfffffffe, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc(vec, 0, (int)0xfffffffe, 0x00020000);
     auto bld = [](const __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff) -> double {
-        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, kAux));
     };
     auto bst = [](const double x, const __amdgpu_buffer_rsrc_t r, const unsigned voff, const unsigned soff) {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, x), r, voff, soff, 0);
@@ -1985,7 +2096,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                                                                 __builtin_bit_cast(u32x2_t, av[2 * j + 1])[0], __builtin_bit_cast(u32x2_t, av[2 * j + 1])[1]},
                                                        rV, 16u * j, so_w + (dc.J << 7), 0);
         }
-        if (bad && lane == 0) sh.flag = 1;
+        if (bad && lane == 0) { sh.flag = 1; if constexpr (TEAM) team_st(gteam, 1u); }
         FPROF_MARK(3);                            // 3: stores
         if (finish_extra && dc.nsub > dc.nc) {
             // Tiles below the diagonal beyond the carried ones (thin plans: a few per component): this wave finishes them itself, three at
@@ -2054,19 +2165,51 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     //      walk their columns in level order - dependencies always point to lower levels, so some wave can always proceed - and the loads
     //      of a wave's next column go out early whenever that column is already ready, across level boundaries too. ----
     const bool thin = pl[28] != 0u;
-    auto spin_timeout = [&]() { if (lane == 0) { sh.flag = 1; atomicAdd(a.queue + 15, 1u); } };      // (a miscount must not hang the GPU: the step is rejected, the counter says so)
+    // (a miscount must not hang the GPU: the step is rejected, the counter says so; a team gives up as a whole - the abort word ends
+    // every wait of the launch's teams and fails their components)
+    bool wdead = false;                                   // TEAM: this wave has seen the abort word
+    auto spin_timeout = [&]() {
+        if (lane == 0) {
+            sh.flag = 1;
+            if constexpr (TEAM) { if (team_ld(tm.ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u); team_st(tm.ctl + 9, 1u); team_st(gteam, 1u); }
+            else atomicAdd(a.queue + 15, 1u);
+        }
+        if constexpr (TEAM) wdead = true;
+    };
     auto pend_load = [&](const uint32_t J) -> int {
-        return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ts.pend[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if constexpr (TEAM) return __builtin_amdgcn_readfirstlane((int)team_ld(gteam + 16 + J));
+        else return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ts.pend[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    };
+    // wait until `ready()`; TEAM: the abort word is looked at every 256 polls
+    auto pend_wait = [&](auto ready) {
+        if (TEAM && wdead) return;
+        int spins = 0;
+        while (!ready()) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if constexpr (TEAM) { if ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane((int)team_ld(tm.ctl + 9)) != 0) { wdead = true; sh.flag = 1; break; } }
+            if (spins > (1 << 22)) { spin_timeout(); break; }
+        }
+    };
+    // what a finished column / a waiting column needs around its counter: the column's rows have left the wave (TEAM: have reached
+    // L2 - the reader's loads bypass its own L1), and the reader's loads are issued after the counter was seen
+    auto publish_fence = [&]() {
+        if constexpr (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    };
+    auto observe_fence = [&]() {
+        if constexpr (TEAM) asm volatile("" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
     // this wave's next column after position q of level l (levels ascending / descending); false: none left
     auto next_up = [&](int &l, int &q) -> bool {
-        q += kWaves;
-        while (q >= (int)level_ptr[l + 1]) { if (++l >= n_levels) return false; q = (int)level_ptr[l] + wave; }
+        q += GW;
+        while (q >= (int)level_ptr[l + 1]) { if (++l >= n_levels) return false; q = (int)level_ptr[l] + gw; }
         return true;
     };
     auto next_down = [&](int &l, int &q) -> bool {
-        q += kWaves;
-        while (q >= (int)level_ptr[l + 1]) { if (--l < 0) return false; q = (int)level_ptr[l] + wave; }
+        q += GW;
+        while (q >= (int)level_ptr[l + 1]) { if (--l < 0) return false; q = (int)level_ptr[l] + gw; }
         return true;
     };
     auto factor_thin = [&]() -> bool {
@@ -2074,9 +2217,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
         (void)fprof;
         FPROF_DECL
-        for (int q = tid; q < NB; q += kBlockThreads) ts.pend[hdr[pl[27] + 32 * q]] = (int)hdr[pl[27] + 32 * q + 22];       // children per column
-        __syncthreads();
-        int l = 0, q = (int)level_ptr[0] + wave - kWaves;
+        if constexpr (TEAM) {
+            for (int q = gt; q < NB; q += GT) team_st(gteam + 16 + hdr[pl[27] + 32 * q], hdr[pl[27] + 32 * q + 22]);
+        } else {
+            for (int q = tid; q < NB; q += kBlockThreads) ts.pend[hdr[pl[27] + 32 * q]] = (int)hdr[pl[27] + 32 * q + 22];       // children per column
+        }
+        tsync();
+        int l = 0, q = (int)level_ptr[0] + gw - GW;
         bool have = next_up(l, q), pre = false;
         ColDesc dn;
         ColPre pn;
@@ -2084,9 +2231,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         while (have) {
             const ColDesc dc = dn;
             if (!pre) {                                   // not prefetched: wait for the children, then load
-                int spins = 0;
-                while (pend_load(dc.J) != 0) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 22)) { spin_timeout(); break; } }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                pend_wait([&]() { return pend_load(dc.J) == 0; });
+                observe_fence();
                 issue_column(dc, pn);
             }
             FPROF_MARK(5);                                // 5: waiting for children
@@ -2095,20 +2241,27 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             if (have) {
                 dn = load_desc(q);
                 next_ready = pend_load(dn.J) == 0;
-                if (next_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                if (next_ready) observe_fence();
             }
             run_column(dc, pn, next_ready, dn, true, xd, fprof, ft_, ft0_);
             pre = next_ready;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // the column's rows are out before its parent hears of it
-            if (lane == 0 && dc.parent != kNone) __hip_atomic_fetch_sub(&ts.pend[dc.parent], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            publish_fence();                                               // the column's rows are out before its parent hears of it
+            if (lane == 0 && dc.parent != kNone) {
+                if constexpr (TEAM) __hip_atomic_fetch_sub(gteam + 16 + dc.parent, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else __hip_atomic_fetch_sub(&ts.pend[dc.parent], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
-        __syncthreads();
+        tsync();
+        if constexpr (TEAM) {                             // a bad pivot anywhere in the team rejects the step for everyone
+            if (tid == 0 && team_ld(gteam) != 0u) sh.flag = 1;
+            __syncthreads();
+        }
         FPROF_FLUSH();
         return sh.flag == 0;
     };
 
     auto factor = [&]() -> bool {
-        if (thin) return factor_thin();
+        if (thin || TEAM) return factor_thin();           // (a team only ever takes thin plans: solve_tree_kernel)
         double *xd = ts.x[wave];                          // (sh.flag was reset before the caller's last barrier)
         unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
         (void)fprof;
@@ -2250,8 +2403,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (lane < 16) bst(yo, rV, bo_r, so_step + (dc.J << 7));
     };
     auto back_substitute = [&]() {
-        if (thin) {       // no barrier per level: a column starts when its parent is solved (ts.pend[parent] == 1; all counters are 0 after the factorization)
-            int l = n_levels - 1, q = (int)level_ptr[l] + wave - kWaves;
+        if (thin || TEAM) {       // no barrier per level: a column starts when its parent is solved (pend[parent] == 1; all counters are 0 after the factorization)
+            int l = n_levels - 1, q = (int)level_ptr[l] + gw - GW;
             bool have = next_down(l, q), pre = false;
             ColDesc dn;
             BackPre pn;
@@ -2259,9 +2412,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             while (have) {
                 const ColDesc dc = dn;
                 if (!pre) {
-                    int spins = 0;
-                    while (dc.parent != kNone && pend_load(dc.parent) == 0) { __builtin_amdgcn_s_sleep(2); if (++spins > (1 << 22)) { spin_timeout(); break; } }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    pend_wait([&]() { return dc.parent == kNone || pend_load(dc.parent) != 0; });
+                    observe_fence();
                     issue_back(dc, pn);
                 }
                 have = next_down(l, q);
@@ -2269,14 +2421,17 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 if (have) {
                     dn = load_desc(q);
                     next_ready = dn.parent == kNone || pend_load(dn.parent) != 0;
-                    if (next_ready) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    if (next_ready) observe_fence();
                 }
                 run_back(dc, pn, next_ready, dn);
                 pre = next_ready;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) __hip_atomic_store(&ts.pend[dc.J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                publish_fence();
+                if (lane == 0) {
+                    if constexpr (TEAM) team_st(gteam + 16 + dc.J, 1u);
+                    else __hip_atomic_store(&ts.pend[dc.J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
             }
-            __syncthreads();
+            tsync();
             return;
         }
         for (int l = n_levels - 1; l >= 0; --l) {
@@ -2305,11 +2460,12 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     double gmax = 0.0;
     {
         double m = 0.0;
-        for (int i = tid; i < n; i += kBlockThreads) {
-            vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
-            m = fmax(m, fabs(vx[i] - clampb(vx[i] - vg[i])));
+        for (int i = gt; i < n; i += GT) {
+            vscale[i] = 1.0 / (1.0 + sqrt(ldd(vadiag + i)));
+            const double xi = ldd(vx + i);
+            m = fmax(m, fabs(xi - clampb(xi - ldd(vg + i))));
         }
-        gmax = block_max<kBlockThreads>(m, sh);
+        gmax = tmax(m);
     }
     double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
     bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
@@ -2332,13 +2488,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         // (The vector passes of this loop take FOUR elements per thread and step, every load of the step issued before the first use: a
         // load from the workspace is ~1-2 k cycles, and an element at a time each pass paid that once per element - index n is the
         // vectors' zero slot, so an index past the end reads zeros and stores nothing.)
-        for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+        for (int i0 = gt; i0 < n; i0 += 4 * GT) {
             double sc[4], dg[4], ad[4], gg[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); sc[u] = vscale[i]; dg[u] = vdiag[i]; ad[u] = vadiag[i]; gg[u] = vg[i]; }
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); sc[u] = ldd(vscale + i); dg[u] = ldd(vdiag + i); ad[u] = ldd(vadiag + i); gg[u] = ldd(vg + i); }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int i = i0 + u * kBlockThreads;
+                const int i = i0 + u * GT;
                 if (i >= n) break;
                 if (!reuse_diagonal) { dg[u] = fmin(fmax(sc[u] * sc[u] * ad[u], kMinLmDiag), kMaxLmDiag); vdiag[i] = dg[u]; }
                 vD[i] = sqrt(dg[u] / radius) / sc[u];                        // D / s (the column tasks add D^2 to their diagonal tiles)
@@ -2346,8 +2502,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
         }
         reuse_diagonal = true;
-        if (tid == 0) sh.flag = 0;                        // raised by a non-positive pivot
-        __syncthreads();
+        if (tid == 0) { sh.flag = 0; if constexpr (TEAM) { if (tm.r == 0) team_st(gteam, 0u); } }     // raised by a non-positive pivot
+        tsync();
         PROF_MARK(LFR_TREE_SLOT_SCALE);
         bool valid = factor();                            // (reads A, writes the factor: J^T J at x stays in A until a trial point is swept)
         PROF_MARK(1);
@@ -2356,13 +2512,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
             double partial = 0.0, gd_part = 0.0, dm_part = 0.0;
-            for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+            for (int i0 = gt; i0 < n; i0 += 4 * GT) {
                 double gi[4], Di[4], st[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); gi[u] = vg[i]; Di[u] = vD[i]; st[u] = vstep[i]; }
+                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); gi[u] = ldd(vg + i); Di[u] = ldd(vD + i); st[u] = ldd(vstep + i); }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int i = i0 + u * kBlockThreads;
+                    const int i = i0 + u * GT;
                     if (i >= n) break;
                     const double dl = -st[u];
                     vdelta[i] = dl;
@@ -2371,7 +2527,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     dm_part = isfinite(dl) ? fmax(dm_part, fabs(dl)) : INFINITY;
                 }
             }
-            block_reduce3<kBlockThreads>(partial, gd_part, dm_part, ts);
+            treduce3(partial, gd_part, dm_part);
             model_cost_change = 0.5 * partial; g_dot_delta = gd_part; dir_max = dm_part;
             valid = isfinite(dir_max) && model_cost_change > 0.0;
         }
@@ -2389,12 +2545,12 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
             int n_iter = 0;
             for (;;) {
-                for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+                for (int i0 = gt; i0 < n; i0 += 4 * GT) {
                     double xo[4], dl[4];
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xo[u] = vx[i]; dl[u] = vdelta[i]; }
+                    for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xo[u] = ldd(vx + i); dl[u] = ldd(vdelta + i); }
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlockThreads; if (i < n) vxc[i] = clampb(__dadd_rn(xo[u], __dmul_rn(alpha, dl[u]))); }
+                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GT; if (i < n) vxc[i] = clampb(__dadd_rn(xo[u], __dmul_rn(alpha, dl[u]))); }
                 }
                 PROF_MARK(4);
                 cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
@@ -2406,8 +2562,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
                 if (current.value_valid) {
                     double p = 0.0;
-                    for (int i = tid; i < n; i += kBlockThreads) p += vdelta[i] * vgn[i];
-                    current.gradient = block_sum<kBlockThreads>(p, sh);
+                    for (int i = gt; i < n; i += GT) p += ldd(vdelta + i) * ldd(vgn + i);
+                    current.gradient = tsum(p);
                     current.gradient_valid = isfinite(current.gradient);
                 }
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
@@ -2417,7 +2573,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
         }
         if (!ls_ok) {
-            for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
+            for (int i = gt; i < n; i += GT) vxc[i] = clampb(__dadd_rn(ldd(vx + i), ldd(vdelta + i)));
             cost_c = sweep(vxc, vgn);
             matrix_valid = false;
             ++exec_passes;
@@ -2426,10 +2582,10 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
         // step norm, and - should the candidate be accepted - its norm and projected gradient, in one pass
         double sn = 0.0, xn = 0.0, gm = 0.0;
-        for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+        for (int i0 = gt; i0 < n; i0 += 4 * GT) {
             double xo[4], xc[4], gn[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xo[u] = vx[i]; xc[u] = vxc[i]; gn[u] = vgn[i]; }
+            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xo[u] = ldd(vx + i); xc[u] = ldd(vxc + i); gn[u] = ldd(vgn + i); }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {            // (past the end: zeros, which add nothing)
                 sn += (xo[u] - xc[u]) * (xo[u] - xc[u]);
@@ -2437,21 +2593,21 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 gm = fmax(gm, fabs(xc[u] - clampb(xc[u] - gn[u])));
             }
         }
-        block_reduce3<kBlockThreads>(sn, xn, gm, ts);
+        treduce3(sn, xn, gm);
         const double step_norm = sqrt(sn);
         if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
         const double cost_change = cost - cost_cand;
         if (fabs(cost_change) <= kFunctionTol * cost) break;
         const double rel = cost_change / model_cost_change;
         if (rel > kMinRelDecrease) {
-            for (int i0 = tid; i0 < n; i0 += 4 * kBlockThreads) {
+            for (int i0 = gt; i0 < n; i0 += 4 * GT) {
                 double xc[4], gn[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * kBlockThreads, n); xc[u] = vxc[i]; gn[u] = vgn[i]; }
+                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xc[u] = ldd(vxc + i); gn[u] = ldd(vgn + i); }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * kBlockThreads; if (i < n) { vx[i] = xc[u]; vg[i] = gn[u]; } }
+                for (int u = 0; u < 4; ++u) { const int i = i0 + u * GT; if (i < n) { vx[i] = xc[u]; vg[i] = gn[u]; } }
             }
-            __syncthreads();
+            tsync();
             x_norm = sqrt(xn);
             cost = cost_cand;
             matrix_valid = true;              // the accepted candidate is the last evaluated point: its J^T J is in the tiles
@@ -2469,15 +2625,16 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     }
     PROF_MARK(4);
     PROF_FLUSH();
-    __syncthreads();
-    for (int p = tid; p < 8 * NB; p += kBlockThreads) {
+    tsync();
+    if constexpr (TEAM) { if (team_ld(tm.ctl + 9) != 0u) term = LFR_TERM_FAILURE; }      // a wait of this launch's teams gave up: nothing computed since can be trusted
+    for (int p = gt; p < 8 * NB; p += GT) {
         const uint32_t v = ipos[p];
         if (v == kNone) continue;
         double *out = a.positions + 2 * (size_t)a.node_ids[d.node_off + v];
-        out[0] = term != LFR_TERM_FAILURE ? vx[2 * p] : 0.0;
-        out[1] = term != LFR_TERM_FAILURE ? vx[2 * p + 1] : 0.0;
+        out[0] = term != LFR_TERM_FAILURE ? ldd(vx + 2 * p) : 0.0;
+        out[1] = term != LFR_TERM_FAILURE ? ldd(vx + 2 * p + 1) : 0.0;
     }
-    if (tid == 0) {
+    if (tid == 0 && (!TEAM || tm.r == 0)) {
         CompInfoDev inf;
         inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
         inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
@@ -2501,7 +2658,125 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
         const int ci = __builtin_amdgcn_readfirstlane(next_ci);
         __syncthreads();
         if (ci < 0) break;
-        solve_tree_component<kBlockThreads>(a, ci, sh, ts);
+        TeamCtx tm;
+        solve_tree_component<kBlockThreads, false>(a, ci, sh, ts, tm);
+        __syncthreads();
+    }
+}
+
+// The same with TEAMS (the comment above TeamCtx).  Workgroups register with their XCC id; kTeamMax consecutive registrations of one XCD
+// form a UNIT whose members share an L2.  A unit starts as one team led by its rank 0.  The leader of a team takes the next component
+// from the class's queue - handed out by expected work, descending, and the wanted team size is a monotone function of that key - and
+// tells its members {component, team size} through their mailboxes; when the component wants a smaller team than the current one the
+// team splits into equal sub-teams for good (the first keeps the component, the leaders of the others go to the queue themselves).
+// A plan that is not "thin" (dense components: barrier schedule) is solved by the leader alone while its members wait.
+// Workgroups that cannot complete a unit (their XCD received no multiple of kTeamMax of them) work as teams of one.
+__device__ __forceinline__ int tree_team_size(const KernelArgs &a, const int ci) {
+    const CompDesc d = a.descs[ci];
+    const uint32_t work = (uint32_t)d.n_var * (1u + ((uint32_t)d.n_nodes - d.n_var > 1u ? 1u : 0u));      // = k_wg_order_keys
+    int t = 1;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) if ((2 << k) <= kTeamMax && work >= a.team_work[k]) t = 2 << k;
+    return t;
+}
+template <int kBlockThreads>
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((kBlockThreads + 255) / 256, (kBlockThreads + 255) / 256))) void solve_tree_team_kernel(const KernelArgs a) {
+    __shared__ BlockShared sh;
+    __shared__ TreeShared ts;
+    __shared__ unsigned int bc[4];
+    const int tid = threadIdx.x;
+    unsigned int *const ctl = a.team_ctl;
+    if (tid == 0) {
+        const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u;             // XCC_ID [3:0]
+        const unsigned slot = __hip_atomic_fetch_add(ctl + xcc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the XCD's count is out before the total says "everyone has registered")
+        __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned unit = slot / kTeamMax;
+        // the unit is complete when kTeamMax (unit + 1) workgroups of this XCD have registered; once the whole grid has registered
+        // and it still is not, it never will be
+        bool complete = false;
+        if (unit < (unsigned)kTeamUnitsPerXcc) {
+            int spins = 0;
+            for (;;) {
+                if (team_ld(ctl + xcc) >= (unit + 1u) * kTeamMax) { complete = true; break; }
+                if (team_ld(ctl + 8) >= gridDim.x) { complete = team_ld(ctl + xcc) >= (unit + 1u) * kTeamMax; break; }
+                __builtin_amdgcn_s_sleep(4);
+                if ((++spins & 255) == 0 && (team_ld(ctl + 9) != 0u || (spins >> 25) != 0)) {
+                    if (team_ld(ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u);
+                    team_st(ctl + 9, 1u);
+                    break;
+                }
+            }
+        }
+        bc[0] = xcc * kTeamUnitsPerXcc + (complete ? unit : 0u); bc[1] = slot % kTeamMax; bc[2] = complete ? (unsigned)kTeamMax : 1u;
+    }
+    __syncthreads();
+    const unsigned unit_slot = __builtin_amdgcn_readfirstlane(bc[0]);
+    const int rank = (int)__builtin_amdgcn_readfirstlane(bc[1]);
+    int S = (int)__builtin_amdgcn_readfirstlane(bc[2]);
+    int L = S == 1 ? rank : 0;                            // leader of my team: ranks [L, L + S) of the unit
+    unsigned int *const mbox = ctl + 16 + 16 * unit_slot, *const bars = mbox + 8;
+    TeamCtx tm;
+    tm.ctl = ctl;
+    __syncthreads();
+    for (;;) {
+        if (tid == 0) {
+            unsigned msg = kTeamMsgEnd;
+            if (rank == L) {
+                const int k = a.desc_begin + (int)atomicAdd(a.queue + a.cls, 1u);
+                if (k < a.desc_end && team_ld(ctl + 9) == 0u) {
+                    const int ci = (int)a.wg_order[k - a.wg_begin];
+                    const bool thin = reinterpret_cast<const uint32_t *>(a.workspace + a.ws_off[ci])[28] != 0u;
+                    const int t = thin ? min(S, tree_team_size(a, ci)) : 0;                // 0: the leader alone, the team stays as it is
+                    msg = (t == 0 ? 0u : (unsigned)(32 - __builtin_clz((unsigned)t)) << 28) | (unsigned)(ci + 1);
+                }
+                if (msg == kTeamMsgEnd || (msg >> 28) != 0u) {
+                    for (int m = L + 1; m < L + S; ++m) {                                  // (a member clears its mailbox when it has read it)
+                        int spins = 0;
+                        while (team_ld(mbox + m) != 0u && (++spins >> 22) == 0) __builtin_amdgcn_s_sleep(1);
+                        team_st(mbox + m, msg);
+                    }
+                }
+            } else {
+                int spins = 0;
+                for (;;) {
+                    msg = team_ld(mbox + rank);
+                    if (msg != 0u) { team_st(mbox + rank, 0u); break; }
+                    __builtin_amdgcn_s_sleep(8);
+                    if ((++spins & 255) == 0 && (team_ld(ctl + 9) != 0u || (spins >> 25) != 0)) {
+                        if (team_ld(ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u);
+                        team_st(ctl + 9, 1u);
+                        msg = kTeamMsgEnd;
+                        break;
+                    }
+                }
+            }
+            bc[3] = msg;
+        }
+        __syncthreads();
+        const unsigned msg = __builtin_amdgcn_readfirstlane(bc[3]);
+        __syncthreads();
+        if (msg == kTeamMsgEnd) break;
+        const int ci = (int)(msg & 0x0fffffffu) - 1;
+        bool alone = (msg >> 28) == 0u;                   // (leader only: a component whose plan keeps the barrier schedule; the team stays)
+        if (!alone) {
+            const int s_new = 1 << ((int)(msg >> 28) - 1);
+            const int L_new = L + ((rank - L) / s_new) * s_new;
+            const bool mine = L_new == L;                 // the component stays with the first sub-team
+            if (L_new != L) tm.target = 0;                // (a counter nobody has used yet)
+            S = s_new; L = L_new;
+            if (!mine) continue;                          // detached: my sub-team's leader goes to the queue itself
+            alone = S == 1;
+        }
+        if (alone) {
+            TeamCtx solo;
+            solve_tree_component<kBlockThreads, false>(a, ci, sh, ts, solo);
+        } else {
+            tm.S = S; tm.r = rank - L; tm.bar = bars + L;
+            tm.red = a.team_red + (size_t)unit_slot * kTeamRedPerUnit + (size_t)(L / 2) * (2 * kTeamMax * 4);
+            if (tid == 0 && tm.r == 0) atomicAdd(ctl + 10, 1u);           // (statistics: components solved by a team)
+            solve_tree_component<kBlockThreads, true>(a, ci, sh, ts, tm);
+        }
         __syncthreads();
     }
 }
@@ -2632,6 +2907,12 @@ struct lfr_batch {
     int tree_levels_max = 0;                             // KC_GLOBAL: levels of the deepest elimination tree
     int64_t tree_blocks = 0, tree_updates = 0;           // KC_GLOBAL: 16-row columns / left-looking tile updates per factorization, summed over the class
     int tree_begin = 0;                                  // first descriptor of the class; per component of the class: columns, tiles, 16x16x16 updates, levels, sweep items
+    // teams of workgroups per component (solve_tree_team_kernel): control words + reduction slots at the tail of the workspace,
+    // the work thresholds of teams of 2 / 4 / 8 (LFR_TREE_TEAM), the workgroups the class's components ask for together
+    unsigned int *d_team_ctl = nullptr;
+    double *d_team_red = nullptr;
+    uint32_t team_work[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+    int team_wgs = 0;
     std::vector<int64_t> tree_comp_stats;                // 5 per component
     int64_t sky_tiles = 0, sky_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
@@ -2905,8 +3186,43 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         b->tree_comp_stats.insert(b->tree_comp_stats.end(), cs, cs + 5);
     }
     b->tree_begin = g0;
+    // Teams (the comment above TeamCtx): a component whose hand-out key reaches team_work[k] is solved by 2 << k workgroups.
+    // LFR_TREE_TEAM="w2,w4[,w8]" sets the thresholds, "0" switches teams off.  Defaults from the cap-sized sparse workload: one
+    // workgroup runs ~0.11 us per row and LM iteration, iteration counts vary 10-40 whatever the size, so everything above ~700 rows
+    // can end a launch on its own.
+    {
+        uint32_t w[3] = {700u, 1500u, 0xffffffffu};
+        if (const char *e = getenv("LFR_TREE_TEAM")) {
+            unsigned v[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
+            const int got = sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]);
+            if (got >= 1 && v[0] == 0u) w[0] = w[1] = w[2] = 0xffffffffu;
+            else if (got >= 2) { w[0] = v[0]; w[1] = std::max(v[0], v[1]); w[2] = got >= 3 ? std::max(w[1], v[2]) : 0xffffffffu; }
+        }
+        int64_t wgs = 0;
+        bool any = false;
+        for (int i = 0; i < ng; ++i) {
+            const CompDesc &d = b->descs[g0 + i];
+            const uint32_t work = (uint32_t)d.n_var * (1u + ((uint32_t)d.n_nodes - d.n_var > 1u ? 1u : 0u));
+            int t = 1;
+            for (int k = 0; k < 3; ++k) if ((2 << k) <= kTeamMax && work >= w[k]) t = 2 << k;
+            if (plans[i].blob[28] == 0u) t = 1;
+            any = any || t > 1;
+            wgs += t;
+        }
+        b->team_wgs = 0;
+        if (any && b->n_desc < (1 << 28)) {
+            for (int k = 0; k < 3; ++k) b->team_work[k] = w[k];
+            b->team_wgs = (int)std::min<int64_t>(256, (wgs + 31) / 32 * 32);
+        }
+    }
+    const uint64_t team_off = ws;
+    if (b->team_wgs) ws += (kTeamCtlWords + 1) / 2 + 8ull * kTeamUnitsPerXcc * kTeamRedPerUnit;
     if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
     b->d_workspace = (double *)b->ws_slab.base;
+    if (b->team_wgs) {
+        b->d_team_ctl = reinterpret_cast<unsigned int *>(b->d_workspace + team_off);
+        b->d_team_red = b->d_workspace + team_off + (kTeamCtlWords + 1) / 2;
+    }
     // the plans' words: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
     size_t got = 0;
     double *stage = (double *)b->ctx->pinned_acquire(std::max<uint64_t>(hdr_total, 1) * sizeof(double), &got);
@@ -3258,6 +3574,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.wg_order = b->d_wg_order; a.wg_begin = b->class_begin[lfr::KC_BLOCK];
     a.edge_ref = b->d_edge_ref; a.edge_word = b->d_edge_word;
     a.f_row = nullptr; a.f_disp1 = a.f_disp2 = a.f_sim = nullptr;
+    a.team_ctl = b->d_team_ctl; a.team_red = b->d_team_red;
+    for (int k = 0; k < 3; ++k) a.team_work[k] = b->team_work[k];
     if (b->fused) {
         const lfr::DevGraph &dgr = *b->dev_hold->graph;
         a.f_row = dgr.flow_row; a.f_disp1 = dgr.disp1; a.f_disp2 = dgr.disp2; a.f_sim = dgr.sim;
@@ -3279,6 +3597,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {
         HIP_TRY(hipStreamWaitEvent(st, b->ev_order, 0));
         HIP_TRY(hipMemsetAsync(a.queue, 0, 64, st));                       // the classes' component queues
+        if (b->d_team_ctl) HIP_TRY(hipMemsetAsync(b->d_team_ctl, 0, kTeamCtlWords * sizeof(unsigned int), st));   // registrations, mailboxes, barrier counters of the teams
     }
 
     // The packed classes go out as ONE launch on the caller's stream (solve_packed_kernel); the few
@@ -3303,7 +3622,8 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
             default: {
                 // elimination-tree kernel: one 512-thread workgroup per CU (two waves per SIMD), static LDS only
-                hipLaunchKernelGGL((solve_tree_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu)), dim3(kThreadsG), 0, cs, a);
+                if (b->d_team_ctl) hipLaunchKernelGGL((solve_tree_team_kernel<kThreadsG>), dim3(std::max(32, std::min(b->team_wgs, b->ctx->n_cu / 32 * 32))), dim3(kThreadsG), 0, cs, a);
+                else hipLaunchKernelGGL((solve_tree_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu)), dim3(kThreadsG), 0, cs, a);
                 break;
             }
         }
@@ -3501,6 +3821,18 @@ int64_t lfr_batch_spin_timeouts(lfr_batch *b) {
     HIP_TRY(hipStreamSynchronize(b->last_stream));
     unsigned int v = 0;
     HIP_TRY(hipMemcpy(&v, reinterpret_cast<unsigned int *>(b->d_prof + 8 * lfr::KC_COUNT) + 15, sizeof v, hipMemcpyDeviceToHost));
+    return (int64_t)v;
+}
+
+// Components the latest solve handed to a TEAM of two or more workgroups (solve_tree_team_kernel); 0 when the batch has none above the
+// thresholds (LFR_TREE_TEAM) or no elimination-tree class at all.
+int64_t lfr_batch_team_runs(lfr_batch *b) {
+    if (!b) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (b->n_solves == 0 || !b->d_team_ctl) return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    unsigned int v = 0;
+    HIP_TRY(hipMemcpy(&v, b->d_team_ctl + 10, sizeof v, hipMemcpyDeviceToHost));
     return (int64_t)v;
 }
 

@@ -553,8 +553,11 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // The kernel addresses A's tiles, the factor's tiles and the vectors through three buffer descriptors with 32-bit BYTE offsets
     // (tile << 11): fewer than 2^21 tiles (4 GB per array) and 32-bit double offsets for the rest - a dense 16 k-node component
     // still fits, a dense 32 k-node one (34 GB of tiles) is refused with an error instead of wrapping around.
-    if (n_tiles >= (1u << 21) || off_vec + (uint64_t)kTreeVectors * out.vec_stride() >= (1ull << 32)) { out.blob.clear(); return; }
+    if (n_tiles >= (1u << 21) || n_edges >= (1ll << 30) || off_vec + (uint64_t)kTreeVectors * out.vec_stride() + out.team_doubles() >= (1ull << 32)) { out.blob.clear(); return; }
     blob[3] = (uint32_t)off_vec; blob[23] = (uint32_t)off_part; blob[24] = (uint32_t)out.vec_stride();
+    // behind the vectors: the words several workgroups working on ONE component meet at (solve_tree_component<.., TEAM>): 16 words
+    // (the bad-pivot flag first) + one dependency counter per column, touched by agent-scope atomics only
+    blob[29] = (uint32_t)(off_vec + (uint64_t)kTreeVectors * out.vec_stride());
     // a model of the factorization's critical path: per level, the column tasks dealt to 8 waves
     {
         uint64_t rounds = 0;
@@ -568,7 +571,8 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
 
 uint64_t TreePlan::vec_stride() const { return 16ull * NB + 16ull; }
 uint64_t TreePlan::header_doubles() const { return blob.size() / 2; }
-uint64_t TreePlan::doubles() const { return blob.empty() ? 0 : (uint64_t)blob[3] + (uint64_t)kTreeVectors * vec_stride(); }
+uint64_t TreePlan::team_doubles() const { return (16ull + (uint64_t)NB + 1) / 2; }
+uint64_t TreePlan::doubles() const { return blob.empty() ? 0 : (uint64_t)blob[3] + (uint64_t)kTreeVectors * vec_stride() + team_doubles(); }
 
 }  // namespace lfr
 

@@ -104,6 +104,7 @@ def lib():
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_batch_spin_timeouts": (i64, [vp]),
+        "lfr_batch_team_runs": (i64, [vp]),
         "lfr_batch_tree_stats": (i64, [vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
         "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, C.c_int, vp]),
@@ -127,7 +128,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_team_runs", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -478,6 +479,13 @@ class Batch:
     def spin_timeouts(self):
         """Bounded spin-waits of the workgroup kernels that ran out during the latest solve (0 on a healthy run)."""
         n = lib().lfr_batch_spin_timeouts(self._h)
+        if n < 0:
+            _check(int(n))
+        return int(n)
+
+    def team_runs(self):
+        """Components the latest solve handed to a team of two or more workgroups (elimination-tree class)."""
+        n = lib().lfr_batch_team_runs(self._h)
         if n < 0:
             _check(int(n))
         return int(n)

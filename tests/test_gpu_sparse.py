@@ -52,6 +52,33 @@ def test_cap_sized_sparse_components_at_full_size(lfr_lib):
         assert (b.download() == x1).all() and b.spin_timeouts() == 0             # bitwise repeatable
 
 
+def test_teams_of_workgroups_per_component(lfr_lib, monkeypatch):
+    """Round 5: a component above a work threshold is solved by a TEAM of 2 / 4 workgroups on one XCD (LFR_TREE_TEAM).  Same trajectory and
+    positions (to rounding: the reductions meet in another order) as one workgroup per component, bitwise repeatable, no wait gave up;
+    with tiny thresholds more teams than the chip has units queue up and split on the way down the queue."""
+    ma = synthetic.capsized_sparse(n_tracks=2500, seed=7)
+    p = capi.Problem(capi.Graph.from_arrays(ma))
+    out = {}
+    for setting in ("0", "700,1500", "100,200", "100,100"):
+        monkeypatch.setenv("LFR_TREE_TEAM", setting)
+        b = capi.Batch(p, 0)
+        st = b.solve()
+        pos = b.download().copy()
+        info = b.component_info()
+        assert st["n_failed"] == 0 and b.spin_timeouts() == 0, setting
+        assert (b.team_runs() > 0) == (setting != "0"), setting
+        for _ in range(3):
+            b.solve()
+            assert (b.download() == pos).all() and b.spin_timeouts() == 0, setting
+        out[setting] = (pos, info)
+    rows = 2 * out["0"][1]["n_var_nodes"]
+    assert (rows >= 1500).sum() >= 3
+    for setting in ("700,1500", "100,200", "100,100"):
+        assert np.abs(out[setting][0] - out["0"][0]).max() <= 1e-9, setting
+        assert (out[setting][1]["termination"] == out["0"][1]["termination"]).all()
+        assert (out[setting][1]["iterations"] == out["0"][1]["iterations"]).mean() >= 0.99
+
+
 def _explicit(n_images, matches, seed):
     """MatchArrays from explicit (image a, image b) matches between feature 0 of the images (one node per image); flows = consistent
     offsets + noise"""
