@@ -77,6 +77,7 @@ struct KernelArgs {
     unsigned int *team_ctl;
     double *team_red;
     uint32_t team_work[3];
+    unsigned long long *trace;  // -DLFR_TRACE_TREE: [0] = words used, then {s_memtime, type << 56 | wave of the team << 48 | iteration << 32 | column} pairs
 };
 
 // =============================================================================================
@@ -1664,7 +1665,7 @@ struct TreeShared {
     // per wave: four tiles in rows of 18 doubles (the column task turns its accumulators from the matrix cores' layout into
     // lane = row through them; the extra-row tasks stage a diagonal tile there) + 16 doubles (the right-hand side / 1/d)
     double x[LFR_THREADS_G / 64][4 * 288 + 16];
-    double red3[LFR_THREADS_G / 64][3];
+    double red3[LFR_THREADS_G / 64][5];
     int pend[lfr::kTreeMaxFlagColumns];        // "thin" plans: children a column still waits for (factorization) / column solved (back substitution)
 };
 // ---- TEAMS: several workgroups on ONE component (round 5) ----
@@ -1688,19 +1689,19 @@ struct TreeShared {
 // of unit u (a one-slot channel: the leader stores when it reads 0, the member clears), [16 + 16 u + 8 + L] arrival counter of the team
 // led by rank L.  Reduction slots (KernelArgs::team_red): per unit and leader, two parities x members x 4 doubles.
 #ifndef LFR_TEAM_MAX
-#define LFR_TEAM_MAX 4
+#define LFR_TEAM_MAX 8
 #endif
 constexpr int kTeamMax = LFR_TEAM_MAX;                     // workgroups per unit (a power of two <= 8)
 constexpr int kTeamUnitsPerXcc = 256 / kTeamMax;           // a launch has at most 256 workgroups
 constexpr int kTeamCtlWords = 16 + 16 * 8 * kTeamUnitsPerXcc;
-constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 4;
+constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 8;
 constexpr unsigned kTeamMsgEnd = 0xf0000000u;
 static_assert(kTeamMax == 2 || kTeamMax == 4 || kTeamMax == 8, "team size");
 struct TeamCtx {
     int S = 1, r = 0;                 // workgroups in the team, this workgroup's index in it
     unsigned int *bar = nullptr;      // arrival counter of the team (monotonic)
     unsigned int target = 0;          // its value when everyone has arrived at the latest barrier
-    double *red = nullptr;            // reduction slots [2][kTeamMax][4]
+    double *red = nullptr;            // reduction slots [2][kTeamMax][8]
     int par = 0;
     unsigned int *ctl = nullptr;      // control words of the launch ([9] = abort)
     bool dead = false;                // this workgroup has seen the abort word: waits return at once
@@ -1727,17 +1728,17 @@ typedef const __attribute__((address_space(4))) uint32_t *PlanWords;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
-// two sums and a maximum over the workgroup with one pair of barriers
+// four sums and a maximum over the workgroup with one pair of barriers
 template <int kBlockThreads>
-__device__ __forceinline__ void block_reduce3(double &s0, double &s1, double &m0, TreeShared &ts) {
-    s0 = wave_sum(s0); s1 = wave_sum(s1); m0 = wave_max(m0);
+__device__ __forceinline__ void block_reduce5(double &s0, double &s1, double &s2, double &s3, double &m0, TreeShared &ts) {
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3); m0 = wave_max(m0);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) { double *r = ts.red3[threadIdx.x >> 6]; r[0] = s0; r[1] = s1; r[2] = m0; }
+    if ((threadIdx.x & 63) == 0) { double *r = ts.red3[threadIdx.x >> 6]; r[0] = s0; r[1] = s1; r[2] = s2; r[3] = s3; r[4] = m0; }
     __syncthreads();
-    double a = 0.0, b = 0.0, c = ts.red3[0][2];
+    double a = 0.0, b = 0.0, e = 0.0, f = 0.0, c = ts.red3[0][4];
 #pragma unroll
-    for (int w = 0; w < kBlockThreads / 64; ++w) { a += ts.red3[w][0]; b += ts.red3[w][1]; c = fmax(c, ts.red3[w][2]); }
-    s0 = a; s1 = b; m0 = c;
+    for (int w = 0; w < kBlockThreads / 64; ++w) { a += ts.red3[w][0]; b += ts.red3[w][1]; e += ts.red3[w][2]; f += ts.red3[w][3]; c = fmax(c, ts.red3[w][4]); }
+    s0 = a; s1 = b; s2 = e; s3 = f; m0 = c;
 }
 
 template <int kBlockThreads, bool TEAM>
@@ -1746,6 +1747,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     constexpr uint32_t kNone = 0xffffffffu;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
+#if defined(LFR_PROFILE_WGTIME) && LFR_PROFILE_WGTIME == 3
+    const unsigned long long tree_r0_ = wall_clock64();
+#endif
     // the team's threads / waves (TEAM = false: this workgroup alone, and every helper below is what it was before teams existed)
     const int tS = TEAM ? tm.S : 1;
     const int gt = TEAM ? tm.r * kBlockThreads + tid : tid, GT = tS * kBlockThreads;
@@ -1754,6 +1758,22 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     auto ldd = [](const double *p) -> double {
         if constexpr (TEAM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
     };
+#ifdef LFR_TRACE_TREE      // (scripts/tree_trace.py) events of the FIRST component of the hand-out order, LM iterations 2-4
+    int trace_it = 0;
+    const bool traced = a.trace != nullptr && ci == (int)a.wg_order[a.desc_begin - a.wg_begin];
+    auto tr = [&](const unsigned type, const unsigned col) {
+        if (traced && trace_it >= 2 && trace_it <= 4 && lane == 0) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            const unsigned long long i = atomicAdd(a.trace, 2ull);
+            if (i + 2 < (1ull << 20)) { a.trace[2 + i] = t; a.trace[3 + i] = ((unsigned long long)type << 56) | ((unsigned long long)gw << 48) | ((unsigned long long)trace_it << 32) | col; }
+        }
+    };
+#define TR(type, col) tr(type, col)
+#define TR_IT(it) trace_it = (it)
+#else
+#define TR(type, col)
+#define TR_IT(it)
+#endif
     // barrier over the team: every wave's stores have reached L2 before its workgroup arrives
     auto tsync = [&]() {
         if constexpr (TEAM) {
@@ -1801,36 +1821,39 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     }
     tsync();
     // sums and maxima over the team: the workgroup's value first (every thread holds it), then the members' values in a fixed order
-    auto treduce3 = [&](double &s0, double &s1, double &m0) {
-        block_reduce3<kBlockThreads>(s0, s1, m0, ts);
+    auto treduce5 = [&](double &s0, double &s1, double &s2, double &s3, double &m0) {
+        block_reduce5<kBlockThreads>(s0, s1, s2, s3, m0, ts);
         if constexpr (TEAM) {
-            double *slot = tm.red + tm.par * (kTeamMax * 4);
-            if (tid == 0) { slot[4 * tm.r] = s0; slot[4 * tm.r + 1] = s1; slot[4 * tm.r + 2] = m0; }
+            double *slot = tm.red + tm.par * (kTeamMax * 8);
+            if (tid == 0) { double *o = slot + 8 * tm.r; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = m0; }
             tsync();
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0;
+            double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0;
             for (int w = 0; w < tS; ++w) {
-                x0 += ldd(slot + 4 * w); x1 += ldd(slot + 4 * w + 1);
-                const double mw = ldd(slot + 4 * w + 2);
-                x2 = w == 0 ? mw : fmax(x2, mw);
+                x0 += ldd(slot + 8 * w); x1 += ldd(slot + 8 * w + 1); x2 += ldd(slot + 8 * w + 2); x3 += ldd(slot + 8 * w + 3);
+                const double mw = ldd(slot + 8 * w + 4);
+                x4 = w == 0 ? mw : fmax(x4, mw);
             }
-            s0 = x0; s1 = x1; m0 = x2;
+            s0 = x0; s1 = x1; s2 = x2; s3 = x3; m0 = x4;
             tm.par ^= 1;
         }
     };
-    auto tsum = [&](double v) -> double {
-        if constexpr (TEAM) { double z = 0.0, m = 0.0; treduce3(v, z, m); return v; } else return block_sum<kBlockThreads>(v, sh);
-    };
-    auto tmax = [&](double v) -> double {
-        if constexpr (TEAM) { double z0 = 0.0, z1 = 0.0; treduce3(z0, z1, v); return v; } else return block_max<kBlockThreads>(v, sh);
-    };
+    auto treduce4 = [&](double &s0, double &s1, double &s2, double &m0) { double z = 0.0; treduce5(s0, s1, s2, z, m0); };
 
     PROF_DECL
-    // ---- one sweep at xv: the cost, gout = J^T r and the unscaled J^T J in the tiles.  (Starts with a barrier of its own: whatever
-    //      the caller wrote to xv before is visible to the items.) ----
-    auto sweep = [&](const double *xv, double *gout) -> double {
-        tsync();
+    // ---- one sweep at x = xb (trial = false) or at the trial point clamp(xb + alpha dl): the cost, gout = J^T r and the unscaled
+    //      J^T J in the tiles.  The trial point is formed on the fly by whoever needs a coordinate (separately rounded product and
+    //      sum, like Ceres forms its candidate) and STORED by the node pass (xout) - no vector pass, no barrier in front of the
+    //      items: what they read (xb, dl) was published by the barrier of an earlier reduction, what they write (cross blocks,
+    //      partial sums) was last read before one.  Besides the cost the sweep returns what the trust-region loop wants to know
+    //      about the point: sn = |x - xc|^2, xn = |xc|^2, gd = dl . g(xc), gm = max |xc - clamp(xc - g(xc))|. ----
+    struct SweepOut { double cost, sn, xn, gd, gm; };
+    auto sweep = [&](const double *xb, const double *dl, const double alpha, const bool trial, double *xout, double *gout) -> SweepOut {
         TPROF_MARK(2);
         double cost = 0.0;
+        auto point = [&](const uint32_t row) -> double {
+            const double x0 = ldd(xb + row);
+            return trial ? clampb(__dadd_rn(x0, __dmul_rn(alpha, ldd(dl + row)))) : x0;
+        };
         // One item = 8 words (lfr_treeplan.cpp): rows of the node and of the neighbour, the pair's block in A, the record count, the first
         // two records inline.  The item of the NEXT pass is fetched before this one is evaluated, and both records of the usual pair
         // are loaded before the first evaluation: one exposed round trip per pass instead of three dependent ones.
@@ -1846,7 +1869,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             const uint4 it = ia, it2 = ib;                                       // {row, row of the neighbour, cross block, records} {record 0, record 1, further, -}
             const int in = i + GT;
             if (in < n_items) { ia = reinterpret_cast<const uint4 *>(items)[2 * in]; ib = reinterpret_cast<const uint4 *>(items)[2 * in + 1]; }
-            const double xv0 = ldd(xv + it.x), xv1 = ldd(xv + it.x + 1), xu0 = ldd(xv + it.y), xu1 = ldd(xv + it.y + 1);
+            const double xv0 = point(it.x), xv1 = point(it.x + 1), xu0 = point(it.y), xu1 = point(it.y + 1);
             uint4 q0[5], q1[5];
             load_record(it2.x, q0);
             load_record(it.w > 1u ? it2.y : it2.x, q1);
@@ -1892,27 +1915,83 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             i = in;
         }
         TPROF_MARK(3);
-        const double total = tsum(cost);                                    // (barriers inside: cross blocks and partial sums are out)
+        TR(20, 0);
+        SweepOut so;
+        // The node pass: one lane per node sums the node's items in list order.  What it needs that does not depend on the items
+        // (its item range, its point, the diagonal tile) is requested BEFORE the barrier that publishes the items' partial sums; the
+        // cost rides in the reduction behind the node pass: one barrier and one reduction per sweep.
+        struct NodePre { uint32_t ip, i0, i1, dt; double xo0, xo1, dl0, dl1; };
+        auto node_pre = [&](const int p) -> NodePre {
+            NodePre q;
+            q.ip = p < 8 * NB ? ipos[p] : kNone;
+            q.i0 = q.i1 = 0u; q.dt = 0u; q.xo0 = q.xo1 = q.dl0 = q.dl1 = 0.0;
+            if (q.ip != kNone) {
+                q.i0 = node_items[p]; q.i1 = node_items[p + 1]; q.dt = hdr[pl[8] + (p >> 3)];
+                q.xo0 = ldd(xb + 2 * p); q.xo1 = ldd(xb + 2 * p + 1);
+                if (trial) { q.dl0 = ldd(dl + 2 * p); q.dl1 = ldd(dl + 2 * p + 1); }
+            }
+            return q;
+        };
+#ifndef LFR_T_SWEEP_MERGE
+#define LFR_T_SWEEP_MERGE 1
+#endif
+#if LFR_T_SWEEP_MERGE
+        NodePre np = node_pre(gt);
+        tsync();                                                            // cross blocks and partial sums are out
+#else
+        { double z1 = 0.0, z2 = 0.0, z3 = 0.0, z4 = 0.0; treduce5(cost, z1, z2, z3, z4); }
+        const double cost_total = cost;
+        cost = 0.0;
+        NodePre np = node_pre(gt);
+#endif
+        TR(21, 0);
+        double sn = 0.0, xn = 0.0, gd = 0.0, gm = 0.0;
         for (int p = gt; p < 8 * NB; p += GT) {
-            if (ipos[p] == kNone) continue;
+#if LFR_T_SWEEP_MERGE
+            const NodePre nq = np;
+            if (p + GT < 8 * NB) np = node_pre(p + GT);
+#else
+            const NodePre nq = p == gt ? np : node_pre(p);
+#endif
+            if (nq.ip == kNone) continue;
+            const uint32_t i0 = nq.i0, i1 = nq.i1;
+            const double xo0 = nq.xo0, xo1 = nq.xo1, dl0 = nq.dl0, dl1 = nq.dl1;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0;
-            for (uint32_t i = node_items[p]; i < node_items[p + 1]; ++i) {
-                if constexpr (TEAM) {
-                    const double *pp = part + 6 * (size_t)i;
-                    s0 += ldd(pp); s1 += ldd(pp + 1); s2 += ldd(pp + 2); s3 += ldd(pp + 3); s4 += ldd(pp + 4);
-                } else {
-                    const double2 *pp = reinterpret_cast<const double2 *>(part + 6 * (size_t)i);
-                    const double2 u0 = pp[0], u1 = pp[1], u2 = pp[2];
-                    s0 += u0.x; s1 += u0.y; s2 += u1.x; s3 += u1.y; s4 += u2.x;
+#ifndef LFR_T_NODE_BATCH
+#define LFR_T_NODE_BATCH 1
+#endif
+            for (uint32_t ib0 = i0; ib0 < i1; ib0 += (uint32_t)LFR_T_NODE_BATCH) {
+                double u[LFR_T_NODE_BATCH][5];
+#pragma unroll
+                for (int k = 0; k < LFR_T_NODE_BATCH; ++k) {
+                    const double *pp = part + 6 * (size_t)min(ib0 + (uint32_t)k, i1 - 1u);
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) u[k][c] = ldd(pp + c);
+                }
+#pragma unroll
+                for (int k = 0; k < LFR_T_NODE_BATCH; ++k) {
+                    if (ib0 + (uint32_t)k < i1) { s0 += u[k][0]; s1 += u[k][1]; s2 += u[k][2]; s3 += u[k][3]; s4 += u[k][4]; }
                 }
             }
-            double *T = atiles + ((size_t)hdr[pl[8] + (p >> 3)] << 8) + 34 * (p & 7);  // entry (2 slot, 2 slot) of the diagonal tile
+            double *T = atiles + ((size_t)nq.dt << 8) + 34 * (p & 7);  // entry (2 slot, 2 slot) of the diagonal tile
             T[0] = s0; T[16] = s1; T[17] = s2;
             gout[2 * p] = s3; gout[2 * p + 1] = s4;
             vadiag[2 * p] = s0; vadiag[2 * p + 1] = s2;
+            const double xc0 = trial ? clampb(__dadd_rn(xo0, __dmul_rn(alpha, dl0))) : xo0, xc1 = trial ? clampb(__dadd_rn(xo1, __dmul_rn(alpha, dl1))) : xo1;
+            if (trial) { xout[2 * p] = xc0; xout[2 * p + 1] = xc1; }
+            sn += (xo0 - xc0) * (xo0 - xc0) + (xo1 - xc1) * (xo1 - xc1);
+            xn += xc0 * xc0 + xc1 * xc1;
+            gd += dl0 * s3 + dl1 * s4;
+            gm = fmax(gm, fmax(fabs(xc0 - clampb(xc0 - s3)), fabs(xc1 - clampb(xc1 - s4))));
         }
-        tsync();
-        return total;
+        TR(22, 0);
+        treduce5(cost, sn, xn, gd, gm);                                     // (its barrier also publishes the node pass)
+        TR(23, 0);
+#if !LFR_T_SWEEP_MERGE
+        cost = cost_total;
+#endif
+        so.cost = cost; so.sn = sn; so.xn = xn; so.gd = gd; so.gm = gm;
+        return so;
     };
 
     // descriptor of a column task (lfr_treeplan.cpp: col_desc, columns in level order): one pair of scalar loads
@@ -1991,8 +2070,10 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     };
     // what a column task loads before it can start: A's tiles of the column (accumulator layout: row 4 r + kq, column r16), w_J, the
     // LM diagonal of this lane's row, the operands of its first update entry
+    // (two halves: A's tiles, w_J and the LM diagonal do not depend on the column's children - they are requested BEFORE the wave
+    // waits for them; the operands of the first update entry are the children's rows)
     struct ColPre { f64x4 cD, cS0, cS1, cS2; double wj, dd; UpdB o0; UpdY y0; };
-    auto issue_column = [&](const ColDesc &c, ColPre &p) {
+    auto issue_static = [&](const ColDesc &c, ColPre &p) {
         const unsigned so = c.t0 << 11;
 #pragma unroll
         for (int r = 0; r < 4; ++r) p.cD[r] = bld(rA, bo_c + 512u * r, so);
@@ -2011,13 +2092,84 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         }
         p.wj = bld(rV, bo_r, so_w + (c.J << 7));
         p.dd = bld(rV, bo_r, so_D + (c.J << 7));
+    };
+    auto issue_ops = [&](const ColDesc &c, ColPre &p) {
         if (c.ne > 0u) { load_b(c.k0, c.tb0, p.o0); load_y(c.a00, c.a01, c.a02, p.y0); }
+    };
+
+    // ---- "thin" plans (every column carries all its tiles): no barrier per level.  Every column has a STATE word (ts.pend[J] in LDS; a
+    //      team's words in HBM): 0 = not factored yet, 1 = factored (its rows are in the workspace), 2 = solved (back substitution).  The
+    //      waves walk their columns in level order - dependencies always point to lower levels, so some wave can always proceed.
+    //      Round 5: a column does not wait for "all my children are done" any more.  Its left-looking update has one ENTRY per
+    //      descendant that touches it - 5 to 20 entries for the columns near the root, applied in a fixed order (k ascending) - and
+    //      almost all of those descendants were finished long before the last child is: the column task streams through its entries,
+    //      each gated by the state of ITS column k only (one poll refreshes the states of up to 64 entries, a lane each), so that
+    //      when the last child reports, what is left is that child's entry, the turn and the elimination.  Before, the whole chain
+    //      "wait for the children, then one dependent round trip to the workspace per entry" sat on the critical path: half of the
+    //      factorization's time for a 2.4 k-row component. ----
+    const bool thin = pl[28] != 0u;
+    // (a miscount must not hang the GPU: the step is rejected, the counter says so; a team gives up as a whole - the abort word ends
+    // every wait of the launch's teams and fails their components)
+    bool wdead = false;                                   // TEAM: this wave has seen the abort word
+    auto spin_timeout = [&]() {
+        if (lane == 0) {
+            sh.flag = 1;
+            if constexpr (TEAM) { if (team_ld(tm.ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u); team_st(tm.ctl + 9, 1u); team_st(gteam, 1u); }
+            else atomicAdd(a.queue + 15, 1u);
+        }
+        if constexpr (TEAM) wdead = true;
+    };
+    auto state_lane = [&](const uint32_t J) -> int {       // per lane (J may differ between lanes)
+        if constexpr (TEAM) return (int)team_ld(gteam + 16 + J);
+        else return __hip_atomic_load(&ts.pend[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    auto pend_load = [&](const uint32_t J) -> int { return __builtin_amdgcn_readfirstlane(state_lane(J)); };
+    auto state_store = [&](const uint32_t J, const int v) {
+        if constexpr (TEAM) team_st(gteam + 16 + J, (unsigned)v);
+        else __hip_atomic_store(&ts.pend[J], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    // wait until `ready()`; TEAM: the abort word is looked at every 256 polls
+    auto pend_wait = [&](auto ready) {
+        if (TEAM && wdead) return;
+        int spins = 0;
+        while (!ready()) {
+            __builtin_amdgcn_s_sleep(2);
+            ++spins;
+            if constexpr (TEAM) { if ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane((int)team_ld(tm.ctl + 9)) != 0) { wdead = true; sh.flag = 1; break; } }
+            if (spins > (1 << 22)) { spin_timeout(); break; }
+        }
+    };
+    // what a finished column / a waiting column needs around a state word: the column's rows have left the wave (TEAM: have reached
+    // L2 - the reader's loads bypass its own L1), and the reader's loads are issued after the state was seen
+    auto publish_fence = [&]() {
+        if constexpr (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    };
+    auto observe_fence = [&]() {
+        if constexpr (TEAM) asm volatile("" ::: "memory");
+        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // the gate of a column's update entries: entry i of the column (col_upd[e_first + i], column k_i) may be loaded once k_i is factored
+    struct EntryGate { uint32_t e_first, ne, chunk, kl; unsigned long long ok; };
+    auto gate_open = [&](const ColDesc &c) -> EntryGate { return EntryGate{c.e_rest - 2u, c.ne, kNone, kNone, 0ull}; };
+    auto gate_wait = [&](EntryGate &g, const uint32_t i) {
+        const uint32_t c = i >> 6;
+        if (c != g.chunk) {                                // the columns of entries 64 c .. 64 c + 63, one per lane
+            g.chunk = c; g.ok = 0ull;
+            g.kl = (c << 6) + (uint32_t)lane < g.ne ? hdr[pl[26] + 5u * (g.e_first + (c << 6) + (uint32_t)lane)] : kNone;
+        }
+        if ((g.ok >> (i & 63u)) & 1ull) return;
+        pend_wait([&]() {
+            g.ok |= __ballot(g.kl == kNone || state_lane(g.kl) != 0);
+            return ((g.ok >> (i & 63u)) & 1ull) != 0ull;
+        });
+        observe_fence();
     };
 
     // One column task: the updates of the diagonal tile, of w_J and of the carried tiles with the operands in `pn` (accumulators in the
     // matrix cores' layout), a turn through LDS into lane = row, the elimination, whole rows back to the workspace.  `next_ready`: the
     // loads of the wave's next column (descriptor `dn`) go out into `pn` once the accumulators have left their registers.
-    auto run_column = [&](const ColDesc &dc, ColPre &pn, const bool next_ready, const ColDesc &dn, const bool finish_extra, double *xd, unsigned long long *fprof, unsigned long long (&ft_)[6], unsigned long long &ft0_) {
+    auto run_column = [&](const ColDesc &dc, ColPre &pn, EntryGate &gate, const bool gated, const bool next_static, const bool next_ready, const ColDesc &dn, const bool finish_extra, double *xd, unsigned long long *fprof, unsigned long long (&ft_)[6], unsigned long long &ft0_) {
         (void)fprof; (void)ft_; (void)ft0_;
         ColAcc acc;
         acc.cD = pn.cD; acc.cS0 = pn.cS0; acc.cS1 = pn.cS1; acc.cS2 = pn.cS2; acc.wacc = 0.0;
@@ -2027,8 +2179,52 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc.cD[r] += (r16 >> 2) == r ? dd2 : 0.0;
         }
+#ifndef LFR_T_PINGPONG
+#define LFR_T_PINGPONG 1
+#endif
+#if LFR_T_PINGPONG
+        // Further entries (a column near the root of the tree has 5-20 of them: one per descendant that touches it).  Their operands are
+        // all there once the children are done, and a load from the workspace is 1-2 us: with one entry at a time the root chain of a
+        // 2.4 k-row component spent half of the factorization's critical path waiting for operands.  Two operand sets alternate - the
+        // loop's own and the prefetch set, which is free until the next column's loads go out - so an entry's loads are in flight
+        // while the previous entry goes through the matrix cores.
+        {
+            const uint32_t e_end = dc.e_rest - 2u + dc.ne;                   // (entries 1 .. ne - 1 are col_upd[e_rest - 1 .. e_end))
+            uint32_t e = dc.e_rest - 1u;
+            UpdB oB;
+            UpdY yB;
+            uint32_t b0 = kNone, b1 = kNone, b2 = kNone, c0 = kNone, c1 = kNone, c2 = kNone;
+            const bool more = dc.ne > 1u;
+            if (more) { if (gated) gate_wait(gate, 1u); b0 = dc.a10; b1 = dc.a11; b2 = dc.a12; load_b(dc.k1, dc.tb1, oB); load_y(b0, b1, b2, yB); }       // entry 1: its words came with the descriptor
+            uint32_t ei = 1u;                                                // (index of the entry in set B within the column)
+            if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
+            if (more) for (;;) {
+                const bool n1 = e + 1u < e_end;                             // set B holds entry e
+                if (n1) {
+                    if (gated) gate_wait(gate, ei + 1u);
+                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                    c0 = col_upd[5 * (e + 1u) + 2]; c1 = col_upd[5 * (e + 1u) + 3]; c2 = col_upd[5 * (e + 1u) + 4];
+                    load_b(k, tb, pn.o0); load_y(c0, c1, c2, pn.y0);
+                }
+                apply_ops(b0, b1, b2, oB, yB, acc);
+                if (!n1) break;
+                ++e; ++ei;                                                  // the prefetch set holds entry e
+                const bool n2 = e + 1u < e_end;
+                if (n2) {
+                    if (gated) gate_wait(gate, ei + 1u);
+                    const uint32_t k = col_upd[5 * (e + 1u)], tb = col_upd[5 * (e + 1u) + 1];
+                    b0 = col_upd[5 * (e + 1u) + 2]; b1 = col_upd[5 * (e + 1u) + 3]; b2 = col_upd[5 * (e + 1u) + 4];
+                    load_b(k, tb, oB); load_y(b0, b1, b2, yB);
+                }
+                apply_ops(c0, c1, c2, pn.o0, pn.y0, acc);
+                if (!n2) break;
+                ++e; ++ei;
+            }
+        }
+#else
         if (dc.ne > 0u) apply_ops(dc.a00, dc.a01, dc.a02, pn.o0, pn.y0, acc);
         for (uint32_t e = dc.e_rest - 1u; e < dc.e_rest - 2u + dc.ne && dc.ne > 1u; ++e) {    // further entries (a separator's column has one per child)
+            if (gated) gate_wait(gate, e - (dc.e_rest - 2u));
             const uint32_t k = col_upd[5 * e], tb = col_upd[5 * e + 1], a0 = col_upd[5 * e + 2], a1 = col_upd[5 * e + 3], a2 = col_upd[5 * e + 4];
             UpdB o;
             UpdY y;
@@ -2036,10 +2232,12 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             load_y(a0, a1, a2, y);
             apply_ops(a0, a1, a2, o, y, acc);
         }
+#endif
         double wacc = acc.wacc;
         wacc += __shfl_xor(wacc, 16, 64);
         wacc += __shfl_xor(wacc, 32, 64);
         FPROF_MARK(0);                            // 0: loads + left-looking updates
+        TR(3, dc.J);
         // matrix-core layout (row 4 r + kq, column r16) -> lane = row
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -2050,7 +2248,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (kq == 0) xd[1152 + r16] = wj + wacc;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (next_ready) issue_column(dn, pn);     // the next column's loads (the accumulators' registers are free now): in flight during the elimination
+        if (next_static) issue_static(dn, pn);    // the next column's loads (the accumulators' registers are free now): in flight during the elimination
+        if (next_ready) issue_ops(dn, pn);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int nc = (int)dc.nc, nbp = (int)dc.nbp;
         const int s = lane - 17;
@@ -2080,6 +2279,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
         }
         FPROF_MARK(2);                            // 2: elimination
+        TR(4, dc.J);
         if (lane < nbp) bst(my_inv, rV, 8u * (unsigned)lane, so_inv + (dc.J << 7));
         if (is_diag || on) {                      // rows of the diagonal tile and of the carried tiles: whole rows, 16 bytes per store
             const unsigned ro = is_diag ? 8u * (unsigned)(r16 << 4) : 8u * (unsigned)(((1 + (s >> 4)) << 8) + ((s & 15) << 4));
@@ -2160,56 +2360,21 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         }
     };
 
-    // ---- "thin" plans (every column carries all its tiles): no barrier per level.  A column starts when its children in the elimination
-    //      tree are done (ts.pend[J], an LDS counter its children decrement; a child's completion implies its whole subtree's), the waves
-    //      walk their columns in level order - dependencies always point to lower levels, so some wave can always proceed - and the loads
-    //      of a wave's next column go out early whenever that column is already ready, across level boundaries too. ----
-    const bool thin = pl[28] != 0u;
-    // (a miscount must not hang the GPU: the step is rejected, the counter says so; a team gives up as a whole - the abort word ends
-    // every wait of the launch's teams and fails their components)
-    bool wdead = false;                                   // TEAM: this wave has seen the abort word
-    auto spin_timeout = [&]() {
-        if (lane == 0) {
-            sh.flag = 1;
-            if constexpr (TEAM) { if (team_ld(tm.ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u); team_st(tm.ctl + 9, 1u); team_st(gteam, 1u); }
-            else atomicAdd(a.queue + 15, 1u);
-        }
-        if constexpr (TEAM) wdead = true;
-    };
-    auto pend_load = [&](const uint32_t J) -> int {
-        if constexpr (TEAM) return __builtin_amdgcn_readfirstlane((int)team_ld(gteam + 16 + J));
-        else return __builtin_amdgcn_readfirstlane(__hip_atomic_load(&ts.pend[J], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    };
-    // wait until `ready()`; TEAM: the abort word is looked at every 256 polls
-    auto pend_wait = [&](auto ready) {
-        if (TEAM && wdead) return;
-        int spins = 0;
-        while (!ready()) {
-            __builtin_amdgcn_s_sleep(2);
-            ++spins;
-            if constexpr (TEAM) { if ((spins & 255) == 0 && __builtin_amdgcn_readfirstlane((int)team_ld(tm.ctl + 9)) != 0) { wdead = true; sh.flag = 1; break; } }
-            if (spins > (1 << 22)) { spin_timeout(); break; }
-        }
-    };
-    // what a finished column / a waiting column needs around its counter: the column's rows have left the wave (TEAM: have reached
-    // L2 - the reader's loads bypass its own L1), and the reader's loads are issued after the counter was seen
-    auto publish_fence = [&]() {
-        if constexpr (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    };
-    auto observe_fence = [&]() {
-        if constexpr (TEAM) asm volatile("" ::: "memory");
-        else __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    };
     // this wave's next column after position q of level l (levels ascending / descending); false: none left
+    // (the first column of level l goes to wave l mod GW: a chain of single-column levels - the blocks of a top separator - then
+    // alternates between waves, and the parent's wave streams through its finished entries while the child is being eliminated)
+#ifndef LFR_T_ROTATE
+#define LFR_T_ROTATE 1
+#endif
+    auto first_of = [&](const int l) -> int { return LFR_T_ROTATE ? (gw - l % GW + GW) % GW : gw; };
     auto next_up = [&](int &l, int &q) -> bool {
         q += GW;
-        while (q >= (int)level_ptr[l + 1]) { if (++l >= n_levels) return false; q = (int)level_ptr[l] + gw; }
+        while (q >= (int)level_ptr[l + 1]) { if (++l >= n_levels) return false; q = (int)level_ptr[l] + first_of(l); }
         return true;
     };
     auto next_down = [&](int &l, int &q) -> bool {
         q += GW;
-        while (q >= (int)level_ptr[l + 1]) { if (--l < 0) return false; q = (int)level_ptr[l] + gw; }
+        while (q >= (int)level_ptr[l + 1]) { if (--l < 0) return false; q = (int)level_ptr[l] + first_of(l); }
         return true;
     };
     auto factor_thin = [&]() -> bool {
@@ -2217,39 +2382,43 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         unsigned long long *fprof = a.prof ? a.prof + 8 * lfr::KC_COUNT + 8 + 16 * (a.cls - lfr::KC_BLOCK) : nullptr;      // (-DLFR_PROFILE_FACTOR)
         (void)fprof;
         FPROF_DECL
-        if constexpr (TEAM) {
-            for (int q = gt; q < NB; q += GT) team_st(gteam + 16 + hdr[pl[27] + 32 * q], hdr[pl[27] + 32 * q + 22]);
-        } else {
-            for (int q = tid; q < NB; q += kBlockThreads) ts.pend[hdr[pl[27] + 32 * q]] = (int)hdr[pl[27] + 32 * q + 22];       // children per column
-        }
-        tsync();
-        int l = 0, q = (int)level_ptr[0] + gw - GW;
-        bool have = next_up(l, q), pre = false;
+        // (the columns' state words are zeroed by the pass that builds the LM diagonal, in front of its barrier)
+        int l = 0, q = (int)level_ptr[0] + first_of(0) - GW;
+        bool have = next_up(l, q), pre = false, pre_static = false;
         ColDesc dn;
         ColPre pn;
         if (have) dn = load_desc(q);
         while (have) {
             const ColDesc dc = dn;
-            if (!pre) {                                   // not prefetched: wait for the children, then load
-                pend_wait([&]() { return pend_load(dc.J) == 0; });
-                observe_fence();
-                issue_column(dc, pn);
+#ifndef LFR_T_SPLIT_PREFETCH
+#define LFR_T_SPLIT_PREFETCH 2      // 0: a column's loads go out together once its children are done (round 4); 1: the half that does not depend
+                                    // on the children goes out early, for the wave's next column inside the current one; 2: ... AFTER the current
+                                    // column has been published when the next one is not ready yet (the publishing `s_waitcnt vmcnt(0)` waits for
+                                    // every load in flight: a prefetch in front of it delayed the hand-off along the critical path)
+#endif
+            EntryGate gate = gate_open(dc);
+            TR(1, dc.J | (pre ? 0x10000u : 0u) | (dc.ne << 20));
+            if (!pre) {                                   // not prefetched: wait for the column of the first entry, then load its rows
+                if (LFR_T_SPLIT_PREFETCH && !pre_static) issue_static(dc, pn);
+                if (dc.ne > 0u) gate_wait(gate, 0u);
+                if (!LFR_T_SPLIT_PREFETCH) issue_static(dc, pn);
+                issue_ops(dc, pn);
             }
+            TR(2, dc.J);
             FPROF_MARK(5);                                // 5: waiting for children
             have = next_up(l, q);
             bool next_ready = false;
             if (have) {
                 dn = load_desc(q);
-                next_ready = pend_load(dn.J) == 0;
+                next_ready = dn.ne == 0u || pend_load(dn.k0) != 0;          // (its first entry's column is factored: that entry's rows can be requested)
                 if (next_ready) observe_fence();
             }
-            run_column(dc, pn, next_ready, dn, true, xd, fprof, ft_, ft0_);
-            pre = next_ready;
-            publish_fence();                                               // the column's rows are out before its parent hears of it
-            if (lane == 0 && dc.parent != kNone) {
-                if constexpr (TEAM) __hip_atomic_fetch_sub(gteam + 16 + dc.parent, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                else __hip_atomic_fetch_sub(&ts.pend[dc.parent], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
+            run_column(dc, pn, gate, true, LFR_T_SPLIT_PREFETCH == 1 ? have : next_ready, next_ready, dn, true, xd, fprof, ft_, ft0_);
+            pre = next_ready; pre_static = LFR_T_SPLIT_PREFETCH == 1 ? have : next_ready;
+            publish_fence();                                               // the column's rows are out before anyone hears of it
+            if (lane == 0) state_store(dc.J, 1);
+            TR(5, dc.J);
+            if (LFR_T_SPLIT_PREFETCH == 2 && have && !next_ready) { issue_static(dn, pn); pre_static = true; }
         }
         tsync();
         if constexpr (TEAM) {                             // a bad pivot anywhere in the team rejects the step for everyone
@@ -2298,12 +2467,13 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             int q = (int)level_ptr[l] + wave;
             ColDesc dn;
             ColPre pn;
-            if (q < q1) { dn = load_desc(q); issue_column(dn, pn); }
+            if (q < q1) { dn = load_desc(q); issue_static(dn, pn); issue_ops(dn, pn); }
             while (q < q1) {
                 const ColDesc dc = dn;
                 const int qn = q + kWaves;
                 if (qn < q1) dn = load_desc(qn);          // (scalar loads: on their way during the updates below)
-                run_column(dc, pn, qn < q1, dn, false, xd, fprof, ft_, ft0_);
+                EntryGate gate = gate_open(dc);
+                run_column(dc, pn, gate, false, qn < q1, qn < q1, dn, false, xd, fprof, ft_, ft0_);
                 q = qn;
             }
             __syncthreads();
@@ -2350,26 +2520,34 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     // ---- L D L^T y = g with w = L^-1 g: levels top down; y_J = D^-1 (w_J - sum_I U(I,J)^T y_I) through the diagonal tile.  Pipelined
     //      like the factorization: the next column's tiles are on their way while the 16 dependent steps of this one run. ----
     struct BackPre { double m[16], iv, z, tvv[4][4], yv[4][4]; };
-    auto issue_back = [&](const ColDesc &c, BackPre &p) {
+    // (two halves again: the column's own tiles, 1/d and w_J are final since its factorization - requested before the wave waits for
+    // the parent; y of the rows below is what the parent's solution releases)
+    auto issue_back_static = [&](const ColDesc &c, BackPre &p) {
         const unsigned so = c.t0 << 11;
 #pragma unroll
         for (int k = 0; k < 16; ++k) p.m[k] = bld(rU, bo_r + 128u * k, so);
         p.iv = r16 < (int)c.nbp ? bld(rV, bo_r, so_inv + (c.J << 7)) : 0.0;
         p.z = bld(rV, bo_r, so_w + (c.J << 7));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if ((uint32_t)i < c.nsub) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.tvv[i][r] = bld(rU, bo_c + 512u * r, so + 2048u * (1 + i));
+            }
+        }
+    };
+    auto issue_back_y = [&](const ColDesc &c, BackPre &p) {
         const uint32_t rows[4] = {c.i0, c.i1, c.i2, c.i3};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if ((uint32_t)i < c.nsub) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    p.tvv[i][r] = bld(rU, bo_c + 512u * r, so + 2048u * (1 + i));
-                    p.yv[i][r] = bld(rV, bo_k + 32u * r, so_step + (rows[i] << 7));
-                }
+                for (int r = 0; r < 4; ++r) p.yv[i][r] = bld(rV, bo_k + 32u * r, so_step + (rows[i] << 7));
             }
         }
     };
     // one column of the back substitution with its operands in `pn`; the next column's loads go out before the 16 dependent steps
-    auto run_back = [&](const ColDesc &dc, BackPre &pn, const bool next_ready, const ColDesc &dn) {
+    auto run_back = [&](const ColDesc &dc, BackPre &pn, const bool next_static, const bool next_ready, const ColDesc &dn) {
         double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -2388,7 +2566,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         for (int k = 0; k < 16; ++k) m[k] = pn.m[k];
         const double iv = pn.iv;
         double z = pn.z;
-        if (next_ready) issue_back(dn, pn);
+        if (next_static) issue_back_static(dn, pn);
+        if (next_ready) issue_back_y(dn, pn);
         acc += __shfl_xor(acc, 16, 64);
         acc += __shfl_xor(acc, 32, 64);
         z -= acc;
@@ -2403,33 +2582,36 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (lane < 16) bst(yo, rV, bo_r, so_step + (dc.J << 7));
     };
     auto back_substitute = [&]() {
-        if (thin || TEAM) {       // no barrier per level: a column starts when its parent is solved (pend[parent] == 1; all counters are 0 after the factorization)
-            int l = n_levels - 1, q = (int)level_ptr[l] + gw - GW;
-            bool have = next_down(l, q), pre = false;
+        if (thin || TEAM) {       // no barrier per level: a column starts when its parent is solved (state 2; every column is in state 1 after the factorization)
+            int l = n_levels - 1, q = (int)level_ptr[l] + first_of(l) - GW;
+            bool have = next_down(l, q), pre = false, pre_static = false;
             ColDesc dn;
             BackPre pn;
             if (have) dn = load_desc(q);
             while (have) {
                 const ColDesc dc = dn;
+                TR(6, dc.J | (pre ? 0x10000u : 0u));
                 if (!pre) {
-                    pend_wait([&]() { return dc.parent == kNone || pend_load(dc.parent) != 0; });
+                    if (LFR_T_SPLIT_PREFETCH && !pre_static) issue_back_static(dc, pn);
+                    pend_wait([&]() { return dc.parent == kNone || pend_load(dc.parent) == 2; });
                     observe_fence();
-                    issue_back(dc, pn);
+                    if (!LFR_T_SPLIT_PREFETCH) issue_back_static(dc, pn);
+                    issue_back_y(dc, pn);
                 }
+                TR(7, dc.J);
                 have = next_down(l, q);
                 bool next_ready = false;
                 if (have) {
                     dn = load_desc(q);
-                    next_ready = dn.parent == kNone || pend_load(dn.parent) != 0;
+                    next_ready = dn.parent == kNone || pend_load(dn.parent) == 2;
                     if (next_ready) observe_fence();
                 }
-                run_back(dc, pn, next_ready, dn);
-                pre = next_ready;
+                run_back(dc, pn, LFR_T_SPLIT_PREFETCH == 1 ? have : next_ready, next_ready, dn);
+                pre = next_ready; pre_static = LFR_T_SPLIT_PREFETCH == 1 ? have : next_ready;
                 publish_fence();
-                if (lane == 0) {
-                    if constexpr (TEAM) team_st(gteam + 16 + dc.J, 1u);
-                    else __hip_atomic_store(&ts.pend[dc.J], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+                if (lane == 0) state_store(dc.J, 2);
+                TR(8, dc.J);
+                if (LFR_T_SPLIT_PREFETCH == 2 && have && !next_ready) { issue_back_static(dn, pn); pre_static = true; }
             }
             tsync();
             return;
@@ -2439,34 +2621,30 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             int q = (int)level_ptr[l] + wave;
             ColDesc dn;
             BackPre pn;
-            if (q < q1) { dn = load_desc(q); issue_back(dn, pn); }
+            if (q < q1) { dn = load_desc(q); issue_back_static(dn, pn); issue_back_y(dn, pn); }
             while (q < q1) {
                 const ColDesc dc = dn;
                 const int qn = q + kWaves;
                 if (qn < q1) dn = load_desc(qn);
-                run_back(dc, pn, qn < q1, dn);
+                run_back(dc, pn, qn < q1, qn < q1, dn);
                 q = qn;
             }
             __syncthreads();
         }
     };
 
-    // ---- the trust-region loop of solve_component, over vectors in matrix order; the vector passes are fused so that an iteration
-    //      has three reductions beside the sweeps' ----
+    // ---- the trust-region loop of solve_component, over vectors in matrix order.  Round 5: an iteration of a large component is a
+    //      chain of round trips to L2 and of barriers, not arithmetic, so the vector passes are gone except two: the trial point, the
+    //      step / point norms, the projected gradient and the line search's directional derivative come out of the sweep (above),
+    //      an accepted candidate is a swap of pointers, the Jacobi scaling and the dependency counters ride in the pass that builds
+    //      the LM diagonal.  Per iteration: that pass, the factorization, the back substitution, one pass + reduction for the
+    //      model's cost change, and two reductions per sweep. ----
     // (-DLFR_PROFILE_PHASES: 0 sweeps, 1 factorization, 5 scaling, 6 back substitution, 4 everything else - the slots of the LDS kernels)
     int exec_passes = 1;
-    double cost = sweep(vx, vg);
+    SweepOut sw = sweep(vx, vdelta, 0.0, false, vxc, vg);
+    double cost = sw.cost;
     PROF_MARK(0);
-    double gmax = 0.0;
-    {
-        double m = 0.0;
-        for (int i = gt; i < n; i += GT) {
-            vscale[i] = 1.0 / (1.0 + sqrt(ldd(vadiag + i)));
-            const double xi = ldd(vx + i);
-            m = fmax(m, fabs(xi - clampb(xi - ldd(vg + i))));
-        }
-        gmax = tmax(m);
-    }
+    double gmax = sw.gm;
     double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
     bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
@@ -2476,10 +2654,12 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if (step_successful && gmax <= kGradientTol) break;
         if (radius <= kMinRadius) break;
         ++iteration;
+        TR_IT(iteration);
+        TR(10, 0);
         step_successful = false;
         PROF_MARK(4);
         if (!matrix_valid) {           // A holds J^T J of a rejected trial point: re-assemble at x
-            sweep(vx, vg);
+            sweep(vx, vdelta, 0.0, false, vxc, vg);
             ++exec_passes;
             matrix_valid = true;
             PROF_MARK(0);
@@ -2496,22 +2676,33 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * GT;
                 if (i >= n) break;
+                if (iteration == 1) { sc[u] = 1.0 / (1.0 + sqrt(ad[u])); vscale[i] = sc[u]; }       // the Jacobi scaling: fixed at the initial point
                 if (!reuse_diagonal) { dg[u] = fmin(fmax(sc[u] * sc[u] * ad[u], kMinLmDiag), kMaxLmDiag); vdiag[i] = dg[u]; }
                 vD[i] = sqrt(dg[u] / radius) / sc[u];                        // D / s (the column tasks add D^2 to their diagonal tiles)
                 vw[i] = gg[u];
             }
         }
         reuse_diagonal = true;
+        if (thin || TEAM) {            // the columns' state words of the barrier-free schedule: nothing factored yet
+            if constexpr (TEAM) {
+                for (int q = gt; q < NB; q += GT) team_st(gteam + 16 + q, 0u);
+            } else {
+                for (int q = tid; q < NB; q += kBlockThreads) ts.pend[q] = 0;
+            }
+        }
         if (tid == 0) { sh.flag = 0; if constexpr (TEAM) { if (tm.r == 0) team_st(gteam, 0u); } }     // raised by a non-positive pivot
         tsync();
+        TR(11, 0);
         PROF_MARK(LFR_TREE_SLOT_SCALE);
         bool valid = factor();                            // (reads A, writes the factor: J^T J at x stays in A until a trial point is swept)
+        TR(12, 0);
         PROF_MARK(1);
         if (valid) back_substitute();
+        TR(13, 0);
         PROF_MARK(6);
         double model_cost_change = 0.0, g_dot_delta = 0.0, dir_max = 0.0;
         if (valid) {
-            double partial = 0.0, gd_part = 0.0, dm_part = 0.0;
+            double partial = 0.0, gd_part = 0.0, zero = 0.0, dm_part = 0.0;
             for (int i0 = gt; i0 < n; i0 += 4 * GT) {
                 double gi[4], Di[4], st[4];
 #pragma unroll
@@ -2527,7 +2718,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     dm_part = isfinite(dl) ? fmax(dm_part, fabs(dl)) : INFINITY;
                 }
             }
-            treduce3(partial, gd_part, dm_part);
+            treduce4(partial, gd_part, zero, dm_part);
+            TR(14, 0);
             model_cost_change = 0.5 * partial; g_dot_delta = gd_part; dir_max = dm_part;
             valid = isfinite(dir_max) && model_cost_change > 0.0;
         }
@@ -2545,15 +2737,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             LsSample initial{0.0, cost, g_dot_delta, true, true}, previous{0, 0, 0, false, false}, current;
             int n_iter = 0;
             for (;;) {
-                for (int i0 = gt; i0 < n; i0 += 4 * GT) {
-                    double xo[4], dl[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xo[u] = ldd(vx + i); dl[u] = ldd(vdelta + i); }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { const int i = i0 + u * GT; if (i < n) vxc[i] = clampb(__dadd_rn(xo[u], __dmul_rn(alpha, dl[u]))); }
-                }
                 PROF_MARK(4);
-                cost_c = sweep(vxc, vgn);             // also assembles J^T J at the trial point
+                sw = sweep(vx, vdelta, alpha, true, vxc, vgn);             // also assembles J^T J at the trial point
+                cost_c = sw.cost;
                 matrix_valid = false;
                 PROF_MARK(0);
                 ++exec_passes; ++n_ls_evals;
@@ -2561,57 +2747,37 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 current.gradient = 0.0; current.gradient_valid = false;
                 if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
                 if (current.value_valid) {
-                    double p = 0.0;
-                    for (int i = gt; i < n; i += GT) p += ldd(vdelta + i) * ldd(vgn + i);
-                    current.gradient = tsum(p);
+                    current.gradient = sw.gd;                 // delta . g(trial point), summed by the sweep's node pass
                     current.gradient_valid = isfinite(current.gradient);
                 }
+                TR(15, 0);
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
+                TR(16, 0);
                 if (nstep < 0.0) break;
                 previous = current;
                 alpha = nstep;
             }
         }
         if (!ls_ok) {
-            for (int i = gt; i < n; i += GT) vxc[i] = clampb(__dadd_rn(ldd(vx + i), ldd(vdelta + i)));
-            cost_c = sweep(vxc, vgn);
+            sw = sweep(vx, vdelta, 1.0, true, vxc, vgn);
+            cost_c = sw.cost;
             matrix_valid = false;
             ++exec_passes;
         }
         ++n_cand;
         const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
-        // step norm, and - should the candidate be accepted - its norm and projected gradient, in one pass
-        double sn = 0.0, xn = 0.0, gm = 0.0;
-        for (int i0 = gt; i0 < n; i0 += 4 * GT) {
-            double xo[4], xc[4], gn[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xo[u] = ldd(vx + i); xc[u] = ldd(vxc + i); gn[u] = ldd(vgn + i); }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {            // (past the end: zeros, which add nothing)
-                sn += (xo[u] - xc[u]) * (xo[u] - xc[u]);
-                xn += xc[u] * xc[u];
-                gm = fmax(gm, fabs(xc[u] - clampb(xc[u] - gn[u])));
-            }
-        }
-        treduce3(sn, xn, gm);
-        const double step_norm = sqrt(sn);
+        // step norm, and - should the candidate be accepted - its norm and projected gradient: from the sweep
+        const double step_norm = sqrt(sw.sn);
         if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
         const double cost_change = cost - cost_cand;
         if (fabs(cost_change) <= kFunctionTol * cost) break;
         const double rel = cost_change / model_cost_change;
         if (rel > kMinRelDecrease) {
-            for (int i0 = gt; i0 < n; i0 += 4 * GT) {
-                double xc[4], gn[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = min(i0 + u * GT, n); xc[u] = ldd(vxc + i); gn[u] = ldd(vgn + i); }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) { const int i = i0 + u * GT; if (i < n) { vx[i] = xc[u]; vg[i] = gn[u]; } }
-            }
-            tsync();
-            x_norm = sqrt(xn);
+            { double *t = vx; vx = vxc; vxc = t; t = vg; vg = vgn; vgn = t; }      // the candidate becomes x, its gradient g
+            x_norm = sqrt(sw.xn);
             cost = cost_cand;
             matrix_valid = true;              // the accepted candidate is the last evaluated point: its J^T J is in the tiles
-            gmax = gm;
+            gmax = sw.gm;
             step_successful = true;
             ++n_successful;
             const double t = 2.0 * rel - 1.0;
@@ -2639,6 +2805,11 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         inf.iterations = iteration; inf.termination = term; inf.n_successful = n_successful;
         inf.n_ls_evals = n_ls_evals; inf.n_cand_evals = n_cand; inf.exec_passes = exec_passes;
         inf.final_cost = cost;
+#if defined(LFR_PROFILE_WGTIME) && LFR_PROFILE_WGTIME == 3      // diagnostic builds (scripts/sparse_timeline.py): start (100 MHz ticks) in the cost, lifetime << 4 | team size in the termination
+        inf.final_cost = (double)tree_r0_;
+        inf.termination = (int)(((wall_clock64() - tree_r0_) << 4) | (unsigned long long)tS);
+        inf.iterations = iteration | (min(exec_passes, 1023) << 8) | (min(n_successful, 255) << 18);
+#endif
         a.infos[ci] = inf;
     }
 }
@@ -2723,12 +2894,29 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
         if (tid == 0) {
             unsigned msg = kTeamMsgEnd;
             if (rank == L) {
-                const int k = a.desc_begin + (int)atomicAdd(a.queue + a.cls, 1u);
-                if (k < a.desc_end && team_ld(ctl + 9) == 0u) {
+                // A component is solved by EXACTLY the team size its key asks for (its results are a function of that size): a team
+                // takes the head of the queue only if it is large enough - it splits when it is larger - and waits otherwise for a
+                // larger team to take it (the queue hands out by key, descending: whoever has split has seen the last component of
+                // its former size leave).  Look, then pop by compare-and-swap.
+                int spins = 0;
+                for (;;) {
+                    const unsigned head = team_ld(a.queue + a.cls);
+                    const int k = a.desc_begin + (int)head;
+                    if (k >= a.desc_end || team_ld(ctl + 9) != 0u) break;
                     const int ci = (int)a.wg_order[k - a.wg_begin];
                     const bool thin = reinterpret_cast<const uint32_t *>(a.workspace + a.ws_off[ci])[28] != 0u;
-                    const int t = thin ? min(S, tree_team_size(a, ci)) : 0;                // 0: the leader alone, the team stays as it is
-                    msg = (t == 0 ? 0u : (unsigned)(32 - __builtin_clz((unsigned)t)) << 28) | (unsigned)(ci + 1);
+                    const int want = thin ? tree_team_size(a, ci) : 1;
+                    if (want <= S) {
+                        unsigned expect = head;
+                        if (__hip_atomic_compare_exchange_strong(a.queue + a.cls, &expect, head + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                            // (a plan that keeps the barrier schedule: the leader alone - message 0 -, the team stays as it is)
+                            msg = (thin ? (unsigned)(32 - __builtin_clz((unsigned)want)) << 28 : 0u) | (unsigned)(ci + 1);
+                            break;
+                        }
+                        continue;                                  // someone else took it: look again
+                    }
+                    __builtin_amdgcn_s_sleep(16);                  // too large for this team: a larger one will take it
+                    if ((++spins & 255) == 0 && (spins >> 25) != 0) { atomicAdd(a.queue + 15, 1u); team_st(ctl + 9, 1u); break; }
                 }
                 if (msg == kTeamMsgEnd || (msg >> 28) != 0u) {
                     for (int m = L + 1; m < L + S; ++m) {                                  // (a member clears its mailbox when it has read it)
@@ -2773,7 +2961,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
             solve_tree_component<kBlockThreads, false>(a, ci, sh, ts, solo);
         } else {
             tm.S = S; tm.r = rank - L; tm.bar = bars + L;
-            tm.red = a.team_red + (size_t)unit_slot * kTeamRedPerUnit + (size_t)(L / 2) * (2 * kTeamMax * 4);
+            tm.red = a.team_red + (size_t)unit_slot * kTeamRedPerUnit + (size_t)(L / 2) * (2 * kTeamMax * 8);
             if (tid == 0 && tm.r == 0) atomicAdd(ctl + 10, 1u);           // (statistics: components solved by a team)
             solve_tree_component<kBlockThreads, true>(a, ci, sh, ts, tm);
         }
@@ -3191,7 +3379,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     // workgroup runs ~0.11 us per row and LM iteration, iteration counts vary 10-40 whatever the size, so everything above ~700 rows
     // can end a launch on its own.
     {
-        uint32_t w[3] = {700u, 1500u, 0xffffffffu};
+        uint32_t w[3] = {700u, 1500u, 2000u};
         if (const char *e = getenv("LFR_TREE_TEAM")) {
             unsigned v[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
             const int got = sscanf(e, "%u,%u,%u", &v[0], &v[1], &v[2]);
@@ -3575,6 +3763,13 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.edge_ref = b->d_edge_ref; a.edge_word = b->d_edge_word;
     a.f_row = nullptr; a.f_disp1 = a.f_disp2 = a.f_sim = nullptr;
     a.team_ctl = b->d_team_ctl; a.team_red = b->d_team_red;
+    a.trace = nullptr;
+#ifdef LFR_TRACE_TREE
+    static unsigned long long *d_trace = nullptr;
+    if (!d_trace) { HIP_TRY(hipMalloc(&d_trace, ((size_t)1 << 20) * 8 + 64)); }
+    HIP_TRY(hipMemsetAsync(d_trace, 0, 64, st));
+    a.trace = d_trace;
+#endif
     for (int k = 0; k < 3; ++k) a.team_work[k] = b->team_work[k];
     if (b->fused) {
         const lfr::DevGraph &dgr = *b->dev_hold->graph;
@@ -3621,8 +3816,10 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
             case lfr::KC_BLOCK_M: hipLaunchKernelGGL((solve_block_kernel<kThreadsM>), dim3(wgs), dim3(kThreadsM), lds, cs, a, rows); break;
             case lfr::KC_BLOCK_L: hipLaunchKernelGGL((solve_block_kernel<kThreadsL>), dim3(wgs), dim3(kThreadsL), lds, cs, a, rows); break;
             default: {
+                if (const char *e = getenv("LFR_DEBUG_TREE_FIRST")) a.desc_end = std::min(a.desc_end, a.desc_begin + std::max(1, atoi(e)));   // (experiments: only the first k of the hand-out order)
                 // elimination-tree kernel: one 512-thread workgroup per CU (two waves per SIMD), static LDS only
-                if (b->d_team_ctl) hipLaunchKernelGGL((solve_tree_team_kernel<kThreadsG>), dim3(std::max(32, std::min(b->team_wgs, b->ctx->n_cu / 32 * 32))), dim3(kThreadsG), 0, cs, a);
+                // (at least 8 kTeamMax workgroups: whatever the placement, one of the eight XCDs then holds a complete unit)
+                if (b->d_team_ctl) hipLaunchKernelGGL((solve_tree_team_kernel<kThreadsG>), dim3(std::max(8 * kTeamMax, std::min(b->team_wgs, b->ctx->n_cu / 32 * 32))), dim3(kThreadsG), 0, cs, a);
                 else hipLaunchKernelGGL((solve_tree_kernel<kThreadsG>), dim3(std::min(n, b->ctx->n_cu)), dim3(kThreadsG), 0, cs, a);
                 break;
             }
@@ -3741,6 +3938,16 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     if (!stats) return LFR_OK;
 
     HIP_TRY(lfr::stream_wait(st));
+#ifdef LFR_TRACE_TREE
+    if (const char *tf = getenv("LFR_TREE_TRACE_FILE")) {
+        unsigned long long n = 0;
+        HIP_TRY(hipMemcpy(&n, a.trace, 8, hipMemcpyDeviceToHost));
+        n = std::min<unsigned long long>(n, (1ull << 20) - 4);
+        std::vector<unsigned long long> h(n + 2);
+        HIP_TRY(hipMemcpy(h.data(), a.trace, (n + 2) * 8, hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(tf, "wb")) { fwrite(h.data() + 2, 8, n, f); fclose(f); }
+    }
+#endif
 #ifdef LFR_PROFILE_FACTOR
     {
         unsigned long long h[64];
