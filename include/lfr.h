@@ -283,7 +283,8 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
  * polynomial.cc MinimizeInterpolatingPolynomial): for each of n cases, samples holds 15 doubles = (x, value, gradient,
  * value_valid, gradient_valid) of the initial, the previous and the current sample; step[i] = the next step size the kernels
  * compute (negative: the search gives up); register_version 0 = the loop version the packed kernel calls, 1 = the unrolled
- * version of the workgroup-per-component kernel.  Test infrastructure, not part of the solve path. */
+ * version of the workgroup-per-component kernel, 2 = the wave-cooperative form of the elimination-tree kernel (the pieces of the
+ * root isolation a lane each; one case per wave).  Test infrastructure, not part of the solve path. */
 int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, int register_version, double *step);
 
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */

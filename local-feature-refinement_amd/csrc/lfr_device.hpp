@@ -370,7 +370,10 @@ __device__ __forceinline__ double bracketed_root(const double (&q)[M + 1], const
     }
     return x;
 }
-template <int M>
+// W = true: called by a whole wave with wave-uniform arguments - the M monotone pieces are independent, so lane i isolates the root of
+// piece i and the results are read back with v_readlane: one round of safeguarded Newton iterations per level instead of M (the
+// contraction of a line search costs 10-30 k cycles, most of them in these iterations; same arithmetic per piece, same bits).
+template <int M, bool W = false>
 __device__ __forceinline__ void real_roots_in(const double (&q)[M + 1], double lo, double hi, double (&out)[M]) {
     static_assert(M >= 2 && M <= 4, "quadratic, cubic or quartic");
     if constexpr (M == 2) {
@@ -389,21 +392,35 @@ __device__ __forceinline__ void real_roots_in(const double (&q)[M + 1], double l
         double dq[M], bp[M - 1];
 #pragma unroll
         for (int i = 0; i < M; ++i) dq[i] = q[i] * (M - i);
-        real_roots_in<M - 1>(dq, lo, hi, bp);
+        real_roots_in<M - 1, W>(dq, lo, hi, bp);
+        if constexpr (W) {
+            const int l = (int)(threadIdx.x & 63u);
+            double a = lo, b = M == 1 ? hi : bp[0];                  // (lanes beyond M repeat piece 0)
 #pragma unroll
-        for (int i = 0; i < M; ++i) {
-            const double a = i == 0 ? lo : bp[i - 1], b = i == M - 1 ? hi : bp[i];
+            for (int i = 1; i < M; ++i) { if (l == i) { a = bp[i - 1]; b = i == M - 1 ? hi : bp[i]; } }
             const double fa = horner<M>(q, a), fb = horner<M>(q, b);
             double r = a;
             if (fa != 0.0 && fb == 0.0) r = b;
             else if ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0)) r = bracketed_root<M>(q, dq, a, b, fa);
-            out[i] = r;
+#pragma unroll
+            for (int i = 0; i < M; ++i)
+                out[i] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(r), i), __builtin_amdgcn_readlane(__double2loint(r), i));
+        } else {
+#pragma unroll
+            for (int i = 0; i < M; ++i) {
+                const double a = i == 0 ? lo : bp[i - 1], b = i == M - 1 ? hi : bp[i];
+                const double fa = horner<M>(q, a), fb = horner<M>(q, b);
+                double r = a;
+                if (fa != 0.0 && fb == 0.0) r = b;
+                else if ((fa < 0.0 && fb > 0.0) || (fa > 0.0 && fb < 0.0)) r = bracketed_root<M>(q, dq, a, b, fa);
+                out[i] = r;
+            }
         }
     }
 }
 
 // poly_root_real_parts for d[0] x^(M-1) + ... + d[M-1]
-template <int M>
+template <int M, bool W = false>
 __device__ __forceinline__ int poly_root_real_parts_n(const double (&d)[M], double lo, double hi, double (&out)[4]) {
     static_assert(M >= 2 && M <= 5, "derivative of a polynomial with 3..6 coefficients");
     int lead = 0;
@@ -428,12 +445,12 @@ __device__ __forceinline__ int poly_root_real_parts_n(const double (&d)[M], doub
         return 2;
     }
     if constexpr (M >= 5) {
-        if (deg == 4) { const double q[5] = {e[0], e[1], e[2], e[3], e[4]}; real_roots_in<4>(q, lo, hi, out); return 4; }
+        if (deg == 4) { const double q[5] = {e[0], e[1], e[2], e[3], e[4]}; real_roots_in<4, W>(q, lo, hi, out); return 4; }
     }
     if constexpr (M >= 4) {
         const double q[4] = {e[0], e[1], e[2], e[3]};
         double r[3];
-        real_roots_in<3>(q, lo, hi, r);
+        real_roots_in<3, W>(q, lo, hi, r);
         out[0] = r[0]; out[1] = r[1]; out[2] = r[2];
         return 3;
     }
@@ -477,7 +494,7 @@ __device__ __forceinline__ bool solve_dense_n(double (&A)[N][N], double (&b)[N])
 
 // Ceres MinimizeInterpolatingPolynomial over [x_min, x_max] with N constraints: cx/cv/cg = abscissa, right-hand side and
 // "is a gradient constraint" of constraint r, in the order value, gradient per sample; sx = the ns sample abscissae
-template <int N>
+template <int N, bool W = false>
 __device__ __forceinline__ double minimize_interpolating_polynomial_n(const double (&cx)[6], const double (&cv)[6], const bool (&cg)[6],
                                                                       const double (&sx)[3], int ns, double x_min, double x_max) {
     constexpr int deg = N - 1;
@@ -505,7 +522,7 @@ __device__ __forceinline__ double minimize_interpolating_polynomial_n(const doub
         double deriv[N - 1], roots[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < deg; ++i) deriv[i] = poly[i] * (deg - i);
-        const int nr = poly_root_real_parts_n<N - 1>(deriv, x_min, x_max, roots);
+        const int nr = poly_root_real_parts_n<N - 1, W>(deriv, x_min, x_max, roots);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             if (i >= nr || roots[i] < x_min || roots[i] > x_max) continue;
@@ -522,8 +539,9 @@ __device__ __forceinline__ double minimize_interpolating_polynomial_n(const doub
     return best_x;
 }
 
-__device__ __noinline__ double ls_next_step_regs(const LsSample &initial, const LsSample &previous, const LsSample &current,
-                                            double dir_max, int &n_iter) {
+template <bool W>
+__device__ __forceinline__ double ls_next_step_impl(const LsSample &initial, const LsSample &previous, const LsSample &current,
+                                                   double dir_max, int &n_iter) {
     if (++n_iter >= kLsMaxIterations) return -1.0;
     const double lo = kLsMaxContraction * current.x, hi = kLsMinContraction * current.x;
     double step;
@@ -551,15 +569,24 @@ __device__ __noinline__ double ls_next_step_regs(const LsSample &initial, const 
             n += ok[c] ? 1 : 0;
         }
         switch (n) {
-            case 3: step = minimize_interpolating_polynomial_n<3>(cx, cv, cg, sx, ns, lo, hi); break;
-            case 4: step = minimize_interpolating_polynomial_n<4>(cx, cv, cg, sx, ns, lo, hi); break;
-            case 5: step = minimize_interpolating_polynomial_n<5>(cx, cv, cg, sx, ns, lo, hi); break;
-            case 6: step = minimize_interpolating_polynomial_n<6>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 3: step = minimize_interpolating_polynomial_n<3, W>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 4: step = minimize_interpolating_polynomial_n<4, W>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 5: step = minimize_interpolating_polynomial_n<5, W>(cx, cv, cg, sx, ns, lo, hi); break;
+            case 6: step = minimize_interpolating_polynomial_n<6, W>(cx, cv, cg, sx, ns, lo, hi); break;
             default: step = fmin(fmax(current.x * 0.5, lo), hi); break;      // < 3 constraints: not reachable (the initial sample always has both)
         }
     }
     if (step * dir_max < kLsMinStep) return -1.0;
     return step;
+}
+__device__ __noinline__ double ls_next_step_regs(const LsSample &initial, const LsSample &previous, const LsSample &current,
+                                            double dir_max, int &n_iter) {
+    return ls_next_step_impl<false>(initial, previous, current, dir_max, n_iter);
+}
+// the same for a WHOLE wave with wave-uniform arguments (all 64 lanes active): the pieces of the root isolation a lane each
+__device__ __noinline__ double ls_next_step_wave(const LsSample &initial, const LsSample &previous, const LsSample &current,
+                                            double dir_max, int &n_iter) {
+    return ls_next_step_impl<true>(initial, previous, current, dir_max, n_iter);
 }
 
 // ------------------------------------------------------------------------------------------

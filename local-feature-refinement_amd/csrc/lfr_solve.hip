@@ -77,6 +77,7 @@ struct KernelArgs {
     unsigned int *team_ctl;
     double *team_red;
     uint32_t team_work[3];
+    uint32_t team_epoch;        // differs between launches that share the reduction slots
     unsigned long long *trace;  // -DLFR_TRACE_TREE: [0] = words used, then {s_memtime, type << 56 | wave of the team << 48 | iteration << 32 | column} pairs
 };
 
@@ -1694,15 +1695,15 @@ struct TreeShared {
 constexpr int kTeamMax = LFR_TEAM_MAX;                     // workgroups per unit (a power of two <= 8)
 constexpr int kTeamUnitsPerXcc = 256 / kTeamMax;           // a launch has at most 256 workgroups
 constexpr int kTeamCtlWords = 16 + 16 * 8 * kTeamUnitsPerXcc;
-constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 8;
+constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 16;
 constexpr unsigned kTeamMsgEnd = 0xf0000000u;
 static_assert(kTeamMax == 2 || kTeamMax == 4 || kTeamMax == 8, "team size");
 struct TeamCtx {
     int S = 1, r = 0;                 // workgroups in the team, this workgroup's index in it
     unsigned int *bar = nullptr;      // arrival counter of the team (monotonic)
     unsigned int target = 0;          // its value when everyone has arrived at the latest barrier
-    double *red = nullptr;            // reduction slots [2][kTeamMax][8]
-    int par = 0;
+    double *red = nullptr;            // reduction slots [2][kTeamMax][16]: five {value, tag} granules per member
+    unsigned gen = 0, epoch = 0;      // reductions of this team so far; the launch (tags of earlier launches linger in the slots)
     unsigned int *ctl = nullptr;      // control words of the launch ([9] = abort)
     bool dead = false;                // this workgroup has seen the abort word: waits return at once
 };
@@ -1759,10 +1760,14 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         if constexpr (TEAM) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else return *p;
     };
 #ifdef LFR_TRACE_TREE      // (scripts/tree_trace.py) events of the FIRST component of the hand-out order, LM iterations 2-4
+#ifndef LFR_TRACE_IT0
+#define LFR_TRACE_IT0 2
+#define LFR_TRACE_IT1 4
+#endif
     int trace_it = 0;
     const bool traced = a.trace != nullptr && ci == (int)a.wg_order[a.desc_begin - a.wg_begin];
     auto tr = [&](const unsigned type, const unsigned col) {
-        if (traced && trace_it >= 2 && trace_it <= 4 && lane == 0) {
+        if (traced && trace_it >= LFR_TRACE_IT0 && trace_it <= LFR_TRACE_IT1 && lane == 0) {
             const unsigned long long t = __builtin_amdgcn_s_memtime();
             const unsigned long long i = atomicAdd(a.trace, 2ull);
             if (i + 2 < (1ull << 20)) { a.trace[2 + i] = t; a.trace[3 + i] = ((unsigned long long)type << 56) | ((unsigned long long)gw << 48) | ((unsigned long long)trace_it << 32) | col; }
@@ -1821,20 +1826,53 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     }
     tsync();
     // sums and maxima over the team: the workgroup's value first (every thread holds it), then the members' values in a fixed order
+    // A reduction over the team IS a barrier: every workgroup publishes its five values as 16-byte {value, tag} granules (one lane,
+    // one write-through store each; tag = launch << 32 | reduction number) once all its waves' stores have reached L2, and gathers
+    // the members' granules by polling them, a lane per granule - one store and one round of polls instead of an arrival counter,
+    // its polls, and a separate read of the values.  Two sets of slots alternate: a member can only be one reduction ahead.
     auto treduce5 = [&](double &s0, double &s1, double &s2, double &s3, double &m0) {
+        if constexpr (TEAM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         block_reduce5<kBlockThreads>(s0, s1, s2, s3, m0, ts);
         if constexpr (TEAM) {
-            double *slot = tm.red + tm.par * (kTeamMax * 8);
-            if (tid == 0) { double *o = slot + 8 * tm.r; o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3; o[4] = m0; }
-            tsync();
-            double x0 = 0.0, x1 = 0.0, x2 = 0.0, x3 = 0.0, x4 = 0.0;
-            for (int w = 0; w < tS; ++w) {
-                x0 += ldd(slot + 8 * w); x1 += ldd(slot + 8 * w + 1); x2 += ldd(slot + 8 * w + 2); x3 += ldd(slot + 8 * w + 3);
-                const double mw = ldd(slot + 8 * w + 4);
-                x4 = w == 0 ? mw : fmax(x4, mw);
+            ++tm.gen;
+            if (wave == 0) {
+                const unsigned long long tag = ((unsigned long long)tm.epoch << 32) | tm.gen;
+                const __amdgpu_buffer_rsrc_t rR = __builtin_amdgcn_make_buffer_rsrc(tm.red + (tm.gen & 1u) * (kTeamMax * 16), 0, (int)0xfffffffe, 0x00020000);
+                if (lane < 5) {
+                    const double v = lane == 0 ? s0 : lane == 1 ? s1 : lane == 2 ? s2 : lane == 3 ? s3 : m0;
+                    const u32x2_t vb = __builtin_bit_cast(u32x2_t, v);
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{vb[0], vb[1], (unsigned)tag, (unsigned)(tag >> 32)}, rR, (unsigned)(128 * tm.r + 16 * lane), 0, 16);
+                }
+                const int m = lane / 5, j = lane - 5 * m;
+                const bool mine = lane < 5 * tS;
+                double val = 0.0;
+                bool got = !mine || tm.dead;
+                int spins = 0;
+                while (true) {
+                    if (!got) {
+                        const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rR, (unsigned)(128 * m + 16 * j), 0, 16);
+                        if ((((unsigned long long)q[3] << 32) | q[2]) == tag) { got = true; val = __builtin_bit_cast(double, u32x2_t{q[0], q[1]}); }
+                    }
+                    if (__ballot(!got) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                    if ((++spins & 255) == 0 && (__builtin_amdgcn_readfirstlane((int)team_ld(tm.ctl + 9)) != 0 || (spins >> 22) != 0)) {
+                        if (lane == 0) { if (team_ld(tm.ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u); team_st(tm.ctl + 9, 1u); }
+                        tm.dead = true;
+                        break;
+                    }
+                }
+                double x[5];
+#pragma unroll
+                for (int jj = 0; jj < 5; ++jj) {
+                    double acc = readlane_f64(val, jj);
+                    for (int mm = 1; mm < tS; ++mm) { const double t = readlane_f64(val, 5 * mm + jj); acc = jj == 4 ? fmax(acc, t) : acc + t; }
+                    x[jj] = acc;
+                }
+                if (lane == 0) { sh.red[0] = x[0]; sh.red[1] = x[1]; sh.red[2] = x[2]; sh.red[3] = x[3]; sh.red[4] = x[4]; }     // (not ts.red3: slower waves may still be reading it)
             }
-            s0 = x0; s1 = x1; s2 = x2; s3 = x3; m0 = x4;
-            tm.par ^= 1;
+            __syncthreads();
+            s0 = sh.red[0]; s1 = sh.red[1]; s2 = sh.red[2]; s3 = sh.red[3]; m0 = sh.red[4];
+            __syncthreads();
         }
     };
     auto treduce4 = [&](double &s0, double &s1, double &s2, double &m0) { double z = 0.0; treduce5(s0, s1, s2, z, m0); };
@@ -2751,7 +2789,21 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                     current.gradient_valid = isfinite(current.gradient);
                 }
                 TR(15, 0);
-                const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
+                // The next trial step is a pure function of replicated scalars - 10-40 k cycles of polynomial fitting and root
+                // isolation (9-18 us when all eight waves of the CU run it side by side: two waves per SIMD share the issue port).
+                // One wave computes it, the others wait at the barrier; every workgroup of a team does the same and gets the same bits.
+                double nstep;
+                {
+                    int n_iter_w0 = n_iter;
+                    if (wave == 0) {
+                        const double v = ls_next_step_wave(initial, previous, current, dir_max, n_iter_w0);
+                        if (lane == 0) sh.bcast[0] = v;
+                    }
+                    __syncthreads();
+                    nstep = sh.bcast[0];
+                    ++n_iter;                                    // (= what ls_next_step_regs did to wave 0's copy)
+                    __syncthreads();
+                }
                 TR(16, 0);
                 if (nstep < 0.0) break;
                 previous = current;
@@ -2889,6 +2941,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
     unsigned int *const mbox = ctl + 16 + 16 * unit_slot, *const bars = mbox + 8;
     TeamCtx tm;
     tm.ctl = ctl;
+    tm.epoch = a.team_epoch;
     __syncthreads();
     for (;;) {
         if (tid == 0) {
@@ -2961,7 +3014,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
             solve_tree_component<kBlockThreads, false>(a, ci, sh, ts, solo);
         } else {
             tm.S = S; tm.r = rank - L; tm.bar = bars + L;
-            tm.red = a.team_red + (size_t)unit_slot * kTeamRedPerUnit + (size_t)(L / 2) * (2 * kTeamMax * 8);
+            tm.red = a.team_red + (size_t)unit_slot * kTeamRedPerUnit + (size_t)(L / 2) * (2 * kTeamMax * 16);
             if (tid == 0 && tm.r == 0) atomicAdd(ctl + 10, 1u);           // (statistics: components solved by a team)
             solve_tree_component<kBlockThreads, true>(a, ci, sh, ts, tm);
         }
@@ -3410,6 +3463,8 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     if (b->team_wgs) {
         b->d_team_ctl = reinterpret_cast<unsigned int *>(b->d_workspace + team_off);
         b->d_team_red = b->d_workspace + team_off + (kTeamCtlWords + 1) / 2;
+        // (the reduction slots carry {value, launch << 32 | reduction} granules: tags of an earlier owner of this memory must not match)
+        HIP_TRY(hipMemsetAsync(b->d_team_red, 0, 8ull * kTeamUnitsPerXcc * kTeamRedPerUnit * sizeof(double), st));
     }
     // the plans' words: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
     size_t got = 0;
@@ -3641,7 +3696,8 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
 namespace {
 // samples: 15 doubles per case = (x, value, gradient, value_valid, gradient_valid) of the initial, previous and current sample
 __global__ void ls_next_step_kernel(int64_t n, const double *samples, const double *dir_max, int register_version, double *step) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (version 2 - the wave-cooperative form - takes one case per 64-thread workgroup, every lane with the same arguments)
+    const int64_t i = register_version == 2 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     LsSample s[3];
     for (int k = 0; k < 3; ++k) {
@@ -3649,7 +3705,8 @@ __global__ void ls_next_step_kernel(int64_t n, const double *samples, const doub
         s[k].x = q[0]; s[k].value = q[1]; s[k].gradient = q[2]; s[k].value_valid = q[3] != 0.0; s[k].gradient_valid = q[4] != 0.0;
     }
     int it0 = 0;
-    step[i] = register_version ? ls_next_step_regs(s[0], s[1], s[2], dir_max[i], it0) : ls_next_step(s[0], s[1], s[2], dir_max[i], it0);
+    if (register_version == 2) { const double v = ls_next_step_wave(s[0], s[1], s[2], dir_max[i], it0); if (threadIdx.x == 0) step[i] = v; }
+    else step[i] = register_version ? ls_next_step_regs(s[0], s[1], s[2], dir_max[i], it0) : ls_next_step(s[0], s[1], s[2], dir_max[i], it0);
 }
 }  // namespace
 
@@ -3666,7 +3723,7 @@ int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const d
     hipStream_t st = ctx->s_main;
     HIP_TRY(hipMemcpyAsync(d_s, samples, 120 * (size_t)n, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_d, dir_max, 8 * (size_t)n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(ls_next_step_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, d_s, d_d, register_version, d_a);
+    hipLaunchKernelGGL(ls_next_step_kernel, dim3((unsigned)(register_version == 2 ? n : (n + 63) / 64)), dim3(64), 0, st, n, d_s, d_d, register_version, d_a);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(step, d_a, 8 * (size_t)n, hipMemcpyDeviceToHost, st));
     HIP_TRY(lfr::stream_wait(st));
@@ -3771,6 +3828,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     a.trace = d_trace;
 #endif
     for (int k = 0; k < 3; ++k) a.team_work[k] = b->team_work[k];
+    a.team_epoch = (uint32_t)(b->n_solves + 1);
     if (b->fused) {
         const lfr::DevGraph &dgr = *b->dev_hold->graph;
         a.f_row = dgr.flow_row; a.f_disp1 = dgr.disp1; a.f_disp2 = dgr.disp2; a.f_sim = dgr.sim;

@@ -307,7 +307,7 @@ def ls_next_step_hip(samples, dir_max, register_version=False, device=0):
     n = samples.shape[0]
     dir_max = np.ascontiguousarray(dir_max, np.float64)
     a = np.zeros(n, np.float64)
-    _check(lib().lfr_debug_ls_next_step(device, n, _ptr(samples), _ptr(dir_max), int(bool(register_version)), _ptr(a)))
+    _check(lib().lfr_debug_ls_next_step(device, n, _ptr(samples), _ptr(dir_max), int(register_version), _ptr(a)))
     return a
 
 

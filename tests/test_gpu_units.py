@@ -97,13 +97,15 @@ def test_baseline_configs_at_full_size(lfr_lib, name):
     assert (info["iterations"] == ref["infos"]["iterations"][info["component"]]).all()
 
 
-@pytest.mark.parametrize("register_version", [False, True])
+@pytest.mark.parametrize("register_version", [0, 1, 2])     # loop version / register version / wave-cooperative version
 def test_line_search_contraction_matches_numpy_roots(lfr_lib, register_version):
     """ArmijoLineSearch::DoSearch's step contraction (MinimizeInterpolatingPolynomial over 3..6 value / gradient constraints)
     as the kernels compute it (the packed kernel's loop version and the workgroup kernel's register version), against the numpy restatement (np.roots), including interpolants whose leading coefficients vanish."""
     import ls_cases
     S, dir_max, want = ls_cases.make(4000)
     got = capi.ls_next_step_hip(S, dir_max, register_version)
+    if register_version == 2:                                   # same arithmetic per piece as the register version: the same bits
+        assert (got == capi.ls_next_step_hip(S, dir_max, 1)).all()
     gave_up = want < 0
     assert ((got < 0) == gave_up).all()
     ok = ~gave_up
