@@ -2148,14 +2148,14 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     const bool thin = pl[28] != 0u;
     // (a miscount must not hang the GPU: the step is rejected, the counter says so; a team gives up as a whole - the abort word ends
     // every wait of the launch's teams and fails their components)
-    bool wdead = false;                                   // TEAM: this wave has seen the abort word
+    bool wdead = false;                                   // this wave has run out of patience once (TEAM: or has seen the abort word)
     auto spin_timeout = [&]() {
         if (lane == 0) {
             sh.flag = 1;
             if constexpr (TEAM) { if (team_ld(tm.ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u); team_st(tm.ctl + 9, 1u); team_st(gteam, 1u); }
             else atomicAdd(a.queue + 15, 1u);
         }
-        if constexpr (TEAM) wdead = true;
+        wdead = true;                                     // (this wave gives up waiting for the rest of the solve: one timeout must not cascade into seconds)
     };
     auto state_lane = [&](const uint32_t J) -> int {       // per lane (J may differ between lanes)
         if constexpr (TEAM) return (int)team_ld(gteam + 16 + J);
@@ -2168,7 +2168,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     };
     // wait until `ready()`; TEAM: the abort word is looked at every 256 polls
     auto pend_wait = [&](auto ready) {
-        if (TEAM && wdead) return;
+        if (wdead) return;
         int spins = 0;
         while (!ready()) {
             __builtin_amdgcn_s_sleep(2);
@@ -4029,6 +4029,17 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
                     (double)h[c * 8 + 3] / h[c * 8 + 7], (double)h[c * 8 + 4] / h[c * 8 + 7], (double)h[c * 8 + 5] / h[c * 8 + 7], (double)h[c * 8 + 6] / h[c * 8 + 7]);
     }
 #endif
+    {   // bounded spins that ran out (wave hand-offs of the factorizations, the teams' barriers): a rejected LM step or a failed
+        // component instead of a hung GPU - visible under LFR_VERBOSE, an ERROR under LFR_SPIN_TIMEOUT_FATAL=1 (the GPU tests set it)
+        static const bool verbose = getenv("LFR_VERBOSE") != nullptr;
+        static const bool fatal = [] { const char *e = getenv("LFR_SPIN_TIMEOUT_FATAL"); return e && e[0] == '1'; }();
+        if ((verbose || fatal) && b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {
+            unsigned int v = 0;
+            HIP_TRY(hipMemcpy(&v, a.queue + 15, sizeof v, hipMemcpyDeviceToHost));
+            if (v && verbose) fprintf(stderr, "lfr: %u bounded spin-wait(s) of the workgroup kernels ran out during this solve (rejected LM steps / failed components)\n", v);
+            if (v && fatal) { lfr::set_error("%u bounded spin-wait(s) of the workgroup kernels ran out (LFR_SPIN_TIMEOUT_FATAL=1)", v); return LFR_ERR_HIP; }
+        }
+    }
     memset(stats, 0, sizeof *stats);
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, b->ev[0], b->ev[1]));

@@ -11,6 +11,8 @@ sys.path.insert(0, ROOT)
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a bounded spin-wait of the workgroup kernels that runs out is an ERROR in the tests (a rejected LM step otherwise): VERDICT r4 #7
+    os.environ.setdefault("LFR_SPIN_TIMEOUT_FATAL", "1")
 
 
 @pytest.fixture(scope="session")
