@@ -429,6 +429,12 @@ def main():
             p5, b5 = k5
             g5.to_device(local)
             sp5 = spans(lambda: pipe5(), max(1, min(3, reps)), sync)
+
+            def solver5():                                        # solve.cc:615-638 like for like with the CPU leg: assembly + solve + positions
+                bb = capi.Batch(p5, local)
+                bb.solve(stream, want_stats=False)
+                bb.positions_view()
+            sps5 = spans(solver5, max(1, min(3, reps)), sync)
             n5 = 5
             for _ in range(2):
                 b5.solve(stream, want_stats=False)
@@ -481,6 +487,9 @@ def main():
                 "kernel_ms": {kernel_names[i]: round(float(c5[i]), 3) for i in range(9) if e5[i] > 0},
                 "kernel_edges": {kernel_names[i]: int(e5[i]) for i in range(9) if e5[i] > 0},
                 "total_span_resident_graph_ms": sp5["ms"], "graph_stage": {k: p5.stats()[k] for k in ("tracks_ms", "roots_ms", "graph_cut_ms", "kruskal_rounds", "n_cut_components")},
+                "solver_span_ms": sps5["ms"],
+                "solver_span_what": "solve.cc:615-638 on the GPU, one-shot: device assembly of the batch + solve + positions on the host - the span the CPU leg times",
+                "speedup_vs_cpu_baseline_8_threads": (cpu5["solver_span_ms"] / sps5["ms"]) if cpu5 and "solver_span_ms" in cpu5 else None,
                 "mean_iterations": st5["sum_iterations"] / max(1, st5["n_components"]), "failed": st5["n_failed"], "no_convergence": st5["n_no_convergence"],
                 "setup_s": t_prep5,
                 "cpu_baseline": cpu5,
@@ -499,6 +508,12 @@ def main():
             bs = capi.Batch(ps, local)
             sync()
             t_batch = time.perf_counter() - t0
+
+            def solver_s():                                       # solve.cc:615-638 like for like with the CPU leg (the elimination-tree plans are made on the host here)
+                bb = capi.Batch(ps, local)
+                bb.solve(stream, want_stats=False)
+                bb.positions_view()
+            sps_s = spans(solver_s, max(1, min(3, reps)), sync)
             for _ in range(2):
                 bs.solve(stream, want_stats=False)
             sync()
@@ -527,7 +542,7 @@ def main():
             fact_bytes_s = float(((ts_["tiles"] * 6144.0 + ts_["updates"] * 3072.0) * its).sum())
             sweeps_per_edge = float(sts["exec_passes_edges"]) / max(1, sts["n_edges"])
             sweep_bytes_s = float(sts["exec_passes_edges"]) * 160.0 + float(ts_["items"].sum()) * 150.0 * sweeps_per_edge
-            prof_s = pmc_numbers("r04_pmc_sparse.json")
+            prof_s = pmc_numbers("r05_pmc_sparse.json")
             stale_s = bool(prof_s) and not fresh(prof_s)
             if stale_s:
                 prof_s = None
@@ -541,10 +556,10 @@ def main():
                              "achieved": (fact_bytes_s + sweep_bytes_s) / (mss * 1e-3) / 1e9,
                              "frac": (fact_bytes_s + sweep_bytes_s) / (mss * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "frac_what": "ALGORITHMIC bytes over the step time.  Neither roof binds: the launch lasts as long as its slowest component - "
-                                          "iterations x (levels of dependent column tasks + sweeps) on ONE workgroup, the other CUs done or idle",
+                                          "iterations x (levels of dependent column tasks + sweeps), chains of round trips to L2 on a team of up to 8 workgroups",
                              "algorithmic_bytes": fact_bytes_s + sweep_bytes_s, "factorization_bytes": fact_bytes_s, "sweep_bytes": sweep_bytes_s,
                              "traffic": traffic_s, "traffic_ratio": (traffic_s / (fact_bytes_s + sweep_bytes_s)) if traffic_s else None,
-                             "traffic_source": ("profiles/r04_pmc_sparse.json (committed rocprofv3 PMC passes over this workload with these kernel sources; not measured in this run)"
+                             "traffic_source": ("profiles/r05_pmc_sparse.json (committed rocprofv3 PMC passes over this workload with these kernel sources; not measured in this run)"
                                                 if traffic_s else "none: the committed counters were collected with other kernel sources" if stale_s else None),
                              "fp64": {"achieved": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
@@ -557,7 +572,10 @@ def main():
                 "critical_component": {"rows": int(rowss[big_i]), "iterations": int(infos["iterations"][big_i]), "columns": int(ts_["columns"][big_i]),
                                        "levels": int(ts_["levels"][big_i])},
                 "cpu_baseline": cpu_s,
-                "speedup_vs_cpu_baseline_8_threads": (cpu_s["solver_span_ms"] / mss) if cpu_s and "solver_span_ms" in cpu_s else None,
+                "solver_span_ms": sps_s["ms"],
+                "solver_span_what": "solve.cc:615-638 on the GPU, one-shot: device assembly of the batch incl. the elimination-tree plans (host threads) + "
+                                    "solve + positions on the host - the span the CPU leg times; ms_per_step is the resident solve only",
+                "speedup_vs_cpu_baseline_8_threads": (cpu_s["solver_span_ms"] / sps_s["ms"]) if cpu_s and "solver_span_ms" in cpu_s else None,
                 "spin_timeouts": bs.spin_timeouts(),
                 "workload": "capsized_sparse: synthetic match graph, 1344 images, %d tracks (mean length 6) matched along ring lattices of degree 4 and chained "
                             "by wrong matches, ratio-test similarities; %d directed edges, %d components, %d of them above 192 rows (max %d rows)"
@@ -569,8 +587,10 @@ def main():
                 "max_iterations_large": int(infos["iterations"][bigs].max()) if bigs.any() else 0,
                 "dense_factorization_flops_equivalent": float((rowss[bigs].astype(np.float64) ** 3 / 3.0 * infos["iterations"][bigs]).sum()),
                 "batch_creation_ms": t_batch * 1e3, "failed": sts["n_failed"], "no_convergence": sts["n_no_convergence"], "setup_s": t_preps,
+                "team_components": bs.team_runs(),
                 "note": "round 3 (block-envelope kernel: ~160 dependent 16-column panels per factorization on one wave): 35 ms; round 4: nested "
-                        "dissection + columns by level of the elimination tree, the workgroup's eight waves take independent columns side by side",
+                        "dissection + columns by level of the elimination tree, the workgroup's eight waves take independent columns side by side: 9 ms; "
+                        "round 5: teams of 2 / 4 / 8 workgroups on one XCD per component (LFR_TREE_TEAM), update entries streamed as their columns finish",
             }
             del bs, ps, gs, mas
         ref_bin = os.environ.get("LFR_REFERENCE_SOLVE")

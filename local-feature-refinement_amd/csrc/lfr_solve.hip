@@ -3108,6 +3108,14 @@ size_t block_lds_bytes(int max_rows, bool global_matrix) {
     return (block_vector_doubles(max_rows) - (size_t)max_rows + (size_t)(max_rows + 1) * (max_rows + 2) / 2) * sizeof(double);
 }
 
+// LFR_HOST_TRACE=1: host-side time stamps (us, steady clock) of the calls that make the Solver span, to stderr
+static inline void host_trace(const char *what) {
+    static const bool on = [] { const char *e = getenv("LFR_HOST_TRACE"); return e && e[0] == '1'; }();
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "lfr-host %10.1f us  %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
 #define HIP_TRY(expr)                                                                         \
     do {                                                                                      \
         hipError_t _e = (expr);                                                               \
@@ -3272,7 +3280,9 @@ int create_on_device(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     HIP_TRY(hipMemsetAsync(b->d_positions, 0, sizeof(double) * 2 * (size_t)std::max<int64_t>(N, 1), st));
     HIP_TRY(hipMemsetAsync(b->d_prof, 0, kProfWords * sizeof(unsigned long long), st));
     lfr::DeviceAssembly dev;
+    host_trace("assembly: launches begin");
     const int rc = lfr::assemble_on_device(p, *dp, shard_rank, shard_world, b->slab, dev);     // ends with the one synchronisation
+    host_trace("assembly: summary is back");
     if (rc != LFR_OK) return rc;
     b->h2d_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_asm0).count();
     b->d_descs = dev.d_descs; b->d_edges = dev.d_edges; b->d_node_ids = dev.d_node_ids; b->d_node_inc = dev.d_node_inc;
@@ -3396,7 +3406,9 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     std::vector<lfr::TreePlan> plans(ng);
     {
         std::atomic<int> next{0};
-        const int T = std::max(1, std::min(ng, (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()))));
+        // (a plan is ~1 ms of one core for a cap-sized component and the plans are independent: as many threads as components, up to half
+        // the machine - 32 threads left the 130 plans of the sparse bench workload at 6.5 ms of a 10-ms Solver span)
+        const int T = std::max(1, std::min(ng, (int)std::min(128u, std::max(1u, std::thread::hardware_concurrency() / 2))));
         auto work = [&] {
             for (;;) {
                 const int i = next.fetch_add(1);
@@ -3803,11 +3815,13 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
         for (int cls = 0; cls < lfr::KC_BLOCK; ++cls) if (b->class_edges[cls] > best) { best = b->class_edges[cls]; b->packed_slot = cls; }
     }
     *out = b.release();
+    host_trace("lfr_batch_create returns");
     return LFR_OK;
 }
 
 int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     if (!b) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    host_trace("lfr_batch_solve enters");
     HIP_TRY(hipSetDevice(b->device));
     hipStream_t st = (hipStream_t)hip_stream;
     KernelArgs a;
@@ -3993,6 +4007,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
     }
     HIP_TRY(hipEventRecord(b->ev[1], st));
     b->infos_valid = false;
+    host_trace("lfr_batch_solve: launched");
     if (!stats) return LFR_OK;
 
     HIP_TRY(lfr::stream_wait(st));
@@ -4151,9 +4166,12 @@ int lfr_batch_positions_view(lfr_batch *b, const double **positions) {
         if (!b->h_positions) return LFR_ERR_NOMEM;
     }
     hipStream_t st = b->ctx->s_main;
+    host_trace("positions_view enters");
     if (b->n_solves > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev[1], 0));        // end of the latest solve, whatever stream it ran on
     HIP_TRY(hipMemcpyAsync(b->h_positions, b->d_positions, bytes, hipMemcpyDeviceToHost, st));
+    host_trace("positions_view: copy issued");
     HIP_TRY(lfr::stream_wait(st));
+    host_trace("positions_view: copy done");
     *positions = b->h_positions;
     return LFR_OK;
 }

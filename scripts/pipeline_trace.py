@@ -12,7 +12,9 @@ L = capi.lib()
 L.lfr_hip_warmup(0)
 L.lfr_hip_reserve(0, g.n_nodes, g.n_edges // 2)
 g.to_device(0)
+p = b = pos = None
 for r in range(reps):
+    del p, b, pos                      # (the previous repetition's batch: its destructor waits for s_main - not inside the timed part)
     L.lfr_hip_synchronize(0)
     t0 = time.perf_counter()
     p = capi.Problem(g, device_graph_stage=0)
