@@ -346,6 +346,20 @@ __device__ __forceinline__ double polyval_n(const double (&p)[N], double x) {
     return v;
 }
 
+// Divisions of the register / wave versions below.  -DLFR_LS_FAST_DIV=1 turns them into a multiplication by v_rcp_f64 + two Newton steps
+// inside the normal range (a contraction performs ~45 divisions in dependent chains) - measured SLOWER (round 5: 12.9-21 us per call
+// against 9.8-17.8): the safeguarded Newton iterations of the root isolation stop when two iterates agree to the last bit, and with a
+// reciprocal that is off by an ulp they keep hopping between neighbours until the bracket closes.  IEEE divisions stay.
+#ifndef LFR_LS_FAST_DIV
+#define LFR_LS_FAST_DIV 0
+#endif
+__device__ __forceinline__ double ls_div(double a, double b) {
+#if LFR_LS_FAST_DIV
+    const double ab = fabs(b);
+    if (ab > 1e-280 && ab < 1e280) return a * fast_rcp(b);
+#endif
+    return a / b;
+}
 // real roots of a cubic / quartic inside [lo, hi] (see real_roots_in above): every level returns exactly M ascending values
 template <int M>
 __device__ __forceinline__ double horner(const double (&q)[M + 1], double x) {
@@ -362,7 +376,7 @@ __device__ __forceinline__ double bracketed_root(const double (&q)[M + 1], const
         if (fx == 0.0) break;
         if ((fx < 0.0) == (fa < 0.0)) a = x; else b = x;
         const double d = horner<M - 1>(dq, x);
-        double xn = x - fx / d;
+        double xn = x - ls_div(fx, d);
         if (!(xn > a && xn < b)) xn = 0.5 * (a + b);
         if (!(xn > a && xn < b)) break;                          // the bracket is down to neighbouring numbers
         if (fabs(xn - x) <= 2.220446049250313e-16 * fabs(xn)) { x = xn; break; }
@@ -382,7 +396,7 @@ __device__ __forceinline__ void real_roots_in(const double (&q)[M + 1], double l
         double r0 = lo, r1 = lo;
         if (D >= 0) {
             const double sD = sqrt(D), t = B >= 0 ? -B - sD : -B + sD;          // t = -(B + sign(B) sqrt(D)): no cancellation
-            const double u = t / (2.0 * A), v = t != 0.0 ? (2.0 * C) / t : u;
+            const double u = ls_div(t, 2.0 * A), v = t != 0.0 ? ls_div(2.0 * C, t) : u;
             r0 = fmin(u, v); r1 = fmax(u, v);
             if (!(r0 == r0)) r0 = lo;                                            // (A == 0 or overflow: no usable breakpoint)
             if (!(r1 == r1)) r1 = lo;
@@ -434,14 +448,14 @@ __device__ __forceinline__ int poly_root_real_parts_n(const double (&d)[M], doub
         for (int l = 0; l + i < M; ++l) e[i] = (lead == l) ? d[i + l] : e[i];
     const int deg = M - lead - 1;
     if (deg <= 0) return 0;
-    if (deg == 1) { out[0] = -e[1] / e[0]; return 1; }
+    if (deg == 1) { out[0] = ls_div(-e[1], e[0]); return 1; }
     if (deg == 2) {
         const double a = e[0], b = e[1], c = e[2];
         const double D = b * b - 4 * a * c, sD = sqrt(fabs(D));
         if (D >= 0) {
-            if (b >= 0) { out[0] = (-b - sD) / (2.0 * a); out[1] = (2.0 * c) / (-b - sD); }
-            else        { out[0] = (2.0 * c) / (-b + sD); out[1] = (-b + sD) / (2.0 * a); }
-        } else { out[0] = -b / (2.0 * a); out[1] = -b / (2.0 * a); }
+            if (b >= 0) { out[0] = ls_div(-b - sD, 2.0 * a); out[1] = ls_div(2.0 * c, -b - sD); }
+            else        { out[0] = ls_div(2.0 * c, -b + sD); out[1] = ls_div(-b + sD, 2.0 * a); }
+        } else { out[0] = ls_div(-b, 2.0 * a); out[1] = out[0]; }
         return 2;
     }
     if constexpr (M >= 5) {
@@ -476,7 +490,7 @@ __device__ __forceinline__ bool solve_dense_n(double (&A)[N][N], double (&b)[N])
         }
 #pragma unroll
         for (int i = k + 1; i < N; ++i) {
-            const double f = A[i][k] / A[k][k];
+            const double f = ls_div(A[i][k], A[k][k]);
 #pragma unroll
             for (int j = k; j < N; ++j) A[i][j] -= f * A[k][j];
             b[i] -= f * b[k];
@@ -487,7 +501,7 @@ __device__ __forceinline__ bool solve_dense_n(double (&A)[N][N], double (&b)[N])
         double s = b[k];
 #pragma unroll
         for (int j = k + 1; j < N; ++j) s -= A[k][j] * b[j];
-        b[k] = s / A[k][k];
+        b[k] = ls_div(s, A[k][k]);
     }
     return true;
 }

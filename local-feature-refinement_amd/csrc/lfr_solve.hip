@@ -3408,7 +3408,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         std::atomic<int> next{0};
         // (a plan is ~1 ms of one core for a cap-sized component and the plans are independent: as many threads as components, up to half
         // the machine - 32 threads left the 130 plans of the sparse bench workload at 6.5 ms of a 10-ms Solver span)
-        const int T = std::max(1, std::min(ng, (int)std::min(128u, std::max(1u, std::thread::hardware_concurrency() / 2))));
+        const int T = std::max(1, std::min(ng, (int)std::min(128u, std::max(std::min(8u, std::max(1u, std::thread::hardware_concurrency())), std::thread::hardware_concurrency() / 2))));
         auto work = [&] {
             for (;;) {
                 const int i = next.fetch_add(1);
