@@ -167,10 +167,16 @@ def main():
     shard = (rank, world) if strong else (0, 1)
     flags = capi.FLOWS_STAY_ON_HOST if strong else 0
 
+    def make_batch(problem):
+        """the batch of this rank: a problem whose graph stage already ran over this rank's connected components only is assembled whole;
+        otherwise (one rank, or one giant connected component) the COMPONENTS are dealt out at assembly (snake deal)"""
+        return capi.Batch(problem, local) if problem.cc_sharded else capi.Batch(problem, local, shard[0], shard[1])
+
     def pipeline(keep=None):
-        """solve.cc:487-641 on the GPU: graph stage -> batch assembly -> solve -> positions on the host."""
-        problem = capi.Problem(graph, device_graph_stage=local, flags=flags)
-        batch = capi.Batch(problem, local, shard[0], shard[1])
+        """solve.cc:487-641 on the GPU: graph stage -> batch assembly -> solve -> positions on the host.  N > 1 (strong): every rank runs
+        the union-find pass over the endpoints, then tracks / roots / components / assembly / solve over ITS connected components only."""
+        problem = capi.Problem(graph, device_graph_stage=local, flags=flags, shard=shard if strong else None)
+        batch = make_batch(problem)
         batch.solve(stream, want_stats=False)
         pos = batch.positions_view()
         if keep is not None:
@@ -194,7 +200,7 @@ def main():
         pipeline()
 
     def solver_only():
-        b = capi.Batch(problem, local, shard[0], shard[1])       # problem construction: device assembly of the batch
+        b = make_batch(problem)                                  # problem construction: device assembly of the batch
         b.solve(stream, want_stats=False)
         b.positions_view()
 
@@ -254,7 +260,8 @@ def main():
                                                             "" if strong else "/GPU", "2" if strong else "2+rank"),
                    "step": "all solve kernels over the HBM-resident batch (inputs resident when the timed region starts)",
                    "edges_per_gpu": st["n_edges"], "tracks_per_gpu": st["n_tracks"], "components_per_gpu": st["n_components"],
-                   "parallelism": "components sharded, %d rank(s), no data-path collective" % world},
+                   "parallelism": ("components sharded, %d rank(s), no data-path collective" % world) +
+                                  (" (graph stage, assembly and solve per rank over its connected components of the match graph)" if strong and problem.cc_sharded else "")},
         # the reference's own spans, one-shot, median of `reps` (max over ranks)
         "solver_span": dict(rate(sp_solver), what="solve.cc:615-638: device assembly of the batch (problem construction) + solve + positions on the host"),
         "total_span": dict(rate(sp_total), what="solve.cc:487-641: graph stage + assembly + solve + positions on the host; the graph starts in "
@@ -319,8 +326,8 @@ def main():
 
         def strong_total():
             dist.barrier()
-            p = capi.Problem(gs, device_graph_stage=local, flags=capi.FLOWS_STAY_ON_HOST)
-            b = capi.Batch(p, local, rank, world)
+            p = capi.Problem(gs, device_graph_stage=local, flags=capi.FLOWS_STAY_ON_HOST, shard=(rank, world))
+            b = capi.Batch(p, local) if p.cc_sharded else capi.Batch(p, local, rank, world)
             b.solve(stream, want_stats=False)
             b.positions_view()
             return b

@@ -164,6 +164,16 @@ int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_c
 #define LFR_BUILD_FLOWS_STAY_ON_HOST 1
 int lfr_problem_build_hip_ex(const lfr_graph *g, int device, int64_t max_nodes_in_component,
                              const int64_t *component_override, int flags, lfr_problem **out);
+/* Multi-GPU, one process per GPU (solve.cc:594-597: components are independent; solve.cc:489-541: the constrained spanning forest
+ * never joins two connected components of the match graph, so tracks, roots and components decompose by connected component too):
+ * the graph stage of rank shard_rank of shard_world over ITS connected components only - the k-th connected component in node order
+ * belongs to rank k mod shard_world.  lfr_batch_create(p, device, 0, 1) then assembles this rank's components; the union over the ranks
+ * is the whole problem, every component bit-identical to the unsharded run.  lfr_problem_cc_sharded(p) returns 0 when one connected
+ * component dominates (or the host stage ran): the problem then covers the whole graph and the caller shards the COMPONENTS at
+ * assembly, lfr_batch_create(p, device, shard_rank, shard_world), as with lfr_problem_build_hip_ex. */
+int lfr_problem_build_hip_shard(const lfr_graph *g, int device, int64_t max_nodes_in_component, int flags, int shard_rank, int shard_world,
+                                lfr_problem **out);
+int lfr_problem_cc_sharded(const lfr_problem *p);
 void lfr_problem_free(lfr_problem *p);
 /* The two-way cut this library substitutes for colmap::ComputeNormalizedMinGraphCut(edges, weights, 2)
  * (solve.cc:192; COLMAP wraps Graclus there, a third-party multilevel heuristic that cannot be restated: see

@@ -49,6 +49,10 @@ struct DevGraph {
     // when chunk c has landed, so the assembly gathers a chunk while the next one is still on the wire
     hipEvent_t ev_flows[4] = {nullptr, nullptr, nullptr, nullptr};
     int64_t chunk_row[5] = {0, 0, 0, 0, 0};
+    // A SHARD of another device graph (graph_stage_on_device with shard_world > 1): the matches of the connected components dealt to one
+    // rank, in their original order, with flow_row pointing into the parent's flows; node images, flows and their events are the
+    // parent's (kept alive here, never destroyed by the shard).
+    std::shared_ptr<DevGraph> parent;
     ~DevGraph();
 };
 // The graph's device copy (created on first use, cached on the graph until lfr_graph_evict_device).
@@ -75,7 +79,11 @@ int upload_labels(const Problem &p, int device, bool stage_flows, std::shared_pt
 // host copies of the labels are fetched on demand (Problem::ensure_host_labels).  Returns
 // LFR_GRAPHSTAGE_USE_HOST when the input needs something only the host stage has.
 constexpr int LFR_GRAPHSTAGE_USE_HOST = 1;
-int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p);
+// shard_world > 1: only the connected components of the match graph dealt to shard_rank (the k-th component in node order goes to rank
+// k mod shard_world): tracks, roots, components and - later - the batch of this rank cover exactly those; the other ranks' nodes stay
+// unmatched singletons here.  When one connected component holds most of the matches the deal cannot balance: the stage then runs over
+// the whole graph (p.cc_sharded stays false) and the caller shards the COMPONENTS at batch assembly as before.
+int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p, int shard_rank = 0, int shard_world = 1);
 
 // What the host needs to launch the solve kernels, read back once at the end of the assembly.
 struct AsmSummary {

@@ -755,7 +755,7 @@ DevGraph::~DevGraph() {
         (void)hipStreamSynchronize(ctx->s_copy);
         (void)hipStreamSynchronize(ctx->s_main);
     }
-    for (auto &e : ev_flows) if (e) (void)hipEventDestroy(e);
+    if (!parent) for (auto &e : ev_flows) if (e) (void)hipEventDestroy(e);      // (a shard borrows its parent's events)
 }
 DevProblem::~DevProblem() {
     if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->s_main); }
@@ -969,8 +969,83 @@ int warm_graphstage_primitives(DevCtx *ctx) {
     return rc;
 }
 
-int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p) {
-    const int64_t N = g.n_nodes(), M = g.n_matches();
+// ---- sharding by connected component (multi-GPU: every rank's graph stage, assembly and solve over its own components only) ----
+__global__ void k_cc_is_root(int64_t n, const uint32_t *cc, uint32_t *flag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n) flag[i] = i < n && cc[i] == (uint32_t)i ? 1u : 0u;
+}
+// keep[m] = the connected component of match m is dealt to `rank`; per-rank match counts (one atomic per workgroup and rank present)
+__global__ void k_shard_keep(int64_t M, const uint32_t *n1, const uint32_t *cc, const uint32_t *cc_index, int rank, int world, uint32_t *keep, unsigned long long *per_rank) {
+    __shared__ unsigned int cnt[64];
+    if (threadIdx.x < 64) cnt[threadIdx.x] = 0u;
+    __syncthreads();
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < M) {
+        const int owner = (int)(cc_index[cc[n1[m]]] % (uint32_t)world);
+        keep[m] = owner == rank ? 1u : 0u;
+        atomicAdd(&cnt[owner], 1u);
+    } else if (m == M) keep[m] = 0u;
+    __syncthreads();
+    if (threadIdx.x < world && cnt[threadIdx.x]) atomicAdd(&per_rank[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+__global__ void k_shard_scatter(int64_t M, const uint32_t *keep, const uint32_t *pos, const uint32_t *n1, const uint32_t *n2, const float *sim,
+                                const uint32_t *flow_row, uint32_t *o_n1, uint32_t *o_n2, float *o_sim, uint32_t *o_row) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M || !keep[m]) return;
+    const uint32_t q = pos[m];
+    o_n1[q] = n1[m]; o_n2[q] = n2[m]; o_sim[q] = sim[m];
+    o_row[q] = flow_row ? flow_row[m] : (uint32_t)m;
+}
+// The shard of `full` for (rank, world): connected components (the same union-find kernels as the stage itself), the k-th component in
+// node order to rank k mod world, a STABLE compaction of the matches (their relative order is what the batch layout of a component
+// depends on: the shard's components come out bit-identical to the whole graph's).  per_rank_h[r] = matches of rank r.
+static int shard_dev_graph(const std::shared_ptr<DevGraph> &full, int rank, int world, std::shared_ptr<DevGraph> &out, std::vector<unsigned long long> &per_rank_h) {
+    DevCtx *ctx = full->ctx;
+    hipStream_t st = ctx->s_main;
+    const int64_t N = full->N, M = full->M;
+    DevArena arena;
+    if (!arena.init(ctx, (size_t)12 * N + (size_t)12 * M + ((size_t)8 << 20))) return LFR_ERR_NOMEM;
+    uint32_t *parent = arena.take_n<uint32_t>(N), *cc = arena.take_n<uint32_t>(N), *rflag = arena.take_n<uint32_t>(N + 1), *cc_index = arena.take_n<uint32_t>(N + 1);
+    uint32_t *keep = arena.take_n<uint32_t>(M + 1), *pos = arena.take_n<uint32_t>(M + 1);
+    unsigned long long *per_rank = arena.take_n<unsigned long long>(64);
+    if (!parent || !cc || !rflag || !cc_index || !keep || !pos || !per_rank) { set_error("shard arena exhausted"); return LFR_ERR_NOMEM; }
+    LFR_HIP_TRY(hipMemsetAsync(per_rank, 0, 64 * 8, st));
+    hipLaunchKernelGGL(k_iota, grid_for(N), dim3(kThreads), 0, st, N, parent);
+    for (int i = 0, done = 0; i < kUnionStages; done = kUnionStrides[i], ++i) {
+        if (i) hipLaunchKernelGGL(k_uf_flatten, grid_for(N), dim3(kThreads), 0, st, N, parent);
+        hipLaunchKernelGGL(k_cc_union, grid_for((M + kUnionStrides[i] - 1) / kUnionStrides[i]), dim3(kThreads), 0, st, M, kUnionStrides[i], done, full->n1, full->n2, parent);
+    }
+    hipLaunchKernelGGL(k_cc_labels, grid_for(N), dim3(kThreads), 0, st, N, parent, cc);
+    hipLaunchKernelGGL(k_cc_is_root, grid_for(N + 1), dim3(kThreads), 0, st, N, cc, rflag);
+    int rc;
+    if ((rc = exclusive_sum(arena, rflag, cc_index, N + 1, st)) != LFR_OK) return rc;
+    hipLaunchKernelGGL(k_shard_keep, grid_for(M + 1), dim3(kThreads), 0, st, M, full->n1, cc, cc_index, rank, world, keep, per_rank);
+    if ((rc = exclusive_sum(arena, keep, pos, M + 1, st)) != LFR_OK) return rc;
+    per_rank_h.assign(64, 0);
+    LFR_HIP_TRY(hipMemcpyAsync(per_rank_h.data(), per_rank, 64 * 8, hipMemcpyDeviceToHost, st));
+    LFR_HIP_TRY(stream_wait(st));
+    const int64_t Ms = (int64_t)per_rank_h[rank];
+    std::shared_ptr<DevGraph> dg(new DevGraph());
+    dg->ctx = ctx; dg->N = N; dg->M = Ms; dg->N_cap = N; dg->parent = full;
+    if (!dg->slab.init(ctx, (size_t)16 * std::max<int64_t>(Ms, 1) + 4096)) return LFR_ERR_NOMEM;
+    dg->n1 = dg->slab.take_n<uint32_t>(Ms); dg->n2 = dg->slab.take_n<uint32_t>(Ms); dg->sim = dg->slab.take_n<float>(Ms); dg->flow_row = dg->slab.take_n<uint32_t>(Ms);
+    if (!dg->n1 || !dg->n2 || !dg->sim || !dg->flow_row) { set_error("shard slab exhausted"); return LFR_ERR_NOMEM; }
+    dg->node_image = full->node_image;
+    dg->disp1 = full->disp1; dg->disp2 = full->disp2;
+    dg->flows_staged = full->flows_staged; dg->flows_zero_copy = full->flows_zero_copy; dg->flows_external = full->flows_external;
+    for (int c = 0; c < 4; ++c) dg->ev_flows[c] = full->ev_flows[c];
+    for (int c = 0; c < 5; ++c) dg->chunk_row[c] = full->chunk_row[c];
+    hipLaunchKernelGGL(k_shard_scatter, grid_for(M), dim3(kThreads), 0, st, M, keep, pos, full->n1, full->n2, full->sim, full->flow_row,
+                       dg->n1, dg->n2, dg->sim, dg->flow_row);
+    LFR_HIP_TRY(hipGetLastError());
+    LFR_HIP_TRY(stream_wait(st));                      // (the temporaries go back to the cache)
+    out = dg;
+    return LFR_OK;
+}
+
+int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool stage_flows, Problem &p, int shard_rank, int shard_world) {
+    const int64_t N = g.n_nodes();
+    int64_t M = g.n_matches();
     const char *vb = getenv("LFR_VERBOSE");
     const int trace = vb ? atoi(vb) >= 2 ? atoi(vb) : 0 : 0;      // LFR_VERBOSE=2: lap times, 3: + every round of the parallel greedy
     const auto tr0 = std::chrono::steady_clock::now();
@@ -992,6 +1067,20 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipSetDevice(device));
     hipStream_t st = ctx->s_main;
     lap("device graph ready");
+    p.cc_sharded = false;
+    if (shard_world > 1 && shard_world <= 64 && M > 0) {
+        std::shared_ptr<DevGraph> dgs;
+        std::vector<unsigned long long> per_rank;
+        if ((rc = shard_dev_graph(dg, shard_rank, shard_world, dgs, per_rank)) != LFR_OK) return rc;
+        unsigned long long mx = 0;
+        for (int r = 0; r < shard_world; ++r) mx = std::max(mx, per_rank[r]);
+        // balanced enough (every rank decides the same from the same counts): the largest rank within 5/4 of the mean
+        if (4ull * mx * (unsigned long long)shard_world <= 5ull * (unsigned long long)M + 4096ull * shard_world) {
+            dg = dgs; M = dg->M;
+            p.cc_sharded = true; p.shard_matches = M; p.shard_matches_max = (int64_t)mx;
+        }
+        lap(p.cc_sharded ? "sharded by connected component" : "one connected component dominates: the whole graph on every rank");
+    }
 
     std::shared_ptr<DevProblem> dp(new DevProblem());
     dp->ctx = ctx; dp->graph = dg; dp->N = N;

@@ -150,6 +150,8 @@ struct Problem {
     int ensure_host_labels() const;            // lfr_graphstage.hip
     lfr_problem_stats stats{};
     bool host_batch = true;                // false: labels only, the batch is assembled on the device
+    bool cc_sharded = false;               // the device graph stage ran over one rank's connected components only (graph_stage_on_device)
+    int64_t shard_matches = 0, shard_matches_max = 0;     // cc_sharded: matches of this rank / of the largest rank
     // batch (all solvable components, sorted by kernel class then size descending)
     std::vector<CompDesc> descs;
     std::vector<int64_t> desc_component;   // original component id per desc

@@ -3519,6 +3519,29 @@ int lfr_problem_build_hip_ex(const lfr_graph *g, int device, int64_t max_nodes_i
     return lfr_problem_build_labels(g, max_nodes_in_component, component_override, out);   // host graph stage
 }
 
+// Multi-GPU, one process per GPU: the graph stage of ONE rank.  The constrained spanning forest of solve.cc:489-541 is a global greedy, but
+// it decomposes exactly by connected component of the match graph (no union ever crosses one), and so does everything behind it (roots,
+// components, the size cap, the solve): rank r takes the connected components k = r (mod world) in node order - found by the same
+// union-find pass on every rank - and runs tracks / roots / components over their matches only.  lfr_batch_create(p, device, 0, 1) then
+// assembles exactly this rank's components; positions of the other ranks' nodes stay 0.  Returns with lfr_problem_cc_sharded(p) = 0
+// when one connected component dominates (real data: wrong matches link everything) - the problem then covers the whole graph and the
+// caller shards its components at assembly (lfr_batch_create(p, device, rank, world)) as before.
+int lfr_problem_build_hip_shard(const lfr_graph *g, int device, int64_t max_nodes_in_component, int flags, int shard_rank, int shard_world,
+                                lfr_problem **out) {
+    if (!g || !out || shard_world < 1 || shard_world > 64 || shard_rank < 0 || shard_rank >= shard_world) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    const bool stage_flows = !(flags & LFR_BUILD_FLOWS_STAY_ON_HOST);
+    lfr_problem *h = new lfr_problem();
+    const int rc = lfr::graph_stage_on_device(g->g, max_nodes_in_component, device, stage_flows, h->p, shard_rank, shard_world);
+    if (rc == LFR_OK) { *out = h; return LFR_OK; }
+    delete h;
+    if (rc != lfr::LFR_GRAPHSTAGE_USE_HOST) { *out = nullptr; return rc; }
+    return lfr_problem_build_labels(g, max_nodes_in_component, nullptr, out);      // host graph stage over the whole graph (not sharded)
+}
+int lfr_problem_cc_sharded(const lfr_problem *p) {
+    if (!p) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    return p->p.cc_sharded ? 1 : 0;
+}
+
 int lfr_problem_build_hip(const lfr_graph *g, int device, int64_t max_nodes_in_component, const int64_t *component_override,
                           lfr_problem **out) {
     return lfr_problem_build_hip_ex(g, device, max_nodes_in_component, component_override, 0, out);

@@ -86,6 +86,8 @@ def lib():
         "lfr_problem_build_labels": (C.c_int, [vp, i64, vp, pp]),
         "lfr_problem_build_hip": (C.c_int, [vp, C.c_int, i64, vp, pp]),
         "lfr_problem_build_hip_ex": (C.c_int, [vp, C.c_int, i64, vp, C.c_int, pp]),
+        "lfr_problem_build_hip_shard": (C.c_int, [vp, C.c_int, i64, C.c_int, C.c_int, C.c_int, pp]),
+        "lfr_problem_cc_sharded": (C.c_int, [vp]),
         "lfr_problem_free": (None, [vp]),
         "lfr_bisect_graph": (i64, [i64, vp, vp, vp, vp, vp]),
         "lfr_debug_recursive_cut": (i64, [i64, vp, vp, vp, i64, vp, i64, vp, vp]),
@@ -124,7 +126,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_problem_build_hip_shard", "lfr_problem_cc_sharded", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -352,14 +354,21 @@ class Problem:
     """Tracks, roots, components and the device batch layout (solve.cc:487-606, 79-143)."""
 
     def __init__(self, graph, max_nodes_in_component=0, component_override=None, device_assembly=False,
-                 device_graph_stage=None, flags=0):
+                 device_graph_stage=None, flags=0, shard=None):
         """device_assembly=True: graph stage only; the batch is assembled on the GPU by Batch / solve_hip.
         device_graph_stage=<device ordinal>: tracks/roots/components on that GPU too (implies device_assembly);
-        flags=FLOWS_STAY_ON_HOST: do not stage the flows in HBM (sharded batches gather their rows zero-copy)."""
+        flags=FLOWS_STAY_ON_HOST: do not stage the flows in HBM (sharded batches gather their rows zero-copy);
+        shard=(rank, world): the graph stage over the connected components of the match graph dealt to `rank` only."""
         self.graph = graph
         h = C.c_void_p()
         co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
-        if device_graph_stage is not None:
+        self.cc_sharded = False
+        if device_graph_stage is not None and shard is not None and shard[1] > 1:
+            # multi-GPU: this rank's connected components only (lfr_problem_build_hip_shard); cc_sharded False = the whole graph after all
+            _check(lib().lfr_problem_build_hip_shard(graph._h, int(device_graph_stage), int(max_nodes_in_component), int(flags),
+                                                     int(shard[0]), int(shard[1]), C.byref(h)))
+            self.cc_sharded = bool(lib().lfr_problem_cc_sharded(h))
+        elif device_graph_stage is not None:
             _check(lib().lfr_problem_build_hip_ex(graph._h, int(device_graph_stage), int(max_nodes_in_component), _ptr(co),
                                                   int(flags), C.byref(h)))
         else:

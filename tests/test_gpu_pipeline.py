@@ -326,6 +326,45 @@ def test_bench_two_gpus_over_rccl(lfr_lib):
     assert out["solve"]["failed"] == 0
 
 
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_graph_stage_sharded_by_connected_component(lfr_lib, world):
+    """with one process per GPU every rank used to repeat the whole graph stage.  lfr_problem_build_hip_shard runs tracks /
+    roots / components over the connected components of the match graph dealt to ONE rank (solve.cc:489-541 never joins two of them); the
+    batch of that problem is the rank's share.  The union of the ranks' positions is BITWISE the unsharded solve, the shards' edges and
+    tracks add up, no node is solved twice - for short tracks, with wrong matches (components of several tracks) and with components above
+    the size cap.  A graph that is one giant connected component cannot be dealt out: the problem then covers everything (cc_sharded False)."""
+    for kw in (dict(seed=31, n_images=64, n_tracks=6000),
+               dict(seed=32, n_images=48, n_tracks=3000, eps_out=0.002),
+               dict(seed=33, n_images=24, n_tracks=1500, eps_out=0.004, len_dist="uniform", len_lo=6, len_hi=24)):
+        ma = synthetic.generate(**kw)
+        g = capi.Graph.from_arrays(ma)
+        pw = capi.Problem(g, device_graph_stage=0)
+        bw = capi.Batch(pw, 0)
+        stw = bw.solve()
+        want = bw.download().copy()
+        got = np.zeros_like(want)
+        edges = tracks = comps = 0
+        for r in range(world):
+            pr = capi.Problem(g, device_graph_stage=0, shard=(r, world))
+            assert pr.cc_sharded or kw["seed"] != 31                         # (small graphs with large components may not balance: whole graph + snake deal)
+            br = capi.Batch(pr, 0) if pr.cc_sharded else capi.Batch(pr, 0, r, world)
+            st = br.solve()
+            pos = br.download()
+            assert st["n_failed"] == stw["n_failed"] == 0
+            touched = (pos != 0).any(axis=1)
+            assert not (touched & (got != 0).any(axis=1)).any()             # no node solved by two ranks
+            got[touched] = pos[touched]
+            edges += st["n_edges"]; tracks += st["n_tracks"]; comps += st["n_components"]
+        assert (got == want).all()
+        assert (edges, tracks, comps) == (stw["n_edges"], stw["n_tracks"], stw["n_components"])
+    giant = synthetic.generate(seed=34, n_images=40, n_tracks=800, eps_out=0.05)       # wrong matches link (nearly) everything
+    gg = capi.Graph.from_arrays(giant)
+    pg = capi.Problem(gg, device_graph_stage=0, shard=(0, world))
+    assert not pg.cc_sharded
+    pw = capi.Problem(gg, device_graph_stage=0)
+    assert (pg.labels()[2] == pw.labels()[2]).all()
+
+
 def test_small_component_with_many_edges_takes_the_late_workgroup_path(lfr_lib):
     """No component above 17 nodes, so the device assembly expects packed classes only (three-pass edge sort, no incidence lists, no
     records) - but duplicated matches push one 17-node track beyond 320 edges, into a workgroup class: the assembly's summary has the last
