@@ -528,16 +528,56 @@ struct RoundsArgs {
     int32_t *parent, *count;
     uint32_t *c;
     uint32_t *bar;           // 160 zeroed words
+    int resume, launched0;   // resume = 1: the rounds of ONE prefix block whose pending list (pa, c[0] entries) exists already; launched0 rounds have run
 };
+// Round 5: the same loop on ONE XCD (k_rounds_all<true>, a plain launch).  A round of the greedy rule is a chain of dependent accesses to
+// words everybody shares (parents, bids, image sets); through agent-scope fences every hop leaves the XCD (~2 us) and a barrier writes the
+// whole L2 back, and as separate launches a round costs two kernel boundaries (~43 us for a few thousand pending matches: 76 rounds = 3.3
+// ms of config 5's graph stage).  The workgroups that land on one XCD share its L2: the barrier there is an arrival counter, `s_waitcnt
+// vmcnt(0)` before it (every store has reached L2) and an L1 invalidate behind it - no write-back, nothing leaves the XCD.  The launch
+// is eight times the workgroups that are wanted; every workgroup registers, the ones on other XCDs than the first registrant's leave, the
+// others learn their number and their count when the whole grid has registered.  bar[150]: chosen XCC + 1, [151]: participants,
+// [152]: registered, [153]: arrivals.
+__device__ __forceinline__ void rounds_barrier_xcd(uint32_t *bar, uint32_t &gen, const uint32_t n_blk) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        ++gen;
+        __hip_atomic_fetch_add(&bar[153], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((int)(__hip_atomic_load(&bar[153], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen * n_blk) < 0) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (buffer_inv sc1: this CU's L1; the L2 is the XCD's own)
+    }
+    __syncthreads();
+}
+template <bool XCD>
 __global__ void __launch_bounds__(kPipeThreads) k_rounds_all(RoundsArgs a) {
     uint32_t gen = 0;
-    const uint32_t n_thr = gridDim.x * blockDim.x, tid = blockIdx.x * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
+    uint32_t n_blk = gridDim.x, blk = blockIdx.x;
+    if (XCD) {
+        __shared__ uint32_t s_reg[2];
+        if (threadIdx.x == 0) {
+            const uint32_t xcc = (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 7u) + 1u;
+            uint32_t chosen = atomicCAS(&a.bar[150], 0u, xcc);
+            if (chosen == 0u) chosen = xcc;
+            uint32_t idx = 0xffffffffu;
+            if (chosen == xcc) idx = __hip_atomic_fetch_add(&a.bar[151], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the participant count is out before the total says "everyone has registered")
+            __hip_atomic_fetch_add(&a.bar[152], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (idx != 0xffffffffu) while (__hip_atomic_load(&a.bar[152], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(4);
+            s_reg[0] = idx; s_reg[1] = __hip_atomic_load(&a.bar[151], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        blk = s_reg[0]; n_blk = s_reg[1];
+        if (blk == 0xffffffffu) return;
+    }
+    auto barrier = [&]() { if (XCD) rounds_barrier_xcd(a.bar, gen, n_blk); else rounds_barrier(a.bar, gen); };
+    const uint32_t n_thr = n_blk * blockDim.x, tid = blk * blockDim.x + threadIdx.x, lane = threadIdx.x & 63u;
     Pending *pa = a.pa, *pb = a.pb;
     int cur = 0;                                                  // c[cur] counts pa; both counters are 0 between blocks
-    int launched = 0;
+    int launched = a.launched0;
     for (int64_t k_lo = 0, size = a.first_block; k_lo < a.M; k_lo += size, size *= 2) {
         const int64_t k_hi = k_lo + size < a.M ? k_lo + size : a.M;
-        for (int64_t b = k_lo + (tid - lane); b < k_hi; b += n_thr) {          // (wave-uniform trip count: wave_append is a wave operation)
+        for (int64_t b = k_lo + (tid - lane); !a.resume && b < k_hi; b += n_thr) {          // (wave-uniform trip count: wave_append is a wave operation)
             const int64_t k = b + lane;
             bool large = false;
             uint32_t m = 0;
@@ -554,7 +594,7 @@ __global__ void __launch_bounds__(kPipeThreads) k_rounds_all(RoundsArgs a) {
                 atomicOr(&a.bits[(size_t)y * a.W + (a.node_image[y] >> 6)], 1ull << (a.node_image[y] & 63));
             }
         }
-        rounds_barrier(a.bar, gen);
+        barrier();
         for (;;) {
             const uint32_t n_in = __hip_atomic_load(&a.c[cur], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (n_in == 0) break;
@@ -565,15 +605,16 @@ __global__ void __launch_bounds__(kPipeThreads) k_rounds_all(RoundsArgs a) {
                 const bool valid = i < n_in;
                 round_eval_one(valid, valid ? pa[i] : Pending{0, 0, 0}, a.parent, a.bits, a.W, round_hi, a.minpos, pb, &a.c[cur ^ 1]);
             }
-            rounds_barrier(a.bar, gen);
+            barrier();
             const uint32_t n_out = __hip_atomic_load(&a.c[cur ^ 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (uint32_t i = tid; i < n_out; i += n_thr) round_accept_one(pb[i], round_hi, a.minpos, a.parent, a.count, a.bits, a.W, &a.c[3]);
             if (tid == 0) a.c[cur] = 0u;                          // (everybody read n_in before the barrier above)
-            rounds_barrier(a.bar, gen);
+            barrier();
             Pending *t = pa; pa = pb; pb = t;
             cur ^= 1;
             ++launched;
         }
+        if (a.resume) break;                                      // (one block: the host has the next one's pending list made by the whole chip)
     }
     if (tid == 0) a.c[2] = (uint32_t)launched;
 }
@@ -960,9 +1001,11 @@ int warm_graphstage_primitives(DevCtx *ctx) {
         uint32_t *c = arena.take_n<uint32_t>(16 + 160);
         if (c) {
             LFR_HIP_TRY(hipMemsetAsync(c, 0, 4 * (16 + 160), st));
-            RoundsArgs ra{0, 1024, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, kMaxRounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c, c + 16};
+            RoundsArgs ra{0, 1024, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, kMaxRounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c, c + 16, 0, 0};
             void *kargs[1] = {&ra};
-            if (hipLaunchCooperativeKernel((const void *)k_rounds_all, dim3(256), dim3(kThreads), kargs, 0, st) != hipSuccess) (void)hipGetLastError();
+            if (hipLaunchCooperativeKernel((const void *)k_rounds_all<false>, dim3(256), dim3(kThreads), kargs, 0, st) != hipSuccess) (void)hipGetLastError();
+            LFR_HIP_TRY(hipMemsetAsync(c, 0, 4 * (16 + 160), st));
+            hipLaunchKernelGGL(k_rounds_all<true>, dim3(64), dim3(kThreads), 0, st, ra);      // (the default path's kernel: one XCD)
         }
     }
     LFR_HIP_TRY(stream_wait(st));
@@ -1216,13 +1259,23 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         // invalidate of the eight L2s as a kernel boundary and costs ~28 us; with cooperative_groups' grid.sync() ~130 us (20 ms).  So
         // the loop stays the default and this path is kept as the measured alternative.
         bool done = false;
+        // Round 5, opt-in (LFR_ROUNDS_XCD=1), measured and NOT the default: the first round of a prefix block - every match of the block -
+        // on the whole chip, the block's remaining rounds - a few thousand pending matches each, dozens of rounds - in ONE launch on ONE
+        // XCD (k_rounds_all<true>): three L2-local barriers per round instead of two kernel boundaries.  Config 5's graph stage: 14.4-15.3
+        // ms against 10.9-12.6 for the launch-per-round loop (and 16.4-17.8 with every round on one XCD, the big first rounds included):
+        // 128 workgroups meeting at one L2 word three times per round, and an eighth of the chip's issue slots for the evaluation, cost
+        // more than the kernel boundaries they replace.
+        bool xcd_tail = false;
+        { const char *hx = getenv("LFR_ROUNDS_XCD"); if (hx && hx[0] == '1' && !(getenv("LFR_ROUNDS_COOPERATIVE") && getenv("LFR_ROUNDS_COOPERATIVE")[0] == '1')) xcd_tail = true; }
+        uint32_t *xbar = nullptr;
+        if (xcd_tail) { xbar = rounds_arena.take_n<uint32_t>(160); if (!xbar) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; } }
         const char *hl = getenv("LFR_ROUNDS_COOPERATIVE");
         if (hl && hl[0] == '1') {
             static int blocks_per_cu = -1, n_cu = 0;
             if (blocks_per_cu < 0) {
                 int nb = 0;
                 hipDeviceProp_t prop;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rounds_all, kThreads, 0) == hipSuccess && nb > 0 &&
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rounds_all<false>, kThreads, 0) == hipSuccess && nb > 0 &&
                     hipGetDeviceProperties(&prop, device) == hipSuccess && prop.cooperativeLaunch) { const char *eb = getenv("LFR_ROUNDS_BLOCKS_PER_CU"); blocks_per_cu = std::max(1, std::min(nb, eb ? atoi(eb) : 1)); n_cu = prop.multiProcessorCount; }
                 else blocks_per_cu = 0;
             }
@@ -1230,9 +1283,9 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 uint32_t *bar = rounds_arena.take_n<uint32_t>(160);
                 if (!bar) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
                 LFR_HIP_TRY(hipMemsetAsync(bar, 0, 4 * 160, st));
-                RoundsArgs ra{M, first_block, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, kMaxRounds, bits, minpos, pa, pb, par, cnt, ctr + 8, bar};
+                RoundsArgs ra{M, first_block, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, kMaxRounds, bits, minpos, pa, pb, par, cnt, ctr + 8, bar, 0, 0};
                 void *kargs[1] = {&ra};
-                const hipError_t e = hipLaunchCooperativeKernel((const void *)k_rounds_all, dim3((unsigned)(blocks_per_cu * n_cu)), dim3(kThreads), kargs, 0, st);
+                const hipError_t e = hipLaunchCooperativeKernel((const void *)k_rounds_all<false>, dim3((unsigned)(blocks_per_cu * n_cu)), dim3(kThreads), kargs, 0, st);
                 if (e == hipSuccess) {
                     LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
                     LFR_HIP_TRY(stream_wait(st));
@@ -1262,6 +1315,37 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
             LFR_HIP_TRY(hipMemcpyAsync(h_ctr, rc_ + kRoundBatch, 4, hipMemcpyDeviceToHost, st));
             LFR_HIP_TRY(stream_wait(st));
             uint32_t bound = h_ctr[0];
+            if (xcd_tail && bound > 0) {
+                if (launched + 1 > kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;
+                hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);         // rc_[0] = pending, rc_[1..] = 0
+                const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;
+                hipLaunchKernelGGL(k_round_eval, grid_for_items(bound, kEvalItems), dim3(kThreads), 0, st, rc_, pa, par, bits, W, round_hi, minpos, pb, rc_ + 1);
+                hipLaunchKernelGGL(k_round_accept, grid_for(bound), dim3(kThreads), 0, st, rc_ + 1, pb, round_hi, minpos, par, cnt, bits, W, ctr + 3);
+                std::swap(pa, pb);
+                ++launched;
+                // the survivors (pa, rc_[1] entries) finish their rounds on one XCD
+                LFR_HIP_TRY(hipMemsetAsync(xbar, 0, 4 * 160, st));
+                LFR_HIP_TRY(hipMemsetAsync(ctr + 8, 0, 4 * 8, st));
+                LFR_HIP_TRY(hipMemcpyAsync(ctr + 8, rc_ + 1, 4, hipMemcpyDeviceToDevice, st));
+                RoundsArgs ra{M, first_block, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, kMaxRounds, bits, minpos, pa, pb, par, cnt, ctr + 8, xbar, 1, (int)launched};
+                // (every participant must be resident at once - they meet at barriers: never more workgroups per CU than half of what the
+                // occupancy query admits; a larger request hung the launch until its timeout)
+                static int occ = -1;
+                if (occ < 0) { int nb = 0; occ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_rounds_all<true>, kThreads, 0) == hipSuccess ? nb : 2; }
+                int per_cu = std::max(1, std::min(4, occ / 2));
+                if (const char *eb = getenv("LFR_ROUNDS_BLOCKS_PER_CU")) per_cu = std::max(1, std::min(per_cu, atoi(eb)));
+                hipLaunchKernelGGL(k_rounds_all<true>, dim3((unsigned)(per_cu * ctx->n_cu)), dim3(kThreads), 0, st, ra);
+                LFR_HIP_TRY(hipGetLastError());
+                LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
+                LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
+                LFR_HIP_TRY(stream_wait(st));
+                if (h_ctr[4]) return LFR_GRAPHSTAGE_USE_HOST;                          // a path-shaped dependency chain: sequential anyway
+                if (((int64_t)h_ctr[2] - launched) & 1) std::swap(pa, pb);              // (the kernel swapped its lists once per round)
+                rounds += 1 + ((int64_t)h_ctr[2] - launched);
+                launched = h_ctr[2];
+                if (trace > 2) fprintf(stderr, "lfr graph stage:   block [%lld, %lld): %lld rounds so far\n", (long long)k_lo, (long long)k_hi, (long long)rounds);
+                bound = 0;
+            }
             while (bound > 0) {
                 if (launched + kRoundBatch > kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;   // a path-shaped dependency chain: sequential anyway
                 hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
