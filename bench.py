@@ -458,7 +458,7 @@ def main():
             wg5 = rows5 > 32                                      # the workgroup classes (a dense LDL^T per LM iteration)
             fact_flops = float((rows5[wg5] ** 3 / 3.0 * info5["iterations"][wg5]).sum())
             eval_flops = float(st5["exec_passes_edges"]) * FLOP_PER_EDGE_EVAL
-            prof5 = pmc_numbers("r04_pmc_config5.json")
+            prof5 = pmc_numbers("r05_pmc_config5.json")
             stale5 = bool(prof5) and not fresh(prof5)
             if stale5:
                 prof5 = None
@@ -480,7 +480,7 @@ def main():
                              "traffic_ratio": (traffic5 / alg_bytes5) if traffic5 else None,
                              "algorithmic_bytes": alg_bytes5,
                              "algorithmic_bytes_what": "per executed sweep and edge: the 80 B record (nothing else leaves the CU)",
-                             "traffic_source": ("profiles/r04_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
+                             "traffic_source": ("profiles/r05_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
                                                 "not measured in this run)" if traffic5 else
                                                 "none: the committed counters were collected with other kernel sources (kernel_source_sha256 differs)" if stale5 else None),
                              "fp64": {"achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",

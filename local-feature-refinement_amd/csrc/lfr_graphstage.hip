@@ -544,7 +544,7 @@ __device__ __forceinline__ void rounds_barrier_xcd(uint32_t *bar, uint32_t &gen,
     if (threadIdx.x == 0) {
         ++gen;
         __hip_atomic_fetch_add(&bar[153], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while ((int)(__hip_atomic_load(&bar[153], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen * n_blk) < 0) __builtin_amdgcn_s_sleep(1);
+        for (int spins = 0; (int)(__hip_atomic_load(&bar[153], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - gen * n_blk) < 0 && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(1);   // (bounded: a miscount ends as garbage labels the tests catch, not as a hung GPU)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // (buffer_inv sc1: this CU's L1; the L2 is the XCD's own)
     }
     __syncthreads();
@@ -563,7 +563,7 @@ __global__ void __launch_bounds__(kPipeThreads) k_rounds_all(RoundsArgs a) {
             if (chosen == xcc) idx = __hip_atomic_fetch_add(&a.bar[151], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the participant count is out before the total says "everyone has registered")
             __hip_atomic_fetch_add(&a.bar[152], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (idx != 0xffffffffu) while (__hip_atomic_load(&a.bar[152], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x) __builtin_amdgcn_s_sleep(4);
+            if (idx != 0xffffffffu) for (int spins = 0; __hip_atomic_load(&a.bar[152], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gridDim.x && spins < (1 << 24); ++spins) __builtin_amdgcn_s_sleep(4);
             s_reg[0] = idx; s_reg[1] = __hip_atomic_load(&a.bar[151], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();

@@ -19,7 +19,7 @@ SHA = kernel_source_sha256()
 
 
 def short(name):
-    m = re.search(r"(solve_block_kernel<[^>]*>|solve_packed_kernel(<[^>]*>)?|solve_tree_kernel<[^>]*>|solve_group_kernel<[^>]*>)", name)
+    m = re.search(r"(solve_block_kernel<[^>]*>|solve_packed_kernel(<[^>]*>)?|solve_tree_team_kernel<[^>]*>|solve_tree_kernel<[^>]*>|solve_group_kernel<[^>]*>)", name)
     return m.group(1).replace(" ", "") if m else None
 
 
@@ -42,14 +42,14 @@ def collect(prefix):
 
 
 p4 = collect("pmc4")
-json.dump(p4, open(os.path.join(prof, TAG + "_pmc_solve_packed_kernel.json"), "w"), indent=1)
+json.dump(dict(p4, kernel_source_sha256=SHA), open(os.path.join(prof, TAG + "_pmc_solve_packed_kernel.json"), "w"), indent=1)
 p5 = collect("pmc5")
 blocks = {k: v for k, v in p5.items() if k.startswith("solve_block_kernel")}
 summary = {"kernel_source_sha256": SHA,
            "workload": "config5 stand-in (scripts/prof_c5.py): one solve = the three LDS classes of solve_block_kernel, concurrent (+ a tiny packed launch)",
-           "source": "scripts/profile_round4.sh: separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; "
+           "source": "scripts/profile_round%s.sh: separate rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE; SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU; "
                      "SQ_WAIT_ANY SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT; SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES) over python scripts/prof_c5.py; "
-                     "per-dispatch means per kernel, summed over the three kernels for the per-solve figures",
+                     "per-dispatch means per kernel, summed over the three kernels for the per-solve figures" % TAG[-1],
            "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); units KB; WRITE_SIZE uncorrected",
            "kernels": blocks}
 summary["hbm_bytes_per_solve"] = sum((2 * c["FETCH_SIZE"]["mean_per_dispatch"] + c["WRITE_SIZE"]["mean_per_dispatch"]) * 1024 for c in blocks.values() if "FETCH_SIZE" in c and "WRITE_SIZE" in c)
@@ -64,11 +64,11 @@ json.dump(summary, open(os.path.join(prof, TAG + "_pmc_config5.json"), "w"), ind
 print(json.dumps({k: v for k, v in summary.items() if k not in ("kernels", "source", "correction", "workload")}, indent=1))
 # cap-sized sparse workload: solve_tree_kernel (one launch per solve, beside three tiny LDS-class launches and a packed one)
 pS = collect("pmcS")
-trees = {k: v for k, v in pS.items() if k.startswith("solve_tree_kernel")}
+trees = {k: v for k, v in pS.items() if k.startswith("solve_tree_kernel") or k.startswith("solve_tree_team_kernel")}
 if trees:
     ssum = {"kernel_source_sha256": SHA,
-            "workload": "cap-sized sparse components (scripts/prof_sparse.py 12000 = bench.py's sparse_capsized_workload): solve_tree_kernel, one launch per solve",
-            "source": "scripts/profile_round4.sh: separate rocprofv3 --pmc passes over python scripts/prof_sparse.py 12000; per-dispatch means",
+            "workload": "cap-sized sparse components (scripts/prof_sparse.py 12000 = bench.py's sparse_capsized_workload): solve_tree_team_kernel (teams of up to 8 workgroups per component; round 4: solve_tree_kernel), one launch per solve",
+            "source": "scripts/profile_round%s.sh: separate rocprofv3 --pmc passes over python scripts/prof_sparse.py 12000; per-dispatch means" % TAG[-1],
             "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section); units KB; WRITE_SIZE uncorrected",
             "kernels": trees}
     ssum["hbm_bytes_per_solve"] = sum((2 * c["FETCH_SIZE"]["mean_per_dispatch"] + c["WRITE_SIZE"]["mean_per_dispatch"]) * 1024 for c in trees.values() if "FETCH_SIZE" in c and "WRITE_SIZE" in c)
@@ -111,8 +111,8 @@ if pk and "FETCH_SIZE" in pk:
                                            "note": "solve_packed_kernel<true>: 8-byte loads of isolated 72-byte flow rows (FETCH_SIZE not doubled: the correction is for 16 B/lane reads); "
                                                    "a row straddles cache lines, ~2x the bytes it needs - the price of not writing and re-reading 400 MB of records in a one-shot run"}
                                           if pk_gather and "FETCH_SIZE" in pk_gather else None),
-           "source": "round 4: scripts/profile_round4.sh (rocprofv3 --kernel-trace --stats of python bench.py --steps 20 --warmup 3 --no-cpu-baseline; separate --pmc passes of "
-                     "python bench.py --steps 5 --warmup 1 --span-reps 1 --no-cpu-baseline --no-long-tracks --no-sparse), summarised by scripts/pmc_summarize.py"}
+           "source": "round %s: scripts/profile_round%s.sh (rocprofv3 --kernel-trace --stats of python bench.py --steps 20 --warmup 3 --no-cpu-baseline; separate --pmc passes of "
+                     "python bench.py --steps 5 --warmup 1 --span-reps 1 --no-cpu-baseline --no-long-tracks --no-sparse), summarised by scripts/pmc_summarize.py" % (TAG[-1], TAG[-1])}
     json.dump(new, open(os.path.join(prof, "pmc_traffic.json"), "w"), indent=1)
     print("pmc_traffic.json:", {k: new[k] for k in ("hbm_bytes_per_launch", "valu_busy", "rocprof_avg_launch_us")})
 # kernel stats of the bench command: the 60 kernels with the largest total duration
@@ -126,6 +126,7 @@ try:
 except (OSError, KeyError) as e:
     print("kernel stats:", e)
 for f in (TAG + "_bench_kernel_stats.csv", TAG + "_dominant_kernel_launches.json", TAG + "_bench_line_under_rocprof.json", TAG + "_bench_line.json",
-          TAG + "_phase_profile_packed_kernel.txt", TAG + "_phase_profile_tree_kernel.txt"):
+          TAG + "_phase_profile_packed_kernel.txt", TAG + "_phase_profile_tree_kernel.txt", TAG + "_tree_timeline.txt", TAG + "_tree_trace.txt", TAG + "_config5_tail.txt",
+          TAG + "_gpu_tests.txt", TAG + "_pipeline_trace_config4.txt", TAG + "_pipeline_trace_config5.txt"):
     if os.path.exists(os.path.join(out, f)):
         shutil.copy(os.path.join(out, f), os.path.join(prof, f))
