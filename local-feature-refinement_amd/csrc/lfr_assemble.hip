@@ -191,6 +191,24 @@ __global__ void k_edge_keys_packed(int64_t n_dir, const uint32_t *node1, const u
     ids[e] = (uint32_t)e;
 }
 
+// Round 5: ... and per MATCH.  The two directions of a match (edge ids 2 m, 2 m + 1) are kept or dropped together and sort next to each other
+// (same component, consecutive ids), so the order of the edges is the order of the matches with every entry doubled: half the keys through
+// the radix passes, and a kernel that writes the pairs out.
+__global__ void k_match_keys_packed(int64_t M, const uint32_t *node1, const int32_t *comp, const int32_t *di_of_comp, const uint8_t *kept,
+                                    uint32_t dropped_key, uint32_t *keys, uint32_t *ids) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const int32_t di = kept[2 * m] ? di_of_comp[comp[node1[m]]] : -1;
+    keys[m] = di < 0 ? dropped_key : (uint32_t)di;
+    ids[m] = (uint32_t)m;
+}
+__global__ void k_expand_match_order(int64_t M, const uint32_t *match_sorted, uint32_t *edge_sorted) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    const uint32_t m = match_sorted[p];
+    reinterpret_cast<uint2 *>(edge_sorted)[p] = make_uint2(2u * m, 2u * m + 1u);
+}
+
 // packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
 // kernel's pair exchange relies on it)
 __global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
@@ -578,7 +596,13 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
                            (uint64_t)C << node_bits, ek0, ei0);
         if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
-    } else {                                          // (32-bit keys in the front halves of the 64-bit key buffers)
+    } else if (!getenv("LFR_EDGE_SORT_BY_EDGE")) {    // (32-bit keys in the front halves of the 64-bit key buffers; one key per MATCH: k_match_keys_packed)
+        uint32_t *k32a = reinterpret_cast<uint32_t *>(ek0), *k32b = reinterpret_cast<uint32_t *>(ek1);
+        uint32_t *mi0 = ei0, *mi1 = ei0 + M;
+        hipLaunchKernelGGL(k_match_keys_packed, grid_for(M), dim3(kThreads), 0, st, M, node1, comp, di, kept, (uint32_t)C, k32a, mi0);
+        if ((rc = sort_pairs(arena, k32a, k32b, mi0, mi1, M, 0, comp_bits, st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_expand_match_order, grid_for(M), dim3(kThreads), 0, st, M, mi1, ei1);
+    } else {                                          // (the same per directed edge: rounds 3-4, kept for A/B)
         uint32_t *k32a = reinterpret_cast<uint32_t *>(ek0), *k32b = reinterpret_cast<uint32_t *>(ek1);
         hipLaunchKernelGGL(k_edge_keys_packed, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, kept, (uint32_t)C, k32a, ei0);
         if ((rc = sort_pairs(arena, k32a, k32b, ei0, ei1, E2, 0, comp_bits, st)) != LFR_OK) return rc;
