@@ -202,11 +202,19 @@ __global__ void k_match_keys_packed(int64_t M, const uint32_t *node1, const int3
     keys[m] = di < 0 ? dropped_key : (uint32_t)di;
     ids[m] = (uint32_t)m;
 }
-__global__ void k_expand_match_order(int64_t M, const uint32_t *match_sorted, uint32_t *edge_sorted) {
+// ... and the record words of both directions with it (words != nullptr: the fused gather's k_edge_words, one walk through the match arrays
+// per match instead of one per directed edge)
+__global__ void k_expand_match_order(int64_t M, const uint32_t *total_edges_p, const uint32_t *match_sorted, const uint32_t *node1, const uint32_t *node2,
+                                     const int32_t *track, const uint32_t *local_of, uint32_t *edge_sorted, uint32_t *words) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= M) return;
     const uint32_t m = match_sorted[p];
     reinterpret_cast<uint2 *>(edge_sorted)[p] = make_uint2(2u * m, 2u * m + 1u);
+    if (words && 2 * p < (int64_t)*total_edges_p) {
+        const uint32_t a = node1[m], b = node2[m];
+        const uint32_t kind = track[a] != track[b] ? 1u : 0u, la = local_of[a], lb = local_of[b];
+        reinterpret_cast<uint2 *>(words)[p] = make_uint2(la | ((lb | (kind << 15)) << 16), lb | ((la | (kind << 15)) << 16));
+    }
 }
 
 // packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
@@ -592,6 +600,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // 5 M keys of config 4 instead of five.  A small component with > 320 edges still lands in a workgroup class: the summary below has
     // the last word and the full sort is redone then.
     const bool expect_workgroup_classes = p.stats.max_component_size > 17;
+    bool words_done = false;                          // the record words came with the match-level order
     if (expect_workgroup_classes) {
         hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
                            (uint64_t)C << node_bits, ek0, ei0);
@@ -601,7 +610,9 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
         uint32_t *mi0 = ei0, *mi1 = ei0 + M;
         hipLaunchKernelGGL(k_match_keys_packed, grid_for(M), dim3(kThreads), 0, st, M, node1, comp, di, kept, (uint32_t)C, k32a, mi0);
         if ((rc = sort_pairs(arena, k32a, k32b, mi0, mi1, M, 0, comp_bits, st)) != LFR_OK) return rc;
-        hipLaunchKernelGGL(k_expand_match_order, grid_for(M), dim3(kThreads), 0, st, M, mi1, ei1);
+        hipLaunchKernelGGL(k_expand_match_order, grid_for(M), dim3(kThreads), 0, st, M, total_edges_p, mi1, node1, node2, track, local,
+                           ei1, fused ? out.d_edge_word : nullptr);
+        words_done = fused;
     } else {                                          // (the same per directed edge: rounds 3-4, kept for A/B)
         uint32_t *k32a = reinterpret_cast<uint32_t *>(ek0), *k32b = reinterpret_cast<uint32_t *>(ek1);
         hipLaunchKernelGGL(k_edge_keys_packed, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, kept, (uint32_t)C, k32a, ei0);
@@ -611,7 +622,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // id, so the pair check only runs on request or on the path that materialises records)
     if (!fused || getenv("LFR_CHECK_PAIRS"))
         hipLaunchKernelGGL(k_check_pairs, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, comp, di, class_sorted, eo, &sum->unpaired);
-    if (fused) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
+    if (fused && !words_done) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
 
     // ---- descriptors + the device copies behind the lazily fetched host mirrors ----
     hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks);
