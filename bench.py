@@ -129,7 +129,7 @@ def main():
                                                   "several ranks may share one GPU (tests)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-long-tracks", action="store_true", help="skip the second, workgroup-kernel dominated workload (config 5 stand-in)")
-    ap.add_argument("--no-sparse", action="store_true", help="skip the third workload (cap-sized sparse components, block-envelope kernel)")
+    ap.add_argument("--no-sparse", action="store_true", help="skip the third workload (cap-sized sparse components, elimination-tree kernel)")
     ap.add_argument("--sparse-tracks", type=int, default=12000)
     ap.add_argument("--cpu-threads", type=int, default=0)
     args = ap.parse_args()

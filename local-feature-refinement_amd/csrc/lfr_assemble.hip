@@ -321,6 +321,9 @@ __global__ void k_incidence(int64_t cap, const uint32_t *total_edges_p, const ui
     if (last) inc[no + ls].out_count = local_edge + 1u;
 }
 
+// (every component, packed classes included - as the host builder does, lfr_graph.cpp: in_begin / in_count of its counting sort.  The OUT
+// words of packed components stay zero here while the host counts them: NodeInc is read by the workgroup kernels only (solve_component,
+// solve_tree_component); the packed kernel walks its record words - ADVICE r4)
 __global__ void k_in_begin(int64_t cap, const uint32_t *total_edges_p, const uint64_t *in_keys_sorted, const uint32_t *edge_off, const uint32_t *node_off,
                            NodeInc *inc) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -1100,8 +1100,13 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     p.host_batch = false;
     { std::lock_guard<std::mutex> lk(p.label_mu); p.devs.clear(); }
     if (N == 0) { p.track.clear(); p.comp.clear(); p.is_root.clear(); p.host_labels_valid = true; return LFR_OK; }
-    if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) return LFR_GRAPHSTAGE_USE_HOST;
-    if (!g.sims_sum_exactly) return LFR_GRAPHSTAGE_USE_HOST;      // atomics would round in an order-dependent way: the reference's sequential sums run on the host
+    // (every hand-back to the host graph stage says why under LFR_VERBOSE / LFR_TIMING: results are the same, the time is not - ADVICE r4)
+    auto use_host = [&](const char *why) {
+        if (vb || getenv("LFR_TIMING")) fprintf(stderr, "lfr graph stage: handed back to the host (%s)\n", why);
+        return LFR_GRAPHSTAGE_USE_HOST;
+    };
+    if (N >= ((int64_t)1 << 31) || M >= ((int64_t)1 << 30)) return use_host("2^31 nodes / 2^30 matches or more");
+    if (!g.sims_sum_exactly) return use_host("similarity sums would round");      // atomics would round in an order-dependent way: the reference's sequential sums run on the host
     if (max_nodes <= 0) max_nodes = (int64_t)g.image_names.size();
     std::shared_ptr<DevGraph> dg;
     int rc = ensure_dev_graph(g, device, stage_flows, dg);       // endpoints on s_main now; the flows start travelling on s_copy
@@ -1233,7 +1238,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     if ((int64_t)h_counts[CNT_MAX_SEG] > serial_limit) {
         const int W = (int)((g.image_names.size() + 63) / 64);
         const size_t bits_bytes = (size_t)N * W * 8;
-        if (bits_bytes > kMaxBitsetBytes) return LFR_GRAPHSTAGE_USE_HOST;
+        if (bits_bytes > kMaxBitsetBytes) return use_host("image bitsets above the cap");
         if (!rounds_arena.init(ctx, bits_bytes + 2 * (size_t)M * sizeof(Pending) + 8 * (size_t)N + 65536)) return LFR_ERR_NOMEM;
         unsigned long long *bits = rounds_arena.take_n<unsigned long long>((size_t)N * W);
         unsigned long long *minpos = rounds_arena.take_n<unsigned long long>(N);
@@ -1289,7 +1294,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 if (e == hipSuccess) {
                     LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
                     LFR_HIP_TRY(stream_wait(st));
-                    if (h_ctr[4]) return LFR_GRAPHSTAGE_USE_HOST;                      // a path-shaped dependency chain: sequential anyway
+                    if (h_ctr[4]) return use_host("a path-shaped dependency chain");                      // a path-shaped dependency chain: sequential anyway
                     rounds = h_ctr[2];
                     if (trace > 2) fprintf(stderr, "lfr graph stage:   %u rounds in one cooperative launch, %u matches accepted\n", h_ctr[2], h_ctr[3]);
                     done = true;
@@ -1316,7 +1321,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
             LFR_HIP_TRY(stream_wait(st));
             uint32_t bound = h_ctr[0];
             if (xcd_tail && bound > 0) {
-                if (launched + 1 > kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;
+                if (launched + 1 > kMaxRounds) return use_host("round limit");
                 hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);         // rc_[0] = pending, rc_[1..] = 0
                 const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;
                 hipLaunchKernelGGL(k_round_eval, grid_for_items(bound, kEvalItems), dim3(kThreads), 0, st, rc_, pa, par, bits, W, round_hi, minpos, pb, rc_ + 1);
@@ -1339,7 +1344,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
                 LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
                 LFR_HIP_TRY(stream_wait(st));
-                if (h_ctr[4]) return LFR_GRAPHSTAGE_USE_HOST;                          // a path-shaped dependency chain: sequential anyway
+                if (h_ctr[4]) return use_host("a path-shaped dependency chain");                          // a path-shaped dependency chain: sequential anyway
                 if (((int64_t)h_ctr[2] - launched) & 1) std::swap(pa, pb);              // (the kernel swapped its lists once per round)
                 rounds += 1 + ((int64_t)h_ctr[2] - launched);
                 launched = h_ctr[2];
@@ -1347,7 +1352,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 bound = 0;
             }
             while (bound > 0) {
-                if (launched + kRoundBatch > kMaxRounds) return LFR_GRAPHSTAGE_USE_HOST;   // a path-shaped dependency chain: sequential anyway
+                if (launched + kRoundBatch > kMaxRounds) return use_host("round limit");   // a path-shaped dependency chain: sequential anyway
                 hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
                 for (int j = 0; j < kRoundBatch; ++j, ++launched) {
                     const unsigned long long round_hi = (unsigned long long)(kMaxRounds - launched) << 32;

@@ -1641,13 +1641,17 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
 //              STORES the pair's 2x2 cross block; the node's diagonal block and gradient are summed over its items in list order by
 //              one lane.  No atomics, no scratch per edge: bitwise reproducible whatever the input (a record is evaluated by the
 //              owner of either end: two evaluations per record, nothing else to exchange).
-//   factor     per level: (1) every tile of the level's columns takes its left-looking update sum_k U(I,k) D_k^-1 U(J,k)^T on the
-//              fp64 matrix cores, one wave per tile, the list of (tile (I,k), tile (J,k), k) precomputed; the right-hand side w_J
-//              rides along in the diagonal tile's task; (2) one wave per column factors the diagonal tile with lane = row in lanes
-//              0-15 (v_readlane broadcasts) while lane 16 carries w_J and lanes 17-63 the rows of the first three tiles below it
-//              through the same steps - a_ic -= (a_ik / d_k) a_ck IS their substitution; (3) columns with more rows than that
-//              substitute the rest four tiles per wave.  A barrier after each phase that had work.
-//   substitute levels top down, one wave per column: z_J = w_J - sum_I U(I,J)^T y_I, then the 16 steps inside the diagonal tile.
+//   factor     THIN plans (every column's rows fit one wave's carried tiles - every cap-sized component measured): one wave per COLUMN
+//              TASK, no workgroup barrier between levels.  A task streams through the column's left-looking update entries
+//              sum_k U(I,k) D_k^-1 U(J,k)^T on the fp64 matrix cores (the right-hand side w_J rides in the diagonal tile) - entry by
+//              entry as the state word of entry column k turns 1 -, then factors the diagonal tile with lane = row in lanes 0-15
+//              (v_readlane broadcasts) while lane 16 carries w_J and lanes 17-63 the rows of the tiles below it through the same steps
+//              (a_ic -= (a_ik / d_k) a_ck IS their substitution), stores, and publishes its own state word.  Waves take the columns of
+//              a level round-robin, rotated by level; with TEAMS the waves of up to 8 workgroups of one XCD share the walk (state words
+//              in the workspace, sc1 loads).  Plans that are not thin keep the level-by-level phases (updates / diagonal tiles / extra
+//              rows) with a barrier after each phase that had work.
+//   substitute levels top down, one wave per column (thin plans: gated by the parent's state word turning 2 instead of a barrier per
+//              level): z_J = w_J - sum_I U(I,J)^T y_I, then the 16 steps inside the diagonal tile.
 // Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k on the diagonal, 1 / d_k in vinv.
 #ifndef LFR_THREADS_G
 #define LFR_THREADS_G 512
@@ -3163,7 +3167,7 @@ struct lfr_batch {
     uint32_t team_work[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     int team_wgs = 0;
     std::vector<int64_t> tree_comp_stats;                // 5 per component
-    int64_t sky_tiles = 0, sky_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
+    int64_t tree_tiles = 0, tree_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
     // fused gather: the packed kernel reads the graph's own flow arrays (kept alive through dev_hold)
     bool fused = false;                                  // the NEXT solve gathers (true until the records have been materialised)
@@ -3378,8 +3382,8 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     return LFR_OK;
 }
 
-// The workgroup kernels' workspace: per-edge scratch, then - for the components of the HBM class - the block-envelope plans
-// (lfr_order.cpp) with their tiles and vectors.  The plans need the components' (source, destination, kind) lists on the host: the
+// The workgroup kernels' workspace: per-edge scratch, then - for the components of the HBM class - the elimination-tree plans
+// (lfr_treeplan.cpp) with their tiles, vectors and team areas.  The plans need the components' (source, destination, kind) lists on the host: the
 // last word of every edge record, fetched with one strided copy when the batch was assembled on the device.
 int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     const int g0 = b->class_begin[lfr::KC_GLOBAL], g1 = b->class_begin[lfr::KC_COUNT];
@@ -3424,15 +3428,15 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     }
     std::vector<uint64_t> off(ng);
     uint64_t ws = (b->es_doubles + 31) / 32 * 32, hdr_total = 0;
-    b->sky_tiles = b->sky_dense_tiles = 0;
+    b->tree_tiles = b->tree_dense_tiles = 0;
     b->tree_levels_max = 0; b->tree_blocks = 0; b->tree_updates = 0;
     for (int i = 0; i < ng; ++i) {
         if (plans[i].blob.empty()) { lfr::set_error("a component is too large for the elimination-tree plan's 32-bit offsets"); return LFR_ERR_UNSUPPORTED; }
         off[i] = ws;
         ws += (plans[i].doubles() + 31) / 32 * 32;
         hdr_total += plans[i].header_doubles();
-        b->sky_tiles += plans[i].n_tiles;
-        b->sky_dense_tiles += (int64_t)plans[i].NB * (plans[i].NB + 1) / 2;
+        b->tree_tiles += plans[i].n_tiles;
+        b->tree_dense_tiles += (int64_t)plans[i].NB * (plans[i].NB + 1) / 2;
         b->tree_levels_max = std::max(b->tree_levels_max, plans[i].n_levels);
         b->tree_blocks += plans[i].NB; b->tree_updates += (int64_t)plans[i].n_updates;
         const int64_t cs[5] = {plans[i].NB, plans[i].n_tiles, (int64_t)plans[i].n_updates, plans[i].n_levels, plans[i].n_items};
@@ -3496,7 +3500,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     if (e1 != hipSuccess || e2 != hipSuccess) { lfr::set_error("upload of the elimination-tree plans failed"); return LFR_ERR_HIP; }
     if (getenv("LFR_VERBOSE"))
         fprintf(stderr, "lfr: %d component(s) above %d rows: elimination-tree plans keep %lld of %lld tiles (%.1f %%) in %lld columns, at most %d levels, workspace %.1f MB\n", ng,
-                lfr::block_max_rows(), (long long)b->sky_tiles, (long long)b->sky_dense_tiles, 100.0 * b->sky_tiles / std::max<int64_t>(1, b->sky_dense_tiles),
+                lfr::block_max_rows(), (long long)b->tree_tiles, (long long)b->tree_dense_tiles, 100.0 * b->tree_tiles / std::max<int64_t>(1, b->tree_dense_tiles),
                 (long long)b->tree_blocks, b->tree_levels_max, ws * 8e-6);
     return LFR_OK;
 }

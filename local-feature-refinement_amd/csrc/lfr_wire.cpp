@@ -122,8 +122,12 @@ void Graph::finish() {
             uint64_t dmax = 0;
             for (uint32_t d : deg) dmax = std::max<uint64_t>(dmax, d);
             const uint32_t spread = emax < emin ? 0u : emax - emin;
-            const uint64_t terms = dmax * std::max<uint64_t>(1, image_names.size());
+            const uint64_t terms = std::min<uint64_t>(M, dmax * std::max<uint64_t>(1, image_names.size()));   // (no sum has more terms than there are matches)
             sims_sum_exactly = terms <= ((uint64_t)1 << (29u - spread));
+            if (!sims_sum_exactly && (getenv("LFR_VERBOSE") || getenv("LFR_TIMING")))
+                fprintf(stderr, "lfr: similarity sums may round (up to %llu terms over %u binades): the graph stage will run on the host\n", (unsigned long long)terms, spread);
+        } else if (!sims_sum_exactly && (getenv("LFR_VERBOSE") || getenv("LFR_TIMING"))) {
+            fprintf(stderr, "lfr: similarities %s: the graph stage will run on the host\n", odd ? "hold inf / nan" : "span more than 10 binades");
         }
     }
 }
