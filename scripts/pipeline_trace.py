@@ -16,6 +16,7 @@ p = b = pos = None
 for r in range(reps):
     del p, b, pos                      # (the previous repetition's batch: its destructor waits for s_main - not inside the timed part)
     L.lfr_hip_synchronize(0)
+    time.sleep(0.01)                   # (an idle gap in the trace: pipeline_trace.sh takes the launches behind the last one as the last repetition)
     t0 = time.perf_counter()
     p = capi.Problem(g, device_graph_stage=0)
     t1 = time.perf_counter()

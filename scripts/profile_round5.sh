@@ -5,7 +5,7 @@
 #      (scripts/prof_c5.py: solve_block_kernel), the cap-sized sparse workload (scripts/prof_sparse.py: solve_tree_team_kernel)
 #   3. phase profile (s_memtime) of the tree kernel, its per-component timeline and the event trace of its critical component, from the
 #      diagnostic builds under lfr_amd/_variants/ (tprof.so, wgtime.so, trace.so); the tail of config 5's launch (wgtime.so)
-#   4. the bench line of an un-profiled run, the GPU tests
+#   4. launch-ordered traces of both one-shot pipelines
 # Every step under its own timeout: a faulting run must not eat the lease.
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/prof_r05; mkdir -p $OUT
 V=$R/local-feature-refinement_amd/lfr_amd/_variants
@@ -30,6 +30,6 @@ cd $R
 bash scripts/pipeline_trace.sh c4 > $OUT/r05_pipeline_trace_config4.txt 2>&1
 bash scripts/pipeline_trace.sh c5 > $OUT/r05_pipeline_trace_config5.txt 2>&1
 grep -o '{"metric.*' $OUT/bench_under_rocprof.log | tail -1 > $OUT/r05_bench_line_under_rocprof.json
-timeout -k 5 900 python bench.py --steps 20 --warmup 3 > $OUT/r05_bench_line.json 2> $OUT/r05_bench.err || echo "bench failed"
-timeout -k 5 1500 python -m pytest tests -m gpu -q 2>&1 | tail -5 > $OUT/r05_gpu_tests.txt
+# (the un-profiled bench line, the GPU tests and smoke(): scripts/final_round5.sh, AFTER `python scripts/pmc_summarize.py r05` here has written
+# profiles/pmc_traffic.json for this tree - bench.py reports roofline.traffic only from a summary whose kernel-source hash matches)
 ls $OUT | head -80
