@@ -689,7 +689,9 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Blocked LDL^T of the damped normal matrix in LDS (packed lower triangle, the right-hand side riding as row n), in place.
-// Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k), d_k stays on the diagonal, 1/d_k goes to vinv[k].
+// Column k keeps the UNSCALED entries a_ik (L_ik = a_ik / d_k) of the rows BELOW its diagonal tile, 1/d_k goes to vinv[k]; the strictly lower part
+// of a diagonal tile holds, transposed, M = (I + D^-1 U^T)^-1 - the tile's substitution as a matrix (round 5, factor_diag) - and its diagonal
+// is left as assembled (nobody reads either again).
 //
 // Right-looking over panels of 16 columns (round 2: 8 columns, three barriers, the diagonal block on one thread).  The serial pieces
 // of a panel - the diagonal tile's elimination and the substitution of the rows below it, 16 dependent steps of ~300 cycles each (the
@@ -698,13 +700,14 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 //     the diagonal tile (k+1, k+1) (fp64 MFMA, K = 16; rows k+1 of panel k are its own), then factor it with lane = row in lanes 0-15
 //     while lanes 16-31 carry the rows of the tile below, (k+2, k+1), through the same steps - a_ic -= (a_ik / d_k) a_ck with a_ck read
 //     from lane c: the diagonal tile's elimination IS their substitution - so the rows the NEXT step's update needs come out final with
-//     the diagonal tile, not ~3000 cycles after it.  Then it stores both tiles and 1/d and publishes `ready`.
+//     the diagonal tile, not ~3000 cycles after it - and lanes 32-47 the rows of the identity, which come out as M.  Then it stores the tile below, M
+//     and 1/d and publishes `ready`.
 //   * WAVE 1 feeds wave 0: in every phase it first applies the panel to the two tiles wave 0 takes next (`lead_t`), and as soon as the
 //     diagonal tile is out it substitutes tile (k+3, k+1), applies panel k+1 to tile (k+3, k+2) - the tile wave 0 carries next - and
 //     says so (`lead`).  With three or more workers it takes no other trailing tile.
 //   * the OTHER waves apply panel k to the tiles right of column block k+1 (two 16x16 tiles in flight per wave, 4 + 4
-//     v_mfma_f64_16x16x4_f64), then to their tiles of column block k+1, wait for `ready`, substitute their rows (lane = row), and meet
-//     at a barrier of their own (an LDS counter; wave 0 is not part of it).
+//     v_mfma_f64_16x16x4_f64), then to their tiles of column block k+1, wait for `ready`, substitute their tiles (tile <- tile M: four MFMAs;
+//     until round 5 fifteen dependent steps with lane = row), and meet at a barrier of their own (an LDS counter; wave 0 is not part of it).
 // Cycles per panel of the 190-row class: 14.3 k with one workgroup barrier per panel and the rows' substitution after the diagonal
 // tile (round 3, first half), 12.6 k now (wave 0: update 1.8 k, waiting for wave 1 3.7 k, elimination + loads/stores 7.0 k) - wave 1's
 // substitution of ONE tile plus its update is what wave 0 still waits for; the other workers are as loaded as wave 0 (11-12 k per phase).
@@ -712,8 +715,11 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 // was built too: wave 0 waits 2.4 k instead of 3.7 k per panel, and its elimination takes 8.6 k instead of 7.0 k; no gain, removed.)
 // (The pivot column through LDS instead of v_readlane - 3.8 k against 4.8 k cycles per tile in the isolated probe - DOUBLES the elimination here:
 // 14 k cycles per panel with seven other waves loading and storing tiles through the same LDS.)
+// Round 5 (M): wave 0 waits for wave 1 17.9 k instead of 42.9 k cycles per 190-row factorization and its update of the diagonal tile takes 17 k instead
+// of 25 k (-DLFR_PROFILE_FACTOR), but carrying and storing M costs its elimination + stores 45 k: the launch gains 2 % (4.35 against 4.44 ms per
+// config-5 solve), the back substitution 7 %.  The stores must stay free of per-store lane-varying branches (see factor_diag).
 // scripts/emul_factor_v2.py is a lane-level CPU model of the FIRST round-3 schedule (one barrier per panel; random wave order + a race
-// detector); the hand-off flags of the current one are argued in the comments at their uses.
+// detector); scripts/factor_lds_sync_model.py models the hand-off words of this one at tile level (tests/test_factor_lds_sync_model.py).
 // A non-positive pivot only raises sh.flag: the phases run to the end on whatever values there are (no data-dependent
 // exit, so no wave can miss a barrier), the caller rejects the step.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -728,10 +734,8 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
 #define FPROF_RESET()
 #define FPROF_FLUSH()
 #endif
-#ifndef LFR_FINE_READY
-#define LFR_FINE_READY 0      // g > 0: the rows' substitution follows the diagonal block in groups of g columns.  Measured: every poll inside the
-                              // unrolled substitution costs registers (g = 1: 414 spilled VGPRs, g = 4: 396, g = 8: 297, one wait up front: 67)
-#endif
+// (A substitution that followed the diagonal tile column by column - a poll per group of g columns inside the unrolled steps - cost registers:
+// g = 1: 414 spilled VGPRs, g = 4: 396, g = 8: 297, one wait up front: 67.  With M there are no steps to follow.)
 template <int kBlockThreads>
 __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int n, BlockShared &sh, unsigned long long *fprof, unsigned int *spin_timeouts) {
     constexpr int kWaves = kBlockThreads / 64;
@@ -743,23 +747,32 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
     const int P = (n + 15) >> 4;                // panels
     const int RT = (n1 + 15) >> 4;              // 16-row tiles
     FPROF_DECL
-    volatile int *ready = &sh.ready;            // 16 * panel + (columns of that panel's diagonal block published)
+    volatile int *ready = &sh.ready;            // 16 * panel + 16: that panel's diagonal tile (the tile below it, M, 1 / d) is published
     const __attribute__((address_space(3))) int *ready_lds = (const __attribute__((address_space(3))) int *)&sh.ready;
 
     // diagonal tile at kb (up to date in LDS): lane = row in lanes 0-15.  Lanes 16-31 hold the rows of the tile BELOW it, (panel+1, panel),
     // up to date as well: the elimination steps that factor the diagonal tile are exactly the rows' substitution for them
     // (a_ic -= (a_ik / d_k) a_ck with a_ck read from lane c), so the tile the NEXT diagonal tile's update needs comes out final together
-    // with the diagonal tile instead of ~3000 cycles after it.  Everything is stored, then `ready` says so.
+    // with the diagonal tile instead of ~3000 cycles after it.  Lanes 32-47 carry the rows of the IDENTITY through the same steps: what
+    // comes out is the substitution as a matrix, M = (I + D^-1 U^T)^-1 (unit upper triangular; U = the tile's strictly lower part, unscaled):
+    // the substitution of any row vector r is r M, and the tile's part of the back substitution is y = M (D^-1 z).  M[i][c], c > i, is
+    // stored where U[c][i] was (nothing reads U again): the other waves substitute their tiles with four MFMAs each instead of fifteen
+    // dependent steps (finish_rows), the back substitution loses its dependent chain inside a tile.  Everything is stored, then `ready` says so.
     auto factor_diag = [&](const int kb, const int panel) {
         const int nbp = min(16, n - kb);                            // pivots; a row beyond them is the right-hand side or padding
-        const int row = kb + 16 * kq + r16;                         // group 0: the diagonal tile, group 1: the tile below
+        const int row = kb + 16 * kq + r16;                         // group 0: the diagonal tile, group 1: the tile below, group 2: identity
         const bool rv = row < n1 && kq <= 1;
         const uint32_t base = tri(rv ? row : kb, kb);
         double a[16];
+        const bool ident = kq == 2;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            const double v = Mat[base + (kq == 0 ? (rv ? min(j, r16) : 0) : j)];
+            // (one address register + immediate offsets: a row of group 0 reads past its diagonal - the next rows' entries, at the very end
+            // of the matrix up to 15 doubles past it, still inside the LDS - and drops what it read; clamping the column per lane cost
+            // sixteen address registers, spilled)
+            const double v = Mat[base + j];
             a[j] = kq == 0 ? ((rv && j <= r16) ? v : (j == r16 ? 1.0 : 0.0)) : (rv ? v : 0.0);
+            a[j] = (ident && j == r16) ? 1.0 : a[j];
         }
         bool bad = false;
         double my_inv = 0.0;                                        // lane k keeps 1 / d_k: one store after the loop instead of a masked one per step
@@ -776,60 +789,94 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             }
         }
         if (lane < nbp) vinv[kb + lane] = my_inv;
-        if (rv) {
+        FPROF_MARK(0);                                              // 0 (wave 0): loads + elimination; the stores report in slot 1
+        // Stores, branch-free (as lane-varying `if`s they became one basic block each, every one reloading its spilled address from scratch
+        // memory, on the factorization's critical path: 6.3 against 4.45 ms per config-5 solve): a lane without an entry writes to scratch
+        // words - sh.red, which every reduction rewrites behind a barrier before reading it.
+        // group 1, the tile below: columns 1-15 (column 0 is unchanged).  Group 0 stores nothing: the pivots are in vinv, the tile's strictly
+        // lower part gives way to M, and nobody reads the diagonal again ...
+        if (kq == 1 && rv) {                                        // (ONE lane-varying branch around fifteen plain stores)
 #pragma unroll
-            for (int c = 0; c < 16; ++c) if (kq == 0 ? c <= r16 : c >= 1) Mat[base + c] = a[c];
+            for (int c = 1; c < 16; ++c) Mat[base + c] = a[c];
+        }
+        // ... except the right-hand-side row when it lies in this tile (the last panel): its entries are the solve's w = L^-1 g
+        if (kb + 16 > n) {                                          // wave-uniform
+            if (kq == 0 && row == n) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) if (c < nbp) Mat[base + c] = a[c];
+            }
+        }
+        // group 2: row i = r16 of M, entries c = i + 1 .. nbp - 1, to (row kb + c, column kb + i)
+        if (ident) {                                                // (sixteen lanes, sixteen scratch words: no two lanes on one address)
+            double *const dummy = &sh.red[r16];
+            const unsigned span = (unsigned)max(nbp - r16 - 1, 0);  // entries of this lane's row (one lane-varying test per store: `c < nbp` on
+            uint32_t at = tri(kb, kb) + (uint32_t)r16;              //  its own became a scalar branch per store)
+#pragma unroll
+            for (int c = 1; c < 16; ++c) {
+                at += (uint32_t)(kb + c);                           // tri(kb + c, kb) + r16
+                double *const dst = (unsigned)(c - r16 - 1) < span ? Mat + at : dummy;
+                *dst = a[c];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // (compiler only: the counter goes out after the data; the LDS keeps a wave's order)
         if (lane == 0) *ready = 16 * panel + 16;
         if (bad && lane == 0) sh.flag = 1;
     };
-    // rows of the tiles R0 (lanes 0-15) and R1 (lanes 16-31; -1: none) against the diagonal tile at kb (a full panel) while wave 0
-    // is still factoring it: a_ic -= sum_{k<c} (a_ik / d_k) a_ck, right-looking over k (the 15 - k updates of a step are independent);
-    // step k starts when column k of the diagonal tile is out
+    // the tiles (R0, panel) and (R1, panel) (R1 = -1: none), rows 16 R .. 16 R + 15, substituted against the diagonal tile at kb (a full
+    // panel): tile <- tile M on the matrix cores, M read from the diagonal tile's strictly lower part once wave 0 has published it
+    // (lane l feeds A[l&15][4kk + (l>>4)] = tile[r16][4kk + kq] and B[4kk + (l>>4)][l&15] = M[4kk + kq][r16], holds D[(l>>4) + 4r][l&15]).
+    // Two accumulator chains per tile: the first pair of wave 1 is on the factorization's critical path.
     auto finish_rows = [&](const int kb, const int panel, const int R0, const int R1) {
-        const int R = kq == 0 ? R0 : (kq == 1 ? R1 : -1);
-        const int row = 16 * R + r16;
-        const bool act = R >= 0 && row < n1;
-        const uint32_t base = tri(act ? row : kb + 15, kb);
-        double r[16];
+        const bool two = R1 >= 0;
+        const int ia0 = min(16 * R0 + r16, n1 - 1), ia1 = min(16 * (two ? R1 : R0) + r16, n1 - 1);      // (clamped: a row beyond the matrix is not stored)
+        const uint32_t oa0 = tri(ia0, kb + kq), oa1 = tri(ia1, kb + kq);
+        double a0[4], a1[4], bm[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) r[c] = Mat[base + c];
-        // (broadcast reads: the same address in every lane; one pointer per row of the diagonal tile, the column is an immediate offset)
-        const double *brow[16];
-#pragma unroll
-        for (int c = 1; c < 16; ++c) brow[c] = Mat + tri(kb + c, kb);
-        const double *vi = vinv + kb;
-        int have = -1;
-#pragma unroll
-        for (int k = 0; k < 15; ++k) {
-            // LFR_FINE_READY = g > 0: the substitution follows the diagonal block in groups of g columns (a poll every g steps)
-            constexpr int kGroup = LFR_FINE_READY > 0 ? LFR_FINE_READY : 16;
-            const int need = 16 * panel + min(16, (k / kGroup + 1) * kGroup);
-            if (k % kGroup == 0) {
-                // spin until wave 0 has published column k.  One opaque instruction sequence: as C++ loops inside the unrolled steps
-                // the 15 polls cost the kernel ~270 spilled registers.
-                int tmp;
-                asm volatile("LFR_POLL_%=:\n\t"
-                             "ds_read_b32 %0, %2\n\t"
-                             "s_waitcnt lgkmcnt(0)\n\t"
-                             "v_readfirstlane_b32 %1, %0\n\t"
-                             "s_cmp_ge_i32 %1, %3\n\t"
-                             "s_cbranch_scc1 LFR_POLLED_%=\n\t"
-                             "s_sleep 1\n\t"
-                             "s_branch LFR_POLL_%=\n"
-                             "LFR_POLLED_%=:"
-                             : "=&v"(tmp), "=&s"(have)
-                             : "v"((uint32_t)(uintptr_t)ready_lds), "s"(need)
-                             : "memory", "scc");
-            }
-            const double tk = r[k] * vi[k];
-#pragma unroll
-            for (int c = k + 1; c < 16; ++c) r[c] = fma(-tk, brow[c][k], r[c]);
+        for (int kk = 0; kk < 4; ++kk) { a0[kk] = Mat[oa0 + 4 * kk]; a1[kk] = Mat[oa1 + 4 * kk]; }
+        {   // spin until wave 0 has published the diagonal tile (one opaque instruction sequence: a C++ loop here made the compiler keep
+            // the operands of both tiles across a call-like region)
+            int tmp, have;
+            const int need = 16 * panel + 16;
+            asm volatile("LFR_POLL_%=:\n\t"
+                         "ds_read_b32 %0, %2\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "v_readfirstlane_b32 %1, %0\n\t"
+                         "s_cmp_ge_i32 %1, %3\n\t"
+                         "s_cbranch_scc1 LFR_POLLED_%=\n\t"
+                         "s_sleep 1\n\t"
+                         "s_branch LFR_POLL_%=\n"
+                         "LFR_POLLED_%=:"
+                         : "=&v"(tmp), "=&s"(have)
+                         : "v"((uint32_t)(uintptr_t)ready_lds), "s"(need)
+                         : "memory", "scc");
         }
-        if (act) {
 #pragma unroll
-            for (int c = 1; c < 16; ++c) Mat[base + c] = r[c];
+        for (int kk = 0; kk < 4; ++kk) {
+            const int i = 4 * kk + kq;                              // row of M this lane feeds, column r16
+            const double v = Mat[tri(kb + max(r16, i), kb + min(r16, i))];   // (i < r16: M[i][r16]; otherwise a valid address, value replaced)
+            bm[kk] = i < r16 ? v : (i == r16 ? 1.0 : 0.0);
+        }
+        f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, d0 = c0, d1 = c0;
+        if (two) {                                                  // wave-uniform
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], bm[0], c0, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[2], bm[2], d0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], bm[0], c1, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[2], bm[2], d1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], bm[1], c0, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[3], bm[3], d0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], bm[1], c1, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[3], bm[3], d1, 0, 0, 0);
+        } else {
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], bm[0], c0, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[2], bm[2], d0, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], bm[1], c0, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[3], bm[3], d0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row0 = 16 * R0 + kq + 4 * r, row1 = 16 * R1 + kq + 4 * r;
+            if (r16 > 0 && row0 < n1) Mat[tri(row0, kb + r16)] = c0[r] + d0[r];                     // (column 0 of M is e_0: unchanged)
+            if (two && r16 > 0 && row1 < n1) Mat[tri(row1, kb + r16)] = c1[r] + d1[r];
         }
     };
     // tile (R, J) -= (rows R of panel kb) (rows J of panel kb / d)^T on the matrix cores: lane l feeds A[l&15][4kk + (l>>4)] and
@@ -884,6 +931,19 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
         store_tile(t0);
         if (two) store_tile(t1);
     };
+    // one tile, two accumulator chains of two MFMAs (on the critical path: wave 1's hand-off tile, wave 0's diagonal tile)
+    auto update_one = [&](const int kb, const int R, const int J) {
+        Tile t;
+        load_tile(kb, R, J, t);
+        f64x4 c2 = {0.0, 0.0, 0.0, 0.0};
+        t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[0], t.b[0], t.c, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[2], t.b[2], c2, 0, 0, 0);
+        t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[1], t.b[1], t.c, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[3], t.b[3], c2, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.c[r] += c2[r];
+        store_tile(t);
+    };
     // the tiles (R, kcol), R >= kcol + 2, of this worker wave, two at a time (tile (kcol + 1, kcol) is wave 0's: substituted inside the
     // diagonal tile's elimination): update by panel kb (kb < 0: none, column block 0), then the rows' substitution against the diagonal
     // tile of panel `kcol`.  Wave 1's first tile is (kcol + 2, kcol): with it final, wave 1 applies panel kcol to tile (kcol + 2, kcol + 1) -
@@ -897,20 +957,23 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
                 wave_lds_sync();
             }
             FPROF_MARK(3);                            // 3: tiles of the next column block (update)
-            finish_rows(16 * kcol, kcol, R0, R1);
-            if (wave == 1 && !told) {
+            if (wave == 1 && !told) {                 // the hand-off tile alone first: wave 0 is waiting for it
                 told = true;
+                finish_rows(16 * kcol, kcol, R0, -1);
                 if (kcol + 1 < P) {                   // (a next diagonal tile exists; R0 = kcol + 2 < RT here)
                     double keep[4];
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) { keep[kk] = ninv[kk]; ninv[kk] = -vinv[16 * kcol + 4 * kk + kq]; }
                     wave_lds_sync();
-                    update_pair(16 * kcol, kcol + 2, kcol + 1, false, kcol + 2, kcol + 1);
+                    update_one(16 * kcol, kcol + 2, kcol + 1);
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) ninv[kk] = keep[kk];
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 if (lane == 0) __hip_atomic_store(&sh.lead, kcol + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (R1 >= 0) finish_rows(16 * kcol, kcol, R1, -1);
+            } else {
+                finish_rows(16 * kcol, kcol, R0, R1);
             }
             FPROF_MARK(4);                            // 4: rows of the next column block (substitution behind the diagonal block)
         }
@@ -938,7 +1001,7 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
     __syncthreads();
     FPROF_RESET();
     // ---- column block 0 ----
-    if (wave == 0) { factor_diag(0, 0); FPROF_MARK(0); }                            // 0: diagonal blocks (wave 0)
+    if (wave == 0) { factor_diag(0, 0); FPROF_MARK(1); }                            // 0: diagonal blocks (wave 0)
     else { column_tiles(-1, 0); worker_barrier(kWorkers); }
     FPROF_MARK(5);                                    // 5: barrier
     // ---- phases: panel k updates what is right of it, column block k+1 comes out final ----
@@ -951,23 +1014,13 @@ __device__ __forceinline__ void factor_lds(double *Mat, double *vinv, const int 
             // wave 0's own (substituted inside the previous elimination) - on top of the earlier panels (wave 1's first trailing pair of
             // the phase before: lead_t); the tile below it, carried through the elimination, needs wave 1's special update (lead).
             spin_until(&sh.lead_t, k);
-            // two accumulator chains of two MFMAs instead of one of four (the chain is on the critical path)
-            Tile t;
-            load_tile(kb, k + 1, k + 1, t);
-            f64x4 c2 = {0.0, 0.0, 0.0, 0.0};
-            t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[0], t.b[0], t.c, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[2], t.b[2], c2, 0, 0, 0);
-            t.c = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[1], t.b[1], t.c, 0, 0, 0);
-            c2 = __builtin_amdgcn_mfma_f64_16x16x4f64(t.a[3], t.b[3], c2, 0, 0, 0);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) t.c[r] += c2[r];
-            store_tile(t);
+            update_one(kb, k + 1, k + 1);
             FPROF_MARK(3);                            // 3 (wave 0): the diagonal tile's update
             spin_until(&sh.lead, k + 1);
             FPROF_MARK(2);                            // 2: wave 0 waiting for wave 1
             wave_lds_sync();
             factor_diag(kb + 16, k + 1);
-            FPROF_MARK(0);
+            FPROF_MARK(1);
         } else {
             // tiles (R, J), k + 2 <= J <= R < RT, J a column block that exists: t-th tile of the row-major lower triangle.  Tiles 0 and 1,
             // (k+2, k+2) and (k+3, k+2), are what wave 0 takes next: wave 1 does them first and says so; the others are dealt round-robin.
@@ -1426,18 +1479,15 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
         bool valid = sh.flag == 0;
         if (valid) {
             {
-                // Back substitution by ONE wave with the vector in registers (n <= 192: three values per lane): a step is a
-                // v_readlane broadcast and one multiply-add per register - ~50 cycles against the ~270 of a step that crosses a
-                // workgroup barrier and an LDS round trip, and there are 2 n steps per solve.  The matrix entries do not depend
-                // on the running vector, so four steps' worth is loaded ahead of the dependent chain.
+                // Back substitution by ONE wave with the vector in registers (n <= 192: three values per lane).
                 if (tid < 64) {
-                    // L D L^T y = g with w = L^-1 g already in row n of the factored matrix (it rode through the factorization):
-                    // z = w; for k = n-1 .. 0: y_k = z_k / d_k, z_j -= a_kj y_k for j < k (a_kj: the UNSCALED row k, so no per-entry
-                    // scaling).  ONE wave, z in registers (n <= 192: three values per lane); a step is a multiply, a v_readlane
-                    // broadcast and one multiply-add per register with a one-instruction address (row base + lane): the kernel is
-                    // VALU-issue bound (one instruction per ~4.8 cycles and wave, scripts/probes/diag16_probe.hip), so the
-                    // instruction count of the step is what counts - the round-2 loop spent ~28 instructions per step, mostly
-                    // index arithmetic and selects, this one ~12.
+                    // L D L^T y = g with w = L^-1 g already in row n of the factored matrix (it rode through the factorization): z = w, then
+                    // 16-row tile by tile from the last: inside the tile y = M (D^-1 z) - M = (I + D^-1 U^T)^-1 sits where the tile's strictly
+                    // lower part was (factor_diag) - a 16 x 16 triangular matrix-vector product whose terms do not depend on one another
+                    // (until round 5: 16 steps, each waiting for the one before: y_k = z_k / d_k, z_j -= a_kj y_k); then z_j -= a_kj y_k for
+                    // the rows j above the tile (a_kj: the UNSCALED row k, so no per-entry scaling), again independent terms.  Lane = row:
+                    // a term is a v_readlane broadcast and one multiply-add per register with a one-instruction address (row base + lane);
+                    // the kernel is VALU-issue bound (one instruction per ~4.8 cycles and wave, scripts/probes/diag16_probe.hip).
                     constexpr int kR = 3;
                     double z[kR], inv[kR], yo[kR];
 #pragma unroll
@@ -1447,46 +1497,44 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                         inv[r] = i < n ? vinv[i] : 0.0;
                         yo[r] = 0.0;
                     }
-#ifndef LFR_BACKSUB_BATCH
-#define LFR_BACKSUB_BATCH 8
-#endif
-                    constexpr int kBsB = LFR_BACKSUB_BATCH;
                     const double *mlane = Mat + tid;                               // + row base (wave-uniform) + 64 r (immediate)
                     auto back_block = [&](auto r0_tag) {
                         constexpr int r0 = decltype(r0_tag)::value;
                         const int lo = 64 * r0;
                         if (lo >= n) return;
-                        auto load = [&](const int kt, double (&m)[kBsB][r0 + 1]) {
+                        const int lrow = tid + lo;                                 // the row this lane holds in register r0
+                        for (int kb = min(n - 1, lo + 63) & ~15; kb >= lo; kb -= 16) {
+                            double m[16][r0 + 1];
 #pragma unroll
-                            for (int u = 0; u < kBsB; ++u) {
-                                const double *row = mlane + tri(min(kt - u, n), 0);          // (rows above n - 1 only pad the first batch)
+                            for (int u = 15; u >= 0; --u) m[u][r0] = (mlane + tri(min(kb + u, n), 0))[64 * r0];     // (rows above n - 1 only pad the last tile)
 #pragma unroll
-                                for (int r = 0; r <= r0; ++r) m[u][r] = row[64 * r];
+                            for (int u = 0; u < 16; ++u) {
+                                const double *row = mlane + tri(min(kb + u, n), 0);
+#pragma unroll
+                                for (int r = 0; r < r0; ++r) m[u][r] = row[64 * r];
                             }
-                        };
-                        auto apply = [&](const int kt, const double (&m)[kBsB][r0 + 1]) {
+                            const double t = z[r0] * inv[r0];
+                            const unsigned rel = (unsigned)(lrow - kb);            // 0..15 inside the tile
+                            double y0 = t, y1 = 0.0;
 #pragma unroll
-                            for (int u = 0; u < kBsB; ++u) {
-                                const int k = kt - u;
-                                const double yv = z[r0] * inv[r0];
-                                double yk = readlane_f64(yv, k & 63);
-                                if (k >= n) yk = 0.0;                                       // wave-uniform
-                                yo[r0] = (tid == (k & 63)) ? yv : yo[r0];
-#pragma unroll
-                                for (int r = 0; r < r0; ++r) z[r] = fma(-m[u][r], yk, z[r]);
-                                z[r0] = fma(-((tid + lo < k) ? m[u][r0] : 0.0), yk, z[r0]);  // (right of column k - 1 the row's storage is the next row)
+                            for (int u = 15; u >= 1; --u) {
+                                if (kb + u < n) {                                  // wave-uniform
+                                    const double tc = readlane_f64(t, (kb + u) & 63);
+                                    const double mv = rel < (unsigned)u ? m[u][r0] : 0.0;      // M[rel][u]
+                                    if (u & 1) y1 = fma(mv, tc, y1); else y0 = fma(mv, tc, y0);
+                                }
                             }
-                        };
-                        int kt = min(n - 1, lo + 63) | (kBsB - 1);                         // batches [kt - kBsB + 1, kt], aligned: never straddle 64 r0
-                        double ma[kBsB][r0 + 1], mb[kBsB][r0 + 1];
-                        load(kt, ma);
-                        for (; kt >= lo; kt -= 2 * kBsB) {
-                            const bool more = kt - kBsB >= lo;
-                            if (more) load(kt - kBsB, mb);
-                            apply(kt, ma);
-                            if (more) {
-                                if (kt - 2 * kBsB >= lo) load(kt - 2 * kBsB, ma);
-                                apply(kt - kBsB, mb);
+                            const double y = y0 + y1;
+                            yo[r0] = rel < 16u ? y : yo[r0];
+                            const bool above = lrow < kb;
+#pragma unroll
+                            for (int u = 0; u < 16; ++u) {
+                                if (kb + u < n) {                                  // wave-uniform
+                                    const double yk = readlane_f64(y, (kb + u) & 63);
+#pragma unroll
+                                    for (int r = 0; r < r0; ++r) z[r] = fma(-m[u][r], yk, z[r]);
+                                    z[r0] = fma(-(above ? m[u][r0] : 0.0), yk, z[r0]);
+                                }
                             }
                         }
                     };

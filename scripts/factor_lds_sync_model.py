@@ -12,8 +12,9 @@ waves - and runs the waves under random interleavings with a vector-clock race d
     with that value (values only grow), a wave that leaves the workers' barrier joins every arrival's clock;
   * some wave can always proceed (deadlock detector), and at the end every tile has gone through the updates and the substitution it is due.
 
-Not modelled: loads whose values are discarded (the inactive lanes of finish_rows read row 15 of the diagonal tile before the poll; clamped
-loads of load_tile), the `flag` word (written with the same value by anyone), the fine-grained `ready` (LFR_FINE_READY = 0 in the build).
+Not modelled: loads whose values are discarded (clamped loads of load_tile; a row of the diagonal tile reads past its diagonal in factor_diag),
+the scratch words lanes without an entry store to (sh.red), the `flag` word (written with the same value by anyone).  Since round 5 the
+substitution of a tile is tile <- tile M with M stored by wave 0 inside the diagonal tile: at tile level the accesses are what they were.
 Tiles are (R, J), 16 x 16 blocks of the packed lower triangle with the right-hand side as row n (n1 = n + 1 rows, RT row tiles, P panels).
 usage: python scripts/factor_lds_sync_model.py"""
 import random
@@ -66,13 +67,16 @@ def programs(n, n_waves, drop_lead_wait=False, drop_ready_wait=False, drop_lead_
             R1 = R0 + K if R0 + K < RT else -1
             rows = [R0] + ([R1] if R1 >= 0 else [])
             if k >= 0: update_pair(w, k, [(R, kcol) for R in rows])      # (1 / d of panel k: the registers loaded at the start of the phase)
-            finish_rows(w, kcol, rows)
-            if w == 1 and not told:
+            if w == 1 and not told:                     # the hand-off tile alone first, the pair's other tile behind the `lead` word
                 told = True
+                finish_rows(w, kcol, rows[:1])
                 if kcol + 1 < P:                        # the tile wave 0 carries through the NEXT diagonal tile's elimination
                     p.append(("r", ("v", kcol)))
                     update_pair(w, kcol, [(kcol + 2, kcol + 1)])
                 p.append(("set", "lead", kcol + 1))
+                if len(rows) > 1: finish_rows(w, kcol, rows[1:])
+            else:
+                finish_rows(w, kcol, rows)
             R0 += 2 * K
         if w == 1 and not told: p.append(("set", "lead", kcol + 1))
 
