@@ -380,3 +380,24 @@ def test_fused_sweep_equals_scratch_sweep(lfr_lib, monkeypatch):
     assert np.abs(x_fused - x_scr).max() < 1e-9
     assert (2 * info_fused["n_var_nodes"] > 32).sum() >= 50            # workgroup classes are what this is about
     assert not (x_fused == x_scr).all()                                # (the two sweeps do differ in the last bits: the switch works)
+
+
+def test_small_systems_in_the_workgroup_kernel(lfr_lib):
+    """Every row count from 2 to 32 in solve_block_kernel (duplicated matches - solve.cc:476-478 keeps them - push small tracks beyond the
+    packed classes' 320 edges): one partial panel, exactly one panel with the right-hand side in a tile of its own, two panels - the shapes the
+    blocked factorization (diagonal tile + substitution matrix M, factor_lds) and the tile-wise back substitution special-case."""
+    ma = synthetic.generate(seed=58, n_images=17, n_tracks=64, len_dist="uniform", len_lo=2, len_hi=17)
+    pairs = ma.to_pairs()
+    for pr in pairs:
+        pr["matches"] = [m for m in pr["matches"] for _ in range(170)]
+    ma2 = synthetic.pairs_to_arrays(pairs)
+    g, p, b, st, pos, ref = solve_both(ma2)
+    info = b.component_info()
+    rows = 2 * info["n_var_nodes"]
+    assert (info["n_edges"] > 320).all() and rows.max() <= 32
+    assert set(range(2, 33, 2)) <= set(rows.tolist()), sorted(set(rows.tolist()))
+    err = np.abs(pos - ref["positions"]).max(axis=1)
+    assert err.max() <= TOL_UNITS, "max |dx| = %.3e units" % err.max()
+    oi = ref["infos"][info["component"]]
+    assert (oi["termination"] == info["termination"]).all() and (oi["iterations"] == info["iterations"]).all()
+    assert b.spin_timeouts() == 0
