@@ -478,6 +478,9 @@ def main():
                              "achieved": alg_bytes5 / (ms5 * 1e-3) / 1e9, "frac": alg_bytes5 / (ms5 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "frac_what": "ALGORITHMIC bytes (below) over the step time; traffic_ratio = counter traffic / algorithmic bytes",
                              "traffic_ratio": (traffic5 / alg_bytes5) if traffic5 else None,
+                             # the kernels write a few MB of results: WRITE_SIZE is spilled registers going out to scratch memory, and as much comes back
+                             "traffic_written": (prof5 or {}).get("hbm_write_bytes_per_solve"),
+                             "traffic_ratio_without_spills": ((traffic5 - 2.0 * prof5["hbm_write_bytes_per_solve"]) / alg_bytes5) if traffic5 and prof5.get("hbm_write_bytes_per_solve") else None,
                              "algorithmic_bytes": alg_bytes5,
                              "algorithmic_bytes_what": "per executed sweep and edge: the 80 B record (nothing else leaves the CU)",
                              "traffic_source": ("profiles/r05_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
