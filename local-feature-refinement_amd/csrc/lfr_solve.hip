@@ -14,7 +14,8 @@
 //   solve_block_kernel         persistent 128/256/512-thread workgroups over the components of up to 192 rows (three LDS-footprint
 //                              classes): packed J^T J in LDS, fused evaluate-and-assemble sweep (four to eight lanes per node, the
 //                              records re-streamed from HBM and nothing else), blocked LDL^T with 16-column panels - the diagonal
-//                              tiles on a wave that runs ahead of the others, trailing updates on the fp64 matrix cores.
+//                              tiles on a wave that runs ahead of the others, trailing updates AND the tiles' substitution (tile x M,
+//                              M = the diagonal tile's substitution as a matrix) on the fp64 matrix cores.
 //   solve_tree_kernel          one 512-thread workgroup per component above 192 rows: sparse LDL^T along the elimination tree of a
 //                              nested-dissection order (lfr_treeplan.cpp), 16x16 tiles in an HBM workspace, columns of one tree level
 //                              factored side by side by the workgroup's waves.
@@ -4109,7 +4110,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
         HIP_TRY(hipMemcpy(h, b->d_prof + 8 * lfr::KC_COUNT + 8, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(b->d_prof + 8 * lfr::KC_COUNT + 8, 0, sizeof h));
         for (int c = 0; c < 4; ++c) for (int w = 0; w < 2; ++w) if (h[16 * c + 8 * w + 7])
-            fprintf(stderr, "lfr-fprof class %d wave %d: factorizations %llu  cycles each: diag %.0f  trailing %.0f  wait %.0f  col-update %.0f  col-finish %.0f  barrier %.0f\n",
+            fprintf(stderr, "lfr-fprof class %d wave %d: factorizations %llu  cycles each: diag %.0f  trailing %.0f  wait %.0f  col-update %.0f  col-finish %.0f  barrier %.0f   (wave 0: diag = loads + elimination, trailing = its stores)\n",
                     lfr::KC_BLOCK + c, w, h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 1] / h[16 * c + 8 * w + 7],
                     (double)h[16 * c + 8 * w + 2] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 3] / h[16 * c + 8 * w + 7],
                     (double)h[16 * c + 8 * w + 4] / h[16 * c + 8 * w + 7], (double)h[16 * c + 8 * w + 5] / h[16 * c + 8 * w + 7]);
