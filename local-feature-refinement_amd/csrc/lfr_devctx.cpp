@@ -6,7 +6,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
+#include <functional>
 #include <memory>
+#include <thread>
 
 #include "lfr_internal.hpp"
 
@@ -217,6 +220,52 @@ DevCtx *dev_ctx(int device) {
     c->limit_pinned = env_mb("LFR_PINNED_CACHE_MB", c->limit_pinned);
     ctxs[device] = c.release();
     return ctxs[device];
+}
+
+// ---------------------------------------------------------------------------- persistent host workers
+namespace {
+struct Pool {
+    std::mutex mu, one;                         // `one`: one run at a time
+    std::condition_variable wake, done;
+    const std::function<void()> *job = nullptr;
+    int tickets = 0, running = 0, n_threads = 0;
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            wake.wait(lk, [&] { return tickets > 0; });
+            --tickets;
+            const std::function<void()> *f = job;
+            lk.unlock();
+            (*f)();
+            lk.lock();
+            if (--running == 0) done.notify_all();
+        }
+    }
+};
+Pool *pool() { static Pool *p = new Pool(); return p; }      // never destroyed: its workers sleep until the process ends
+}  // namespace
+
+void run_on_pool(int threads, const std::function<void()> &work) {
+    if (threads <= 1) { work(); return; }
+    Pool &P = *pool();
+    std::unique_lock<std::mutex> only(P.one, std::try_to_lock);
+    if (!only.owns_lock()) {                    // the pool is busy with another caller's work: threads of our own, as before
+        std::vector<std::thread> th;
+        for (int t = 1; t < threads; ++t) th.emplace_back(work);
+        work();
+        for (auto &t : th) t.join();
+        return;
+    }
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        while (P.n_threads < threads - 1) { std::thread(&Pool::worker, &P).detach(); ++P.n_threads; }
+        P.job = &work; P.tickets = threads - 1; P.running = threads - 1;
+    }
+    P.wake.notify_all();
+    work();
+    std::unique_lock<std::mutex> lk(P.mu);
+    P.done.wait(lk, [&] { return P.running == 0; });
+    P.job = nullptr;
 }
 
 }  // namespace lfr

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <functional>
 #include <vector>
 
 #include "lfr.h"
@@ -128,6 +129,10 @@ inline bool is_lds_class(int cls) { return cls >= KC_BLOCK && cls <= KC_BLOCK_L;
 constexpr int kBlockMaxRows = 192;   // packed lower triangle 192*193/2*8 B = 148.2 KB + 15.4 KB of vectors <= 160 KiB of LDS
 // rows above which a component's matrix lives in the HBM workspace instead of LDS: kBlockMaxRows, or LFR_BLOCK_MAX_ROWS (0..192)
 int block_max_rows();
+// `work` on `threads` threads (the caller is one of them), the others PERSISTENT workers of the process: a batch with elimination-tree
+// components makes ~130 plans of ~1 ms each, and creating as many threads every time cost more than the plans.  `work` pulls its items from
+// a counter of its own.  One call at a time (a second caller runs its work on threads of its own).
+void run_on_pool(int threads, const std::function<void()> &work);
 
 struct Problem {
     const Graph *g = nullptr;

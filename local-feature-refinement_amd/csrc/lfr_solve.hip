@@ -3432,6 +3432,12 @@ int create_from_host(lfr_batch *b, const lfr::Problem &p, int shard_rank, int sh
     return LFR_OK;
 }
 
+// plan i of the elimination-tree class: tab[3 i + 2] doubles from ws[tab[3 i]] (where one copy landed all plans) to ws[tab[3 i + 1]] (its component's workspace)
+__global__ void k_place_plans(double *ws, const uint64_t *tab) {
+    const uint64_t from = tab[3 * blockIdx.x], to = tab[3 * blockIdx.x + 1], n = tab[3 * blockIdx.x + 2];
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) ws[to + i] = ws[from + i];
+}
+
 // The workgroup kernels' workspace: per-edge scratch, then - for the components of the HBM class - the elimination-tree plans
 // (lfr_treeplan.cpp) with their tiles, vectors and team areas.  The plans need the components' (source, destination, kind) lists on the host: the
 // last word of every edge record, fetched with one strided copy when the batch was assembled on the device.
@@ -3445,19 +3451,31 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         }
         return LFR_OK;
     }
+    host_trace("finish_workspace: enters (components above the LDS classes)");
     { const int rc = ensure_mirrors(b); if (rc != LFR_OK) return rc; }
+    host_trace("finish_workspace: host mirrors of the descriptors");
     const int ng = g1 - g0;
     const uint32_t e0 = b->descs[g0].edge_off;
     uint64_t ne = 0;
     for (int i = g0; i < g1; ++i) ne = std::max<uint64_t>(ne, (uint64_t)b->descs[i].edge_off + b->descs[i].n_edges - e0);
-    std::vector<uint32_t> words(ne);
+    // The record words and the plans are megabytes in ~130 allocations made by the pool's workers: handing them back to the system (munmap with
+    // TLB shootdowns on every core a worker ran on) took 1.2 ms at the end of this function - a thread of its own does it while the solve starts.
+    struct PlanTemps { std::vector<uint32_t> words; std::vector<lfr::TreePlan> plans; };
+    struct Later { PlanTemps *p; ~Later() { PlanTemps *q = p; std::thread([q] { delete q; }).detach(); } } later{new PlanTemps()};
+    std::vector<uint32_t> &words = later.p->words;
+    words.resize(ne);
     if (p.host_batch && b->shard_world == 1) {
         for (uint64_t e = 0; e < ne; ++e) words[e] = (uint32_t)p.edges[e0 + e].src | ((uint32_t)p.edges[e0 + e].dst_kind << 16);
     } else if (ne) {
-        HIP_TRY(hipMemcpy2DAsync(words.data(), 4, reinterpret_cast<const char *>(b->d_edges + e0) + 76, sizeof(EdgeRec), 4, ne, hipMemcpyDeviceToHost, st));
+        // (a device-assembled whole batch kept one word per record beside the records: one linear copy.  The strided copy of the records' last
+        // words - 4 bytes of every 80 - took 1.1 ms for 0.3 M records)
+        if (b->d_edge_word) HIP_TRY(hipMemcpyAsync(words.data(), b->d_edge_word + e0, 4 * ne, hipMemcpyDeviceToHost, st));
+        else HIP_TRY(hipMemcpy2DAsync(words.data(), 4, reinterpret_cast<const char *>(b->d_edges + e0) + 76, sizeof(EdgeRec), 4, ne, hipMemcpyDeviceToHost, st));
         HIP_TRY(lfr::stream_wait(st));
     }
-    std::vector<lfr::TreePlan> plans(ng);
+    host_trace("finish_workspace: record words on the host");
+    std::vector<lfr::TreePlan> &plans = later.p->plans;
+    plans.resize(ng);
     {
         std::atomic<int> next{0};
         // (a plan is ~1 ms of one core for a cap-sized component and the plans are independent: as many threads as components, up to half
@@ -3471,11 +3489,9 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
                 lfr::tree_plan(d.n_var, d.n_edges, words.data() + (d.edge_off - e0), plans[i]);
             }
         };
-        std::vector<std::thread> th;
-        for (int t = 1; t < T; ++t) th.emplace_back(work);
-        work();
-        for (auto &t : th) t.join();
+        lfr::run_on_pool(T, work);                 // (persistent workers: creating 127 threads per batch was most of the 4 ms this step took)
     }
+    host_trace("finish_workspace: plans made");
     std::vector<uint64_t> off(ng);
     uint64_t ws = (b->es_doubles + 31) / 32 * 32, hdr_total = 0;
     b->tree_tiles = b->tree_dense_tiles = 0;
@@ -3524,6 +3540,9 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
     }
     const uint64_t team_off = ws;
     if (b->team_wgs) ws += (kTeamCtlWords + 1) / 2 + 8ull * kTeamUnitsPerXcc * kTeamRedPerUnit;
+    // behind everything: where the plans' words land in ONE copy before a kernel moves each to its component's workspace, + {from, to, doubles} per plan
+    const uint64_t land_off = ws;
+    ws += hdr_total + 3ull * (uint64_t)ng;
     if (!b->ws_slab.init(b->ctx, ws * sizeof(double))) return LFR_ERR_NOMEM;
     b->d_workspace = (double *)b->ws_slab.base;
     if (b->team_wgs) {
@@ -3533,20 +3552,29 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         HIP_TRY(hipMemsetAsync(b->d_team_red, 0, 8ull * kTeamUnitsPerXcc * kTeamRedPerUnit * sizeof(double), st));
     }
     // the plans' words: staged in one pinned buffer (it must outlive the asynchronous copies: waited for below)
+    host_trace("finish_workspace: workspace allocated, team area cleared");
     size_t got = 0;
-    double *stage = (double *)b->ctx->pinned_acquire(std::max<uint64_t>(hdr_total, 1) * sizeof(double), &got);
+    double *stage = (double *)b->ctx->pinned_acquire((hdr_total + 3ull * (uint64_t)ng) * sizeof(double), &got);
     if (!stage) return LFR_ERR_NOMEM;
-    uint64_t so = 0;
-    for (int i = 0; i < ng; ++i) {
-        memcpy(stage + so, plans[i].blob.data(), plans[i].blob.size() * 4);
-        if (hipMemcpyAsync(b->d_workspace + off[i], stage + so, plans[i].header_doubles() * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
-            b->ctx->pinned_release(stage, got); lfr::set_error("hipMemcpyAsync of a plan failed"); return LFR_ERR_HIP;
+    {
+        // (one copy + one kernel instead of a copy per plan: 130 small copies took 1.6 ms)
+        uint64_t so = 0;
+        uint64_t *tab = reinterpret_cast<uint64_t *>(stage + hdr_total);
+        for (int i = 0; i < ng; ++i) {
+            memcpy(stage + so, plans[i].blob.data(), plans[i].blob.size() * 4);
+            tab[3 * i] = land_off + so; tab[3 * i + 1] = off[i]; tab[3 * i + 2] = plans[i].header_doubles();
+            so += plans[i].header_doubles();
         }
-        so += plans[i].header_doubles();
+        if (hipMemcpyAsync(b->d_workspace + land_off, stage, (hdr_total + 3ull * (uint64_t)ng) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+            b->ctx->pinned_release(stage, got); lfr::set_error("hipMemcpyAsync of the plans failed"); return LFR_ERR_HIP;
+        }
+        hipLaunchKernelGGL(k_place_plans, dim3((unsigned)ng), dim3(256), 0, st, b->d_workspace, reinterpret_cast<const uint64_t *>(b->d_workspace + land_off + hdr_total));
     }
     hipError_t e1 = hipMemcpyAsync(b->d_ws_off + g0, off.data(), ng * sizeof(uint64_t), hipMemcpyHostToDevice, st);
     hipError_t e2 = hipStreamSynchronize(st);
+    host_trace("finish_workspace: plans uploaded");
     b->ctx->pinned_release(stage, got);
+    host_trace("finish_workspace: staging buffer back");
     if (e1 != hipSuccess || e2 != hipSuccess) { lfr::set_error("upload of the elimination-tree plans failed"); return LFR_ERR_HIP; }
     if (getenv("LFR_VERBOSE"))
         fprintf(stderr, "lfr: %d component(s) above %d rows: elimination-tree plans keep %lld of %lld tiles (%.1f %%) in %lld columns, at most %d levels, workspace %.1f MB\n", ng,
@@ -3855,6 +3883,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
     int rc = p.host_batch ? create_from_host(b.get(), p, shard_rank, shard_world) : create_on_device(b.get(), p, shard_rank, shard_world);
     if (rc != LFR_OK) return rc;
     if ((rc = finish_workspace(b.get(), p)) != LFR_OK) return rc;
+    host_trace("lfr_batch_create: workspace done");
     if (!(b->ev_fork = ctx->event_acquire(false))) return LFR_ERR_HIP;
     if (b->class_begin[lfr::KC_COUNT] > b->class_begin[lfr::KC_BLOCK]) {       // workgroup classes run beside the packed launch
         if (!(b->side_stream = ctx->side_stream(0))) return LFR_ERR_HIP;
@@ -3879,6 +3908,7 @@ int lfr_batch_create(const lfr_problem *ph, int device, int shard_rank, int shar
             if (!(b->ev_order = ctx->event_acquire(false))) return LFR_ERR_HIP;
             HIP_TRY(hipEventRecord(b->ev_order, so));
         }
+        host_trace("lfr_batch_create: hand-out order enqueued");
         const int lds_s = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK], 2), false);
         const int lds_m = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_M], 2), false);
         const int lds_l = (int)block_lds_bytes(std::max(b->class_max_rows[lfr::KC_BLOCK_L], 2), false);

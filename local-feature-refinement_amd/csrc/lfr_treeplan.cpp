@@ -26,7 +26,10 @@
 // Everything is a deterministic function of the component's record list.  The blob written here is what the kernel reads
 // (solve_tree_component in lfr_solve.hip); tests/test_tree_plan.py executes it on the CPU against a dense solve.
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <numeric>
@@ -243,7 +246,16 @@ void put(std::vector<uint32_t> &blob, uint32_t hdr_slot, const std::vector<T> &v
 }  // namespace
 
 void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out) {
+    static const bool plan_timing = getenv("LFR_PLAN_TIMING") != nullptr;            // laps of one plan to stderr (where does batch creation go?)
+    auto lap_t0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!plan_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "lfr plan (%d nodes, %lld records): %8.3f ms  %s\n", n_var, (long long)n_edges, std::chrono::duration<double, std::milli>(t - lap_t0).count(), what);
+        lap_t0 = t;
+    };
     const Csr g = build_adj(n_var, n_edges, words);
+    lap("adjacency");
     // ---- nested dissection of the variable nodes' graph -> segments ----
     // (The unit is the NODE, not the track: the tracks of the graph stage can be long - chains of short feature tracks joined by wrong
     // matches that the image-disjoint rule accepted - and a lattice of 30 nodes dissects as well as a chain of tracks does.  A short
@@ -279,6 +291,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
         std::iota(all.begin(), all.end(), 0);
         d.run(std::move(all));
     }
+    lap("meta graph + nested dissection");
     const int S = (int)segs.size();
     // ---- blocks: children before parents (segments were created parent first: reverse index order) ----
     std::vector<int64_t> sub_weight(S, 0);
@@ -334,6 +347,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     const int NB = (int)blocks.size();
     std::vector<int32_t> blk(n_var, -1), slot(n_var, 0);
     for (int b = 0; b < NB; ++b) for (size_t i = 0; i < blocks[b].size(); ++i) { blk[blocks[b][i]] = b; slot[blocks[b][i]] = (int32_t)i; }
+    lap("blocks");
     // ---- block-level symbolic factorization ----
     std::vector<std::vector<int32_t>> st(NB);                   // struct(J), sorted
     {
@@ -380,6 +394,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
     // rows of every block row: rowlist[I] = columns k < I with a tile (I, k), ascending, with the tile's id
     std::vector<std::vector<std::pair<int32_t, uint32_t>>> rowlist(NB);
     for (int k = 0; k < NB; ++k) for (size_t i = 0; i < st[k].size(); ++i) rowlist[st[k][i]].push_back({k, colptr[k] + 1u + (uint32_t)i});
+    lap("symbolic factorization, levels");
     // ---- rows the column task carries through the diagonal tile's elimination; the rest are "extra row" tasks ----
     // lanes 16 = right-hand side, 17 .. 63 = rows 0-15 of the first two tiles below the diagonal and rows 0-14 of the third
     std::vector<uint32_t> ncarry(NB), x_ptr(n_levels + 1, 0), x_tasks;
@@ -447,6 +462,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
         }
         col_upd_ptr[NB] = (uint32_t)(col_upd.size() / 5);
     }
+    lap("update lists");
     // ---- column descriptors in execution order (level by level): everything a column task needs to start its loads comes with ONE
     //      pair of scalar loads - {J, diagonal tile, carried tiles, pivots, update entries, first further entry, entry 0 (5 words), entry 1,
     //      tiles below the diagonal, rows of the first four of them} - instead of a chain of dependent lookups ----
@@ -466,6 +482,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
         dsc[22] = n_children[J];
         dsc[23] = p1_first[J];                                         // the tile tasks of the tiles this column does not carry: p1_first .. + (tiles below - carried)
     }
+    lap("column descriptors");
     // ---- sweep items ----
     const uint32_t n_pad = 16u * (uint32_t)NB;
     std::vector<uint32_t> ipos(8 * (size_t)NB, 0xffffffffu), node_items(8 * (size_t)NB + 1, 0), items, item_edges;
@@ -525,6 +542,7 @@ void tree_plan(int n_var, int64_t n_edges, const uint32_t *words, TreePlan &out)
         for (int pad = 0; pad < 8; ++pad) items.push_back(pad == 2 ? 0xffffffffu : 0u);        // one item past the end (the sweep reads one ahead)
     }
     const uint32_t n_items = (uint32_t)(items.size() / 8) - 1;
+    lap("sweep items");
     // ---- the blob ----
     std::vector<uint32_t> &blob = out.blob;
     blob.assign(kTreeHdrWords, 0);
