@@ -3561,10 +3561,17 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
         uint64_t so = 0;
         uint64_t *tab = reinterpret_cast<uint64_t *>(stage + hdr_total);
         for (int i = 0; i < ng; ++i) {
-            memcpy(stage + so, plans[i].blob.data(), plans[i].blob.size() * 4);
             tab[3 * i] = land_off + so; tab[3 * i + 1] = off[i]; tab[3 * i + 2] = plans[i].header_doubles();
             so += plans[i].header_doubles();
         }
+        std::atomic<int> next{0};
+        lfr::run_on_pool(std::min(ng, 16), [&] {                    // (megabytes of words into the pinned buffer: a few workers, not one)
+            for (;;) {
+                const int i = next.fetch_add(1);
+                if (i >= ng) break;
+                memcpy(stage + (tab[3 * i] - land_off), plans[i].blob.data(), plans[i].blob.size() * 4);
+            }
+        });
         if (hipMemcpyAsync(b->d_workspace + land_off, stage, (hdr_total + 3ull * (uint64_t)ng) * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
             b->ctx->pinned_release(stage, got); lfr::set_error("hipMemcpyAsync of the plans failed"); return LFR_ERR_HIP;
         }
