@@ -296,6 +296,11 @@ int lfr_debug_eval_edges(int device, int64_t n, const float *flows, const float 
  * version of the workgroup-per-component kernel, 2 = the wave-cooperative form of the elimination-tree kernel (the pieces of the
  * root isolation a lane each; one case per wave).  Test infrastructure, not part of the solve path. */
 int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const double *dir_max, int register_version, double *step);
+/* The library's persistent host workers (they make the elimination-tree plans of a batch, solve.cc:79-143 for components above 192 rows:
+ * the reference builds one problem per pool thread, solve.cc:617-635): `items` increments of one counter dealt to `threads` threads, the
+ * caller among them, `reps` times.  Returns the number of increments performed (items * reps when nothing was lost).  Callable from
+ * several threads at once (a caller that finds the workers busy runs on threads of its own).  Test infrastructure. */
+int64_t lfr_debug_pool_selftest(int threads, int64_t items, int reps);
 
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,

@@ -3,6 +3,7 @@
 
 #include <sys/mman.h>
 
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -269,3 +270,19 @@ void run_on_pool(int threads, const std::function<void()> &work) {
 }
 
 }  // namespace lfr
+
+extern "C" int64_t lfr_debug_pool_selftest(int threads, int64_t items, int reps) {
+    int64_t done = 0;
+    for (int r = 0; r < reps; ++r) {
+        std::atomic<int64_t> next{0}, count{0};
+        lfr::run_on_pool(threads, [&] {
+            for (;;) {
+                const int64_t i = next.fetch_add(1);
+                if (i >= items) break;
+                count.fetch_add(1);
+            }
+        });
+        done += count.load();
+    }
+    return done;
+}
