@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -226,14 +227,26 @@ DevCtx *dev_ctx(int device) {
 // ---------------------------------------------------------------------------- persistent host workers
 namespace {
 struct Pool {
-    std::mutex mu, one;                         // `one`: one run at a time
-    std::condition_variable wake, done;
+    std::mutex mu, one;                         // `one`: one run_on_pool at a time
+    std::condition_variable wake, done, task_done;
     const std::function<void()> *job = nullptr;
     int tickets = 0, running = 0, n_threads = 0;
+    std::deque<std::shared_ptr<PoolTask>> tasks;
+    void grow(int n) { while (n_threads < n) { std::thread(&Pool::worker, this).detach(); ++n_threads; } }     // (mu held)
+    void run_task(std::unique_lock<std::mutex> &lk) {                                                             // (mu held, a task queued)
+        std::shared_ptr<PoolTask> t = tasks.front();
+        tasks.pop_front();
+        lk.unlock();
+        t->fn();
+        lk.lock();
+        t->done = true;
+        task_done.notify_all();
+    }
     void worker() {
         std::unique_lock<std::mutex> lk(mu);
         for (;;) {
-            wake.wait(lk, [&] { return tickets > 0; });
+            wake.wait(lk, [&] { return tickets > 0 || !tasks.empty(); });
+            if (!tasks.empty()) { run_task(lk); continue; }
             --tickets;
             const std::function<void()> *f = job;
             lk.unlock();
@@ -259,7 +272,7 @@ void run_on_pool(int threads, const std::function<void()> &work) {
     }
     {
         std::lock_guard<std::mutex> lk(P.mu);
-        while (P.n_threads < threads - 1) { std::thread(&Pool::worker, &P).detach(); ++P.n_threads; }
+        P.grow(threads - 1);
         P.job = &work; P.tickets = threads - 1; P.running = threads - 1;
     }
     P.wake.notify_all();
@@ -267,6 +280,29 @@ void run_on_pool(int threads, const std::function<void()> &work) {
     std::unique_lock<std::mutex> lk(P.mu);
     P.done.wait(lk, [&] { return P.running == 0; });
     P.job = nullptr;
+}
+
+std::shared_ptr<PoolTask> pool_async(std::function<void()> fn) {
+    Pool &P = *pool();
+    std::shared_ptr<PoolTask> t = std::make_shared<PoolTask>();
+    t->fn = std::move(fn);
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        const unsigned hw = std::thread::hardware_concurrency();
+        P.grow((int)std::min(64u, std::max(4u, hw / 2)));
+        P.tasks.push_back(t);
+    }
+    P.wake.notify_one();
+    return t;
+}
+
+void pool_wait(const std::shared_ptr<PoolTask> &t) {
+    Pool &P = *pool();
+    std::unique_lock<std::mutex> lk(P.mu);
+    while (!t->done) {
+        if (!P.tasks.empty()) P.run_task(lk);   // (a waiting thread works: tasks that spawn and wait for tasks cannot starve each other of workers)
+        else P.task_done.wait(lk);
+    }
 }
 
 }  // namespace lfr

@@ -305,18 +305,18 @@ void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_
             for (size_t k = 0; k < child[s].ea.size(); ++k) { child[s].ea[k] = down[child[s].ea[k]]; child[s].eb[k] = down[child[s].eb[k]]; }
     }
     std::vector<int> sub[2];
-    std::future<void> second;
+    std::shared_ptr<PoolTask> second;
     bool spawned = false;
     // (a thread costs 0.1-1 ms to start: only halves whose own bisection takes longer than that: -DLFR_CUT_SPAWN_MIN; the labels do not depend on it)
-    constexpr size_t spawn_min = LFR_CUT_SPAWN_MIN;
+    static const size_t spawn_min = [] { const char *e = getenv("LFR_CUT_SPAWN_MIN"); return e ? (size_t)atoll(e) : (size_t)LFR_CUT_SPAWN_MIN; }();   // (experiments)
     if (!child[0].ea.empty() && child[1].ea.size() >= spawn_min) {
         if (g_cut_tasks.fetch_add(1) < 64) {
-            second = std::async(std::launch::async, [&] { cut_rec(child[1], node_weights, max_weight, sub[1]); });
+            second = pool_async([&] { cut_rec(child[1], node_weights, max_weight, sub[1]); });
             spawned = true;
         } else g_cut_tasks.fetch_sub(1);
     }
     if (!child[0].ea.empty()) cut_rec(child[0], node_weights, max_weight, sub[0]);
-    if (spawned) { second.get(); g_cut_tasks.fetch_sub(1); }
+    if (spawned) { pool_wait(second); g_cut_tasks.fetch_sub(1); }
     else if (!child[1].ea.empty()) cut_rec(child[1], node_weights, max_weight, sub[1]);
     out.assign(n, -1);
     int max_idx = 0;

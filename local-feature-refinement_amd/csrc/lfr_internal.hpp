@@ -133,6 +133,12 @@ int block_max_rows();
 // components makes ~130 plans of ~1 ms each, and creating as many threads every time cost more than the plans.  `work` pulls its items from
 // a counter of its own.  One call at a time (a second caller runs its work on threads of its own).
 void run_on_pool(int threads, const std::function<void()> &work);
+// One task for the same workers (the size cap's recursion hands the second half of a bisection to one: creating a thread per half cost
+// 0.1-1 ms each).  pool_wait returns when the task has run; while it waits the caller runs queued tasks itself, so tasks may spawn and wait
+// for tasks of their own.
+struct PoolTask { std::function<void()> fn; bool done = false; };
+std::shared_ptr<PoolTask> pool_async(std::function<void()> fn);
+void pool_wait(const std::shared_ptr<PoolTask> &t);
 
 struct Problem {
     const Graph *g = nullptr;
