@@ -680,6 +680,60 @@ __device__ __forceinline__ double group_sum(double v) { return group_reduce<S>(v
 template <int S>
 __device__ __forceinline__ double group_max(double v) { return group_reduce<S>(v, [](double a, double b) { return fmax(a, b); }); }
 
+// ---- 64-bit DPP (gfx90a+ "DP ALU DPP": fp64 VOP1/VOP2 take a DPP source operand, control row_newbcast only) ----
+// row_newbcast:K hands every lane of a 16-lane row the value of the row's lane K, inside the consuming instruction: the pivot-row
+// broadcasts of the elimination need neither the LDS crossbar (ds_swizzle: two LDS instructions and a round trip per double) nor a
+// register.  bank_mask restricts the WRITE to 4-lane banks of the row (the other lanes keep dst), which splits a row into two
+// 8-lane groups with their own pivot lanes.
+// (asm, not __builtin_amdgcn_update_dpp: the builtin is declared for 32-bit operands in this clang.  hipcc does not see inside an
+// asm statement: every statement below opens with s_nop 1, which covers "VALU write -> DPP read of the same VGPR" (2 wait states)
+// whatever was scheduled in front of it.)
+template <int K>
+__device__ __forceinline__ double bcast16_f64(double v) {             // lane K of the own 16-lane row
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v), "n"(K));
+    return r;
+}
+template <int K>
+__device__ __forceinline__ double bcast8_f64(double v) {              // lane K of the own 8-lane group (two groups per row)
+    double r;
+    asm("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0x3\n\t"
+        "v_mov_b64_dpp %0, %1 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "=&v"(r) : "v"(v), "n"(K), "n"(K + 8));
+    return r;
+}
+// h_i += nf * (h_i of lane K of the row), i = 0..N-1, as N v_fmac_f64_dpp
+#define LFR_FMAC_DPP(i) "v_fmac_f64_dpp %" #i ", %" #i ", %[nf] row_newbcast:%[k] row_mask:0xf bank_mask:%[bank]\n\t"
+template <int K, int BANK>
+__device__ __forceinline__ void fmac_bcast(double nf, double &a) {
+    asm volatile("s_nop 1\n\t" LFR_FMAC_DPP(0) : "+v"(a) : [nf] "v"(nf), [k] "n"(K), [bank] "n"(BANK));
+}
+template <int K, int BANK>
+__device__ __forceinline__ void fmac_bcast(double nf, double &a, double &b) {
+    asm volatile("s_nop 1\n\t" LFR_FMAC_DPP(0) LFR_FMAC_DPP(1) : "+v"(a), "+v"(b) : [nf] "v"(nf), [k] "n"(K), [bank] "n"(BANK));
+}
+template <int K, int BANK>
+__device__ __forceinline__ void fmac_bcast(double nf, double &a, double &b, double &c) {
+    asm volatile("s_nop 1\n\t" LFR_FMAC_DPP(0) LFR_FMAC_DPP(1) LFR_FMAC_DPP(2) : "+v"(a), "+v"(b), "+v"(c) : [nf] "v"(nf), [k] "n"(K), [bank] "n"(BANK));
+}
+template <int K, int BANK>
+__device__ __forceinline__ void fmac_bcast(double nf, double &a, double &b, double &c, double &d) {
+    asm volatile("s_nop 1\n\t" LFR_FMAC_DPP(0) LFR_FMAC_DPP(1) LFR_FMAC_DPP(2) LFR_FMAC_DPP(3)
+                 : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : [nf] "v"(nf), [k] "n"(K), [bank] "n"(BANK));
+}
+#undef LFR_FMAC_DPP
+// columns [C0, CL) of h, then rhs, four to a statement
+template <int K, int BANK, int C0, int CL>
+__device__ __forceinline__ void fmac_bcast_row(double nf, double (&h)[CL], double &rhs) {
+    constexpr int n = CL - C0;                       // live columns; rhs rides as column n
+    if constexpr (n >= 4) {
+        fmac_bcast<K, BANK>(nf, h[C0], h[C0 + 1], h[C0 + 2], h[C0 + 3]);
+        fmac_bcast_row<K, BANK, C0 + 4, CL>(nf, h, rhs);
+    } else if constexpr (n == 3) fmac_bcast<K, BANK>(nf, h[C0], h[C0 + 1], h[C0 + 2], rhs);
+    else if constexpr (n == 2) fmac_bcast<K, BANK>(nf, h[C0], h[C0 + 1], rhs);
+    else if constexpr (n == 1) fmac_bcast<K, BANK>(nf, h[C0], rhs);
+    else fmac_bcast<K, BANK>(nf, rhs);
+}
+
 // value of lane (K mod 32-lane window) selected by a bit-mask swizzle: new = (lane & AND) | K
 template <int AND, int K>
 __device__ __forceinline__ double swz_bcast(double v) { return swizzle_f64<(K << 5) | AND>(v); }

@@ -123,6 +123,9 @@ struct KernelArgs {
 #define PROF_SWEEP_MARK(i)
 #define PROF_FACTOR_MARK(i) PROF_MARK(i)
 #endif
+#ifndef LFR_GJ_DPP
+#define LFR_GJ_DPP 2               // elimination of the 16-row (1) and also the 8-row (2) packed class with DPP row broadcasts; 0: ds_swizzle
+#endif
 enum : int { PH_SOLVE = 0, PH_EVAL_INIT = 1, PH_EVAL_LS = 2, PH_EVAL_CAND = 3, PH_REEVAL = 4, PH_DONE = 5 };
 
 // Gauss-Jordan elimination of the damped normal equations held one row per lane, no pivoting (SPD);
@@ -145,6 +148,26 @@ struct GaussJordan {
                                                int row, int part, int n_steps) {
         constexpr int pk = K % LPR, ck = K / LPR;                      // part / register holding column K
         constexpr int c0 = (K + 1) / LPR;                              // first register with a live column (> K)
+#if LFR_GJ_DPP
+        if constexpr (LPR == 1 && (NV == 16 || (NV == 8 && LFR_GJ_DPP >= 2))) {
+            // One row per lane, the group inside one 16-lane DPP row: the pivot row reaches the rank-1 update as the DPP operand of
+            // the v_fmac_f64 itself (row_newbcast:K) - one instruction per column and no LDS crossbar (until round 6: two ds_swizzle
+            // and an fma per column, 75 % of the kernel's LDS instructions).  NV == 8: two groups per DPP row, the update is issued
+            // per half with a bank mask (lanes 0-7 take lane K, lanes 8-15 lane K + 8).
+            const double piv = (NV == 16) ? bcast16_f64<K>(h[K]) : bcast8_f64<K>(h[K]);
+            minpiv = fmin(minpiv, piv);
+            double nf = -(h[K] * fast_rcp(piv));
+            const bool is_k = row == K;
+            nf = is_k ? 0.0 : nf;                                      // (the pivot lane's own row stays: h += 0 * h)
+            piv_own = is_k ? piv : piv_own;
+            if constexpr (NV == 16) fmac_bcast_row<K, 0xf, c0, CL>(nf, h, rhs);
+            else { fmac_bcast_row<K, 0x3, c0, CL>(nf, h, rhs); fmac_bcast_row<K + 8, 0xc, c0, CL>(nf, h, rhs); }
+            if constexpr (K + 1 < CL && K + 1 < NV) {
+                if (K + 1 < n_steps) GaussJordan<NV, LPR, K + 1, CL>::run(h, rhs, piv_own, minpiv, row, part, n_steps);
+            }
+            return;
+        }
+#endif
         double pr[CL];
 #pragma unroll
         for (int c = c0; c < CL; ++c) pr[c] = swz_bcast<kPartAnd, K % 32>(h[c]);
