@@ -43,6 +43,16 @@ __device__ __forceinline__ double fast_sqrt(double x) {
     g = fma(g, e, g);
     return fma(fma(-g, g, x), h, g);                   // final residual correction
 }
+// 1/sqrt(x) for finite x in the normal range: v_rsq_f64 + two coupled Goldschmidt steps (g -> sqrt x, h -> 1 / (2 sqrt x))
+__device__ __forceinline__ double fast_rsqrt(double x) {
+    const double r = __builtin_amdgcn_rsq(x);
+    double g = x * r, h = 0.5 * r;
+    double e = fma(-h, g, 0.5);
+    g = fma(g, e, g); h = fma(h, e, h);
+    e = fma(-h, g, 0.5);
+    h = fma(h, e, h);
+    return h + h;
+}
 // A literal pinned into an SGPR pair at the point of use: without it the compiler hoists the ten
 // series coefficients below out of the solve loop and parks them in 20 VGPRs for the whole kernel
 // (plus a v_mov_b64 in front of every v_fmac).  SALU moves issue beside the other wave's VALU work.
@@ -89,61 +99,77 @@ struct EdgeOut {
 // (Lr_i*Lc_j)*d by rounding only, ~1e-16 relative).
 // WANT_JAC = false evaluates the cost only: no derivative sums, no rho', no corrected residual/jacobian
 // (o.cost is the only valid output).
+// AT_ZERO (wave-uniform, run time): both end points are the origin - the first evaluation of every solve (solve.cc:609-612 starts
+// from zero displacements).  The Lagrange basis at 0 is {0, 1, 0}, its derivative {-1, 0, 1}: the interpolant is the centre flow and its
+// partials are central differences - 10 conversions and 4 subtractions instead of 18 conversions, the basis and 54 multiply-adds,
+// with the same bits (the general form multiplies by those exact zeros and ones).
 template <bool WANT_JAC>
 __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, int kind, int tukey_variant,
-                                          double x1r, double x1c, double x2r, double x2c, EdgeOut &o) {
-    const double row = fmax(fmin(x1r, 0.5), -0.5), col = fmax(fmin(x1c, 0.5), -0.5);
-    const bool row_in = (row == x1r), col_in = (col == x1c);     // cost.cc:38,41
-    const double lc[3] = {2. * col * (col - .5), (-4.) * (col - .5) * (col + .5), 2. * col * (col + .5)};
-    const double dlc[3] = {2. * col + 2. * (col - .5), (-4.) * (col - .5) + (-4.) * (col + .5), 2. * col + 2. * (col + .5)};
+                                          double x1r, double x1c, double x2r, double x2c, EdgeOut &o, const bool at_zero = false) {
     double f0 = 0., f1 = 0., dr0 = 0., dr1 = 0., dc0 = 0., dc1 = 0.;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        // The flows never change during a solve, so the compiler would hoist the f32->f64
-        // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
-        // The conversions are volatile asm: they stay next to their use (and read the resident
-        // float registers directly).
-        const double a0 = cvt_pinned(flow[6 * i]), a1 = cvt_pinned(flow[6 * i + 1]), b0 = cvt_pinned(flow[6 * i + 2]),
-                     b1 = cvt_pinned(flow[6 * i + 3]), c0 = cvt_pinned(flow[6 * i + 4]), c1 = cvt_pinned(flow[6 * i + 5]);
-        const double t0 = lc[0] * a0 + lc[1] * b0 + lc[2] * c0;
-        const double t1 = lc[0] * a1 + lc[1] * b1 + lc[2] * c1;
-        const double lri = (i == 0) ? 2. * row * (row - .5) : (i == 1) ? (-4.) * (row - .5) * (row + .5) : 2. * row * (row + .5);
-        f0 += lri * t0; f1 += lri * t1;
+    if (at_zero) {
+        f0 = cvt_pinned(flow[8]); f1 = cvt_pinned(flow[9]);
         if (WANT_JAC) {
-            const double u0 = dlc[0] * a0 + dlc[1] * b0 + dlc[2] * c0;
-            const double u1 = dlc[0] * a1 + dlc[1] * b1 + dlc[2] * c1;
-            const double dlri = (i == 0) ? 2. * row + 2. * (row - .5) : (i == 1) ? (-4.) * (row - .5) + (-4.) * (row + .5)
-                                                                                 : 2. * row + 2. * (row + .5);
-            dr0 += dlri * t0; dr1 += dlri * t1;
-            dc0 += lri * u0; dc1 += lri * u1;
+            dr0 = cvt_pinned(flow[14]) - cvt_pinned(flow[2]); dr1 = cvt_pinned(flow[15]) - cvt_pinned(flow[3]);
+            dc0 = cvt_pinned(flow[10]) - cvt_pinned(flow[6]); dc1 = cvt_pinned(flow[11]) - cvt_pinned(flow[7]);
         }
-    }
-    if (WANT_JAC) {
-        if (!row_in) { dr0 = 0.; dr1 = 0.; }
-        if (!col_in) { dc0 = 0.; dc1 = 0.; }
+    } else {
+        const double row = fmax(fmin(x1r, 0.5), -0.5), col = fmax(fmin(x1c, 0.5), -0.5);
+        const bool row_in = (row == x1r), col_in = (col == x1c);     // cost.cc:38,41
+        const double lc[3] = {2. * col * (col - .5), (-4.) * (col - .5) * (col + .5), 2. * col * (col + .5)};
+        const double dlc[3] = {2. * col + 2. * (col - .5), (-4.) * (col - .5) + (-4.) * (col + .5), 2. * col + 2. * (col + .5)};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            // The flows never change during a solve, so the compiler would hoist the f32->f64
+            // conversions out of the iteration loop and keep 36 extra VGPRs alive per edge slot.
+            // The conversions are volatile asm: they stay next to their use (and read the resident
+            // float registers directly).
+            const double a0 = cvt_pinned(flow[6 * i]), a1 = cvt_pinned(flow[6 * i + 1]), b0 = cvt_pinned(flow[6 * i + 2]),
+                         b1 = cvt_pinned(flow[6 * i + 3]), c0 = cvt_pinned(flow[6 * i + 4]), c1 = cvt_pinned(flow[6 * i + 5]);
+            const double t0 = lc[0] * a0 + lc[1] * b0 + lc[2] * c0;
+            const double t1 = lc[0] * a1 + lc[1] * b1 + lc[2] * c1;
+            const double lri = (i == 0) ? 2. * row * (row - .5) : (i == 1) ? (-4.) * (row - .5) * (row + .5) : 2. * row * (row + .5);
+            f0 += lri * t0; f1 += lri * t1;
+            if (WANT_JAC) {
+                const double u0 = dlc[0] * a0 + dlc[1] * b0 + dlc[2] * c0;
+                const double u1 = dlc[0] * a1 + dlc[1] * b1 + dlc[2] * c1;
+                const double dlri = (i == 0) ? 2. * row + 2. * (row - .5) : (i == 1) ? (-4.) * (row - .5) + (-4.) * (row + .5)
+                                                                                     : 2. * row + 2. * (row + .5);
+                dr0 += dlri * t0; dr1 += dlri * t1;
+                dc0 += lri * u0; dc1 += lri * u1;
+            }
+        }
+        if (WANT_JAC) {
+            if (!row_in) { dr0 = 0.; dr1 = 0.; }
+            if (!col_in) { dc0 = 0.; dc1 = 0.; }
+        }
     }
     const double r0 = x2r - x1r - f0, r1 = x2c - x1c - f1;       // cost.cc:87
     const double s = r0 * r0 + r1 * r1;
     const double w = cvt_pinned(simf);
-    double rho0, rho1;
+    double rho0, sq;
     if (kind == 0) {                                              // CauchyLoss(0.25)
         const double sum = 1.0 + s * kCauchyC;
         rho0 = kCauchyB * log_ge1(sum);
-        rho1 = WANT_JAC ? fmax(DBL_MIN, fast_rcp(sum)) : 1.0;
+        // Corrector (rho'' <= 0 branch): sqrt(w rho') = sqrt(w / sum) = w rsqrt(w sum): one reciprocal square root instead of a
+        // reciprocal and a square root.  Outside the normal range (w = 0, a non-finite residual) the two-step form decides.
+        const double p = w * sum;
+        sq = 0.0;
+        if (WANT_JAC) sq = (p > 1e-290 && p < 1e290) ? w * fast_rsqrt(p) : sqrt(w * fmax(DBL_MIN, 1.0 / sum));
     } else {                                                      // TukeyLoss(0.0625)
         const double k0 = (tukey_variant == 1) ? kTukeyA2 / 6.0 : kTukeyA2 / 3.0;
         const double k1 = (tukey_variant == 1) ? 0.5 : 1.0;
+        double rho1;
         if (s <= kTukeyA2) {
             const double v = 1.0 - s / kTukeyA2, v2 = v * v;
             rho0 = k0 * (1.0 - v2 * v);
             rho1 = k1 * v2;
         } else { rho0 = k0; rho1 = 0.0; }
+        sq = WANT_JAC ? fast_sqrt(rho1 * w) : 0.0;
     }
     rho0 *= w;
     o.cost = 0.5 * rho0;
     if (!WANT_JAC) return;
-    rho1 *= w;
-    const double sq = fast_sqrt(rho1);  // Corrector, rho'' <= 0 branch
     o.r0 = r0 * sq; o.r1 = r1 * sq; o.sq = sq;
     if (WANT_JAC) {
         o.j00 = (-1.0 - dr0) * sq; o.j01 = (-dc0) * sq;
@@ -658,18 +684,37 @@ constexpr int kSwizzleXor16 = (0x10 << 10) | 0x1F;
 // xor-32 exchange (the two halves of the wave): ds_bpermute through __shfl_xor
 __device__ __forceinline__ double xor32_f64(double v) { return __shfl_xor(v, 32, 64); }
 
+// dpp_f64 for a source that stays live: the destination is a fresh register pair (an empty asm "defines" it), so no copy of v is
+// made in front of the two v_mov_b32_dpp (dpp_f64 ties the destination to its source: right when the source dies there)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64_keep(double v) {
+    int ul, uh;
+    asm volatile("" : "=v"(ul), "=v"(uh));
+    const int lo = __builtin_amdgcn_update_dpp(ul, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(uh, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// the lanes of the 4-lane banks in BANK take v through the permutation, the others keep `old`
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_f64_merge(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANK, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANK, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppIdentity = 0xE4;         // quad_perm [0,1,2,3]
+
 template <int S, typename Op>
 __device__ __forceinline__ double group_reduce(double v, Op op) {
     static_assert(S == 8 || S == 16 || S == 32 || S == 64, "group size");
     if (S == 8) {
-        v = op(v, dpp_f64<kDppHalfMirror>(v));
-        v = op(v, dpp_f64<kDppQuadXor1>(v));
-        v = op(v, dpp_f64<kDppQuadXor2>(v));
+        v = op(v, dpp_f64_keep<kDppHalfMirror>(v));
+        v = op(v, dpp_f64_keep<kDppQuadXor1>(v));
+        v = op(v, dpp_f64_keep<kDppQuadXor2>(v));
     } else {
-        v = op(v, dpp_f64<kDppRowRor + 8>(v));
-        v = op(v, dpp_f64<kDppRowRor + 4>(v));
-        v = op(v, dpp_f64<kDppRowRor + 2>(v));
-        v = op(v, dpp_f64<kDppRowRor + 1>(v));
+        v = op(v, dpp_f64_keep<kDppRowRor + 8>(v));
+        v = op(v, dpp_f64_keep<kDppRowRor + 4>(v));
+        v = op(v, dpp_f64_keep<kDppRowRor + 2>(v));
+        v = op(v, dpp_f64_keep<kDppRowRor + 1>(v));
         if (S >= 32) v = op(v, swizzle_f64<kSwizzleXor16>(v));
         if (S == 64) v = op(v, xor32_f64(v));
     }
@@ -732,6 +777,43 @@ __device__ __forceinline__ void fmac_bcast_row(double nf, double (&h)[CL], doubl
     else if constexpr (n == 2) fmac_bcast<K, BANK>(nf, h[C0], h[C0 + 1], rhs);
     else if constexpr (n == 1) fmac_bcast<K, BANK>(nf, h[C0], rhs);
     else fmac_bcast<K, BANK>(nf, rhs);
+}
+
+// Four sums at once.  S >= 16: a TRANSPOSED butterfly - after the xor-8 step the lower half of a 16-lane row carries the partial sums
+// of a (b), the upper half those of c (d); after the mirror step inside 8 lanes each quad carries one of the four; two quad steps, then
+// the totals are handed to every lane by row_newbcast.  7 + 7 + 7 + 3 + 3 + 4 = 31 instructions against 4 x 12 for four butterflies
+// (4 x 20 with the copies the tied dpp_f64 made until round 6).  Every lane of the group ends with the bit-identical four sums.
+#ifndef LFR_SUM4_WIDE
+#define LFR_SUM4_WIDE 1
+#endif
+template <int S>
+__device__ __forceinline__ void group_sum4(double &a, double &b, double &c, double &d) {
+    if constexpr (S == 8 || (S >= 32 && LFR_SUM4_WIDE == 0)) {
+        a = group_sum<S>(a); b = group_sum<S>(b); c = group_sum<S>(c); d = group_sum<S>(d);
+    } else {
+        double ra = dpp_f64_keep<kDppRowRor + 8>(c);                 // every lane: its partner's c
+        ra = dpp_f64_merge<kDppRowRor + 8, 0x3>(ra, a);              // lanes 0-7: the partner's a instead
+        const double ka = dpp_f64_merge<kDppIdentity, 0xc>(a, c);    // lanes 0-7: own a, lanes 8-15: own c
+        const double P = ka + ra;
+        double rb = dpp_f64_keep<kDppRowRor + 8>(d);
+        rb = dpp_f64_merge<kDppRowRor + 8, 0x3>(rb, b);
+        const double kb = dpp_f64_merge<kDppIdentity, 0xc>(b, d);
+        const double Q = kb + rb;
+        double rt = dpp_f64_keep<kDppHalfMirror>(Q);
+        rt = dpp_f64_merge<kDppHalfMirror, 0x5>(rt, P);              // banks 0, 2 (lanes 0-3, 8-11): the mirror lane's P
+        const double kt = dpp_f64_merge<kDppIdentity, 0xa>(P, Q);    // banks 1, 3 keep Q
+        double T = kt + rt;
+        T += dpp_f64_keep<kDppQuadXor2>(T);
+        T += dpp_f64_keep<kDppQuadXor1>(T);                           // quads 0..3 of the row: sums of a, b, c, d over the row
+        if (S >= 32) T += swizzle_f64<kSwizzleXor16>(T);
+        if (S == 64) T += xor32_f64(T);
+        asm("s_nop 1\n\t"
+            "v_mov_b64_dpp %0, %4 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64_dpp %1, %4 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64_dpp %2, %4 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+            "v_mov_b64_dpp %3, %4 row_newbcast:12 row_mask:0xf bank_mask:0xf"
+            : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(T));
+    }
 }
 
 // value of lane (K mod 32-lane window) selected by a bit-mask swizzle: new = (lane & AND) | K

@@ -200,7 +200,8 @@ struct GroupLds {
     double g[NV];              // J^T r of the last evaluation
     double x[NV + 2];          // evaluation point; slots 2*n_var, 2*n_var+1 stay 0 (constants)
     // cold per-group state (line-search bookkeeping, counters): lives here, not in VGPRs
-    double ls_prev_x, ls_prev_value, ls_prev_gradient, dir_max;
+    double ls_prev_x, ls_prev_value, ls_prev_gradient;
+    double step_norm2, xnorm2;  // |x - x_trial|^2 and |x_trial|^2 of the current trial point (written with it, read by the decision after the sweep)
     int ls_prev_flags, ls_iter, n_successful, n_ls_evals, n_cand, exec_passes;
 };
 
@@ -300,6 +301,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     }
     if (sl < NV) L.x[sl] = 0.0;
     if (sl < 2) L.x[NV + sl] = 0.0;
+    for (int i = sl; i < NV * LD; i += S) L.A[i] = 0.0;           // rows >= nv2 stay zero for the whole solve (the sweeps re-zero rows < nv2)
 
     // ---- group state (uniform inside a group; 'row' values are identical in the LPR lanes of a row) ----
     int phase = have ? PH_EVAL_INIT : PH_DONE;
@@ -314,6 +316,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
     if (sl == 0) { L.n_successful = 0; L.n_ls_evals = 0; L.n_cand = 0; L.exec_passes = 0; L.ls_iter = 0; L.ls_prev_flags = 0; }
 
+    bool at_zero = true;                              // wave-uniform: the first sweep evaluates every edge at the origin (PH_EVAL_INIT)
     PROF_DECL
     PROF_MARK(0);                                     // 0: prologue (edge load)
     for (;;) {
@@ -334,10 +337,11 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double *A = L.A;
                 const double aii = is_row ? A[row * LD + row] : 1.0;
                 if (ps && !reuse_diagonal) diag = fmin(fmax(scale * scale * aii, kMinLmDiag), kMaxLmDiag);
-                const double Dl = sqrt(diag / radius);
                 // (S A S + D^2) y = S g  <=>  (A + S^-1 D^2 S^-1) (S y) = g: the unscaled system with the same Jacobi-
-                // scaled LM diagonal gives the step directly and saves two multiplies and an LDS read per element
-                const double dd = Dl * Dl * inv_scale * inv_scale;
+                // scaled LM diagonal gives the step directly and saves two multiplies and an LDS read per element.
+                // D^2 = diag / radius (Ceres squares sqrt(diag / radius): the same up to two roundings; radius is in [1e-32, 1e16])
+                const double dd = diag * fast_rcp(radius) * (inv_scale * inv_scale);
+                const double dd_lane = is_row ? dd : 1.0;             // padded rows are identity
                 double rhs = is_row ? gi : 0.0;
                 const double rhs0 = rhs;
                 double piv_own = 1.0;
@@ -351,10 +355,16 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
 #pragma unroll
                     for (int c = 0; c < CL; ++c) {
                         const int j = LPR * c + part;
-                        double v = 0.0;
-                        if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]);
-                        if (j == row) v = is_row ? v + dd : 1.0;
-                        h[c] = v;
+                        if constexpr (NV == 32) {     // (the unconditional form below lets the 24 loads run ahead together: 40-60 spilled VGPRs here)
+                            double v = 0.0;
+                            if (is_row && j < nv2) v = (j <= row ? A[row * LD + j] : A[j * LD + row]);
+                            if (j == row) v = is_row ? v + dd : 1.0;
+                            h[c] = v;
+                        } else {
+                            // rows >= nv2 of A are zero (prologue), so columns beyond the system and padded rows read 0 without a mask
+                            const double v = (j <= row ? A[row * LD + j] : A[j * LD + row]);
+                            h[c] = (j == row) ? v + dd_lane : v;
+                        }
                     }
                     PROF_MARK(5);                     // 5: step setup (diagonal, h build)
                     ISA_MARK("gauss_jordan");
@@ -381,16 +391,21 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const unsigned long long badmask = __ballot(is_row && !isfinite(step));
                 const unsigned long long gmask = (S == 64) ? ~0ull : ((1ull << (S & 63)) - 1);
                 const bool bad = ((badmask >> ((gid * S) & 63)) & gmask) != 0;
-                const double mcc = 0.5 * group_sum<S>(own ? (-rhs0 * step + dd * step * step) : 0.0);
                 const double dl = step;
-                const double gdd = group_sum<S>(own ? gi * dl : 0.0);
-                const double dmx = group_max<S>(fabs(dl));
+                // the four sums of an LM step in one transposed butterfly: model change, g . delta, and |x - x_trial|^2, |x_trial|^2 of
+                // the full step's trial point (the decision after the sweep reads the last two from LDS; a line-search contraction
+                // recomputes them for its point, and only it needs max |delta| and g_new . delta)
+                const double xt_full = clampb(__dadd_rn(xi, dl));
+                double mcc = own ? (-rhs0 * step + dd * step * step) : 0.0, gdd = own ? gi * dl : 0.0;
+                double sn2 = own ? (xi - xt_full) * (xi - xt_full) : 0.0, xn2 = own ? xt_full * xt_full : 0.0;
+                group_sum4<S>(mcc, gdd, sn2, xn2);
+                mcc *= 0.5;
                 if (ps) {
                     reuse_diagonal = true;
                     const bool valid = !fail && !bad && mcc > 0.0;
                     if (!valid) {
                         if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; phase = PH_DONE; }
-                        else { radius = radius / ldexp(1.0, 1 + n_reject); ++n_reject; }      // StepIsInvalid -> StepRejected(0)
+                        else { radius = ldexp(radius, -(1 + n_reject)); ++n_reject; }          // StepIsInvalid -> StepRejected(0): radius / 2^(1 + n_reject)
                     } else {
                         n_invalid = 0;
                         model_cost_change = mcc; delta = dl; g_dot_delta = gdd;
@@ -399,8 +414,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                         // next test (config 4: every final iteration, 0.1 % of the others): evaluate the cost only;
                         // if the solve does not stop there, the same point is evaluated again in full.
                         cost_only = mcc <= kFunctionTol * cost;
-                        if (sl == 0) { L.dir_max = dmx; L.ls_iter = 0; L.ls_prev_flags = 0; }
-                        xt = clampb(__dadd_rn(xi, delta));
+                        if (sl == 0) { L.step_norm2 = sn2; L.xnorm2 = xn2; L.ls_iter = 0; L.ls_prev_flags = 0; }
+                        xt = xt_full;
                         if (own) L.x[row] = xt;
                         phase = PH_EVAL_LS;
                     }
@@ -440,7 +455,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
                 EdgeOut o;
                 ISA_MARK("eval");
-                eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o, at_zero);
                 ISA_MARK("assemble");
                 cost_l += o.cost;
                 if (!jac) continue;
@@ -496,6 +511,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 cost_l += o.cost;
             }
         }
+        at_zero = false;
         wave_lds_sync();
         PROF_MARK(2);                                 // 2: edge sweep (evaluate + assemble)
         // cross-lane quantities of every possible transition (uniform control flow)
@@ -503,9 +519,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         const double xe = (phase == PH_EVAL_INIT || phase == PH_REEVAL) ? xi : xt;     // row: the evaluated point
         const double gnew = is_row ? L.g[row] : 0.0;
         const double gmax_new = group_max<S>(is_row ? fabs(xe - clampb(xe - gnew)) : 0.0);
-        const double gdc = group_sum<S>(own ? delta * gnew : 0.0);
-        const double step_norm2 = group_sum<S>(own ? (xi - xt) * (xi - xt) : 0.0);
-        const double xnorm2_new = group_sum<S>(own ? xt * xt : 0.0);
+        const double step_norm2 = L.step_norm2, xnorm2_new = L.xnorm2;     // of the trial point (group-uniform LDS reads)
 
         PROF_MARK(3);                                 // 3: post-sweep reductions
         // ======================= C: transitions (no cross-lane operations below) =======================
@@ -525,8 +539,8 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
             // evaluation of the same point in full next round; nothing is counted for this one.
             cost_only = false;
             const bool armijo = isfinite(cost_e) && !(cost_e > cost + kLsSufficientDecrease * g_dot_delta * alpha);
-            const bool stop = armijo && (sqrt(step_norm2) <= kParameterTol * (x_norm + kParameterTol) ||
-                                         fabs(cost - cost_e) <= kFunctionTol * cost);
+            const double ptol = kParameterTol * (x_norm + kParameterTol);
+            const bool stop = armijo && (step_norm2 <= ptol * ptol || fabs(cost - cost_e) <= kFunctionTol * cost);
             if (stop) {
                 if (sl == 0) atomicAdd(&L.n_ls_evals, 1);
                 decide = true; cost_cand = cost_e;
@@ -539,6 +553,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
             } else {
                 // rare: contraction.  Every lane of the group reads the same bookkeeping from LDS,
                 // computes the same next step; lane 0 writes the bookkeeping back.
+                // (cross-lane work inside this group-uniform branch: whole groups take it, the butterflies stay inside the group)
+                const double gdc = group_sum<S>(own ? delta * gnew : 0.0);
+                const double dir_max = group_max<S>(fabs(delta));
                 LsSample initial{0.0, cost, g_dot_delta, true, true}, previous, current;
                 const int pf = L.ls_prev_flags;
                 previous.x = L.ls_prev_x; previous.value = L.ls_prev_value; previous.gradient = L.ls_prev_gradient;
@@ -547,7 +564,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 current.gradient = value_valid ? gdc : 0.0;
                 current.gradient_valid = value_valid && isfinite(gdc);
                 int ls_iter = L.ls_iter;
-                const double nstep = ls_next_step(initial, previous, current, L.dir_max, ls_iter);
+                const double nstep = ls_next_step(initial, previous, current, dir_max, ls_iter);
                 wave_lds_sync();
                 if (sl == 0) {
                     L.ls_iter = ls_iter;
@@ -556,34 +573,35 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 }
                 if (nstep < 0.0) {                                                  // search failed: full step
                     xt = clampb(__dadd_rn(xi, delta));
-                    if (own) L.x[row] = xt;
                     phase = PH_EVAL_CAND;
                 } else {
                     alpha = nstep;
                     xt = clampb(__dadd_rn(xi, __dmul_rn(alpha, delta)));
-                    if (own) L.x[row] = xt;
                 }
+                if (own) L.x[row] = xt;
+                const double sn2 = group_sum<S>(own ? (xi - xt) * (xi - xt) : 0.0), xn2 = group_sum<S>(own ? xt * xt : 0.0);
+                if (sl == 0) { L.step_norm2 = sn2; L.xnorm2 = xn2; }
             }
         } else if (phase == PH_EVAL_CAND) {
             decide = true; cost_cand = isfinite(cost_e) ? cost_e : DBL_MAX;
         }
         if (decide) {
             if (sl == 0) atomicAdd(&L.n_cand, 1);
-            const double step_norm = sqrt(step_norm2);
             const double cost_change = cost - cost_cand;
-            if (step_norm <= kParameterTol * (x_norm + kParameterTol)) phase = PH_DONE;          // candidate discarded
+            const double ptol = kParameterTol * (x_norm + kParameterTol);
+            if (step_norm2 <= ptol * ptol) phase = PH_DONE;                                      // candidate discarded (|step| <= tol, squared)
             else if (fabs(cost_change) <= kFunctionTol * cost) phase = PH_DONE;                  // candidate discarded
             else {
-                const double rel = cost_change / model_cost_change;
+                const double rel = cost_change * fast_rcp(model_cost_change);       // (model_cost_change > 0: the step was valid)
                 if (rel > kMinRelDecrease) {
-                    xi = xt; x_norm = sqrt(xnorm2_new); cost = cost_cand; gi = gnew; gmax = gmax_new;
+                    xi = xt; x_norm = fast_sqrt(xnorm2_new); cost = cost_cand; gi = gnew; gmax = gmax_new;
                     step_successful = true;
                     if (sl == 0) atomicAdd(&L.n_successful, 1);
                     const double t = 2.0 * rel - 1.0;
-                    radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+                    radius = fmin(kMaxRadius, radius * fast_rcp(fmax(1.0 / 3.0, 1.0 - t * t * t)));
                     n_reject = 0; reuse_diagonal = false; a_dirty = false;
                 } else {
-                    radius = radius / ldexp(1.0, 1 + n_reject); ++n_reject;          // StepRejected
+                    radius = ldexp(radius, -(1 + n_reject)); ++n_reject;             // StepRejected: radius / 2^(1 + n_reject)
                     a_dirty = true;
                 }
                 phase = PH_SOLVE;
