@@ -69,17 +69,34 @@ __device__ __forceinline__ double cvt_pinned(float x) {
 // log(x) for finite x >= 1 (the Cauchy loss evaluates log(1 + s/b)): x = m * 2^e with m in
 // [sqrt(1/2), sqrt(2)), log m = 2 atanh((m-1)/(m+1)) by its odd series (|z| <= 0.1716, 11 terms),
 // e*ln2 added in two pieces.  ~35 instructions instead of ~90 of the generic libm log; error ~1 ulp.
-__device__ __forceinline__ double log_ge1(double x) {
+// The series coefficients 1/23 ... 1/3: either literals pinned into SGPR pairs at their use (22 s_mov_b32 per call, plus the moves that
+// restore what those SGPRs held), or - LogCoef::regs, for callers with VGPRs to spare - eleven values the caller keeps in registers
+// across its whole solve loop (v_fma_f64 takes them as its addend: no instruction per use).
+struct LogCoef {
+    double c[11];          // 1/23, 1/21, ..., 1/3
+    __device__ __forceinline__ void load() {
+#pragma unroll
+        for (int i = 0; i < 11; ++i) { c[i] = 1.0 / (23.0 - 2.0 * i); asm volatile("" : "+v"(c[i])); }     // opaque: not rematerialised per use
+    }
+};
+__device__ __forceinline__ double log_ge1(double x, const LogCoef *lc = nullptr) {
     int e = __builtin_amdgcn_frexp_exp(x);             // x = f * 2^e, f in [0.5, 1)
     double m = __builtin_amdgcn_frexp_mant(x);
     if (m < 0.70710678118654752440) { m *= 2.0; --e; }
     const double z = (m - 1.0) * fast_rcp(m + 1.0);
     const double w = z * z;
-    double p = sgpr_const(1.0 / 23.0);
-    p = fma(p, w, sgpr_const(1.0 / 21.0)); p = fma(p, w, sgpr_const(1.0 / 19.0)); p = fma(p, w, sgpr_const(1.0 / 17.0));
-    p = fma(p, w, sgpr_const(1.0 / 15.0)); p = fma(p, w, sgpr_const(1.0 / 13.0)); p = fma(p, w, sgpr_const(1.0 / 11.0));
-    p = fma(p, w, sgpr_const(1.0 / 9.0)); p = fma(p, w, sgpr_const(1.0 / 7.0)); p = fma(p, w, sgpr_const(1.0 / 5.0));
-    p = fma(p, w, sgpr_const(1.0 / 3.0));
+    double p;
+    if (lc) {
+        p = lc->c[0];
+#pragma unroll
+        for (int i = 1; i < 11; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(w), "v"(lc->c[i]));     // (not v_mov + v_fmac)
+    } else {
+        p = sgpr_const(1.0 / 23.0);
+        p = fma(p, w, sgpr_const(1.0 / 21.0)); p = fma(p, w, sgpr_const(1.0 / 19.0)); p = fma(p, w, sgpr_const(1.0 / 17.0));
+        p = fma(p, w, sgpr_const(1.0 / 15.0)); p = fma(p, w, sgpr_const(1.0 / 13.0)); p = fma(p, w, sgpr_const(1.0 / 11.0));
+        p = fma(p, w, sgpr_const(1.0 / 9.0)); p = fma(p, w, sgpr_const(1.0 / 7.0)); p = fma(p, w, sgpr_const(1.0 / 5.0));
+        p = fma(p, w, sgpr_const(1.0 / 3.0));
+    }
     const double lm = fma(2.0 * z * w, p, 2.0 * z);    // log(m)
     const double ed = (double)e;
     return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
@@ -105,7 +122,8 @@ struct EdgeOut {
 // with the same bits (the general form multiplies by those exact zeros and ones).
 template <bool WANT_JAC>
 __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, int kind, int tukey_variant,
-                                          double x1r, double x1c, double x2r, double x2c, EdgeOut &o, const bool at_zero = false) {
+                                          double x1r, double x1c, double x2r, double x2c, EdgeOut &o, const bool at_zero = false,
+                                          const LogCoef *lc = nullptr) {
     double f0 = 0., f1 = 0., dr0 = 0., dr1 = 0., dc0 = 0., dc1 = 0.;
     if (at_zero) {
         f0 = cvt_pinned(flow[8]); f1 = cvt_pinned(flow[9]);
@@ -147,16 +165,24 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     const double r0 = x2r - x1r - f0, r1 = x2c - x1c - f1;       // cost.cc:87
     const double s = r0 * r0 + r1 * r1;
     const double w = cvt_pinned(simf);
-    double rho0, sq;
-    if (kind == 0) {                                              // CauchyLoss(0.25)
+    double rho0, sq = 0.0;
+    // Cauchy edges (intra-track, kind 0) take a path of their own when the whole wave has no other kind: a wave-uniform branch
+    // instead of the exec-mask bracket of a divergent if / else around every evaluation
+    const bool all_cauchy = !__any(kind != 0);
+    if (all_cauchy || kind == 0) {                                // CauchyLoss(0.25)
         const double sum = 1.0 + s * kCauchyC;
-        rho0 = kCauchyB * log_ge1(sum);
-        // Corrector (rho'' <= 0 branch): sqrt(w rho') = sqrt(w / sum) = w rsqrt(w sum): one reciprocal square root instead of a
-        // reciprocal and a square root.  Outside the normal range (w = 0, a non-finite residual) the two-step form decides.
-        const double p = w * sum;
-        sq = 0.0;
-        if (WANT_JAC) sq = (p > 1e-290 && p < 1e290) ? w * fast_rsqrt(p) : sqrt(w * fmax(DBL_MIN, 1.0 / sum));
-    } else {                                                      // TukeyLoss(0.0625)
+        rho0 = kCauchyB * log_ge1(sum, lc);
+        if (WANT_JAC) {
+            // Corrector (rho'' <= 0 branch): sqrt(w rho') = sqrt(w / sum) = w rsqrt(w sum): one reciprocal square root instead of a
+            // reciprocal and a square root.  Outside the positive normal range (w <= 0, a non-finite residual) the two-step form
+            // decides, behind a wave-uniform branch (class mask 0x100: +normal).
+            const double p = w * sum;
+            const bool normal = __builtin_amdgcn_class(p, 0x100);
+            sq = w * fast_rsqrt(p);
+            if (__any(!normal)) sq = normal ? sq : sqrt(w * fmax(DBL_MIN, 1.0 / sum));
+        }
+    }
+    if (!all_cauchy && kind != 0) {                               // TukeyLoss(0.0625)
         const double k0 = (tukey_variant == 1) ? kTukeyA2 / 6.0 : kTukeyA2 / 3.0;
         const double k1 = (tukey_variant == 1) ? 0.5 : 1.0;
         double rho1;

@@ -123,6 +123,17 @@ struct KernelArgs {
 #define PROF_SWEEP_MARK(i)
 #define PROF_FACTOR_MARK(i) PROF_MARK(i)
 #endif
+// Experiments (scripts/ab_packed.py builds them as variants): what a phase of the packed kernel costs, measured by running it TWICE
+// with unchanged results (round 6, config 4, 0.45 ms: atomics +15 %, evaluation +21 %, matrix build + elimination +16 %,
+// reductions +2 %, zeroing +2 % - profiles/r06_ablation_packed_kernel.txt)
+#ifdef LFR_DOUBLE_ATOMICS          // every term of the assembly added as two halves
+#define LFR_ASM_ADD(p, v) do { const double v_ = 0.5 * (v); atomicAdd(p, v_); atomicAdd(p, v_); } while (0)
+#else
+#define LFR_ASM_ADD(p, v) atomicAdd(p, v)
+#endif
+#ifndef LFR_LOG_REGS
+#define LFR_LOG_REGS 1             // 8- / 16-row classes: the logarithm's series coefficients live in VGPRs (0: literals moved into SGPRs at every use)
+#endif
 #ifndef LFR_GJ_DPP
 #define LFR_GJ_DPP 2               // elimination of the 16-row (1) and also the 8-row (2) packed class with DPP row broadcasts; 0: ds_swizzle
 #endif
@@ -194,7 +205,7 @@ struct GaussJordan {
 };
 
 template <int NV>
-struct GroupLds {
+struct alignas(16) GroupLds {
     static constexpr int LD = NV + 1;
     double A[NV * LD];         // J^T J (lower triangle) of the last evaluation
     double g[NV];              // J^T r of the last evaluation
@@ -317,6 +328,11 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
     if (sl == 0) { L.n_successful = 0; L.n_ls_evals = 0; L.n_cand = 0; L.exec_passes = 0; L.ls_iter = 0; L.ls_prev_flags = 0; }
 
     bool at_zero = true;                              // wave-uniform: the first sweep evaluates every edge at the origin (PH_EVAL_INIT)
+    // the logarithm's series coefficients in 22 VGPRs for the whole solve where the class has them to spare (8- and 16-row classes)
+    constexpr bool kLogRegs = NV <= 16 && LPR == 1 && LFR_LOG_REGS;
+    LogCoef logc;
+    if constexpr (kLogRegs) logc.load();
+    const LogCoef *lcp = kLogRegs ? &logc : nullptr;
     PROF_DECL
     PROF_MARK(0);                                     // 0: prologue (edge load)
     for (;;) {
@@ -371,7 +387,11 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                     GaussJordan<NV, LPR, 0, CL>::run(h, rhs, piv_own, minpiv, row, part, nv2_max);
                 };
                 const int c_hi = (nv2_max + LPR - 1) / LPR;          // wave-uniform
+#ifdef LFR_ABL_GJ              // matrix build + elimination twice (the first result discarded through an opaque reset)
+#define LFR_CL(n) do { lm_solve(std::integral_constant<int, n>{}); asm volatile("" : "+v"(rhs), "+v"(piv_own), "+v"(minpiv)); rhs = rhs0; piv_own = 1.0; minpiv = 1.0; lm_solve(std::integral_constant<int, n>{}); } while (0)
+#else
 #define LFR_CL(n) lm_solve(std::integral_constant<int, n>{})
+#endif
                 if constexpr (CPL == 8 && LPR == 1) {             // rows come in pairs: even sizes only
                     if (c_hi <= 2) LFR_CL(2); else if (c_hi <= 4) LFR_CL(4); else if (c_hi <= 6) LFR_CL(6); else LFR_CL(8);
                 } else if constexpr (CPL == 8) {
@@ -398,6 +418,10 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double xt_full = clampb(__dadd_rn(xi, dl));
                 double mcc = own ? (-rhs0 * step + dd * step * step) : 0.0, gdd = own ? gi * dl : 0.0;
                 double sn2 = own ? (xi - xt_full) * (xi - xt_full) : 0.0, xn2 = own ? xt_full * xt_full : 0.0;
+#ifdef LFR_ABL_RED             // every reduction twice
+                { double a_ = mcc, b_ = gdd, c_ = sn2, d_ = xn2; asm volatile("" : "+v"(a_), "+v"(b_), "+v"(c_), "+v"(d_)); group_sum4<S>(a_, b_, c_, d_);
+                  asm volatile("" :: "v"(a_), "v"(b_), "v"(c_), "v"(d_)); }
+#endif
                 group_sum4<S>(mcc, gdd, sn2, xn2);
                 mcc *= 0.5;
                 if (ps) {
@@ -429,8 +453,14 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         if (!__any(pe)) continue;
         const bool jac = !cost_only;                  // (cost_only is only ever set in PH_EVAL_LS)
         if (pe && jac) {
-            for (int i = sl; i < nv2 * LD; i += S) L.A[i] = 0.0;       // rows >= nv2 are never touched
-            if (sl < NV) L.g[sl] = 0.0;
+            // rows >= nv2 are never touched.  16-byte stores: as many LDS instructions went into this zeroing as into the atomics
+            double2 *A2 = reinterpret_cast<double2 *>(L.A);
+            for (int i = sl; i < (nv2 * LD + 1) / 2; i += S) A2[i] = make_double2(0.0, 0.0);
+            if (sl < NV / 2) reinterpret_cast<double2 *>(L.g)[sl] = make_double2(0.0, 0.0);
+#ifdef LFR_ABL_ZERO            // the zeroing twice
+            wave_lds_sync();
+            for (int i = sl; i < (nv2 * LD + 1) / 2; i += S) A2[i] = make_double2(0.0, 0.0);
+#endif
         }
         wave_lds_sync();
         PROF_MARK(6);                                 // 6: zero J^T J
@@ -455,7 +485,17 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const int ra = es < n_var ? 2 * es : -1, rb = ed < n_var ? 2 * ed : -1;
                 EdgeOut o;
                 ISA_MARK("eval");
-                eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o, at_zero);
+                eval_edge<true>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o, at_zero, lcp);
+#ifdef LFR_ABL_EVAL            // the evaluation twice (the second on opaque copies of the positions), results averaged (= unchanged)
+                {
+                    double y0 = L.x[xa], y1 = L.x[xa + 1], y2 = L.x[xb], y3 = L.x[xb + 1];
+                    asm volatile("" : "+v"(y0), "+v"(y1), "+v"(y2), "+v"(y3));
+                    EdgeOut o2;
+                    eval_edge<true>(flow_k, sim_k, ekind, tv, y0, y1, y2, y3, o2, at_zero, lcp);
+                    o.cost = 0.5 * (o.cost + o2.cost); o.r0 = 0.5 * (o.r0 + o2.r0); o.r1 = 0.5 * (o.r1 + o2.r1); o.sq = 0.5 * (o.sq + o2.sq);
+                    o.j00 = 0.5 * (o.j00 + o2.j00); o.j01 = 0.5 * (o.j01 + o2.j01); o.j10 = 0.5 * (o.j10 + o2.j10); o.j11 = 0.5 * (o.j11 + o2.j11);
+                }
+#endif
                 ISA_MARK("assemble");
                 cost_l += o.cost;
                 if (!jac) continue;
@@ -474,16 +514,16 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 const double c1 = c_own1 + dpp_f64<kDppQuadXor1>(c_send1);
                 const double c2 = c_own2 + dpp_f64<kDppQuadXor1>(c_send2);
                 if (ra >= 0) {
-                    atomicAdd(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10 + p_w);
-                    atomicAdd(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
-                    atomicAdd(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11 + p_w);
-                    atomicAdd(&g[ra], o.j00 * o.r0 + o.j10 * o.r1 + p_g0);
-                    atomicAdd(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1 + p_g1);
+                    LFR_ASM_ADD(&A[ra * LD + ra], o.j00 * o.j00 + o.j10 * o.j10 + p_w);
+                    LFR_ASM_ADD(&A[(ra + 1) * LD + ra], o.j01 * o.j00 + o.j11 * o.j10);
+                    LFR_ASM_ADD(&A[(ra + 1) * LD + ra + 1], o.j01 * o.j01 + o.j11 * o.j11 + p_w);
+                    LFR_ASM_ADD(&g[ra], o.j00 * o.r0 + o.j10 * o.r1 + p_g0);
+                    LFR_ASM_ADD(&g[ra + 1], o.j01 * o.r0 + o.j11 * o.r1 + p_g1);
                 }
                 if (ra >= 0 && rb >= 0) {
                     const int r1 = rb + q, k1 = ra, r2 = rb + 1 - q, k2 = ra + 1;
-                    atomicAdd(&A[rb > ra ? r1 * LD + k1 : k1 * LD + r1], c1);
-                    atomicAdd(&A[rb > ra ? r2 * LD + k2 : k2 * LD + r2], c2);
+                    LFR_ASM_ADD(&A[rb > ra ? r1 * LD + k1 : k1 * LD + r1], c1);
+                    LFR_ASM_ADD(&A[rb > ra ? r2 * LD + k2 : k2 * LD + r2], c2);
                 }
             }
         } else {
@@ -506,7 +546,7 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
                 EdgeOut o;
                 (void)ra; (void)rb;
                 ISA_MARK("eval_cost_only");
-                eval_edge<false>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o);
+                eval_edge<false>(flow_k, sim_k, ekind, tv, L.x[xa], L.x[xa + 1], L.x[xb], L.x[xb + 1], o, false, lcp);
                 ISA_MARK("cost_only_loop");
                 cost_l += o.cost;
             }
@@ -515,6 +555,9 @@ __device__ __forceinline__ void solve_group_body(const KernelArgs &a, const int 
         wave_lds_sync();
         PROF_MARK(2);                                 // 2: edge sweep (evaluate + assemble)
         // cross-lane quantities of every possible transition (uniform control flow)
+#ifdef LFR_ABL_RED
+        { double a_ = cost_l; asm volatile("" : "+v"(a_)); a_ = group_sum<S>(a_); asm volatile("" :: "v"(a_)); a_ = group_max<S>(a_); asm volatile("" :: "v"(a_)); }
+#endif
         const double cost_e = group_sum<S>(cost_l);
         const double xe = (phase == PH_EVAL_INIT || phase == PH_REEVAL) ? xi : xt;     // row: the evaluated point
         const double gnew = is_row ? L.g[row] : 0.0;
