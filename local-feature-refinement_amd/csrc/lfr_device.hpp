@@ -87,9 +87,12 @@ __device__ __forceinline__ double log_ge1(double x, const LogCoef *lc = nullptr)
     const double w = z * z;
     double p;
     if (lc) {
-        p = lc->c[0];
-#pragma unroll
-        for (int i = 1; i < 11; ++i) asm("v_fma_f64 %0, %1, %2, %3" : "=v"(p) : "v"(p), "v"(w), "v"(lc->c[i]));     // (not v_mov + v_fmac)
+        // one statement: ten dependent v_fma_f64 (not v_mov + v_fmac each, and no pad state after every statement)
+        asm("v_fma_f64 %0, %1, %2, %3\n\tv_fma_f64 %0, %0, %2, %4\n\tv_fma_f64 %0, %0, %2, %5\n\tv_fma_f64 %0, %0, %2, %6\n\t"
+            "v_fma_f64 %0, %0, %2, %7\n\tv_fma_f64 %0, %0, %2, %8\n\tv_fma_f64 %0, %0, %2, %9\n\tv_fma_f64 %0, %0, %2, %10\n\t"
+            "v_fma_f64 %0, %0, %2, %11\n\tv_fma_f64 %0, %0, %2, %12"
+            : "=&v"(p) : "v"(lc->c[0]), "v"(w), "v"(lc->c[1]), "v"(lc->c[2]), "v"(lc->c[3]), "v"(lc->c[4]), "v"(lc->c[5]), "v"(lc->c[6]),
+              "v"(lc->c[7]), "v"(lc->c[8]), "v"(lc->c[9]), "v"(lc->c[10]));
     } else {
         p = sgpr_const(1.0 / 23.0);
         p = fma(p, w, sgpr_const(1.0 / 21.0)); p = fma(p, w, sgpr_const(1.0 / 19.0)); p = fma(p, w, sgpr_const(1.0 / 17.0));
@@ -165,24 +168,22 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
     const double r0 = x2r - x1r - f0, r1 = x2c - x1c - f1;       // cost.cc:87
     const double s = r0 * r0 + r1 * r1;
     const double w = cvt_pinned(simf);
-    double rho0, sq = 0.0;
+    double rho0 = 0.0, sq = 0.0;
     // Cauchy edges (intra-track, kind 0) take a path of their own when the whole wave has no other kind: a wave-uniform branch
     // instead of the exec-mask bracket of a divergent if / else around every evaluation
-    const bool all_cauchy = !__any(kind != 0);
-    if (all_cauchy || kind == 0) {                                // CauchyLoss(0.25)
+    auto cauchy = [&]() {                                         // CauchyLoss(0.25)
         const double sum = 1.0 + s * kCauchyC;
         rho0 = kCauchyB * log_ge1(sum, lc);
         if (WANT_JAC) {
             // Corrector (rho'' <= 0 branch): sqrt(w rho') = sqrt(w / sum) = w rsqrt(w sum): one reciprocal square root instead of a
             // reciprocal and a square root.  Outside the positive normal range (w <= 0, a non-finite residual) the two-step form
-            // decides, behind a wave-uniform branch (class mask 0x100: +normal).
+            // decides (class mask 0x2ff: everything but +normal; one v_cmp_class and a skipped branch on the usual path).
             const double p = w * sum;
-            const bool normal = __builtin_amdgcn_class(p, 0x100);
             sq = w * fast_rsqrt(p);
-            if (__any(!normal)) sq = normal ? sq : sqrt(w * fmax(DBL_MIN, 1.0 / sum));
+            if (__builtin_amdgcn_class(p, 0x2ff)) sq = sqrt(w * fmax(DBL_MIN, 1.0 / sum));
         }
-    }
-    if (!all_cauchy && kind != 0) {                               // TukeyLoss(0.0625)
+    };
+    auto tukey = [&]() {                                          // TukeyLoss(0.0625)
         const double k0 = (tukey_variant == 1) ? kTukeyA2 / 6.0 : kTukeyA2 / 3.0;
         const double k1 = (tukey_variant == 1) ? 0.5 : 1.0;
         double rho1;
@@ -192,7 +193,10 @@ __device__ __forceinline__ void eval_edge(const float (&flow)[18], float simf, i
             rho1 = k1 * v2;
         } else { rho0 = k0; rho1 = 0.0; }
         sq = WANT_JAC ? fast_sqrt(rho1 * w) : 0.0;
-    }
+    };
+    if (__builtin_amdgcn_ballot_w64(kind != 0) == 0ull) cauchy();
+    else if (kind == 0) cauchy();
+    else tukey();
     rho0 *= w;
     o.cost = 0.5 * rho0;
     if (!WANT_JAC) return;
