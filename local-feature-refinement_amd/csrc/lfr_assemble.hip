@@ -651,13 +651,18 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- records: gather the flows (their first consumer); staged flows arrive in chunks on the copy stream ----
     // Every launch walks the whole edge list and keeps the edges of its rows, so chunks whose upload has already finished
     // (all of them when the graph is resident) go out as ONE launch: four filtered passes were 40 % of the gather.
-    const int n_chunks = dg.flows_staged ? kFlowChunks : 1;
+    // A connected-component shard (dg.parent) carries the PARENT's upload events and chunk bounds, but its match indices are compacted:
+    // match m of the shard reads flow row flow_row[m] >= m, which can lie in a later chunk than chunk_row[] says for m.
+    // It waits for every chunk and emits in one pass.
+    const bool shard = (bool)dg.parent;
+    const bool chunked = dg.flows_staged && !shard;
+    const int n_chunks = chunked ? kFlowChunks : 1;
     const bool emit = !fused || expect_workgroup_classes;          // (fused and no workgroup class expected: nothing to write; the summary has the last word)
-    if (!emit && dg.flows_staged)                                     // the solve reads the flows themselves: every chunk must have landed
-        for (int c = 0; c < n_chunks; ++c) if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
+    if ((!emit || shard) && dg.flows_staged)                          // the solve reads the flows themselves / a shard gathers any row: every chunk must have landed
+        for (int c = 0; c < kFlowChunks; ++c) if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
     for (int c = 0; emit && c < n_chunks;) {
         int c2 = c + 1;
-        if (dg.flows_staged) {
+        if (chunked) {
             auto landed = [&](int k) {
                 if (!dg.ev_flows[k]) return true;
                 const hipError_t q = hipEventQuery(dg.ev_flows[k]);
@@ -667,7 +672,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
             if (landed(c)) while (c2 < n_chunks && landed(c2)) ++c2;
             else if (dg.ev_flows[c]) LFR_HIP_TRY(hipStreamWaitEvent(st, dg.ev_flows[c], 0));
         }
-        const int64_t lo = dg.flows_staged ? dg.chunk_row[c] : 0, hi = dg.flows_staged ? dg.chunk_row[c2] : M;
+        const int64_t lo = chunked ? dg.chunk_row[c] : 0, hi = chunked ? dg.chunk_row[c2] : M;
         if (hi > lo || (c == 0 && n_chunks == 1)) {
             if (aligned8)
                 hipLaunchKernelGGL(k_emit_edges<true>, grid_for(5 * E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2,

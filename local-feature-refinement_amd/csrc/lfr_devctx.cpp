@@ -11,6 +11,10 @@
 #include <deque>
 #include <functional>
 #include <memory>
+#include <pthread.h>
+#include <new>
+#include <mutex>
+#include <exception>
 #include <thread>
 
 #include "lfr_internal.hpp"
@@ -231,14 +235,17 @@ struct Pool {
     std::condition_variable wake, done, task_done;
     const std::function<void()> *job = nullptr;
     int tickets = 0, running = 0, n_threads = 0;
+    std::exception_ptr job_err;                 // first exception of a run_on_pool job on a worker (rethrown by run_on_pool)
     std::deque<std::shared_ptr<PoolTask>> tasks;
     void grow(int n) { while (n_threads < n) { std::thread(&Pool::worker, this).detach(); ++n_threads; } }     // (mu held)
     void run_task(std::unique_lock<std::mutex> &lk) {                                                             // (mu held, a task queued)
         std::shared_ptr<PoolTask> t = tasks.front();
         tasks.pop_front();
         lk.unlock();
-        t->fn();
+        std::exception_ptr err;
+        try { t->fn(); } catch (...) { err = std::current_exception(); }      // (never out of a detached worker; the waiter rethrows)
         lk.lock();
+        t->err = err;
         t->done = true;
         task_done.notify_all();
     }
@@ -250,13 +257,31 @@ struct Pool {
             --tickets;
             const std::function<void()> *f = job;
             lk.unlock();
-            (*f)();
+            std::exception_ptr err;
+            try { (*f)(); } catch (...) { err = std::current_exception(); }
             lk.lock();
+            if (err && !job_err) job_err = err;
             if (--running == 0) done.notify_all();
         }
     }
 };
-Pool *pool() { static Pool *p = new Pool(); return p; }      // never destroyed: its workers sleep until the process ends
+// never destroyed: its workers sleep until the process ends.  A forked child has none of the threads (and possibly a mutex that was
+// held at the fork): it starts with a pool of its own (pthread_atfork; the parent's object is leaked in the child).
+std::atomic<Pool *> g_pool{nullptr};
+std::mutex g_pool_mu;
+Pool *pool() {
+    Pool *p = g_pool.load(std::memory_order_acquire);
+    if (p) return p;
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    p = g_pool.load(std::memory_order_relaxed);
+    if (!p) {
+        static bool registered = false;
+        if (!registered) { registered = true; pthread_atfork(nullptr, nullptr, [] { g_pool.store(nullptr); new (&g_pool_mu) std::mutex(); }); }
+        p = new Pool();
+        g_pool.store(p, std::memory_order_release);
+    }
+    return p;
+}
 }  // namespace
 
 void run_on_pool(int threads, const std::function<void()> &work) {
@@ -276,10 +301,16 @@ void run_on_pool(int threads, const std::function<void()> &work) {
         P.job = &work; P.tickets = threads - 1; P.running = threads - 1;
     }
     P.wake.notify_all();
-    work();
+    std::exception_ptr err;
+    try { work(); } catch (...) { err = std::current_exception(); }       // (the workers still hold `work`: wait for them before unwinding)
     std::unique_lock<std::mutex> lk(P.mu);
     P.done.wait(lk, [&] { return P.running == 0; });
     P.job = nullptr;
+    if (!err) err = P.job_err;
+    P.job_err = nullptr;
+    lk.unlock();
+    only.unlock();
+    if (err) std::rethrow_exception(err);
 }
 
 std::shared_ptr<PoolTask> pool_async(std::function<void()> fn) {
@@ -303,6 +334,7 @@ void pool_wait(const std::shared_ptr<PoolTask> &t) {
         if (!P.tasks.empty()) P.run_task(lk);   // (a waiting thread works: tasks that spawn and wait for tasks cannot starve each other of workers)
         else P.task_done.wait(lk);
     }
+    if (t->err) { const std::exception_ptr e = t->err; t->err = nullptr; lk.unlock(); std::rethrow_exception(e); }
 }
 
 }  // namespace lfr

@@ -315,9 +315,16 @@ void cut_rec(const SubGraph &g, const std::vector<int64_t> &node_weights, int64_
             spawned = true;
         } else g_cut_tasks.fetch_sub(1);
     }
-    if (!child[0].ea.empty()) cut_rec(child[0], node_weights, max_weight, sub[0]);
-    if (spawned) { pool_wait(second); g_cut_tasks.fetch_sub(1); }
-    else if (!child[1].ea.empty()) cut_rec(child[1], node_weights, max_weight, sub[1]);
+    {
+        // the task reads this frame's locals: should the first half throw, it must have finished before the frame unwinds
+        struct Joiner {
+            std::shared_ptr<PoolTask> &t; bool pending;
+            ~Joiner() { if (pending) { try { pool_wait(t); } catch (...) {} g_cut_tasks.fetch_sub(1); } }
+        } joiner{second, spawned};
+        if (!child[0].ea.empty()) cut_rec(child[0], node_weights, max_weight, sub[0]);
+        if (spawned) { joiner.pending = false; g_cut_tasks.fetch_sub(1); pool_wait(second); }       // (rethrows what the second half threw)
+        else if (!child[1].ea.empty()) cut_rec(child[1], node_weights, max_weight, sub[1]);
+    }
     out.assign(n, -1);
     int max_idx = 0;
     for (int s = 0; s < 2; ++s) {

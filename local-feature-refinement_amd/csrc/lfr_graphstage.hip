@@ -997,15 +997,17 @@ int warm_graphstage_primitives(DevCtx *ctx) {
         if ((rc = sort_pairs(arena, k64a, k64b, v32a, v32b, n, 0, 52, st)) != LFR_OK) return rc;
         if ((rc = exclusive_sum(arena, v32a, v32b, n, st)) != LFR_OK) return rc;
     }
-    if (const char *e = getenv("LFR_ROUNDS_COOPERATIVE"); e && e[0] == '1') {   // the cooperative launch of the union-find rounds: an empty list
+    // the two opt-in forms of the union-find rounds (the default is one launch per round and needs no warm-up of its own): an empty list each
+    const char *e_coop = getenv("LFR_ROUNDS_COOPERATIVE"), *e_xcd = getenv("LFR_ROUNDS_XCD");
+    const bool coop = e_coop && e_coop[0] == '1', xcd = e_xcd && e_xcd[0] == '1' && !coop;
+    if (coop || xcd) {
         uint32_t *c = arena.take_n<uint32_t>(16 + 160);
         if (c) {
             LFR_HIP_TRY(hipMemsetAsync(c, 0, 4 * (16 + 160), st));
             RoundsArgs ra{0, 1024, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, kMaxRounds, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, c, c + 16, 0, 0};
             void *kargs[1] = {&ra};
-            if (hipLaunchCooperativeKernel((const void *)k_rounds_all<false>, dim3(256), dim3(kThreads), kargs, 0, st) != hipSuccess) (void)hipGetLastError();
-            LFR_HIP_TRY(hipMemsetAsync(c, 0, 4 * (16 + 160), st));
-            hipLaunchKernelGGL(k_rounds_all<true>, dim3(64), dim3(kThreads), 0, st, ra);      // (the default path's kernel: one XCD)
+            if (coop) { if (hipLaunchCooperativeKernel((const void *)k_rounds_all<false>, dim3(256), dim3(kThreads), kargs, 0, st) != hipSuccess) (void)hipGetLastError(); }
+            else hipLaunchKernelGGL(k_rounds_all<true>, dim3(64), dim3(kThreads), 0, st, ra);      // (LFR_ROUNDS_XCD=1: the rounds on one XCD - measured slower, not the default)
         }
     }
     LFR_HIP_TRY(stream_wait(st));

@@ -5,6 +5,7 @@
 #include <mutex>
 #include <string>
 #include <unordered_map>
+#include <exception>
 #include <functional>
 #include <vector>
 
@@ -136,7 +137,8 @@ void run_on_pool(int threads, const std::function<void()> &work);
 // One task for the same workers (the size cap's recursion hands the second half of a bisection to one: creating a thread per half cost
 // 0.1-1 ms each).  pool_wait returns when the task has run; while it waits the caller runs queued tasks itself, so tasks may spawn and wait
 // for tasks of their own.
-struct PoolTask { std::function<void()> fn; bool done = false; };
+// An exception thrown by the task is kept and rethrown by pool_wait (on a detached worker it would end the process).
+struct PoolTask { std::function<void()> fn; bool done = false; std::exception_ptr err; };
 std::shared_ptr<PoolTask> pool_async(std::function<void()> fn);
 void pool_wait(const std::shared_ptr<PoolTask> &t);
 

@@ -2899,6 +2899,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             valid = isfinite(dir_max) && model_cost_change > 0.0;
         }
         if (!valid) {
+            // (a team's bad-pivot word is reset by the leader at the top of the next iteration; every member must have
+            // read it first - no sweep or reduction, hence no team barrier, lies on this path otherwise)
+            if constexpr (TEAM) tsync();
             if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
             radius = radius / decrease_factor;
             decrease_factor *= 2.0;

@@ -364,6 +364,10 @@ class Problem:
         h = C.c_void_p()
         co = None if component_override is None else np.ascontiguousarray(component_override, np.int64)
         self.cc_sharded = False
+        if shard is not None and device_graph_stage is None:
+            raise ValueError("Problem(shard=...) needs device_graph_stage: the host graph stage is not sharded (deal the components with Batch(p, dev, rank, world))")
+        if shard is not None and component_override is not None:
+            raise ValueError("Problem(shard=...) cannot be combined with component_override (lfr_problem_build_hip_shard has no override)")
         if device_graph_stage is not None and shard is not None and shard[1] > 1:
             # multi-GPU: this rank's connected components only (lfr_problem_build_hip_shard); cc_sharded False = the whole graph after all
             _check(lib().lfr_problem_build_hip_shard(graph._h, int(device_graph_stage), int(max_nodes_in_component), int(flags),

@@ -35,3 +35,15 @@ def test_struct_layouts_match_header():
     # field counts/sizes of the two stats structs as declared in lfr.h
     assert ctypes.sizeof(capi.ProblemStats) == 9 * 8 + 6 * 8        # (tie_resorts: round 4)
     assert ctypes.sizeof(capi.SolveStats) == 12 * 8 + 5 * 8 + 4 * 8
+
+
+def test_problem_shard_arguments_are_checked(lfr_lib):
+    """Problem(shard=...) used to be ignored silently without a device graph stage, and dropped component_override."""
+    import numpy as np
+    import pytest
+    from lfr_amd import synthetic
+    g = capi.Graph.from_arrays(synthetic.generate(seed=5, n_images=8, n_tracks=20))
+    with pytest.raises(ValueError):
+        capi.Problem(g, shard=(0, 2))
+    with pytest.raises(ValueError):
+        capi.Problem(g, device_graph_stage=0, shard=(0, 2), component_override=np.zeros(g.n_nodes, np.int64))

@@ -365,6 +365,37 @@ def test_graph_stage_sharded_by_connected_component(lfr_lib, world):
     assert (pg.labels()[2] == pw.labels()[2]).all()
 
 
+def test_sharded_problem_first_on_a_cold_graph(lfr_lib):
+    """a connected-component shard carries its parent's upload events and chunk bounds, but its match indices are
+    compacted - the record gather of a shard built FIRST on a graph whose flows are still on their way to HBM (flags = 0: staged, chunked
+    upload on the copy stream) filtered on the wrong index and could read rows that had not landed.  Long tracks: workgroup classes, so the
+    assembly writes records.  Every rank's problem is built on a fresh Graph (cold), before any unsharded problem uploaded the flows."""
+    ma = synthetic.generate(seed=3, n_images=96, n_tracks=600, len_dist="uniform", len_lo=20, len_hi=60, eps_out=0.0005)
+    world = 2
+    got = None
+    edges = 0
+    for r in range(world):
+        g = capi.Graph.from_arrays(ma)                                       # cold: nothing of it is in HBM yet
+        pr = capi.Problem(g, device_graph_stage=0, shard=(r, world))         # flags = 0: the flows are staged by this very call
+        br = capi.Batch(pr, 0) if pr.cc_sharded else capi.Batch(pr, 0, r, world)
+        st = br.solve()
+        assert st["n_failed"] == 0
+        pos = br.download().copy()
+        if got is None:
+            got = np.zeros_like(pos)
+        touched = (pos != 0).any(axis=1)
+        assert not (touched & (got != 0).any(axis=1)).any()
+        got[touched] = pos[touched]
+        edges += st["n_edges"]
+    gw = capi.Graph.from_arrays(ma)
+    pw = capi.Problem(gw, device_graph_stage=0)
+    bw = capi.Batch(pw, 0)
+    stw = bw.solve()
+    want = bw.download()
+    assert edges == stw["n_edges"]
+    assert (got == want).all()
+
+
 def test_small_component_with_many_edges_takes_the_late_workgroup_path(lfr_lib):
     """No component above 17 nodes, so the device assembly expects packed classes only (three-pass edge sort, no incidence lists, no
     records) - but duplicated matches push one 17-node track beyond 320 edges, into a workgroup class: the assembly's summary has the last
