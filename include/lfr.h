@@ -10,6 +10,17 @@
  *
  * Units/axes: positions[2n] = di (row / y), positions[2n+1] = dj (col / x) of node n, in the
  * solver's unit (16 px * fact at extraction resolution; colmap_utils.py:133-136).
+ *
+ * Undefined inputs (the reference defines none of them; tests/test_gpu_undefined_inputs.py pins the library against the oracle):
+ *   - similarity == 0 is a legal weight: the edge drops out of the cost (ScaledLoss(.., 0), solve.cc:111,120);
+ *   - similarity < 0, +-inf or NaN, or a flow entry that is not finite, makes the evaluation of ITS component non-finite: no LM
+ *     step of that component is ever valid, it terminates LFR_TERM_FAILURE after ten invalid steps and keeps zero displacements
+ *     (Ceres: a non-finite evaluation fails, IsSolutionUsable() is false and solve.cc:609-612 left the positions at 0).  Every other
+ *     component - also one packed into the same wavefront - is solved exactly as if the bad match were not there;
+ *   - a NaN similarity additionally leaves the order-dependent graph stage (tracks and roots sort by similarity, solve.cc:489-582)
+ *     undefined in the reference itself; the library never emits a non-finite displacement, but which node of a tie becomes a
+ *     root may differ from a given Ceres build;
+ *   - all-zero flow grids (SKIP_REFINEMENT, compute_match_graph.py:150-152): every component converges at iteration 0, all zeros.
  */
 #ifndef LFR_H
 #define LFR_H
