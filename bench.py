@@ -178,7 +178,7 @@ def main():
         problem = capi.Problem(graph, device_graph_stage=local, flags=flags, shard=shard if strong else None)
         batch = make_batch(problem)
         batch.solve(stream, want_stats=False)
-        pos = batch.positions_view()
+        pos = batch.positions_view_f32()
         if keep is not None:
             keep.extend([problem, batch, pos])
 
@@ -202,7 +202,16 @@ def main():
     def solver_only():
         b = make_batch(problem)                                  # problem construction: device assembly of the batch
         b.solve(stream, want_stats=False)
-        b.positions_view()
+        b.positions_view_f32()
+
+    def d2h(fn):
+        ts = []
+        for _ in range(5):
+            sync(); t0 = time.perf_counter(); fn(); ts.append((time.perf_counter() - t0) * 1e3)
+        return statistics.median(ts)
+    positions_ms = {"f32": d2h(batch.positions_view_f32), "f64": d2h(batch.positions_view),
+                    "what": "the spans read the results back as float32 (converted on the device: the precision the reference's SolutionFile "
+                            "holds, solve.cc:661-664); f64 = the same read-back in the solver's own precision (until round 5 inside the spans)"}
 
     reps = max(1, args.span_reps)
     sp_total = spans(total_cold, reps, sync)
@@ -224,6 +233,7 @@ def main():
     torch.cuda.synchronize()
     dist.barrier()
     elapsed = time.perf_counter() - t_start
+    elapsed_local = elapsed
     elapsed = dist.max_over_ranks(elapsed)
 
     # ---- per-kernel durations of the timed steps (HIP events recorded on the launch stream) ----
@@ -263,7 +273,8 @@ def main():
                    "parallelism": ("components sharded, %d rank(s), no data-path collective" % world) +
                                   (" (graph stage, assembly and solve per rank over its connected components of the match graph)" if strong and problem.cc_sharded else "")},
         # the reference's own spans, one-shot, median of `reps` (max over ranks)
-        "solver_span": dict(rate(sp_solver), what="solve.cc:615-638: device assembly of the batch (problem construction) + solve + positions on the host"),
+        "solver_span": dict(rate(sp_solver), what="solve.cc:615-638: device assembly of the batch (problem construction) + solve + positions on the host (float32)"),
+        "positions_d2h_ms": positions_ms,
         "total_span": dict(rate(sp_total), what="solve.cc:487-641: graph stage + assembly + solve + positions on the host; the graph starts in "
                                                 "(pinned) host memory, its PCIe upload (%.0f MB) is inside" % (graph.n_edges / 2 * 156e-6)),
         "total_span_resident_graph": dict(rate(sp_total_res), what="solve.cc:487-641 with the match graph already in HBM (lfr_graph_to_device at ingest / "
@@ -318,6 +329,27 @@ def main():
                            "assembly_incl_flow_wait": st["h2d_ms"]}
         res["solve"] = {"converged": st["n_converged"], "no_convergence": st["n_no_convergence"], "failed": st["n_failed"],
                         "mean_iterations": st["sum_iterations"] / max(1, st["n_components"])}
+    if world > 1:
+        # Self-verification of a multi-GPU line: how many ranks the process group really had (an all-reduced count of
+        # ones), which device each rank ran on (name, PCI bus id / uuid where torch exposes them), what each rank solved and how long
+        # its K steps took locally - the headline is total edges / the slowest rank's time.
+        props = torch.cuda.get_device_properties(local)
+        me = {"rank": rank, "local_device": int(local), "name": torch.cuda.get_device_name(local),
+              "pci_bus_id": getattr(props, "pci_bus_id", None), "uuid": str(getattr(props, "uuid", "")) or None,
+              "edges": int(st["n_edges"]), "components": int(st["n_components"]), "ms_per_step_local": elapsed_local / args.steps * 1e3,
+              "cc_sharded": bool(problem.cc_sharded), "pid": os.getpid()}
+        ranks_seen = int(round(dist.sum_over_ranks(1.0)))
+        per_rank = dist.gather_objects(me)
+        if rank == 0:
+            ms = [r["ms_per_step_local"] for r in per_rank]
+            res["multi_gpu"] = {"ranks_seen": ranks_seen, "backend": torch.distributed.get_backend(), "per_rank": per_rank,
+                                "distinct_devices": len({(r["pci_bus_id"], r["uuid"], r["local_device"]) for r in per_rank}),
+                                "edges_sum_over_ranks": int(sum(r["edges"] for r in per_rank)), "edges_headline": int(edges_total),
+                                "ms_per_step_min": min(ms), "ms_per_step_max": max(ms)}
+            n1 = os.environ.get("LFR_BENCH_N1_VALUE")
+            if n1:
+                res["multi_gpu"]["efficiency_vs_n1"] = value / (world * float(n1))
+                res["multi_gpu"]["n1_value"] = float(n1)
     if world > 1 and not strong:
         # strong scaling beside the weak headline: ONE graph (seed 2), components sharded on the device, Total span
         mas = ma if rank == 0 else synthetic.config4(n_tracks=args.tracks, seed=2)
@@ -329,7 +361,7 @@ def main():
             p = capi.Problem(gs, device_graph_stage=local, flags=capi.FLOWS_STAY_ON_HOST, shard=(rank, world))
             b = capi.Batch(p, local) if p.cc_sharded else capi.Batch(p, local, rank, world)
             b.solve(stream, want_stats=False)
-            b.positions_view()
+            b.positions_view_f32()
             return b
         bs = strong_total()
         sst = dist.allreduce_stats(bs.solve(stream, want_stats=True))
@@ -428,7 +460,7 @@ def main():
                 p5 = capi.Problem(g5, device_graph_stage=local)
                 b5 = capi.Batch(p5, local)
                 b5.solve(stream, want_stats=False)
-                b5.positions_view()
+                b5.positions_view_f32()
                 if keep is not None:
                     keep.extend([p5, b5])
             k5 = []
@@ -440,7 +472,7 @@ def main():
             def solver5():                                        # solve.cc:615-638 like for like with the CPU leg: assembly + solve + positions
                 bb = capi.Batch(p5, local)
                 bb.solve(stream, want_stats=False)
-                bb.positions_view()
+                bb.positions_view_f32()
             sps5 = spans(solver5, max(1, min(3, reps)), sync)
             n5 = 5
             for _ in range(2):
@@ -522,7 +554,7 @@ def main():
             def solver_s():                                       # solve.cc:615-638 like for like with the CPU leg (the elimination-tree plans are made on the host here)
                 bb = capi.Batch(ps, local)
                 bb.solve(stream, want_stats=False)
-                bb.positions_view()
+                bb.positions_view_f32()
             sps_s = spans(solver_s, max(1, min(3, reps)), sync)
             for _ in range(2):
                 bs.solve(stream, want_stats=False)

@@ -287,6 +287,10 @@ int lfr_batch_download(lfr_batch *b, double *positions);
 /* The same without the final host copy: *positions points at the batch's pinned staging buffer (2 * n_nodes
  * doubles, nodes outside the shard read 0), valid until the next solve / download / free of this batch. */
 int lfr_batch_positions_view(lfr_batch *b, const double **positions);
+/* The same in the precision the reference's SolutionFile holds (solve.cc:661-664 casts every displacement to float): converted on
+ * the device, so half the bytes cross PCIe.  *positions: 2 * n_nodes floats in a pinned buffer of the batch, each the float nearest
+ * to the double lfr_batch_positions_view would return; valid until the next solve / view / free of this batch. */
+int lfr_batch_positions_view_f32(lfr_batch *b, const float **positions);
 /* per solved component of the shard, in batch order: original component id, iterations,
  * termination, final cost (any pointer may be NULL). Returns the count. */
 int64_t lfr_batch_component_info(lfr_batch *b, int64_t *component, int32_t *iterations, int32_t *termination,
@@ -323,6 +327,14 @@ int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *p
  * disjoint node sets of `positions` (the thread pool of solve.cc:617-635 with GPUs as workers). */
 int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices, int tukey_variant, double *positions,
                         lfr_solve_stats *stats);
+
+/* solve.cc:487-641 over several GPUs from ONE process, the graph stage included: device k runs tracks / roots / components, the assembly
+ * and the solve over the connected components of the match graph dealt to shard k (lfr_problem_build_hip_shard) - nothing is computed
+ * on one GPU for the others.  problem_stats: what the stdout lines of solve.cc:534-606 need, summed / maximised over the shards.
+ * A graph that is one connected component cannot be dealt out: every device then holds the whole problem and solves its share of the
+ * components (as lfr_solve_hip_multi).  positions: 2 * n_nodes doubles, every node written (zeros where nothing is solved). */
+int lfr_solve_graph_hip_multi(const lfr_graph *g, const int *devices, int n_devices, int64_t max_nodes_in_component, int tukey_variant,
+                              double *positions, lfr_problem_stats *problem_stats, lfr_solve_stats *stats);
 
 /* ---------------------------------------------------------------------------------------------
  * A12  SolutionFile emit.                                                     solve.cc:644-679

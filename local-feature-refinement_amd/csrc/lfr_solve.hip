@@ -3324,6 +3324,8 @@ struct lfr_batch {
     // pinned staging of the positions (downloads, zero-copy view)
     double *h_positions = nullptr;
     size_t h_positions_bytes = 0;
+    float *h_positions_f32 = nullptr, *d_positions_f32 = nullptr;      // lfr_batch_positions_view_f32: converted on the device, half the copy
+    size_t h_positions_f32_bytes = 0, d_positions_f32_bytes = 0;
     // events / streams
     static constexpr int kSlots = 64;                    // event ring: timings of the last 64 solves
     static constexpr int kEvPerSlot = 2 * (lfr::KC_COUNT + 1);
@@ -3353,6 +3355,8 @@ struct lfr_batch {
             for (auto &w : wg_stream) if (w) (void)hipStreamSynchronize(w);
             (void)hipStreamSynchronize(ctx->s_main);
             if (h_positions) ctx->pinned_release(h_positions, h_positions_bytes);
+            if (h_positions_f32) ctx->pinned_release(h_positions_f32, h_positions_f32_bytes);
+            if (d_positions_f32) ctx->dev_release(d_positions_f32, d_positions_f32_bytes);
         }
         if (ctx) {                                      // (every stream this batch used has been waited for above: the events are idle)
             for (auto &e : ev_ring) ctx->event_release(e, true);
@@ -4389,6 +4393,37 @@ int lfr_batch_positions_view(lfr_batch *b, const double **positions) {
     return LFR_OK;
 }
 
+namespace { __global__ void k_positions_to_f32(int64_t n, const double *in, float *out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i + 1 < n) {            // n is even (two coordinates per node): one 16-byte load, one 8-byte store per thread
+        const double2 v = reinterpret_cast<const double2 *>(in)[i];
+        reinterpret_cast<float2 *>(out)[i] = make_float2((float)v.x, (float)v.y);
+    }
+} }
+
+int lfr_batch_positions_view_f32(lfr_batch *b, const float **positions) {
+    if (!b || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    HIP_TRY(hipSetDevice(b->device));
+    const int64_t n = 2 * std::max<int64_t>(b->n_graph_nodes, 1);
+    const size_t bytes = sizeof(float) * (size_t)n;
+    if (!b->h_positions_f32) {
+        b->h_positions_f32 = (float *)b->ctx->pinned_acquire(bytes, &b->h_positions_f32_bytes);
+        if (!b->h_positions_f32) return LFR_ERR_NOMEM;
+    }
+    if (!b->d_positions_f32) {
+        b->d_positions_f32 = (float *)b->ctx->dev_acquire(bytes, &b->d_positions_f32_bytes);
+        if (!b->d_positions_f32) return LFR_ERR_NOMEM;
+    }
+    hipStream_t st = b->ctx->s_main;
+    if (b->n_solves > 0) HIP_TRY(hipStreamWaitEvent(st, b->ev[1], 0));        // end of the latest solve, whatever stream it ran on
+    hipLaunchKernelGGL(k_positions_to_f32, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, st, n, b->d_positions, b->d_positions_f32);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(b->h_positions_f32, b->d_positions_f32, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(lfr::stream_wait(st));
+    *positions = b->h_positions_f32;
+    return LFR_OK;
+}
+
 int lfr_batch_download(lfr_batch *b, double *positions) {
     if (!b || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
     const double *view = nullptr;
@@ -4518,6 +4553,94 @@ int lfr_solve_hip_multi(const lfr_problem *p, const int *devices, int n_devices,
             stats->ref_cost_passes_edges += s.ref_cost_passes_edges; stats->exec_passes_edges += s.exec_passes_edges;
             stats->ref_passes_nodes += s.ref_passes_nodes; stats->sum_final_cost += s.sum_final_cost;
             stats->kernel_ms = std::max(stats->kernel_ms, s.kernel_ms); stats->h2d_ms = std::max(stats->h2d_ms, s.h2d_ms);
+        }
+    }
+    return LFR_OK;
+}
+
+// solve.cc:487-641 over several GPUs from one process, the GRAPH STAGE INCLUDED (lfr_solve_hip_multi shards the solve of
+// a problem whose tracks / roots / components one GPU computed): device k builds the problem of the connected components of the match
+// graph dealt to shard k (lfr_problem_build_hip_shard), assembles, solves and downloads it; when the graph cannot be dealt out (one giant
+// connected component) every device holds the whole problem and takes its share of the components, as lfr_solve_hip_multi does.
+int lfr_solve_graph_hip_multi(const lfr_graph *g, const int *devices, int n_devices, int64_t max_nodes_in_component, int tukey_variant,
+                              double *positions, lfr_problem_stats *problem_stats, lfr_solve_stats *stats) {
+    if (!g || !devices || n_devices < 1 || n_devices > 64 || !positions) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    const size_t n = (size_t)g->g.n_nodes();
+    memset(positions, 0, sizeof(double) * 2 * n);
+    std::vector<int> rcs(n_devices, LFR_OK);
+    std::vector<lfr_solve_stats> sts(n_devices);
+    std::vector<lfr_problem_stats> pst(n_devices);
+    std::vector<int> sharded(n_devices, 0);
+    std::vector<std::string> errs(n_devices);
+    // entries of the device list that name the same GPU take turns at the graph stage and the assembly (one context, one pair of
+    // streams: the stages are written for one caller per device); their solves overlap
+    static std::mutex dev_mu[64];
+    auto work = [&](int k) {
+        lfr_problem *pr = nullptr;
+        lfr_batch *bt = nullptr;
+        {
+            std::lock_guard<std::mutex> turn(dev_mu[devices[k] & 63]);
+            rcs[k] = n_devices == 1 ? lfr_problem_build_hip_ex(g, devices[k], max_nodes_in_component, nullptr, 0, &pr)
+                                    : lfr_problem_build_hip_shard(g, devices[k], max_nodes_in_component, LFR_BUILD_FLOWS_STAY_ON_HOST, k, n_devices, &pr);
+            if (rcs[k] == LFR_OK) {
+                sharded[k] = pr->p.cc_sharded ? 1 : 0;
+                pst[k] = pr->p.stats;
+                rcs[k] = sharded[k] || n_devices == 1 ? lfr_batch_create(pr, devices[k], 0, 1, tukey_variant, &bt)
+                                                      : lfr_batch_create(pr, devices[k], k, n_devices, tukey_variant, &bt);
+            }
+        }
+        std::unique_ptr<lfr_batch> guard(bt);
+        if (rcs[k] == LFR_OK) rcs[k] = lfr_batch_solve(bt, bt->ctx->s_main, &sts[k]);
+        if (rcs[k] == LFR_OK) {
+            // disjoint node sets per shard.  A connected-component shard is a WHOLE problem of its own (every other node reads 0 in its
+            // view): only its nonzero entries may be written, the other shards' nodes live in the same array
+            if (sharded[k] && n_devices > 1) {
+                const double *view = nullptr;
+                rcs[k] = lfr_batch_positions_view(bt, &view);
+                if (rcs[k] == LFR_OK) for (size_t i = 0; i < 2 * n; ++i) if (view[i] != 0.0) positions[i] = view[i];
+            } else rcs[k] = lfr_batch_download(bt, positions);
+        }
+        if (rcs[k] != LFR_OK) errs[k] = lfr_last_error();
+        guard.reset();
+        if (pr) lfr_problem_free(pr);
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < n_devices; ++k) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < n_devices; ++k) if (rcs[k] != LFR_OK) { lfr::set_error("device %d: %s", devices[k], errs[k].c_str()); return rcs[k]; }
+    if (problem_stats) {
+        lfr_problem_stats a = pst[0];
+        for (int k = 1; k < n_devices; ++k) {
+            const lfr_problem_stats &b = pst[k];
+            if (sharded[0] && sharded[k]) {                 // per-shard counts add up; a whole-graph problem (no shard) is the same on every device
+                a.n_tracks += b.n_tracks; a.n_components += b.n_components; a.n_cut_components += b.n_cut_components;
+                a.n_solved_components += b.n_solved_components; a.n_solved_tracks += b.n_solved_tracks;
+                a.n_solved_edges += b.n_solved_edges; a.n_solved_nodes += b.n_solved_nodes;
+                a.max_track_size = std::max(a.max_track_size, b.max_track_size);
+                a.max_component_size = std::max(a.max_component_size, b.max_component_size);
+                a.kruskal_rounds = std::max(a.kruskal_rounds, b.kruskal_rounds); a.tie_resorts = std::max(a.tie_resorts, b.tie_resorts);
+            }
+            a.tracks_ms = std::max(a.tracks_ms, b.tracks_ms); a.roots_ms = std::max(a.roots_ms, b.roots_ms);
+            a.graph_cut_ms = std::max(a.graph_cut_ms, b.graph_cut_ms); a.assemble_ms = std::max(a.assemble_ms, b.assemble_ms);
+        }
+        // a shard keeps the node numbering of the whole graph: the nodes of the OTHER shards are isolated in it, each a track and a
+        // component of its own - counted once per foreign shard in the sums above
+        int n_sh = 0;
+        for (int k = 0; k < n_devices; ++k) n_sh += sharded[k];
+        if (sharded[0] && n_sh > 1) { a.n_tracks -= (int64_t)(n_sh - 1) * (int64_t)n; a.n_components -= (int64_t)(n_sh - 1) * (int64_t)n; }
+        *problem_stats = a;
+    }
+    if (stats) {
+        *stats = sts[0];
+        for (int k = 1; k < n_devices; ++k) {
+            const lfr_solve_stats &s2 = sts[k];
+            stats->n_components += s2.n_components; stats->n_edges += s2.n_edges; stats->n_nodes += s2.n_nodes; stats->n_tracks += s2.n_tracks;
+            stats->n_converged += s2.n_converged; stats->n_no_convergence += s2.n_no_convergence; stats->n_failed += s2.n_failed;
+            stats->sum_iterations += s2.sum_iterations; stats->ref_jacobian_passes_edges += s2.ref_jacobian_passes_edges;
+            stats->ref_cost_passes_edges += s2.ref_cost_passes_edges; stats->exec_passes_edges += s2.exec_passes_edges;
+            stats->ref_passes_nodes += s2.ref_passes_nodes; stats->sum_final_cost += s2.sum_final_cost;
+            stats->kernel_ms = std::max(stats->kernel_ms, s2.kernel_ms); stats->h2d_ms = std::max(stats->h2d_ms, s2.h2d_ms);
         }
     }
     return LFR_OK;

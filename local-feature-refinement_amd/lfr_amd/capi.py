@@ -103,6 +103,7 @@ def lib():
         "lfr_batch_solve": (C.c_int, [vp, vp, C.POINTER(SolveStats)]),
         "lfr_batch_download": (C.c_int, [vp, vp]),
         "lfr_batch_positions_view": (C.c_int, [vp, pp]),
+        "lfr_batch_positions_view_f32": (C.c_int, [vp, pp]),
         "lfr_batch_timing": (C.c_int, [vp, C.c_int, C.POINTER(C.c_double), vp, vp]),
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_batch_spin_timeouts": (i64, [vp]),
@@ -114,6 +115,7 @@ def lib():
         "lfr_debug_pool_selftest": (i64, [C.c_int, i64, C.c_int]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
+        "lfr_solve_graph_hip_multi": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp, C.POINTER(ProblemStats), C.POINTER(SolveStats)]),
         "lfr_write_solution": (C.c_int, [vp, vp, C.c_char_p, C.POINTER(i64)]),
         "lfr_apply_displacements": (C.c_int, [vp, vp, C.c_char_p, vp, i64, i64]),
     }
@@ -127,11 +129,11 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_problem_build_hip_shard", "lfr_problem_cc_sharded", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_pool_selftest", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_problem_build_hip_shard", "lfr_problem_cc_sharded", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_batch_positions_view_f32", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_pool_selftest", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_team_runs", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_team_runs", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_solve_graph_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -421,6 +423,18 @@ class Problem:
         return pos, (st.as_dict() if want_stats else None)
 
 
+def solve_graph_hip_multi(graph, devices, max_nodes_in_component=0, tukey_variant="ceres1"):
+    """Graph stage, assembly and solve sharded over several GPUs from this process (lfr_solve_graph_hip_multi): device k takes the
+    connected components of the match graph dealt to shard k.  Returns (positions[n, 2], problem stats, solve stats)."""
+    n = graph.n_nodes
+    pos = np.zeros((n, 2), np.float64)
+    pst, st = ProblemStats(), SolveStats()
+    dev = np.ascontiguousarray(devices, np.int32)
+    _check(lib().lfr_solve_graph_hip_multi(graph._h, _ptr(dev), len(dev), int(max_nodes_in_component), TUKEY[tukey_variant], _ptr(pos),
+                                          C.byref(pst), C.byref(st)))
+    return pos, pst.as_dict(), st.as_dict()
+
+
 def solve_hip_multi(problem, devices, tukey_variant="ceres1"):
     """Shard a host-assembled problem over several GPUs from this process (one host thread per device)."""
     n = problem.graph.n_nodes
@@ -479,6 +493,17 @@ class Batch:
             return np.zeros((0, 2), np.float64)
         buf = (C.c_double * (2 * n)).from_address(p.value)
         return np.frombuffer(buf, dtype=np.float64).reshape(n, 2)
+
+    def positions_view_f32(self):
+        """The same as [n, 2] float32 - the precision of the reference's SolutionFile (solve.cc:661-664) - converted on the device:
+        half the bytes over PCIe."""
+        n = self.problem.graph.n_nodes
+        p = C.c_void_p()
+        _check(lib().lfr_batch_positions_view_f32(self._h, C.byref(p)))
+        if n == 0:
+            return np.zeros((0, 2), np.float32)
+        buf = (C.c_float * (2 * n)).from_address(p.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(n, 2)
 
     def tree_stats(self):
         """Per component (order of component_info): columns / tiles / 16x16x16 updates per factorization / levels / sweep items of the

@@ -69,6 +69,25 @@ def max_over_ranks(value):
     return float(t.item())
 
 
+def sum_over_ranks(value):
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return float(value)
+    t = _tensor([float(value)])
+    td.all_reduce(t, op=td.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_objects(obj):
+    """[obj of rank 0, obj of rank 1, ...] on every rank (small picklable records: the bench line's per-rank evidence)."""
+    import torch.distributed as td
+    if not (td.is_available() and td.is_initialized()) or td.get_world_size() == 1:
+        return [obj]
+    out = [None] * td.get_world_size()
+    td.all_gather_object(out, obj)
+    return out
+
+
 def shutdown():
     import torch.distributed as td
     if td.is_available() and td.is_initialized():

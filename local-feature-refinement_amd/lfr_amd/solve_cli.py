@@ -240,7 +240,36 @@ def _main(argv, state):
             return 2
     n_nodes = graph.n_nodes
     positions = np.zeros((n_nodes, 2), np.float64)                        # solve.cc:609-612
-    if n_nodes > 0:
+    sharded_multi = (n_nodes > 0 and len(gpus) > 1 and override is None and os.environ.get("LFR_HOST_ASSEMBLY") != "1"
+                     and os.environ.get("LFR_HOST_GRAPH_STAGE") != "1" and os.environ.get("LFR_MULTI_SHARED_STAGE") != "1")
+    if sharded_multi:
+        # several GPUs, one process: every GPU runs the graph stage, the assembly and the solve over ITS connected components of the
+        # match graph (lfr_solve_graph_hip_multi).  The stdout lines of solve.cc:534-641 come out in the reference's order once the
+        # shards' counts are merged; LFR_MULTI_SHARED_STAGE=1: the graph stage on the first GPU, the solve sharded (round 5).
+        warm_join()
+        try:
+            variant = os.environ.get("LFR_TUKEY_VARIANT", "ceres1")
+            t1 = time.perf_counter()
+            positions, st, sst = capi.solve_graph_hip_multi(graph, gpus, 0, variant)
+            t2 = time.perf_counter()
+        except (capi.LfrError, KeyError) as e:
+            sys.stderr.write("FATAL: HIP solve failed: %s\n" % e)
+            return 2
+        print("# tracks: %d" % st["n_tracks"])                            # solve.cc:534
+        print("max track size: %d" % st["max_track_size"])                # solve.cc:549
+        print("Graph-cut time: %dms" % int(st["graph_cut_ms"]))           # solve.cc:589
+        print("# components: %d" % st["n_components"])                    # solve.cc:591
+        print("max component size: %d" % st["max_component_size"])        # solve.cc:606
+        if st["n_cut_components"]:
+            sys.stderr.write("note: %d component(s) above the size cap (#images nodes) were split by the built-in deterministic "
+                             "bisection, not by COLMAP/Graclus as the reference does (solve.cc:192): the refined positions of this input are "
+                             "NOT reference-equivalent; supply the reference's components through LFR_COMPONENTS_FILE for that "
+                             "(DESIGN.md, section 3)\n" % st["n_cut_components"])
+        # (the shards' graph stages and solves are one call: "Solver time" is that call less the slowest shard's graph stage)
+        stage_ms = st["tracks_ms"] + st["roots_ms"] + st["graph_cut_ms"]
+        print("Solver time: %dms" % int(max(0.0, (t2 - t1) * 1e3 - stage_ms)))     # solve.cc:638
+        print("Total time: %dms" % int((t2 - t_start) * 1e3))             # solve.cc:641
+    elif n_nodes > 0:
         try:
             # graph stage + batch assembly on the GPU (falls back to the host stage for the graph cut /
             # huge connected components); LFR_HOST_GRAPH_STAGE=1 / LFR_HOST_ASSEMBLY=1 force the host paths

@@ -267,6 +267,10 @@ def test_bench_two_ranks_on_one_gpu(lfr_lib, scaling):
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == scaling
+    mg = out["multi_gpu"]                       # the line verifies itself: ranks counted by an all-reduce, per-rank records
+    assert mg["ranks_seen"] == 2 and [r["rank"] for r in mg["per_rank"]] == [0, 1] and mg["backend"] == "gloo"
+    assert len({r["pid"] for r in mg["per_rank"]}) == 2 and mg["edges_sum_over_ranks"] == mg["edges_headline"]
+    assert mg["ms_per_step_max"] <= out["ms_per_step"] * 1.001
     one_graph = out["config"]["edges_per_gpu"] if scaling == "weak" else None
     if scaling == "weak":
         assert "strong_scaling" in out and out["strong_scaling"]["edges"] > 0 and "weak_scaling" not in out
@@ -324,6 +328,8 @@ def test_bench_two_gpus_over_rccl(lfr_lib):
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["weak_scaling"]["edges"] > 0
     assert out["solve"]["failed"] == 0
+    mg = out["multi_gpu"]
+    assert mg["ranks_seen"] == 2 and mg["backend"] == "nccl" and mg["distinct_devices"] == 2
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
@@ -416,3 +422,65 @@ def test_small_component_with_many_edges_takes_the_late_workgroup_path(lfr_lib):
     info = bd.component_info()
     assert (info["n_edges"] > 320).any() and (2 * info["n_var_nodes"] <= 32).all()      # the case this test is about
     assert (got == want).all()
+
+
+def test_positions_view_f32_is_the_rounded_f64_view(lfr_lib):
+    """lfr_batch_positions_view_f32: the displacements as the reference's SolutionFile holds them (float, solve.cc:661-664), converted
+    on the device - every value the float nearest to the double of lfr_batch_positions_view, also for a shard (other nodes read 0)."""
+    ma = synthetic.generate(seed=51, n_images=32, n_tracks=5000, eps_out=0.001)
+    g = capi.Graph.from_arrays(ma)
+    p = capi.Problem(g, device_graph_stage=0)
+    b = capi.Batch(p, 0)
+    b.solve()
+    v64 = np.array(b.positions_view(), copy=True)
+    v32 = np.array(b.positions_view_f32(), copy=True)
+    assert v32.dtype == np.float32 and v32.shape == v64.shape
+    assert (v32 == v64.astype(np.float32)).all() and np.abs(v32).max() > 0
+    bs = capi.Batch(p, 0, 1, 3)
+    bs.solve()
+    assert (np.array(bs.positions_view_f32()) == np.array(bs.positions_view()).astype(np.float32)).all()
+
+
+
+def test_graph_stage_sharded_in_the_one_process_multi_gpu_entry(lfr_lib, tmp_path):
+    """lfr_solve_graph_hip_multi - the drop-in's LFR_GPUS path - runs tracks / roots / components, the assembly and the
+    solve per device over the connected components dealt to it (here four shards on GPU 0): positions BITWISE the one-GPU pipeline's,
+    the stdout counts (# tracks, max track size, # components, max component size) merged from the shards; a graph that is one connected
+    component falls back to sharing out the components of the whole problem.  The CLI with LFR_GPUS=0,0 writes the same SolutionFile
+    and the same stdout counts as with one GPU."""
+    import os
+    import subprocess
+    import sys
+    for kw in (dict(seed=61, n_images=64, n_tracks=6000), dict(seed=62, n_images=48, n_tracks=3000, eps_out=0.002),
+               dict(seed=34, n_images=40, n_tracks=800, eps_out=0.05)):
+        ma = synthetic.generate(**kw)
+        g = capi.Graph.from_arrays(ma)
+        pw = capi.Problem(g, device_graph_stage=0)
+        bw = capi.Batch(pw, 0)
+        stw = bw.solve()
+        want = bw.download().copy()
+        pst = pw.stats()
+        g2 = capi.Graph.from_arrays(ma)                               # cold graph: the multi entry uploads what it needs itself
+        pos, mst, sst = capi.solve_graph_hip_multi(g2, [0, 0, 0, 0])
+        assert (pos == want).all()
+        for k in ("n_tracks", "max_track_size", "n_components", "max_component_size", "n_cut_components", "n_solved_edges"):
+            assert mst[k] == pst[k], k
+        for k in ("n_components", "n_edges", "n_tracks", "n_converged", "sum_iterations"):
+            assert sst[k] == stw[k], k
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    solve = os.path.join(root, "multi-view-refinement", "build", "solve")
+    pb = str(tmp_path / "m.pb")
+    capi.write_matching_file(pb, synthetic.generate(seed=63, n_images=32, n_tracks=2000, eps_out=0.001))
+    outs = {}
+    for name, gpus in (("one", None), ("two", "0,0")):
+        env = dict(os.environ)
+        env.pop("LFR_GPUS", None)
+        if gpus:
+            env["LFR_GPUS"] = gpus
+        out = str(tmp_path / (name + ".pb"))
+        r = subprocess.run([sys.executable, solve, "--matches_file", pb, "--output_file", out], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if not l.startswith(("Graph-cut time", "Solver time", "Total time"))]
+        outs[name] = (lines, open(out, "rb").read())
+    assert outs["one"][0] == outs["two"][0]
+    assert outs["one"][1] == outs["two"][1]
