@@ -130,6 +130,7 @@ except (OSError, KeyError) as e:
     print("kernel stats:", e)
 for f in (TAG + "_bench_kernel_stats.csv", TAG + "_dominant_kernel_launches.json", TAG + "_bench_line_under_rocprof.json", TAG + "_bench_line.json",
           TAG + "_phase_profile_packed_kernel.txt", TAG + "_phase_profile_tree_kernel.txt", TAG + "_tree_timeline.txt", TAG + "_tree_trace.txt", TAG + "_config5_tail.txt",
-          TAG + "_gpu_tests.txt", TAG + "_pipeline_trace_config4.txt", TAG + "_pipeline_trace_config5.txt"):
+          TAG + "_gpu_tests.txt", TAG + "_pipeline_trace_config4.txt", TAG + "_pipeline_trace_config5.txt", TAG + "_pmc_packed_instruction_mix.txt",
+          TAG + "_ablation_packed_kernel.txt", TAG + "_smoke.txt"):
     if os.path.exists(os.path.join(out, f)):
         shutil.copy(os.path.join(out, f), os.path.join(prof, f))
