@@ -490,7 +490,7 @@ def main():
             wg5 = rows5 > 32                                      # the workgroup classes (a dense LDL^T per LM iteration)
             fact_flops = float((rows5[wg5] ** 3 / 3.0 * info5["iterations"][wg5]).sum())
             eval_flops = float(st5["exec_passes_edges"]) * FLOP_PER_EDGE_EVAL
-            prof5 = pmc_numbers("r05_pmc_config5.json")
+            prof5 = pmc_numbers("r06_pmc_config5.json")
             stale5 = bool(prof5) and not fresh(prof5)
             if stale5:
                 prof5 = None
@@ -515,7 +515,7 @@ def main():
                              "traffic_ratio_without_spills": ((traffic5 - 2.0 * prof5["hbm_write_bytes_per_solve"]) / alg_bytes5) if traffic5 and prof5.get("hbm_write_bytes_per_solve") else None,
                              "algorithmic_bytes": alg_bytes5,
                              "algorithmic_bytes_what": "per executed sweep and edge: the 80 B record (nothing else leaves the CU)",
-                             "traffic_source": ("profiles/r05_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
+                             "traffic_source": ("profiles/r06_pmc_config5.json (committed rocprofv3 PMC passes over this workload with these kernel sources, 2*FETCH_SIZE + WRITE_SIZE; "
                                                 "not measured in this run)" if traffic5 else
                                                 "none: the committed counters were collected with other kernel sources (kernel_source_sha256 differs)" if stale5 else None),
                              "fp64": {"achieved": (fact_flops + eval_flops) / (ms5 * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -584,7 +584,7 @@ def main():
             fact_bytes_s = float(((ts_["tiles"] * 6144.0 + ts_["updates"] * 3072.0) * its).sum())
             sweeps_per_edge = float(sts["exec_passes_edges"]) / max(1, sts["n_edges"])
             sweep_bytes_s = float(sts["exec_passes_edges"]) * 160.0 + float(ts_["items"].sum()) * 150.0 * sweeps_per_edge
-            prof_s = pmc_numbers("r05_pmc_sparse.json")
+            prof_s = pmc_numbers("r06_pmc_sparse.json")
             stale_s = bool(prof_s) and not fresh(prof_s)
             if stale_s:
                 prof_s = None
@@ -601,7 +601,7 @@ def main():
                                           "iterations x (levels of dependent column tasks + sweeps), chains of round trips to L2 on a team of up to 8 workgroups",
                              "algorithmic_bytes": fact_bytes_s + sweep_bytes_s, "factorization_bytes": fact_bytes_s, "sweep_bytes": sweep_bytes_s,
                              "traffic": traffic_s, "traffic_ratio": (traffic_s / (fact_bytes_s + sweep_bytes_s)) if traffic_s else None,
-                             "traffic_source": ("profiles/r05_pmc_sparse.json (committed rocprofv3 PMC passes over this workload with these kernel sources; not measured in this run)"
+                             "traffic_source": ("profiles/r06_pmc_sparse.json (committed rocprofv3 PMC passes over this workload with these kernel sources; not measured in this run)"
                                                 if traffic_s else "none: the committed counters were collected with other kernel sources" if stale_s else None),
                              "fp64": {"achieved": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                                       "frac": (fact_flops_s + eval_flops_s) / (mss * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

@@ -23,7 +23,7 @@ for r in range(reps):
     b = capi.Batch(p, 0)
     t2 = time.perf_counter()
     b.solve(None, want_stats=False)
-    pos = b.positions_view()
+    pos = b.positions_view_f32()
     t3 = time.perf_counter()
     print("rep %d: graph stage %.3f ms, batch %.3f ms, solve + positions %.3f ms, total %.3f ms" % (r, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t3 - t0) * 1e3), flush=True)
     print("MARK rep %d end" % r, flush=True)
