@@ -317,6 +317,14 @@ int lfr_debug_ls_next_step(int device, int64_t n, const double *samples, const d
  * several threads at once (a caller that finds the workers busy runs on threads of its own).  Test infrastructure. */
 int64_t lfr_debug_pool_selftest(int threads, int64_t items, int reps);
 
+/* The pipeline's stable device sort of (key, value) pairs (graph stage: matches by similarity, solve.cc:489-497; assembly: nodes and
+ * edges by component, solve.cc:563-597 - the reference sorts on the host with std::sort / visits in order): n pairs of key_bytes (4 or 8)
+ * byte unsigned keys and 32-bit values, ascending by key bits [begin_bit, end_bit), equal keys in input order.  use_library 0 = the
+ * library's driver (one-sweep radix passes with ONE clearing fill per sort above 256 K pairs, lfr_sort.hpp), 1 = rocprim::radix_sort_pairs.
+ * Test infrastructure, not part of the solve path. */
+int lfr_debug_sort_pairs(int device, int64_t n, int key_bytes, const void *keys, const uint32_t *vals, int begin_bit, int end_bit,
+                         int use_library, void *keys_out, uint32_t *vals_out);
+
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
                   lfr_solve_stats *stats);

@@ -449,11 +449,11 @@ template <class K, class V>
 int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
+    LFR_HIP_TRY(sort_pairs_raw(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("assembly: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
+    LFR_HIP_TRY(sort_pairs_raw(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st));
     return LFR_OK;
 }
 template <class T>
@@ -714,3 +714,51 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 }
 
 }  // namespace lfr
+
+namespace {
+template <class K>
+int debug_sort(int64_t n, const void *keys, const uint32_t *vals, int begin_bit, int end_bit, int use_library, void *keys_out, uint32_t *vals_out) {
+    K *kin = nullptr, *kout = nullptr;
+    uint32_t *vin = nullptr, *vout = nullptr;
+    void *tmp = nullptr;
+    size_t bytes = 0;
+    int rc = LFR_OK;
+    auto body = [&]() -> int {
+        LFR_HIP_TRY(hipMalloc(&kin, sizeof(K) * n));
+        LFR_HIP_TRY(hipMalloc(&kout, sizeof(K) * n));
+        LFR_HIP_TRY(hipMalloc(&vin, 4 * n));
+        LFR_HIP_TRY(hipMalloc(&vout, 4 * n));
+        LFR_HIP_TRY(hipMemcpy(kin, keys, sizeof(K) * n, hipMemcpyHostToDevice));
+        LFR_HIP_TRY(hipMemcpy(vin, vals, 4 * n, hipMemcpyHostToDevice));
+        if (use_library) {
+            LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, nullptr));
+            LFR_HIP_TRY(hipMalloc(&tmp, bytes));
+            LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, nullptr));
+        } else {
+            LFR_HIP_TRY(lfr::sort_pairs_raw(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, nullptr));
+            LFR_HIP_TRY(hipMalloc(&tmp, bytes));
+            LFR_HIP_TRY(hipMemset(tmp, 0xff, bytes));          // the driver must clear what it relies on
+            LFR_HIP_TRY(lfr::sort_pairs_raw(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, nullptr));
+        }
+        LFR_HIP_TRY(hipDeviceSynchronize());
+        LFR_HIP_TRY(hipMemcpy(keys_out, kout, sizeof(K) * n, hipMemcpyDeviceToHost));
+        LFR_HIP_TRY(hipMemcpy(vals_out, vout, 4 * n, hipMemcpyDeviceToHost));
+        return LFR_OK;
+    };
+    rc = body();
+    (void)hipFree(kin); (void)hipFree(kout); (void)hipFree(vin); (void)hipFree(vout); (void)hipFree(tmp);
+    return rc;
+}
+}  // namespace
+
+extern "C" int lfr_debug_sort_pairs(int device, int64_t n, int key_bytes, const void *keys, const uint32_t *vals, int begin_bit, int end_bit,
+                                    int use_library, void *keys_out, uint32_t *vals_out) {
+    if (n <= 0 || !keys || !vals || !keys_out || !vals_out || (key_bytes != 4 && key_bytes != 8) || begin_bit < 0 || end_bit <= begin_bit ||
+        end_bit > 8 * key_bytes) {
+        lfr::set_error("lfr_debug_sort_pairs: bad arguments");
+        return LFR_ERR_ARG;
+    }
+    if (hipSetDevice(device) != hipSuccess) { lfr::set_error("lfr_debug_sort_pairs: no device %d", device); return LFR_ERR_HIP; }
+    return key_bytes == 4 ? debug_sort<uint32_t>(n, keys, vals, begin_bit, end_bit, use_library, keys_out, vals_out)
+                          : debug_sort<unsigned long long>(n, keys, vals, begin_bit, end_bit, use_library, keys_out, vals_out);
+}

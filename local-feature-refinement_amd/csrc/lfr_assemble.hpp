@@ -18,7 +18,8 @@
 // passes (one launch per 8 key bits) are the shorter road.  Only .hip translation units see this.
 #ifdef __HIPCC__
 #include <rocprim/rocprim.hpp>
-using LfrRadixSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)256 * 1024>;
+#include "lfr_sort.hpp"          // LfrRadixSortConfig, sort_pairs_raw: one fill per radix sort instead of 1 + 2 per digit place
+using lfr::LfrRadixSortConfig;
 #endif
 
 namespace lfr {

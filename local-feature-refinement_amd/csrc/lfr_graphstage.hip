@@ -67,11 +67,11 @@ template <class K, class V>
 int sort_pairs(DevArena &arena, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
     if (n <= 0) return LFR_OK;
     size_t bytes = 0;
-    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
+    LFR_HIP_TRY(sort_pairs_raw(nullptr, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st));
     ArenaMark mark(arena);
     void *tmp = arena.take(bytes);
     if (!tmp) { set_error("graph stage: device arena exhausted (sort of %lld items)", (long long)n); return LFR_ERR_NOMEM; }
-    LFR_HIP_TRY(rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st));
+    LFR_HIP_TRY(sort_pairs_raw(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st));
     return LFR_OK;
 }
 // sums of the values of equal adjacent keys (rocPRIM reduce_by_key); *n_runs (device) = number of distinct runs

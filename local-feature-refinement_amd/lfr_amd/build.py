@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(_HERE))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 SOURCES = ["lfr_wire.cpp", "lfr_graph.cpp", "lfr_treeplan.cpp", "lfr_devctx.cpp", "lfr_solve.hip", "lfr_assemble.hip", "lfr_graphstage.hip"]
-HEADERS = ["lfr_internal.hpp", "lfr_device.hpp", "lfr_assemble.hpp", "lfr_devctx.hpp"]
+HEADERS = ["lfr_internal.hpp", "lfr_device.hpp", "lfr_assemble.hpp", "lfr_devctx.hpp", "lfr_sort.hpp"]
 OUT = os.path.join(_HERE, "liblfr_hip.so")
 
 
