@@ -217,6 +217,62 @@ __global__ void k_expand_match_order(int64_t M, const uint32_t *total_edges_p, c
     }
 }
 
+// Round 6: the match-level order BEFORE the counts.  k_count_edges' 2.5 M atomics on 147 k counters (config 4) were 0.106 ms of a 0.76 ms
+// assembly; the matches are sorted by component anyway - by the component's RANK in the batch, which needs the counts.  Sorted by the
+// component's id instead (known from the graph stage), the runs of equal keys ARE the counts (no atomic), and the rank order is a
+// permutation of whole runs: position of a match in the batch = its component's edge offset + its position in the run.  The sort is
+// stable on the match id, so the records of a component come out in the order they always had.
+// A match is in the reduced program when it is kept and one end is a variable; both directions go together and - a track lies inside
+// one component - both ends are in one component: anything else is flagged like an unpaired record.
+__global__ void k_match_keys_comp(int64_t M, const uint32_t *node1, const uint32_t *node2, const int32_t *comp, const uint8_t *is_var, uint8_t *kept,
+                                  uint32_t dropped_key, uint32_t *keys, uint32_t *ids, uint32_t *flag) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t a = node1[m], b = node2[m];
+    const bool var = is_var[a] || is_var[b];                 // both ends constant: not in the reduced program
+    const bool k0 = kept[2 * m] && var, k1 = kept[2 * m + 1] && var;
+    kept[2 * m] = k0; kept[2 * m + 1] = k1;
+    const int32_t ca = comp[a];
+    if (k0 != k1 || (k0 && comp[b] != ca)) *flag = 1u;
+    keys[m] = k0 ? (uint32_t)ca : dropped_key;
+    ids[m] = (uint32_t)m;
+}
+// one thread per sorted match; the LAST of a run gallops back to its first (runs are short: a handful of reads) and writes the run
+__global__ void k_match_runs(int64_t M, const uint32_t *keys, uint32_t n_comp, uint32_t *run_begin, uint32_t *c_edges) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t k = keys[i];
+    if (k >= n_comp || (i + 1 < M && keys[i + 1] == k)) return;
+    int64_t hi = i, step = 1;                                // keys[hi] == k
+    while (hi - step >= 0 && keys[hi - step] == k) { hi -= step; step <<= 1; }
+    int64_t lo = hi - step < -1 ? -1 : hi - step;            // keys[lo] != k (or lo == -1)
+    while (hi - lo > 1) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] == k) hi = mid; else lo = mid;
+    }
+    run_begin[k] = (uint32_t)hi;
+    c_edges[k] = 2u * (uint32_t)(i + 1 - hi);
+}
+// ... and every match to its place: both directions' edge ids (and record words, k_expand_match_order) at the component's offset
+__global__ void k_place_matches(int64_t M, const uint32_t *keys, const uint32_t *match_sorted, uint32_t n_comp, const int32_t *di_of_comp,
+                                const uint32_t *edge_off, const uint32_t *run_begin, const uint32_t *node1, const uint32_t *node2,
+                                const int32_t *track, const uint32_t *local_of, uint32_t *edge_sorted, uint32_t *words) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= M) return;
+    const uint32_t c = keys[p];
+    if (c >= n_comp) return;
+    const int32_t di = di_of_comp[c];
+    if (di < 0) return;
+    const uint32_t q = (edge_off[di] >> 1) + ((uint32_t)p - run_begin[c]);
+    const uint32_t m = match_sorted[p];
+    reinterpret_cast<uint2 *>(edge_sorted)[q] = make_uint2(2u * m, 2u * m + 1u);
+    if (words) {
+        const uint32_t a = node1[m], b = node2[m];
+        const uint32_t kind = track[a] != track[b] ? 1u : 0u, la = local_of[a], lb = local_of[b];
+        reinterpret_cast<uint2 *>(words)[q] = make_uint2(la | ((lb | (kind << 15)) << 16), lb | ((la | (kind << 15)) << 16));
+    }
+}
+
 // packed classes: records 2i, 2i+1 of a component must be the two directions of one match (the solve
 // kernel's pair exchange relies on it)
 __global__ void k_check_pairs(int64_t cap, const uint32_t *total_edges_p, const uint32_t *edge_sorted, const uint32_t *node1, const uint32_t *node2,
@@ -550,7 +606,23 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
     hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
-    if (M > 256 * C) {                                // (see k_count_edges_by_node)
+    // Packed classes only (the graph stage's largest component says that no workgroup class can exist): the matches go through their
+    // sort now, by component id, and the runs are the edge counts (k_match_keys_comp).  LFR_EDGE_SORT_BY_EDGE / LFR_MATCH_SORT_LATE keep
+    // the older orders for A/B.
+    TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);      // edge keys / ids of the edge order below
+    if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
+    const bool expect_workgroup_classes = p.stats.max_component_size > 17;
+    const bool match_sort_first = !expect_workgroup_classes && !getenv("LFR_EDGE_SORT_BY_EDGE") && !getenv("LFR_MATCH_SORT_LATE");
+    uint32_t *mkey_sorted = nullptr, *match_sorted = nullptr, *run_begin = nullptr;
+    int rc;
+    if (match_sort_first) {
+        TAKE(rb, uint32_t, C + 1);                   // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
+        uint32_t *mk0 = reinterpret_cast<uint32_t *>(ek0), *mk1 = mk0 + M, *mi0 = mk1 + M, *mi1 = mi0 + M;
+        hipLaunchKernelGGL(k_match_keys_comp, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, (uint32_t)C, mk0, mi0, &sum->unpaired);
+        if ((rc = sort_pairs(arena, mk0, mk1, mi0, mi1, M, 0, comp_bits, st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_match_runs, grid_for(M), dim3(kThreads), 0, st, M, mk1, (uint32_t)C, rb, ce);
+        mkey_sorted = mk1; match_sorted = mi1; run_begin = rb;
+    } else if (M > 256 * C) {                         // (see k_count_edges_by_node)
         TAKE(ne, uint32_t, N);
         LFR_HIP_TRY(hipMemsetAsync(ne, 0, 4 * (size_t)N, st));
         hipLaunchKernelGGL(k_count_edges_by_node, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, is_var, kept, ne);
@@ -564,7 +636,6 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
     hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
-    int rc;
     if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
     uint32_t *perm = id1;                  // perm[i] = component of desc i
@@ -596,15 +667,16 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     hipLaunchKernelGGL(k_node_locals, grid_for(N), dim3(kThreads), 0, st, N, total_nodes_p, ni1, comp, di, no, out.d_node_ids, local);
 
     // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
-    TAKE(ek0, uint64_t, E2); TAKE(ek1, uint64_t, E2); TAKE(ei0, uint32_t, E2); TAKE(ei1, uint32_t, E2);
-    if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
     // Packed classes carry zeros in the source-node bits (their order is component, then edge id - the sort is stable): when the graph
     // stage's largest component says that no workgroup class can exist, only the component bits are sorted - three radix passes over the
     // 5 M keys of config 4 instead of five.  A small component with > 320 edges still lands in a workgroup class: the summary below has
     // the last word and the full sort is redone then.
-    const bool expect_workgroup_classes = p.stats.max_component_size > 17;
     bool words_done = false;                          // the record words came with the match-level order
-    if (expect_workgroup_classes) {
+    if (match_sort_first) {                           // (sorted before the counts: every match to its component's place)
+        hipLaunchKernelGGL(k_place_matches, grid_for(M), dim3(kThreads), 0, st, M, mkey_sorted, match_sorted, (uint32_t)C, di, eo, run_begin, node1, node2,
+                           track, local, ei1, fused ? out.d_edge_word : nullptr);
+        words_done = fused;
+    } else if (expect_workgroup_classes) {
         hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
                            (uint64_t)C << node_bits, ek0, ei0);
         if ((rc = sort_pairs(arena, ek0, ek1, ei0, ei1, E2, 0, node_bits + comp_bits, st)) != LFR_OK) return rc;
