@@ -325,6 +325,11 @@ int64_t lfr_debug_pool_selftest(int threads, int64_t items, int reps);
 int lfr_debug_sort_pairs(int device, int64_t n, int key_bytes, const void *keys, const uint32_t *vals, int begin_bit, int end_bit,
                          int use_library, void *keys_out, uint32_t *vals_out);
 
+/* The pipeline's one-launch exclusive prefix sum (lfr_sort.hpp: decoupled look-back over states that lie in a stage's zero block): n items
+ * of item_bytes (4 or 8) byte unsigned integers; out[i] = in[0] + ... + in[i-1] (32-bit sums wrap, 64-bit sums must stay below 2^62).
+ * Test infrastructure, not part of the solve path. */
+int lfr_debug_exclusive_sum(int device, int64_t n, int item_bytes, const void *in, void *out);
+
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,
                   lfr_solve_stats *stats);

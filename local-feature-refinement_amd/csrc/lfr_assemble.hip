@@ -112,10 +112,11 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uin
 // per component: solvable? class; the three sort keys of the batch order
 // batch order = class, then edges descending, then variables descending, then id: one 52-bit key (a stable sort keeps the ids
 // ascending inside ties).  Three LSD passes over 32-bit keys cost three block sorts and thirty merge launches of ~6 us each.
-__global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges,
-                            unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
+__global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, uint32_t *c_edges, const uint32_t *run_begin,
+                            const uint32_t *run_end, unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
+    if (run_begin) c_edges[c] = 2u * (run_end[c] - run_begin[c]);       // matches sorted before the counts (k_match_keys_comp): both directions of every match of the run
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
     if (solvable && c_nodes[c] > 32767) *too_big = 1u;
     const unsigned long long kv = 0xffffu - min(c_var[c], 0xffffu);             // descending
@@ -237,21 +238,15 @@ __global__ void k_match_keys_comp(int64_t M, const uint32_t *node1, const uint32
     keys[m] = k0 ? (uint32_t)ca : dropped_key;
     ids[m] = (uint32_t)m;
 }
-// one thread per sorted match; the LAST of a run gallops back to its first (runs are short: a handful of reads) and writes the run
-__global__ void k_match_runs(int64_t M, const uint32_t *keys, uint32_t n_comp, uint32_t *run_begin, uint32_t *c_edges) {
+// one thread per sorted match: the first of a run writes where it begins, the last where it ends (both start at zero: no run, no edges);
+// k_comp_keys turns the pair into the component's edge count
+__global__ void k_match_runs(int64_t M, const uint32_t *keys, uint32_t n_comp, uint32_t *run_begin, uint32_t *run_end) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const uint32_t k = keys[i];
-    if (k >= n_comp || (i + 1 < M && keys[i + 1] == k)) return;
-    int64_t hi = i, step = 1;                                // keys[hi] == k
-    while (hi - step >= 0 && keys[hi - step] == k) { hi -= step; step <<= 1; }
-    int64_t lo = hi - step < -1 ? -1 : hi - step;            // keys[lo] != k (or lo == -1)
-    while (hi - lo > 1) {
-        const int64_t mid = (lo + hi) >> 1;
-        if (keys[mid] == k) hi = mid; else lo = mid;
-    }
-    run_begin[k] = (uint32_t)hi;
-    c_edges[k] = 2u * (uint32_t)(i + 1 - hi);
+    if (k >= n_comp) return;
+    if (i == 0 || keys[i - 1] != k) run_begin[k] = (uint32_t)i;
+    if (i + 1 == M || keys[i + 1] != k) run_end[k] = (uint32_t)(i + 1);
 }
 // ... and every match to its place: both directions' edge ids (and record words, k_expand_match_order) at the component's offset
 __global__ void k_place_matches(int64_t M, const uint32_t *keys, const uint32_t *match_sorted, uint32_t n_comp, const int32_t *di_of_comp,
@@ -558,6 +553,17 @@ size_t assembly_output_bytes(int64_t N, int64_t M, int64_t C) {
 
 static inline int nbits(uint64_t x) { int b = 1; while (x >>= 1) ++b; return b; }      // bits needed for values 0..x
 
+__global__ void k_fill_regions(FillRegions r) {
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (int j = 0; j < r.n; ++j) {
+        const unsigned int b = r.byte_value[j] * 0x01010101u;
+        const size_t n16 = r.bytes[j] / 16, tail = r.bytes[j] - 16 * n16;
+        uint4 *q = static_cast<uint4 *>(r.ptr[j]);
+        for (size_t i = tid; i < n16; i += stride) q[i] = make_uint4(b, b, b, b);
+        if (tid < tail) static_cast<unsigned char *>(r.ptr[j])[16 * n16 + tid] = (unsigned char)r.byte_value[j];
+    }
+}
+
 int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, int shard_world, DevArena &slab, DeviceAssembly &out) {
     const DevGraph &dg = *dp.graph;
     DevCtx *ctx = dp.ctx;
@@ -602,7 +608,10 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(cn, uint32_t, C + 1); TAKE(cv, uint32_t, C + 1); TAKE(ce, uint32_t, C + 1); TAKE(ct, uint32_t, C + 1);
     TAKE(ts, uint32_t, T + 1); TAKE(dn, uint32_t, C + 1); TAKE(de, uint32_t, C + 1);
     TAKE(ws_size, unsigned long long, C + 1);
-    LFR_HIP_TRY(hipMemsetAsync(arena.base + zero_mark, 0, arena.top - zero_mark, st));
+    TAKE(run_begin, uint32_t, C + 1); TAKE(run_end, uint32_t, C + 1);       // (k_match_runs)
+    const size_t scan_words = scan_state_words(C + 1);                      // look-back states of the four prefix sums below (exclusive_sum_one_launch)
+    TAKE(scan_state, unsigned long long, 4 * scan_words);
+    {   FillRegions fr; fr.add(arena.base + zero_mark, arena.top - zero_mark, 0); LFR_HIP_TRY(fill_regions(fr, st)); }
     TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
     hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
@@ -613,15 +622,15 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
     const bool expect_workgroup_classes = p.stats.max_component_size > 17;
     const bool match_sort_first = !expect_workgroup_classes && !getenv("LFR_EDGE_SORT_BY_EDGE") && !getenv("LFR_MATCH_SORT_LATE");
-    uint32_t *mkey_sorted = nullptr, *match_sorted = nullptr, *run_begin = nullptr;
+    uint32_t *mkey_sorted = nullptr, *match_sorted = nullptr;
     int rc;
     if (match_sort_first) {
-        TAKE(rb, uint32_t, C + 1);                   // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
+        // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
         uint32_t *mk0 = reinterpret_cast<uint32_t *>(ek0), *mk1 = mk0 + M, *mi0 = mk1 + M, *mi1 = mi0 + M;
         hipLaunchKernelGGL(k_match_keys_comp, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, (uint32_t)C, mk0, mi0, &sum->unpaired);
         if ((rc = sort_pairs(arena, mk0, mk1, mi0, mi1, M, 0, comp_bits, st)) != LFR_OK) return rc;
-        hipLaunchKernelGGL(k_match_runs, grid_for(M), dim3(kThreads), 0, st, M, mk1, (uint32_t)C, rb, ce);
-        mkey_sorted = mk1; match_sorted = mi1; run_begin = rb;
+        hipLaunchKernelGGL(k_match_runs, grid_for(M), dim3(kThreads), 0, st, M, mk1, (uint32_t)C, run_begin, run_end);
+        mkey_sorted = mk1; match_sorted = mi1;
     } else if (M > 256 * C) {                         // (see k_count_edges_by_node)
         TAKE(ne, uint32_t, N);
         LFR_HIP_TRY(hipMemsetAsync(ne, 0, 4 * (size_t)N, st));
@@ -635,7 +644,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
     TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
+    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
     if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
     uint32_t *perm = id1;                  // perm[i] = component of desc i
@@ -648,16 +657,16 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
 
     TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
     hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, cn, ce, dn, de, di);
-    if ((rc = exclusive_sum(arena, dn, no, C + 1, st)) != LFR_OK) return rc;
-    if ((rc = exclusive_sum(arena, de, eo, C + 1, st)) != LFR_OK) return rc;
+    LFR_HIP_TRY(exclusive_sum_one_launch(dn, no, C + 1, scan_state + 0 * scan_words, st));
+    LFR_HIP_TRY(exclusive_sum_one_launch(de, eo, C + 1, scan_state + 1 * scan_words, st));
     const uint32_t *total_nodes_p = no + C, *total_edges_p = eo + C;
 
     // ---- launch geometry + workspace offsets ----
     TAKE(es_size, unsigned long long, C + 1); TAKE(es_scan, unsigned long long, C + 1); TAKE(ws_scan, unsigned long long, C + 1);
     hipLaunchKernelGGL(k_summary, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, perm, cv, ce, ct, sum, es_size);
     hipLaunchKernelGGL(k_ws_sizes, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, cv, sum, ws_size);
-    if ((rc = exclusive_sum(arena, es_size, es_scan, C + 1, st)) != LFR_OK) return rc;
-    if ((rc = exclusive_sum(arena, ws_size, ws_scan, C + 1, st)) != LFR_OK) return rc;
+    LFR_HIP_TRY(exclusive_sum_one_launch(es_size, es_scan, C + 1, scan_state + 2 * scan_words, st));
+    LFR_HIP_TRY(exclusive_sum_one_launch(ws_size, ws_scan, C + 1, scan_state + 3 * scan_words, st));
     hipLaunchKernelGGL(k_offsets, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, es_scan, ws_scan, no, eo, sum, out.d_es_off, out.d_ws_off);
 
     // ---- local node numbering: nodes by (desc, variable first, node id) ----
@@ -822,6 +831,32 @@ int debug_sort(int64_t n, const void *keys, const uint32_t *vals, int begin_bit,
     return rc;
 }
 }  // namespace
+
+template <class T>
+static int debug_scan(int64_t n, const void *in, void *out) {
+    T *din = nullptr, *dout = nullptr;
+    unsigned long long *state = nullptr;
+    auto body = [&]() -> int {
+        LFR_HIP_TRY(hipMalloc(&din, sizeof(T) * n));
+        LFR_HIP_TRY(hipMalloc(&dout, sizeof(T) * n));
+        LFR_HIP_TRY(hipMalloc(&state, 8 * lfr::scan_state_words(n)));
+        LFR_HIP_TRY(hipMemcpy(din, in, sizeof(T) * n, hipMemcpyHostToDevice));
+        LFR_HIP_TRY(hipMemset(dout, 0xee, sizeof(T) * n));
+        LFR_HIP_TRY(hipMemset(state, 0, 8 * lfr::scan_state_words(n)));
+        LFR_HIP_TRY(lfr::exclusive_sum_one_launch(din, dout, n, state, nullptr));
+        LFR_HIP_TRY(hipDeviceSynchronize());
+        LFR_HIP_TRY(hipMemcpy(out, dout, sizeof(T) * n, hipMemcpyDeviceToHost));
+        return LFR_OK;
+    };
+    const int rc = body();
+    (void)hipFree(din); (void)hipFree(dout); (void)hipFree(state);
+    return rc;
+}
+extern "C" int lfr_debug_exclusive_sum(int device, int64_t n, int item_bytes, const void *in, void *out) {
+    if (n <= 0 || !in || !out || (item_bytes != 4 && item_bytes != 8)) { lfr::set_error("lfr_debug_exclusive_sum: bad arguments"); return LFR_ERR_ARG; }
+    if (hipSetDevice(device) != hipSuccess) { lfr::set_error("lfr_debug_exclusive_sum: no device %d", device); return LFR_ERR_HIP; }
+    return item_bytes == 4 ? debug_scan<uint32_t>(n, in, out) : debug_scan<unsigned long long>(n, in, out);
+}
 
 extern "C" int lfr_debug_sort_pairs(int device, int64_t n, int key_bytes, const void *keys, const uint32_t *vals, int begin_bit, int end_bit,
                                     int use_library, void *keys_out, uint32_t *vals_out) {

@@ -137,4 +137,28 @@ __host__ __device__ inline int snake_shard(int64_t i, int world) {
 constexpr int kPipeThreads = 256;
 inline dim3 pipe_grid(int64_t n) { return dim3((unsigned)((n < 1 ? 1 : n) + kPipeThreads - 1) / kPipeThreads); }
 
+#ifdef __HIPCC__
+// Several byte fills in ONE launch.  hipMemsetAsync is a launch of its own per call - two when the size is not a multiple of its fill
+// width (the N bytes of is_root) - at 4-5 us each on an otherwise busy stream; a stage's initial values (a zero block, a block of -1,
+// a byte array) go out together instead.  Regions start 16-byte aligned (arena blocks are 256-byte aligned).
+struct FillRegions {
+    static constexpr int kMax = 4;
+    void *ptr[kMax];
+    unsigned long long bytes[kMax];
+    unsigned int byte_value[kMax];
+    int n = 0;
+    void add(void *p, size_t b, unsigned int v) { if (b) { ptr[n] = p; bytes[n] = b; byte_value[n] = v & 0xffu; ++n; } }
+};
+__global__ void k_fill_regions(FillRegions r);
+inline hipError_t fill_regions(const FillRegions &r, hipStream_t st) {
+    if (r.n == 0) return hipSuccess;
+    unsigned long long words = 0;
+    for (int j = 0; j < r.n; ++j) words += r.bytes[j] / 16 + 1;
+    const unsigned long long per_block = (unsigned long long)kPipeThreads * 8;       // eight 16-byte stores per thread
+    const unsigned int blocks = (unsigned int)((words + per_block - 1) / per_block < 1 ? 1 : ((words + per_block - 1) / per_block > 65536 ? 65536 : (words + per_block - 1) / per_block));
+    hipLaunchKernelGGL(k_fill_regions, dim3(blocks), dim3(kPipeThreads), 0, st, r);
+    return hipGetLastError();
+}
+#endif
+
 }  // namespace lfr

@@ -294,6 +294,11 @@ __device__ __forceinline__ ulonglong2 image_signature(int32_t im) {
 __global__ void k_kruskal(int64_t cap, int64_t serial_limit, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
                           const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
                           int32_t *count, ulonglong2 *sig) {
+    // (Round 6, measured and dropped: dealing the segments to the threads BY LENGTH.  In the order they come in, config 4's 147 k components
+    // of 6..136 matches keep a wave busy 3.3 times the mean length; dealt by length over the whole list the factor is 1.00 and the kernel
+    // ran 613 us instead of 288, dealt inside a workgroup of 256 / 512 / 1024 threads through LDS 324 / 329 / 375 us.  Neighbouring
+    // threads replaying neighbouring components - one stretch of the ordered list, nodes numbered close together - is worth more than
+    // equal lengths: the kernel is bound by memory transactions, not by its longest lane.  profiles/r06_ab/kruskal_by_length.txt)
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
     const int64_t lo = starts[s], hi = starts[s + 1];
@@ -1159,10 +1164,18 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     TAKE(counts, uint32_t, CNT_WORDS);
     TAKE(flags, uint32_t, M + 1); TAKE(rflag, uint32_t, N + 1); TAKE(tsize, uint32_t, N);
     TAKE(score, double, N); TAKE(best, unsigned long long, N); TAKE(cflag, uint32_t, N + 1); TAKE(csize, uint32_t, N);
-    LFR_HIP_TRY(hipMemsetAsync(arena.base + zero_mark, 0, arena.top - zero_mark, st));
-    LFR_HIP_TRY(hipMemsetAsync(dp->is_root, 0, (size_t)N, st));
-    TAKE(bnode, int32_t, N);
-    LFR_HIP_TRY(hipMemsetAsync(bnode, 0xff, 4 * (size_t)N, st));          // -1
+    // look-back states of the stage's prefix sums (exclusive_sum_one_launch: no init launch for states that start in the zero block)
+    const size_t scan_words_m = scan_state_words(M + 1), scan_words_n = scan_state_words(N + 1);
+    TAKE(scan_state, unsigned long long, scan_words_m + 2 * scan_words_n);
+    const size_t zero_bytes = arena.top - zero_mark;
+    TAKE(bnode, int32_t, N); TAKE(mp_parent, uint32_t, N);                // (next to each other: one region of -1 / of "no track yet")
+    {   // the stage's initial values in one launch (the memsets were 5 launches before the first kernel, 2 more before the meta-components)
+        FillRegions fr;
+        fr.add(arena.base + zero_mark, zero_bytes, 0);
+        fr.add(dp->is_root, (size_t)N, 0);
+        fr.add(bnode, (size_t)(reinterpret_cast<char *>(mp_parent + N) - reinterpret_cast<char *>(bnode)), 0xff);
+        LFR_HIP_TRY(fill_regions(fr, st));
+    }
     LFR_HIP_TRY(hipEventRecord(ev[0], st));
 
     // 1. connected components of the match graph (conflicts ignored)
@@ -1203,7 +1216,10 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         if ((rc = three_sorts()) != LFR_OK) return rc;
         hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
     }
-    if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc;
+    // (the one long prefix sum of the stage: rocPRIM's larger tiles keep the look-back chain short - 20.6 us with its init launch
+    // against 26.9 us for the one-launch kernel at 2.5 M flags; the short sums below are the other way round)
+    if (M + 1 > (int64_t)1 << 20) { if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc; }
+    else LFR_HIP_TRY(exclusive_sum_one_launch(flags, segid, M + 1, scan_state, st));
     const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
     hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
     hipLaunchKernelGGL(k_seg_maxlen, grid_few(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
@@ -1233,7 +1249,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     if (trace && ev_begin) {
         float a = 0.f;
         (void)hipEventElapsedTime(&a, ev_begin, ev[0]);
-        fprintf(stderr, "lfr graph stage: device time of the memsets before the first kernel: %.3f ms (zero block %zu bytes)\n", a, arena.top - zero_mark);
+        fprintf(stderr, "lfr graph stage: device time of the memsets before the first kernel: %.3f ms (zero block %zu bytes)\n", a, zero_bytes);
         (void)hipEventDestroy(ev_begin);
     }
     DevArena rounds_arena;
@@ -1375,7 +1391,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     // 5. track ids (roots in ascending node index), sizes
     TAKE(rrank, uint32_t, N + 1);
     hipLaunchKernelGGL(k_root_flags, grid_for(N), dim3(kThreads), 0, st, N, par, rflag);
-    if ((rc = exclusive_sum(arena, rflag, rrank, N + 1, st)) != LFR_OK) return rc;
+    LFR_HIP_TRY(exclusive_sum_one_launch(rflag, rrank, N + 1, scan_state + scan_words_m, st));
     hipLaunchKernelGGL(k_track_ids, grid_for(N), dim3(kThreads), 0, st, N, par, rrank, dp->track, tsize, counts);
     LFR_HIP_TRY(hipEventRecord(ev[1], st));
 
@@ -1389,12 +1405,11 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipEventRecord(ev[2], st));
 
     // components of the track meta-graph, numbered by their smallest track (solve.cc:292-300)
-    TAKE(mp_parent, uint32_t, N); TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);
-    LFR_HIP_TRY(hipMemsetAsync(mp_parent, 0xff, 4 * (size_t)N, st));                     // (here: smallest track per connected component)
+    TAKE(mp, uint32_t, N); TAKE(crank, uint32_t, N + 1);                                 // (mp_parent - here: smallest track per connected component - starts at ~0: the stage's first fill)
     hipLaunchKernelGGL(k_cc_min_track, grid_for(N), dim3(kThreads), 0, st, N, cc, dp->track, mp_parent);
     hipLaunchKernelGGL(k_track_label, grid_for(N), dim3(kThreads), 0, st, N, cc, dp->track, mp_parent, mp);
     hipLaunchKernelGGL(k_comp_flags, grid_for(N), dim3(kThreads), 0, st, N, counts, mp, cflag);
-    if ((rc = exclusive_sum(arena, cflag, crank, N + 1, st)) != LFR_OK) return rc;
+    LFR_HIP_TRY(exclusive_sum_one_launch(cflag, crank, N + 1, scan_state + scan_words_m + scan_words_n, st));
     hipLaunchKernelGGL(k_comp_sizes, grid_few(N), dim3(kThreads), 0, st, N, counts, mp, crank, tsize, csize);
     hipLaunchKernelGGL(k_max_csize, grid_few(N), dim3(kThreads), 0, st, N, counts, csize);
     hipLaunchKernelGGL(k_node_comp, grid_for(N), dim3(kThreads), 0, st, N, dp->track, mp, crank, dp->comp);

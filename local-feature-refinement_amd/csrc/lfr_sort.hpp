@@ -1,4 +1,4 @@
-// Stable key/value sort for the device pipeline (graph stage, batch assembly, hand-out order).
+// Device primitives of the pipeline (graph stage, batch assembly): the stable key/value sort, and a one-launch exclusive prefix sum (below).
 //
 // rocPRIM's one-sweep radix sort enqueues, on top of its kernels, one hipMemsetAsync for the digit histograms and TWO per digit place
 // (the decoupled-look-back states of that pass and its ordered block counter): a 52-bit sort is 7 places = 15 fills of ~4-5 us each, and
@@ -158,6 +158,100 @@ hipError_t sort_pairs_raw(void *tmp, size_t &bytes, const K *kin, K *kout, const
     if (big && !sortdetail::aliasing(kin, kout, vin, vout, n))
         return sortdetail::onesweep_pairs(tmp, bytes, kin, kout, vin, vout, (unsigned int)n, (unsigned)begin_bit, (unsigned)end_bit, st);
     return rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st);
+}
+
+// ---- exclusive prefix sum in ONE launch ----
+// rocprim::exclusive_scan is two launches (init_lookback_scan_state_kernel + the scan): seven scans in the config-4 pipeline, 33 us of
+// init kernels.  The pipeline stages clear one zero block at their start anyway; a scan whose look-back states lie in that block needs no
+// init launch.  Single pass, decoupled look-back: a block takes a ticket (blocks are numbered in the order they start, so every
+// predecessor is running or done - no deadlock whatever the dispatch order), scans its tile of 2048 items, publishes PARTIAL | aggregate,
+// wave 0 walks back 64 predecessors at a time to the nearest COMPLETE, publishes COMPLETE | inclusive prefix.  State word: flag in the top
+// two bits, value below (sums of 64-bit items must stay under 2^62: they are counts of doubles / bytes here).
+constexpr int kScanThreads = 256, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
+inline size_t scan_state_words(int64_t n) { return 1 + (size_t)((n + kScanTile - 1) / kScanTile); }       // ticket + one per tile; must be ZERO at launch
+
+template <class T>
+__global__ __launch_bounds__(kScanThreads) void k_exclusive_sum(const T *__restrict__ in, T *__restrict__ out, int64_t n, unsigned long long *state) {
+    constexpr unsigned long long kPartial = 1ull << 62, kComplete = 2ull << 62, kFlags = 3ull << 62;
+    constexpr unsigned long long kValue = sizeof(T) == 4 ? 0xffffffffull : ~kFlags;
+    __shared__ unsigned long long s_wave[kScanThreads / 64];
+    __shared__ unsigned long long s_prefix;
+    __shared__ unsigned int s_bid;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_bid = atomicAdd(reinterpret_cast<unsigned int *>(state), 1u);
+    __syncthreads();
+    const unsigned int bid = s_bid;
+    const int64_t base = (int64_t)bid * kScanTile + (int64_t)tid * kScanItems;
+    T v[kScanItems];
+    if (base + kScanItems <= n) {
+        constexpr int per = 16 / sizeof(T);
+        for (int q = 0; q < kScanItems / per; ++q) {
+            const uint4 w = reinterpret_cast<const uint4 *>(in + base)[q];
+            if constexpr (sizeof(T) == 4) { v[4 * q] = w.x; v[4 * q + 1] = w.y; v[4 * q + 2] = w.z; v[4 * q + 3] = w.w; }
+            else { v[2 * q] = (T)w.x | ((T)w.y << 32); v[2 * q + 1] = (T)w.z | ((T)w.w << 32); }
+        }
+    } else {
+        for (int k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : (T)0;
+    }
+    unsigned long long tsum = 0;
+    for (int k = 0; k < kScanItems; ++k) tsum += v[k];
+    unsigned long long incl = tsum;
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long wave_off = 0, agg = 0;
+    for (int w = 0; w < kScanThreads / 64; ++w) { if (w < wave) wave_off += s_wave[w]; agg += s_wave[w]; }
+    unsigned long long excl = wave_off + incl - tsum;
+    if (wave == 0) {
+        unsigned long long *bs = state + 1;
+        if (lane == 0) __hip_atomic_store(bs + bid, (bid == 0 ? kComplete : kPartial) | (agg & kValue), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long prefix = 0;
+        if (bid > 0) {
+            for (int64_t j = (int64_t)bid - 1;; j -= 64) {
+                const int64_t idx = j - lane;
+                unsigned long long s, complete, upto;
+                for (;;) {
+                    s = idx >= 0 ? __hip_atomic_load(bs + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kComplete;      // before the first tile: nothing
+                    complete = __ballot((s & kFlags) == kComplete);
+                    upto = complete ? (((complete & (0ull - complete)) << 1) - 1ull) : ~0ull;          // lanes up to the nearest COMPLETE
+                    if ((__ballot((s & kFlags) == 0ull) & upto) == 0ull) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                unsigned long long val = ((1ull << lane) & upto) ? (s & kValue) : 0ull;
+                for (int d = 32; d >= 1; d >>= 1) val += __shfl_xor(val, d);
+                prefix += val;
+                if (complete) break;
+            }
+            if (lane == 0) __hip_atomic_store(bs + bid, kComplete | ((prefix + agg) & kValue), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) s_prefix = prefix;
+    }
+    __syncthreads();
+    excl += s_prefix;
+    if (base + kScanItems <= n) {
+        T o[kScanItems];
+        for (int k = 0; k < kScanItems; ++k) { o[k] = (T)excl; excl += v[k]; }
+        constexpr int per = 16 / sizeof(T);
+        for (int q = 0; q < kScanItems / per; ++q) {
+            uint4 w;
+            if constexpr (sizeof(T) == 4) w = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+            else w = make_uint4((unsigned int)o[2 * q], (unsigned int)(o[2 * q] >> 32), (unsigned int)o[2 * q + 1], (unsigned int)(o[2 * q + 1] >> 32));
+            reinterpret_cast<uint4 *>(out + base)[q] = w;
+        }
+    } else {
+        for (int k = 0; k < kScanItems && base + k < n; ++k) { out[base + k] = (T)excl; excl += v[k]; }
+    }
+}
+// `state`: scan_state_words(n) zeroed 64-bit words (in the stage's zero block), used by this one call only
+template <class T>
+inline hipError_t exclusive_sum_one_launch(const T *in, T *out, int64_t n, unsigned long long *state, hipStream_t st) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit unsigned items");
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_exclusive_sum<T>, dim3((unsigned)((n + kScanTile - 1) / kScanTile)), dim3(kScanThreads), 0, st, in, out, n, state);
+    return hipGetLastError();
 }
 
 }   // namespace lfr

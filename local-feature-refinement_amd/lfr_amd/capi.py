@@ -114,6 +114,7 @@ def lib():
         "lfr_debug_tree_plan": (i64, [i32, i64, vp, vp, i64, vp]),
         "lfr_debug_pool_selftest": (i64, [C.c_int, i64, C.c_int]),
         "lfr_debug_sort_pairs": (C.c_int, [C.c_int, i64, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+        "lfr_debug_exclusive_sum": (C.c_int, [C.c_int, i64, C.c_int, vp, vp]),
         "lfr_solve_hip": (C.c_int, [vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_hip_multi": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.POINTER(SolveStats)]),
         "lfr_solve_graph_hip_multi": (C.c_int, [vp, vp, C.c_int, i64, C.c_int, vp, C.POINTER(ProblemStats), C.POINTER(SolveStats)]),
@@ -130,7 +131,7 @@ def lib():
 
 EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_from_matches_file", "lfr_graph_from_matches_file_device",
            "lfr_graph_from_arrays", "lfr_graph_from_arrays_device_flows", "lfr_graph_to_device", "lfr_graph_evict_device",
-           "lfr_problem_build_hip_ex", "lfr_problem_build_hip_shard", "lfr_problem_cc_sharded", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_batch_positions_view_f32", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_pool_selftest", "lfr_debug_sort_pairs", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
+           "lfr_problem_build_hip_ex", "lfr_problem_build_hip_shard", "lfr_problem_cc_sharded", "lfr_hip_reserve", "lfr_hip_trim", "lfr_batch_positions_view", "lfr_batch_positions_view_f32", "lfr_bisect_graph", "lfr_debug_eval_edges", "lfr_debug_ls_next_step", "lfr_debug_tree_plan", "lfr_debug_pool_selftest", "lfr_debug_sort_pairs", "lfr_debug_exclusive_sum", "lfr_debug_recursive_cut", "lfr_hip_synchronize", "lfr_graph_free", "lfr_graph_num_nodes", "lfr_graph_num_edges",
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
@@ -326,6 +327,15 @@ def sort_pairs_hip(keys, vals, begin_bit, end_bit, use_library=False, device=0):
     _check(lib().lfr_debug_sort_pairs(device, keys.size, keys.dtype.itemsize, _ptr(keys), _ptr(vals), int(begin_bit), int(end_bit),
                                       int(bool(use_library)), _ptr(ko), _ptr(vo)))
     return ko, vo
+
+
+def exclusive_sum_hip(values, device=0):
+    """The pipeline's one-launch exclusive prefix sum (lfr_debug_exclusive_sum) of a uint32 / uint64 array."""
+    values = np.ascontiguousarray(values)
+    assert values.dtype in (np.uint32, np.uint64)
+    out = np.empty_like(values)
+    _check(lib().lfr_debug_exclusive_sum(device, values.size, values.dtype.itemsize, _ptr(values), _ptr(out)))
+    return out
 
 
 def bisect_graph(edges, weights):

@@ -13,7 +13,8 @@ MERGE_LIMIT = 256 * 1024
 
 
 def expected(keys, vals, begin_bit, end_bit):
-    mask = (np.uint64(1) << np.uint64(end_bit - begin_bit)) - np.uint64(1)
+    width = end_bit - begin_bit
+    mask = np.uint64(0xFFFFFFFFFFFFFFFF) if width == 64 else (np.uint64(1) << np.uint64(width)) - np.uint64(1)
     digits = (keys.astype(np.uint64) >> np.uint64(begin_bit)) & mask
     order = np.argsort(digits, kind="stable")
     return keys[order], vals[order]
@@ -66,3 +67,23 @@ def test_bad_arguments(lfr_lib):
         capi.sort_pairs_hip(k, k, 0, 40)
     with pytest.raises(capi.LfrError):
         capi.sort_pairs_hip(k, k, 8, 8)
+
+
+@pytest.mark.parametrize("dtype", [np.uint32, np.uint64])
+@pytest.mark.parametrize("n", [1, 7, 2047, 2048, 2049, 150_001, 2_500_001, 20_000_000])
+def test_one_launch_exclusive_sum(lfr_lib, dtype, n):
+    """The stages' prefix sums (flags -> ids, sizes -> offsets): one launch, look-back states in the stage's zero block.  Exact integers."""
+    rng = np.random.default_rng(n)
+    hi = 2 if n > 10_000_000 else (200 if dtype == np.uint32 else 2 ** 40)
+    v = rng.integers(0, hi, n, dtype=np.uint64).astype(dtype)
+    got = capi.exclusive_sum_hip(v)
+    want = np.zeros(n, np.uint64)                     # (uint64 throughout: a Python 0 in the concatenation would promote to float64)
+    want[1:] = np.cumsum(v.astype(np.uint64))[:-1]
+    assert (got == want.astype(dtype)).all()
+
+
+def test_exclusive_sum_of_32_bit_items_wraps(lfr_lib):
+    v = np.full(5000, 0xF0000000, np.uint32)
+    got = capi.exclusive_sum_hip(v)
+    want = (np.arange(5000, dtype=np.uint64) * np.uint64(0xF0000000)).astype(np.uint32)
+    assert (got == want).all()
