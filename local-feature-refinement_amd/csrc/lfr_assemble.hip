@@ -37,28 +37,59 @@ __device__ __forceinline__ void edge_ends(const uint32_t *node1, const uint32_t 
     dst = (e & 1) ? a : b;
 }
 
-// kept = same track or same component (solve.cc:105,114); marks nodes with a kept out-edge
-__global__ void k_mark_kept(int64_t n_dir, const uint32_t *node1, const uint32_t *node2, const int32_t *track,
-                            const int32_t *comp, uint8_t *kept, uint8_t *opt) {
-    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= n_dir) return;
-    uint32_t s, d;
-    edge_ends(node1, node2, e, s, d);
-    const bool k = track[s] == track[d] || comp[s] == comp[d];
-    kept[e] = k;
-    if (k) opt[s] = 1;
+// kept = same track or same component (solve.cc:105,114); marks nodes with a kept out-edge.  One thread per MATCH: the test is symmetric,
+// both directions are kept or dropped together.  match_key (optional): the key of the match-level sort - the component of the match
+// (a track lies inside one component, so both ends agree; anything else is flagged) with the edge kind (inter-track, solve.cc:114-123)
+// in bit 31, dropped_key for a dropped match.
+__global__ void k_mark_kept(int64_t M, const uint32_t *node1, const uint32_t *node2, const int32_t *track, const int32_t *comp, uint8_t *kept,
+                            uint8_t *opt, uint32_t dropped_key, uint32_t *match_key, uint32_t *flag) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t a = node1[m], b = node2[m];
+    const int32_t ta = track[a], tb = track[b], ca = comp[a], cb = comp[b];
+    const bool k = ta == tb || ca == cb;
+    reinterpret_cast<uint16_t *>(kept)[m] = k ? (uint16_t)0x0101 : (uint16_t)0;      // directed edges 2m and 2m + 1
+    if (k) { opt[a] = 1; opt[b] = 1; if (ca != cb) *flag = 1u; }
+    if (match_key) match_key[m] = k ? ((uint32_t)ca | (ta != tb ? 0x80000000u : 0u)) : dropped_key;
 }
 
+// variable = has a kept out-edge and is not its track's root (solve.cc:127,133-141); sizes of the tracks.  node_key (optional): the key
+// of the node sort - component, variables before constants - whose runs are the components' node counts (k_node_runs); without it the
+// counts are taken here, one atomic per node and counter.
 __global__ void k_mark_var(int64_t n_nodes, const uint8_t *opt, const uint8_t *is_root, const int32_t *track, const int32_t *comp,
-                           uint8_t *is_var, uint32_t *c_nodes, uint32_t *c_var, uint32_t *t_size, int32_t *t_comp) {
+                           uint8_t *is_var, uint32_t *c_nodes, uint32_t *c_var, uint32_t *t_size, int32_t *t_comp, uint32_t *node_key, uint32_t *node_id) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= n_nodes) return;
-    const bool v = opt[n] && !is_root[n];                    // solve.cc:127,133-141
+    const bool v = opt[n] && !is_root[n];
+    const int32_t c = comp[n], t = track[n];
     is_var[n] = v;
-    atomicAdd(&c_nodes[comp[n]], 1u);
-    if (v) atomicAdd(&c_var[comp[n]], 1u);
-    atomicAdd(&t_size[track[n]], 1u);
-    t_comp[track[n]] = comp[n];
+    if (node_key) { node_key[n] = ((uint32_t)c << 1) | (v ? 0u : 1u); node_id[n] = (uint32_t)n; }
+    else { atomicAdd(&c_nodes[c], 1u); if (v) atomicAdd(&c_var[c], 1u); }
+    atomicAdd(&t_size[t], 1u);
+    t_comp[t] = c;
+}
+// nodes sorted by (component, variables first): where a component's run begins, where its variables end, where it ends (all start at
+// zero; k_comp_keys turns them into the counts)
+__global__ void k_node_runs(int64_t N, const uint32_t *keys, uint32_t *run_begin, uint32_t *var_end, uint32_t *run_end) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t k = keys[i], c = k >> 1;
+    const bool first = i == 0 || (keys[i - 1] >> 1) != c, last = i + 1 == N || (keys[i + 1] >> 1) != c;
+    if (first) run_begin[c] = (uint32_t)i;
+    if ((k & 1u) && (first || keys[i - 1] != k)) var_end[c] = (uint32_t)i;      // the first constant
+    if (last) { run_end[c] = (uint32_t)(i + 1); if (!(k & 1u)) var_end[c] = (uint32_t)(i + 1); }      // (no constant at all)
+}
+// ... and every node of a solved component to its place in the batch: position in the run = local index
+__global__ void k_place_nodes(int64_t N, const uint32_t *keys, const uint32_t *node_sorted, const int32_t *di_of_comp, const uint32_t *node_off,
+                              const uint32_t *run_begin, uint32_t *node_ids, uint32_t *local_of) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    const uint32_t c = keys[p] >> 1;
+    const int32_t di = di_of_comp[c];
+    if (di < 0) return;
+    const uint32_t l = (uint32_t)p - run_begin[c], n = node_sorted[p];
+    node_ids[node_off[di] + l] = n;
+    local_of[n] = l;
 }
 
 // one thread per MATCH: both directions are kept or dropped together (same track / same component and "an end is variable" are
@@ -112,10 +143,12 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uin
 // per component: solvable? class; the three sort keys of the batch order
 // batch order = class, then edges descending, then variables descending, then id: one 52-bit key (a stable sort keeps the ids
 // ascending inside ties).  Three LSD passes over 32-bit keys cost three block sorts and thirty merge launches of ~6 us each.
-__global__ void k_comp_keys(int64_t n_comp, const uint32_t *c_nodes, const uint32_t *c_var, uint32_t *c_edges, const uint32_t *run_begin,
-                            const uint32_t *run_end, unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
+__global__ void k_comp_keys(int64_t n_comp, uint32_t *c_nodes, uint32_t *c_var, uint32_t *c_edges, const uint32_t *run_begin,
+                            const uint32_t *run_end, const uint32_t *node_begin, const uint32_t *node_var_end, const uint32_t *node_end,
+                            unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_comp) return;
+    if (node_begin) { c_nodes[c] = node_end[c] - node_begin[c]; c_var[c] = node_var_end[c] - node_begin[c]; }      // nodes sorted before the counts (k_node_runs)
     if (run_begin) c_edges[c] = 2u * (run_end[c] - run_begin[c]);       // matches sorted before the counts (k_match_keys_comp): both directions of every match of the run
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
     if (solvable && c_nodes[c] > 32767) *too_big = 1u;
@@ -225,18 +258,15 @@ __global__ void k_expand_match_order(int64_t M, const uint32_t *total_edges_p, c
 // stable on the match id, so the records of a component come out in the order they always had.
 // A match is in the reduced program when it is kept and one end is a variable; both directions go together and - a track lies inside
 // one component - both ends are in one component: anything else is flagged like an unpaired record.
-__global__ void k_match_keys_comp(int64_t M, const uint32_t *node1, const uint32_t *node2, const int32_t *comp, const uint8_t *is_var, uint8_t *kept,
-                                  uint32_t dropped_key, uint32_t *keys, uint32_t *ids, uint32_t *flag) {
+__global__ void k_match_keys_comp(int64_t M, const uint32_t *node1, const uint32_t *node2, const uint8_t *is_var, uint8_t *kept,
+                                  uint32_t dropped_key, uint32_t *keys, uint32_t *ids) {
     const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const uint32_t a = node1[m], b = node2[m];
-    const bool var = is_var[a] || is_var[b];                 // both ends constant: not in the reduced program
-    const bool k0 = kept[2 * m] && var, k1 = kept[2 * m + 1] && var;
-    kept[2 * m] = k0; kept[2 * m + 1] = k1;
-    const int32_t ca = comp[a];
-    if (k0 != k1 || (k0 && comp[b] != ca)) *flag = 1u;
-    keys[m] = k0 ? (uint32_t)ca : dropped_key;
-    ids[m] = (uint32_t)m;
+    const uint32_t pk = keys[m];                             // k_mark_kept: component | kind << 31, or dropped_key
+    const bool in = pk != dropped_key && (is_var[node1[m]] || is_var[node2[m]]);     // both ends constant: not in the reduced program
+    if (!in && pk != dropped_key) reinterpret_cast<uint16_t *>(kept)[m] = 0;
+    keys[m] = in ? (pk & 0x7fffffffu) : dropped_key;
+    ids[m] = (uint32_t)m | (pk & 0x80000000u);               // the kind travels with the id (M < 2^30)
 }
 // one thread per sorted match: the first of a run writes where it begins, the last where it ends (both start at zero: no run, no edges);
 // k_comp_keys turns the pair into the component's edge count
@@ -251,7 +281,7 @@ __global__ void k_match_runs(int64_t M, const uint32_t *keys, uint32_t n_comp, u
 // ... and every match to its place: both directions' edge ids (and record words, k_expand_match_order) at the component's offset
 __global__ void k_place_matches(int64_t M, const uint32_t *keys, const uint32_t *match_sorted, uint32_t n_comp, const int32_t *di_of_comp,
                                 const uint32_t *edge_off, const uint32_t *run_begin, const uint32_t *node1, const uint32_t *node2,
-                                const int32_t *track, const uint32_t *local_of, uint32_t *edge_sorted, uint32_t *words) {
+                                const uint32_t *local_of, uint32_t *edge_sorted, uint32_t *words) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= M) return;
     const uint32_t c = keys[p];
@@ -259,11 +289,10 @@ __global__ void k_place_matches(int64_t M, const uint32_t *keys, const uint32_t 
     const int32_t di = di_of_comp[c];
     if (di < 0) return;
     const uint32_t q = (edge_off[di] >> 1) + ((uint32_t)p - run_begin[c]);
-    const uint32_t m = match_sorted[p];
+    const uint32_t mk = match_sorted[p], m = mk & 0x7fffffffu, kind = mk >> 31;
     reinterpret_cast<uint2 *>(edge_sorted)[q] = make_uint2(2u * m, 2u * m + 1u);
     if (words) {
-        const uint32_t a = node1[m], b = node2[m];
-        const uint32_t kind = track[a] != track[b] ? 1u : 0u, la = local_of[a], lb = local_of[b];
+        const uint32_t la = local_of[node1[m]], lb = local_of[node2[m]];
         reinterpret_cast<uint2 *>(words)[q] = make_uint2(la | ((lb | (kind << 15)) << 16), lb | ((la | (kind << 15)) << 16));
     }
 }
@@ -609,12 +638,12 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     TAKE(ts, uint32_t, T + 1); TAKE(dn, uint32_t, C + 1); TAKE(de, uint32_t, C + 1);
     TAKE(ws_size, unsigned long long, C + 1);
     TAKE(run_begin, uint32_t, C + 1); TAKE(run_end, uint32_t, C + 1);       // (k_match_runs)
+    TAKE(node_begin, uint32_t, C + 1); TAKE(node_var_end, uint32_t, C + 1); TAKE(node_end, uint32_t, C + 1);      // (k_node_runs)
     const size_t scan_words = scan_state_words(C + 1);                      // look-back states of the four prefix sums below (exclusive_sum_one_launch)
     TAKE(scan_state, unsigned long long, 4 * scan_words);
     {   FillRegions fr; fr.add(arena.base + zero_mark, arena.top - zero_mark, 0); LFR_HIP_TRY(fill_regions(fr, st)); }
     TAKE(kept, uint8_t, E2); TAKE(is_var, uint8_t, N); TAKE(tc, int32_t, T + 1);
-    hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, track, comp, kept, opt);
-    hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc);
+    TAKE(nk0, uint32_t, N); TAKE(nk1, uint32_t, N); TAKE(ni0, uint32_t, N); TAKE(ni1, uint32_t, N); TAKE(local, uint32_t, N);
     // Packed classes only (the graph stage's largest component says that no workgroup class can exist): the matches go through their
     // sort now, by component id, and the runs are the edge counts (k_match_keys_comp).  LFR_EDGE_SORT_BY_EDGE / LFR_MATCH_SORT_LATE keep
     // the older orders for A/B.
@@ -622,12 +651,24 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (fused) ei1 = out.d_edge_ref;                  // the sorted edge ids ARE the packed kernel's gather list
     const bool expect_workgroup_classes = p.stats.max_component_size > 17;
     const bool match_sort_first = !expect_workgroup_classes && !getenv("LFR_EDGE_SORT_BY_EDGE") && !getenv("LFR_MATCH_SORT_LATE");
+    // The nodes go through THEIR sort before the counts as well - by (component, variables first): the runs are the components' node and
+    // variable counts (k_mark_var's two atomics per node on 147 k counters were half of its 54 us), a node's position in its run is its
+    // local index.  LFR_NODE_SORT_LATE keeps the older order (by the component's rank in the batch) for A/B.
+    const bool node_sort_first = !getenv("LFR_NODE_SORT_LATE");
     uint32_t *mkey_sorted = nullptr, *match_sorted = nullptr;
+    // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
+    uint32_t *mk0 = reinterpret_cast<uint32_t *>(ek0), *mk1 = mk0 + M, *mi0 = mk1 + M, *mi1 = mi0 + M;
     int rc;
+    hipLaunchKernelGGL(k_mark_kept, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, track, comp, kept, opt, (uint32_t)C,
+                       match_sort_first ? mk0 : nullptr, &sum->unpaired);
+    hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc,
+                       node_sort_first ? nk0 : nullptr, ni0);
+    if (node_sort_first) {
+        if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, std::min(32, nbits((uint64_t)2 * C)), st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_node_runs, grid_for(N), dim3(kThreads), 0, st, N, nk1, node_begin, node_var_end, node_end);
+    }
     if (match_sort_first) {
-        // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
-        uint32_t *mk0 = reinterpret_cast<uint32_t *>(ek0), *mk1 = mk0 + M, *mi0 = mk1 + M, *mi1 = mi0 + M;
-        hipLaunchKernelGGL(k_match_keys_comp, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, (uint32_t)C, mk0, mi0, &sum->unpaired);
+        hipLaunchKernelGGL(k_match_keys_comp, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, is_var, kept, (uint32_t)C, mk0, mi0);
         if ((rc = sort_pairs(arena, mk0, mk1, mi0, mi1, M, 0, comp_bits, st)) != LFR_OK) return rc;
         hipLaunchKernelGGL(k_match_runs, grid_for(M), dim3(kThreads), 0, st, M, mk1, (uint32_t)C, run_begin, run_end);
         mkey_sorted = mk1; match_sorted = mi1;
@@ -644,7 +685,8 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
     TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
+    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end,
+                       node_sort_first ? node_begin : nullptr, node_var_end, node_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
     if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
     hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
     uint32_t *perm = id1;                  // perm[i] = component of desc i
@@ -670,10 +712,13 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     hipLaunchKernelGGL(k_offsets, grid_for(C + 1), dim3(kThreads), 0, st, C, class_sorted, es_scan, ws_scan, no, eo, sum, out.d_es_off, out.d_ws_off);
 
     // ---- local node numbering: nodes by (desc, variable first, node id) ----
-    TAKE(nk0, uint32_t, N); TAKE(nk1, uint32_t, N); TAKE(ni0, uint32_t, N); TAKE(ni1, uint32_t, N); TAKE(local, uint32_t, N);
-    hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, di, is_var, (uint32_t)(2 * C), nk0, ni0);
-    if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, std::min(32, nbits((uint64_t)2 * C)), st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_node_locals, grid_for(N), dim3(kThreads), 0, st, N, total_nodes_p, ni1, comp, di, no, out.d_node_ids, local);
+    if (node_sort_first) {
+        hipLaunchKernelGGL(k_place_nodes, grid_for(N), dim3(kThreads), 0, st, N, nk1, ni1, di, no, node_begin, out.d_node_ids, local);
+    } else {
+        hipLaunchKernelGGL(k_node_keys, grid_for(N), dim3(kThreads), 0, st, N, comp, di, is_var, (uint32_t)(2 * C), nk0, ni0);
+        if ((rc = sort_pairs(arena, nk0, nk1, ni0, ni1, N, 0, std::min(32, nbits((uint64_t)2 * C)), st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_node_locals, grid_for(N), dim3(kThreads), 0, st, N, total_nodes_p, ni1, comp, di, no, out.d_node_ids, local);
+    }
 
     // ---- edge order: kept edges by (desc, source node, edge id); packed classes by (desc, edge id) ----
     // Packed classes carry zeros in the source-node bits (their order is component, then edge id - the sort is stable): when the graph
@@ -683,7 +728,7 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     bool words_done = false;                          // the record words came with the match-level order
     if (match_sort_first) {                           // (sorted before the counts: every match to its component's place)
         hipLaunchKernelGGL(k_place_matches, grid_for(M), dim3(kThreads), 0, st, M, mkey_sorted, match_sorted, (uint32_t)C, di, eo, run_begin, node1, node2,
-                           track, local, ei1, fused ? out.d_edge_word : nullptr);
+                           local, ei1, fused ? out.d_edge_word : nullptr);
         words_done = fused;
     } else if (expect_workgroup_classes) {
         hipLaunchKernelGGL(k_edge_keys, grid_for(E2), dim3(kThreads), 0, st, E2, node1, node2, comp, di, class_sorted, kept, node_bits,
