@@ -37,20 +37,28 @@ __device__ __forceinline__ void edge_ends(const uint32_t *node1, const uint32_t 
     dst = (e & 1) ? a : b;
 }
 
-// kept = same track or same component (solve.cc:105,114); marks nodes with a kept out-edge.  One thread per MATCH: the test is symmetric,
-// both directions are kept or dropped together.  match_key (optional): the key of the match-level sort - the component of the match
-// (a track lies inside one component, so both ends agree; anything else is flagged) with the edge kind (inter-track, solve.cc:114-123)
-// in bit 31, dropped_key for a dropped match.
+// kept = same track or same component (solve.cc:105,114); marks nodes with a kept out-edge.  The test is symmetric: both directions
+// of a match are kept or dropped together.  match_key (optional): the key of the match-level sort - the component of the match
+// (a track lies inside one component, so both ends agree) with the edge kind (inter-track, solve.cc:114-123) in bit 31, dropped_key for
+// a dropped match.
 __global__ void k_mark_kept(int64_t M, const uint32_t *node1, const uint32_t *node2, const int32_t *track, const int32_t *comp, uint8_t *kept,
-                            uint8_t *opt, uint32_t dropped_key, uint32_t *match_key, uint32_t *flag) {
-    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= M) return;
-    const uint32_t a = node1[m], b = node2[m];
-    const int32_t ta = track[a], tb = track[b], ca = comp[a], cb = comp[b];
-    const bool k = ta == tb || ca == cb;
-    reinterpret_cast<uint16_t *>(kept)[m] = k ? (uint16_t)0x0101 : (uint16_t)0;      // directed edges 2m and 2m + 1
-    if (k) { opt[a] = 1; opt[b] = 1; if (ca != cb) *flag = 1u; }
-    if (match_key) match_key[m] = k ? ((uint32_t)ca | (ta != tb ? 0x80000000u : 0u)) : dropped_key;
+                            uint8_t *opt, uint32_t dropped_key, uint32_t *match_key) {
+    // Two threads per match, one per direction, and no gather that is not needed (same track: the components are not compared; only the
+    // even direction writes the key and needs its end's component).  Measured on config 4: 51 us this way, 65 us with all four gathers
+    // unconditionally, 54 us with one thread per match doing both ends; without the key 37 us, but then k_match_keys_comp gathers the
+    // component again (29 us instead of 15): the kernel is a chain of two dependent gathers and lives on the number of them in flight.
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= 2 * M) return;
+    uint32_t s, d;
+    edge_ends(node1, node2, e, s, d);
+    const bool same_track = track[s] == track[d], keyed = match_key && !(e & 1);
+    int32_t cs = 0;
+    bool k = same_track;
+    if (!same_track) { cs = comp[s]; k = cs == comp[d]; }
+    else if (keyed) cs = comp[s];
+    kept[e] = k;
+    if (k) opt[s] = 1;
+    if (keyed) match_key[e >> 1] = k ? ((uint32_t)cs | (same_track ? 0u : 0x80000000u)) : dropped_key;
 }
 
 // variable = has a kept out-edge and is not its track's root (solve.cc:127,133-141); sizes of the tracks.  node_key (optional): the key
@@ -659,8 +667,8 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // (keys and ids of the M matches: the four quarters of the first 64-bit edge-key buffer)
     uint32_t *mk0 = reinterpret_cast<uint32_t *>(ek0), *mk1 = mk0 + M, *mi0 = mk1 + M, *mi1 = mi0 + M;
     int rc;
-    hipLaunchKernelGGL(k_mark_kept, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, track, comp, kept, opt, (uint32_t)C,
-                       match_sort_first ? mk0 : nullptr, &sum->unpaired);
+    hipLaunchKernelGGL(k_mark_kept, grid_for(E2), dim3(kThreads), 0, st, M, node1, node2, track, comp, kept, opt, (uint32_t)C,
+                       match_sort_first ? mk0 : nullptr);
     hipLaunchKernelGGL(k_mark_var, grid_for(N), dim3(kThreads), 0, st, N, opt, dp.is_root, track, comp, is_var, cn, cv, ts, tc,
                        node_sort_first ? nk0 : nullptr, ni0);
     if (node_sort_first) {
