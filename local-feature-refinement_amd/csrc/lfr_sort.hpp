@@ -12,6 +12,9 @@
 // rocprim::radix_sort_pairs as before.  Only .hip translation units see this header.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <cstring>                // (rocPRIM's texture_cache_iterator.hpp calls memset without it)
+
 #include <rocprim/rocprim.hpp>
 
 #include <cstdint>
@@ -29,11 +32,19 @@ namespace rd = ::rocprim::detail;
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // bytes == 0 on entry with tmp == nullptr: size query.  Keys/values must not alias their outputs.
-template <class K, class V>
+// Tile shapes.  rocPRIM has no tuned one-sweep configuration for gfx950; what it falls back to took 277 / 112 / 96 us for the three sorts
+// of config 4 - 2.5 M (u64, u32) pairs over 52 bits, 2.5 M (u32, u32) over 18, 0.88 M (u32, u32) over 19 - on an MI355X.  Measured with
+// scripts/probes/sort_probe.hip over ten shapes (profiles/r06_ab/sort_probe.txt): histogram 1024 x 8 with sort 1024 x 8 is the best of
+// them for the two long ones (248 / 105 us), sort 1024 x 4 for the short one (65 us): below ~2 M pairs a tile of 8192 leaves half of the
+// 256 CUs without a block.
+using OnesweepLong = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8, rocprim::block_radix_rank_algorithm::match>;
+using OnesweepShort = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 4>, 8, rocprim::block_radix_rank_algorithm::match>;
+constexpr unsigned int kOnesweepShortBelow = 2u << 20;
+
+template <class sort_config, class K, class V>
 hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const V *vin, V *vout, unsigned int n, unsigned int begin_bit,
                           unsigned int end_bit, hipStream_t st) {
     using offset_type = unsigned int;
-    using sort_config = typename LfrRadixSortConfig::onesweep_config;
     using config = rd::wrapped_radix_sort_onesweep_config<sort_config, K, V>;
     using decomposer_t = ::rocprim::identity_decomposer;
 
@@ -132,6 +143,19 @@ inline bool single_fill_enabled() {
     static const bool on = [] { const char *s = std::getenv("LFR_SORT_ROCPRIM"); return !(s && s[0] == '1'); }();
     return on;
 }
+template <class K, class V>
+hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const V *vin, V *vout, unsigned int n, unsigned int begin_bit,
+                          unsigned int end_bit, hipStream_t st) {
+#ifdef LFR_SORT_ONESWEEP_CONFIG
+    return onesweep_pairs<LFR_SORT_ONESWEEP_CONFIG>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);      // (sort_probe.hip: shapes for A/B)
+#else
+    static const int forced = [] { const char *e = std::getenv("LFR_SORT_TILES"); return e ? std::atoi(e) : 0; }();     // 1 = rocPRIM's default, 2 = long, 3 = short
+    if (forced == 1) return onesweep_pairs<typename LfrRadixSortConfig::onesweep_config>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+    if (forced == 3 || (forced == 0 && n < kOnesweepShortBelow)) return onesweep_pairs<OnesweepShort>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+    return onesweep_pairs<OnesweepLong>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+#endif
+}
+
 template <class K, class V>
 inline bool aliasing(const K *kin, const K *kout, const V *vin, const V *vout, int64_t n) {
     auto overlap = [n](const void *a, size_t sa, const void *b, size_t sb) {
