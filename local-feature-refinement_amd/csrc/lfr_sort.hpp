@@ -32,14 +32,22 @@ namespace rd = ::rocprim::detail;
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // bytes == 0 on entry with tmp == nullptr: size query.  Keys/values must not alias their outputs.
-// Tile shapes.  rocPRIM has no tuned one-sweep configuration for gfx950; what it falls back to took 277 / 112 / 96 us for the three sorts
-// of config 4 - 2.5 M (u64, u32) pairs over 52 bits, 2.5 M (u32, u32) over 18, 0.88 M (u32, u32) over 19 - on an MI355X.  Measured with
-// scripts/probes/sort_probe.hip over ten shapes (profiles/r06_ab/sort_probe.txt): histogram 1024 x 8 with sort 1024 x 8 is the best of
-// them for the two long ones (248 / 105 us), sort 1024 x 4 for the short one (65 us): below ~2 M pairs a tile of 8192 leaves half of the
-// 256 CUs without a block.
-using OnesweepLong = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 8>, 8, rocprim::block_radix_rank_algorithm::match>;
-using OnesweepShort = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 4>, 8, rocprim::block_radix_rank_algorithm::match>;
+// Tile shapes and digit widths.  rocPRIM has no tuned one-sweep configuration for gfx950; what it falls back to (8-bit digits) took
+// 277 / 112 / 96 us for the three sorts of config 4 - 2.5 M (u64, u32) pairs over 52 bits, 2.5 M (u32, u32) over 18, 0.88 M (u32, u32)
+// over 19 - on an MI355X.  Measured with scripts/probes/sort_probe.hip (profiles/r06_ab/sort_probe.txt):
+//   tiles   histogram 1024 x 8 with sort 1024 x 8 is the best of ten shapes for the long sorts (248 / 105 us), sort 1024 x 4 for the
+//           short one (65 us: below ~2 M pairs a tile of 8192 leaves half of the 256 CUs without a block);
+//   digits  a pass costs about the same for 8 and 9 bits and a fifth more for 10 (11 bits do not fit the LDS), so the width that needs
+//           the fewest passes wins, the narrower one on a tie: 52 bits in six 9-bit passes 226 us, 18 bits in two 9-bit passes 74 us,
+//           19 bits in two 10-bit passes 55 us.
+template <unsigned int Bits, unsigned int Items>
+using OnesweepShape = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, Items>, Bits, rocprim::block_radix_rank_algorithm::match>;
 constexpr unsigned int kOnesweepShortBelow = 2u << 20;
+inline unsigned int onesweep_digit_bits(unsigned int key_bits) {
+    unsigned int best = 8, passes = (key_bits + 7) / 8;
+    for (unsigned int d = 9; d <= 10; ++d) if ((key_bits + d - 1) / d < passes) { best = d; passes = (key_bits + d - 1) / d; }
+    return best;
+}
 
 template <class sort_config, class K, class V>
 hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const V *vin, V *vout, unsigned int n, unsigned int begin_bit,
@@ -149,10 +157,15 @@ hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const
 #ifdef LFR_SORT_ONESWEEP_CONFIG
     return onesweep_pairs<LFR_SORT_ONESWEEP_CONFIG>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);      // (sort_probe.hip: shapes for A/B)
 #else
-    static const int forced = [] { const char *e = std::getenv("LFR_SORT_TILES"); return e ? std::atoi(e) : 0; }();     // 1 = rocPRIM's default, 2 = long, 3 = short
+    static const int forced = [] { const char *e = std::getenv("LFR_SORT_TILES"); return e ? std::atoi(e) : 0; }();     // 1 = rocPRIM's default, 2 = 8-bit digits only
     if (forced == 1) return onesweep_pairs<typename LfrRadixSortConfig::onesweep_config>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
-    if (forced == 3 || (forced == 0 && n < kOnesweepShortBelow)) return onesweep_pairs<OnesweepShort>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
-    return onesweep_pairs<OnesweepLong>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+    switch (forced == 2 ? 8u : onesweep_digit_bits(end_bit - begin_bit)) {
+        case 10: return onesweep_pairs<OnesweepShape<10, 8>>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+        case 9: return onesweep_pairs<OnesweepShape<9, 8>>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+        default: break;
+    }
+    if (n < kOnesweepShortBelow) return onesweep_pairs<OnesweepShape<8, 4>>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
+    return onesweep_pairs<OnesweepShape<8, 8>>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
 #endif
 }
 
