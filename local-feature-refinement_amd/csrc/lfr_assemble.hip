@@ -436,10 +436,12 @@ __global__ void k_inc_counts(int64_t n, NodeInc *inc) {
 
 __global__ void k_fill_descs(int64_t cap, const uint32_t *class_sorted, const uint32_t *perm, const uint32_t *edge_off, const uint32_t *node_off,
                              const uint32_t *c_nodes, const uint32_t *c_var, const uint32_t *c_edges, const uint32_t *c_tracks,
-                             CompDesc *descs, uint32_t *desc_tracks) {
+                             CompDesc *descs, uint32_t *desc_tracks, uint32_t *desc_class, uint32_t *desc_component) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= cap || class_sorted[i] == kNoClass) return;
+    if (i >= cap) return;
     const uint32_t c = perm[i];
+    desc_class[i] = class_sorted[i]; desc_component[i] = c;       // the device copies behind the lazily fetched host mirrors (two copy launches before)
+    if (class_sorted[i] == kNoClass) return;
     CompDesc d;
     d.edge_off = edge_off[i]; d.n_edges = c_edges[c]; d.node_off = node_off[i];
     d.n_nodes = (uint16_t)c_nodes[c]; d.n_var = (uint16_t)c_var[c];
@@ -762,9 +764,8 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     if (fused && !words_done) hipLaunchKernelGGL(k_edge_words, grid_for(E2), dim3(kThreads), 0, st, E2, total_edges_p, ei1, node1, node2, track, local, out.d_edge_word);
 
     // ---- descriptors + the device copies behind the lazily fetched host mirrors ----
-    hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks);
-    LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_class, class_sorted, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
-    LFR_HIP_TRY(hipMemcpyAsync(out.d_desc_component, perm, 4 * (size_t)C, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_fill_descs, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, perm, eo, no, cn, cv, ce, ct, out.d_descs, out.d_desc_tracks,
+                       out.d_desc_class, out.d_desc_component);
 
     // ---- incidence lists: workgroup classes only.  The graph stage's largest component tells whether such a class can
     // exist (packed classes take up to 16 variable nodes); when it says no, the lists are skipped and the summary

@@ -15,11 +15,12 @@ for f in glob.glob("$OUT/*memory_copy_trace.csv"):
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "COPY " + r.get("Direction", "") + " " + r.get("Bytes", "")))
 rows.sort()
-# last repetition = after the last gap > 2 ms... find start of the last dense group by scanning back for a gap > 1.5 ms followed by solve kernels
-last_solve = max(i for i, r in enumerate(rows) if "solve_packed" in r[2] or "solve_block" in r[2])
-i = last_solve
-while i > 0 and rows[i][0] - rows[i - 1][1] < 1500000: i -= 1
-grp = rows[i:last_solve + 3]
+# the last repetition: everything that starts inside the host-timed span of the last "rep" line before the final read-back ends (config 5's
+# host cut is a 5 ms hole in the launches: a gap threshold split that repetition in two)
+import re as _re
+tot = [float(m.group(1)) for m in (_re.search(r"total ([0-9.]+) ms", l) for l in open("$OUT/run.log") if l.startswith("rep")) if m]
+last_end = max(r[1] for r in rows)
+grp = [r for r in rows if r[0] >= last_end - (tot[-1] * 1e6 + 30e3)]
 t0 = grp[0][0]
 import re
 busy = 0
