@@ -131,12 +131,6 @@ __global__ void k_sum_node_edges(int64_t n_nodes, const int32_t *comp, const uin
     if (n < n_nodes && n_edges[n]) atomicAdd(&c_edges[comp[n]], n_edges[n]);
 }
 
-__global__ void k_count_tracks(int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_tracks) return;
-    if (t_size[t] >= 2) atomicAdd(&c_tracks[t_comp[t]], 1u);
-}
-
 __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uint32_t block_max) {
     if (rows <= 8 && n_edges <= 24) return KC_G8;
     if (rows <= 16 && n_edges <= 96) return KC_G16;
@@ -153,8 +147,10 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uin
 // ascending inside ties).  Three LSD passes over 32-bit keys cost three block sorts and thirty merge launches of ~6 us each.
 __global__ void k_comp_keys(int64_t n_comp, uint32_t *c_nodes, uint32_t *c_var, uint32_t *c_edges, const uint32_t *run_begin,
                             const uint32_t *run_end, const uint32_t *node_begin, const uint32_t *node_var_end, const uint32_t *node_end,
-                            unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max) {
+                            unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max,
+                            int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < n_tracks && t_size[c] >= 2) atomicAdd(&c_tracks[t_comp[c]], 1u);      // (thread t doubles as track t: k_count_tracks' launch saved)
     if (c >= n_comp) return;
     if (node_begin) { c_nodes[c] = node_end[c] - node_begin[c]; c_var[c] = node_var_end[c] - node_begin[c]; }      // nodes sorted before the counts (k_node_runs)
     if (run_begin) c_edges[c] = 2u * (run_end[c] - run_begin[c]);       // matches sorted before the counts (k_match_keys_comp): both directions of every match of the run
@@ -173,12 +169,17 @@ __global__ void k_class_of_key(int64_t n, const unsigned long long *key, uint32_
 
 
 // after the sort: per desc sizes (0 for unsolvable) + inverse permutation
-__global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, const uint32_t *key_class_sorted, const uint32_t *c_nodes,
+// (sorted_keys != nullptr: the class comes straight from the sorted keys and is written to class_sorted here - k_class_of_key's launch saved
+// on the unsharded road)
+__global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, uint32_t *class_sorted, const unsigned long long *sorted_keys, const uint32_t *c_nodes,
                              const uint32_t *c_edges, uint32_t *d_nodes, uint32_t *d_edges, int32_t *di_of_comp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_comp) return;
     const uint32_t c = perm[i];
-    const bool solvable = key_class_sorted[i] != kNoClass;
+    uint32_t cls;
+    if (sorted_keys) { cls = (uint32_t)(sorted_keys[i] >> 48); class_sorted[i] = cls; }
+    else cls = class_sorted[i];
+    const bool solvable = cls != kNoClass;
     d_nodes[i] = solvable ? c_nodes[c] : 0u;
     d_edges[i] = solvable ? c_edges[c] : 0u;
     di_of_comp[c] = solvable ? (int32_t)i : -1;
@@ -690,25 +691,25 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     } else {
         hipLaunchKernelGGL(k_count_edges, grid_for(M), dim3(kThreads), 0, st, M, node1, node2, comp, is_var, kept, ce);
     }
-    hipLaunchKernelGGL(k_count_tracks, grid_for(T), dim3(kThreads), 0, st, T, ts, tc, ct);
 
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
     TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
-    hipLaunchKernelGGL(k_comp_keys, grid_for(C), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end,
-                       node_sort_first ? node_begin : nullptr, node_var_end, node_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows());
+    hipLaunchKernelGGL(k_comp_keys, grid_for(std::max(C, T)), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end,
+                       node_sort_first ? node_begin : nullptr, node_var_end, node_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows(),
+                       T, ts, tc, ct);
     if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
-    hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
     uint32_t *perm = id1;                  // perm[i] = component of desc i
     uint32_t *class_sorted = k1;
     if (shard_world > 1) {                 // keep this shard's components (same relative order), the rest becomes class 7
+        hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
         hipLaunchKernelGGL(k_shard_class, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, shard_rank, shard_world, k0);
         if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, kClassBits, st)) != LFR_OK) return rc;
         perm = id0; class_sorted = k1;     // (k1 is rewritten by the sort after k_shard_class has read it: stream ordered)
     }
 
     TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
-    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, cn, ce, dn, de, di);
+    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, shard_world > 1 ? nullptr : key64s, cn, ce, dn, de, di);
     LFR_HIP_TRY(exclusive_sum_one_launch(dn, no, C + 1, scan_state + 0 * scan_words, st));
     LFR_HIP_TRY(exclusive_sum_one_launch(de, eo, C + 1, scan_state + 1 * scan_words, st));
     const uint32_t *total_nodes_p = no + C, *total_edges_p = eo + C;
