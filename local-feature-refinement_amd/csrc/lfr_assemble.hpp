@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <memory>
 
 #include "lfr_devctx.hpp"
@@ -147,7 +148,7 @@ struct FillRegions {
     unsigned long long bytes[kMax];
     unsigned int byte_value[kMax];
     int n = 0;
-    void add(void *p, size_t b, unsigned int v) { if (b) { ptr[n] = p; bytes[n] = b; byte_value[n] = v & 0xffu; ++n; } }
+    void add(void *p, size_t b, unsigned int v) { if (b && n < kMax) { ptr[n] = p; bytes[n] = b; byte_value[n] = v & 0xffu; ++n; } else if (b) std::abort(); }       // (more than kMax regions: a programming error)
 };
 __global__ void k_fill_regions(FillRegions r);
 inline hipError_t fill_regions(const FillRegions &r, hipStream_t st) {

@@ -134,7 +134,8 @@ __attribute__((target("avx2"))) int argmax_first_avx2(const int32_t *a, int n) {
     for (; i < n; ++i) if (a[i] == m) return i;
     return -1;
 }
-bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2"); return v; }
+// (LFR_BISECT_HEAP_ONLY: tests run the heap against the scan; the growth order - hence the partition - is the same either way)
+bool have_avx2() { static const bool v = __builtin_cpu_supports("avx2") && !getenv("LFR_BISECT_HEAP_ONLY"); return v; }
 
 void bisect_core(const SubGraph &g, std::vector<char> &side) {
     const int n = (int)g.ids.size();

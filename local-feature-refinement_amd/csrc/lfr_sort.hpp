@@ -26,10 +26,33 @@ namespace lfr {
 using LfrRadixSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)256 * 1024>;
 constexpr size_t kSortMergeLimit = (size_t)256 * 1024;
 
+// The driver below calls rocPRIM's detail kernels with the signatures of rocPRIM 4.2.0 (ROCm 7.2).  Another version takes the library's
+// public entry point for every sort (the results are the same; the fills come back) until the driver has been checked against it.
+#if !defined(LFR_SORT_OWN_DRIVER)
+#if ROCPRIM_VERSION == 400200
+#define LFR_SORT_OWN_DRIVER 1
+#else
+#define LFR_SORT_OWN_DRIVER 0
+#endif
+#endif
+
 namespace sortdetail {
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+template <class K, class V>
+inline bool aliasing(const K *kin, const K *kout, const V *vin, const V *vout, int64_t n) {
+    auto overlap = [n](const void *a, size_t sa, const void *b, size_t sb) {
+        const char *x = static_cast<const char *>(a), *y = static_cast<const char *>(b);
+        return x < y + sb * (size_t)n && y < x + sa * (size_t)n;
+    };
+    return overlap(kin, sizeof(K), kout, sizeof(K)) || overlap(vin, sizeof(V), vout, sizeof(V));
+}
+inline bool single_fill_enabled() {
+    static const bool on = [] { const char *s = std::getenv("LFR_SORT_ROCPRIM"); return LFR_SORT_OWN_DRIVER && !(s && s[0] == '1'); }();
+    return on;
+}
+#if LFR_SORT_OWN_DRIVER
 namespace rd = ::rocprim::detail;
 
-inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // bytes == 0 on entry with tmp == nullptr: size query.  Keys/values must not alias their outputs.
 // Tile shapes and digit widths.  rocPRIM has no tuned one-sweep configuration for gfx950; what it falls back to (8-bit digits) took
@@ -147,10 +170,6 @@ hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const
         variant);
 }
 
-inline bool single_fill_enabled() {
-    static const bool on = [] { const char *s = std::getenv("LFR_SORT_ROCPRIM"); return !(s && s[0] == '1'); }();
-    return on;
-}
 template <class K, class V>
 hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const V *vin, V *vout, unsigned int n, unsigned int begin_bit,
                           unsigned int end_bit, hipStream_t st) {
@@ -168,15 +187,7 @@ hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const
     return onesweep_pairs<OnesweepShape<8, 8>>(tmp, bytes, kin, kout, vin, vout, n, begin_bit, end_bit, st);
 #endif
 }
-
-template <class K, class V>
-inline bool aliasing(const K *kin, const K *kout, const V *vin, const V *vout, int64_t n) {
-    auto overlap = [n](const void *a, size_t sa, const void *b, size_t sb) {
-        const char *x = static_cast<const char *>(a), *y = static_cast<const char *>(b);
-        return x < y + sb * (size_t)n && y < x + sa * (size_t)n;
-    };
-    return overlap(kin, sizeof(K), kout, sizeof(K)) || overlap(vin, sizeof(V), vout, sizeof(V));
-}
+#endif   // LFR_SORT_OWN_DRIVER
 }   // namespace sortdetail
 
 // rocprim::radix_sort_pairs' two-call protocol (tmp == nullptr: size query, valid for either driver), ascending, stable, result in
@@ -188,12 +199,16 @@ hipError_t sort_pairs_raw(void *tmp, size_t &bytes, const K *kin, K *kout, const
         size_t lib = 0, own = 0;
         hipError_t e = rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, lib, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st);
         if (e != hipSuccess) return e;
+#if LFR_SORT_OWN_DRIVER
         if (big && (e = sortdetail::onesweep_pairs(nullptr, own, kin, kout, vin, vout, (unsigned int)n, (unsigned)begin_bit, (unsigned)end_bit, st)) != hipSuccess) return e;
+#endif
         bytes = lib > own ? lib : own;
         return hipSuccess;
     }
+#if LFR_SORT_OWN_DRIVER
     if (big && !sortdetail::aliasing(kin, kout, vin, vout, n))
         return sortdetail::onesweep_pairs(tmp, bytes, kin, kout, vin, vout, (unsigned int)n, (unsigned)begin_bit, (unsigned)end_bit, st);
+#endif
     return rocprim::radix_sort_pairs<LfrRadixSortConfig>(tmp, bytes, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st);
 }
 

@@ -282,6 +282,44 @@ def test_bisection_equals_its_naive_restatement(lfr_lib):
         assert got == want, (case, e.tolist(), w.tolist())
 
 
+_ARGMAX_CHILD = """
+import json, sys
+import numpy as np
+sys.path.insert(0, %r)
+from lfr_amd import capi
+rng = np.random.default_rng(78)
+out = []
+for case in range(120):
+    n = int(rng.integers(2, 300))
+    m = int(rng.integers(n, 40 * n))
+    a = rng.integers(0, n, m); b = rng.integers(0, n, m)
+    keep = a != b
+    e = np.stack([a[keep], b[keep]], 1).astype(np.int32)
+    w = rng.choice([0, 1, 1, 5, 5, 50, 100, 700], len(e)).astype(np.int32)
+    side = capi.bisect_graph(e, w)
+    out.append(sorted(side.items()))
+print(json.dumps(out))
+"""
+
+
+def test_bisection_heap_and_vector_scan_grow_the_same_region(lfr_lib):
+    """Dense graphs take the arg-max of the region growing with an AVX2 scan over a plain array, sparse ones (and hosts without AVX2) with
+    the indexed heap: the same (largest attachment, smallest id), so the same partition.  The same 120 random multigraphs (ties
+    everywhere, up to 300 nodes of mean degree up to 80) through both, each in its own process (the choice is read once)."""
+    import json, os, subprocess, sys
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "local-feature-refinement_amd")
+    runs = []
+    for heap_only in (False, True):
+        env = dict(os.environ)
+        env.pop("LFR_BISECT_HEAP_ONLY", None)
+        if heap_only:
+            env["LFR_BISECT_HEAP_ONLY"] = "1"
+        r = subprocess.run([sys.executable, "-c", _ARGMAX_CHILD % pkg], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        runs.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert runs[0] == runs[1]
+
+
 def test_parallel_cut_is_schedule_independent(lfr_lib):
     """The two halves of a bisection are cut on two threads (big halves only): the labels must not depend on the schedule -
     the same dense meta graph (one giant component, thousands of edges per half) cut eight times gives the same components,
