@@ -122,6 +122,42 @@ __global__ void k_cc_sim_keys(int64_t M, const uint32_t *n1, const float *sim, c
     key[m] = ((uint64_t)cc[n1[m]] << 32) | (uint64_t)(~sim_key(sim[m]));
     ids[m] = (uint32_t)m;
 }
+// Round 6: the usual case needs no 52-bit sort either.  Real match graphs fall into small connected components (config 4: 147 k of
+// 6..136 matches) - or into one giant one, which keeps the sort above.  The matches are grouped by component with a sort over the
+// component bits alone (two 10-bit passes instead of six 9-bit ones over 64-bit keys), and inside a component every match finds its
+// place by COUNTING the matches that precede it in the reference's order (descending (sim, n1, n2), equal triples by match id): the
+// comparison is the full one, so there are no ties to repair and no long-tie fallback.  A workgroup stages the records of the segments
+// that touch its 256 positions in LDS (16 B per match: ~sim key, n1, n2, id), so a record is gathered about once.
+constexpr int kRankSortMax = 1024;                   // longest segment the counting handles (LDS window: 256 + 2 x longest records, 36 KB at most)
+__global__ void k_match_records(int64_t M, const uint32_t *n1, const uint32_t *n2, const float *sim, const uint32_t *cc, uint4 *rec, uint32_t *key, uint32_t *ids) {
+    const int64_t m = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const uint32_t a = n1[m];
+    rec[m] = make_uint4(~sim_key(sim[m]), a, n2[m], (uint32_t)m);
+    key[m] = cc[a];
+    ids[m] = (uint32_t)m;
+}
+__device__ __forceinline__ bool rank_precedes(const uint4 &q, const uint4 &me) {          // q comes before me in the reference's order
+    return q.x < me.x || (q.x == me.x && (q.y > me.y || (q.y == me.y && (q.z > me.z || (q.z == me.z && q.w < me.w)))));
+}
+__global__ __launch_bounds__(kThreads) void k_rank_sort(int64_t M, const uint32_t *grouped, const uint4 *rec, const uint32_t *flags, const uint32_t *seg_id,
+                                                        const uint32_t *starts, uint32_t *order) {
+    extern __shared__ uint4 s_rec[];                  // kThreads + 2 x (longest segment) records: the host knows the longest segment by now
+    const int64_t b0 = (int64_t)blockIdx.x * kThreads;
+    if (b0 >= M) return;
+    const int64_t b1 = b0 + kThreads < M ? b0 + kThreads : M;
+    const int64_t w_lo = starts[seg_id[b0] + flags[b0] - 1u], w_hi = starts[seg_id[b1 - 1] + flags[b1 - 1]];     // the segments that touch [b0, b1)
+    for (int64_t j = w_lo + threadIdx.x; j < w_hi; j += kThreads) s_rec[j - w_lo] = rec[grouped[j]];
+    __syncthreads();
+    const int64_t i = b0 + threadIdx.x;
+    if (i >= M) return;
+    const uint32_t sg = seg_id[i] + flags[i] - 1u;
+    const int64_t lo = starts[sg], hi = starts[sg + 1];
+    const uint4 me = s_rec[i - w_lo];
+    uint32_t rank = 0;
+    for (int64_t j = lo; j < hi; ++j) rank += rank_precedes(s_rec[j - w_lo], me) ? 1u : 0u;
+    order[lo + rank] = me.w;
+}
 __global__ void k_gather_u64(int64_t n, const uint32_t *idx, const uint64_t *src, uint64_t *dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[idx[i]];
@@ -1191,11 +1227,13 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
 
     // 2. matches grouped by connected component, inside a component in the reference's order: descending (sim, n1, n2).
     //    One sort over (component | ~sim) + the tie fix; the exact three-sort order only if a run of equal similarities is too long for it
-    TAKE(khi, uint64_t, M); TAKE(khi2, uint64_t, M); TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
+    TAKE(rec, uint4, M);                              // (the 64-bit keys of the one-sort road share these 16 M bytes with the records of the counting road)
+    uint64_t *const khi = reinterpret_cast<uint64_t *>(rec), *const khi2 = khi + M;
+    TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
     TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
     TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(segid, uint32_t, M + 1);
     TAKE(starts, uint32_t, std::min(N, M) + 2);
-    uint32_t *const order = id1;
+    uint32_t *order = id1;
     int max_tie_run = kMaxTieRun;
     if (const char *e = getenv("LFR_MAX_TIE_RUN")) max_tie_run = std::max(0, atoi(e));     // (tests: 0 = always the three sorts)
     auto three_sorts = [&]() -> int {
@@ -1207,22 +1245,50 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         hipLaunchKernelGGL(k_cc_keys, grid_for(M), dim3(kThreads), 0, st, M, id0, n1, cc, ck0);
         return sort_pairs(arena, ck0, ck1, id0, id1, M, 0, node_bits, st);                // stable: -> order
     };
-    if (max_tie_run > 0) {
-        hipLaunchKernelGGL(k_cc_sim_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, sim, cc, khi, id0);
-        if ((rc = sort_pairs(arena, khi, khi2, id0, id1, M, 0, 32 + node_bits, st)) != LFR_OK) return rc;
-        hipLaunchKernelGGL(k_tie_fix, grid_for(M), dim3(kThreads), 0, st, M, khi2, order, n1, n2, max_tie_run, counts);
-        hipLaunchKernelGGL(k_seg_flags_hi, grid_for(M), dim3(kThreads), 0, st, M, khi2, flags);
-    } else {
-        if ((rc = three_sorts()) != LFR_OK) return rc;
-        hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
-    }
-    // (the one long prefix sum of the stage: rocPRIM's larger tiles keep the look-back chain short - 20.6 us with its init launch
-    // against 26.9 us for the one-launch kernel at 2.5 M flags; the short sums below are the other way round)
-    if (M + 1 > (int64_t)1 << 20) { if ((rc = exclusive_sum(arena, flags, segid, M + 1, st)) != LFR_OK) return rc; }
-    else LFR_HIP_TRY(exclusive_sum_one_launch(flags, segid, M + 1, scan_state, st));
     const int64_t seg_cap = std::min(N, M) + 1;       // a segment has >= 1 match and >= 2 nodes
-    hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
-    hipLaunchKernelGGL(k_seg_maxlen, grid_few(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
+    bool scan_state_used = false;
+    auto segments = [&]() -> int {                    // flags -> segment ids, starts, longest segment
+        // (the one long prefix sum of the stage: rocPRIM's larger tiles keep the look-back chain short - 20.6 us with its init launch
+        // against 26.9 us for the one-launch kernel at 2.5 M flags; the short sums below are the other way round.  The one-launch sum's
+        // states are good for one use: a second pass over the segments takes the library's.)
+        if (M + 1 > (int64_t)1 << 20 || scan_state_used) { const int r = exclusive_sum(arena, flags, segid, M + 1, st); if (r != LFR_OK) return r; }
+        else { LFR_HIP_TRY(exclusive_sum_one_launch(flags, segid, M + 1, scan_state, st)); scan_state_used = true; }
+        hipLaunchKernelGGL(k_seg_starts, grid_for(std::max<int64_t>(M, 1)), dim3(kThreads), 0, st, M, flags, segid, starts, counts);
+        hipLaunchKernelGGL(k_seg_maxlen, grid_few(seg_cap), dim3(kThreads), 0, st, seg_cap, starts, counts);
+        return LFR_OK;
+    };
+    // The counting road (k_rank_sort) first: group by component, look at the longest segment (the stage's first read-back, which used to
+    // follow the small-component union-find), count inside the segments.  A giant component (or LFR_ONE_SORT_ORDER=1, or the tests'
+    // LFR_MAX_TIE_RUN=0) takes the roads of rounds 3-5: one sort over (component | ~similarity) + tie repair, or the three sorts.
+    bool counts_on_host = false, order_done = false;
+    if (max_tie_run > 0 && !getenv("LFR_ONE_SORT_ORDER")) {
+        hipLaunchKernelGGL(k_match_records, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, cc, rec, ck0, id0);
+        if ((rc = sort_pairs(arena, ck0, ck1, id0, id1, M, 0, node_bits, st)) != LFR_OK) return rc;
+        hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
+        if ((rc = segments()) != LFR_OK) return rc;
+        lap("grouped by connected component");
+        LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(stream_wait(st));
+        lap("first read-back");
+        if ((int64_t)h_counts[CNT_MAX_SEG] <= kRankSortMax) {
+            const size_t window = sizeof(uint4) * ((size_t)kThreads + 2 * (size_t)h_counts[CNT_MAX_SEG]);     // (8 KB for config 4's 136: eight workgroups per CU)
+            hipLaunchKernelGGL(k_rank_sort, grid_for(M), dim3(kThreads), window, st, M, id1, rec, flags, segid, starts, id0);
+            order = id0;
+            counts_on_host = true; order_done = true;
+        }
+    }
+    if (!order_done) {
+        if (max_tie_run > 0) {
+            hipLaunchKernelGGL(k_cc_sim_keys, grid_for(M), dim3(kThreads), 0, st, M, n1, sim, cc, khi, id0);
+            if ((rc = sort_pairs(arena, khi, khi2, id0, id1, M, 0, 32 + node_bits, st)) != LFR_OK) return rc;
+            hipLaunchKernelGGL(k_tie_fix, grid_for(M), dim3(kThreads), 0, st, M, khi2, order, n1, n2, max_tie_run, counts);
+            hipLaunchKernelGGL(k_seg_flags_hi, grid_for(M), dim3(kThreads), 0, st, M, khi2, flags);
+        } else {
+            if ((rc = three_sorts()) != LFR_OK) return rc;
+            hipLaunchKernelGGL(k_seg_flags, grid_for(M), dim3(kThreads), 0, st, M, ck1, flags);
+        }
+        if ((rc = segments()) != LFR_OK) return rc;
+    }
 
     // 3. greedy constrained union-find per connected component: small ones one thread each ...
     TAKE(par, int32_t, N); TAKE(next, int32_t, N); TAKE(tail, int32_t, N); TAKE(cnt, int32_t, N); TAKE(sig, ulonglong2, N);
@@ -1231,11 +1297,13 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     if (const char *e = getenv("LFR_SERIAL_SEGMENT_EDGES")) serial_limit = std::max<int64_t>(0, atoll(e));
     hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
                        dg->node_image, par, next, tail, cnt, sig);
-    // ... large ones in parallel rounds (first read-back: is there any?)
+    // ... large ones in parallel rounds (first read-back: is there any? - the counting road has read the counts already)
     lap("sorts / connected components / small-component union-find enqueued");
-    LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
-    LFR_HIP_TRY(stream_wait(st));
-    lap("first read-back");
+    if (!counts_on_host) {
+        LFR_HIP_TRY(hipMemcpyAsync(h_counts, counts, 4 * CNT_WORDS, hipMemcpyDeviceToHost, st));
+        LFR_HIP_TRY(stream_wait(st));
+        lap("first read-back");
+    }
     if (h_counts[CNT_LONG_TIE]) {
         // a long run of equal similarities: the exact order from the three sorts (the segments - which matches, where - are the same:
         // flags, segment ids and starts stay), the union-find of the small components again from scratch

@@ -222,19 +222,23 @@ def test_round_based_union_find_fuzz(lfr_lib, monkeypatch, cooperative):
     assert n_ok >= 120
 
 
-@pytest.mark.parametrize("max_run", [None, "2", "0"])
-def test_equal_similarities_keep_the_reference_order(lfr_lib, monkeypatch, max_run):
-    """The device stage orders the matches with ONE sort by (connected component, similarity) and puts runs of equal similarities into the
-    reference's (n1, n2) descending order in place (solve.cc:489); a run above kMaxTieRun (LFR_MAX_TIE_RUN) sends it to the three stable
+@pytest.mark.parametrize("road,max_run", [("count", None), ("one_sort", None), ("one_sort", "2"), ("one_sort", "0")])
+def test_equal_similarities_keep_the_reference_order(lfr_lib, monkeypatch, road, max_run):
+    """Three roads to the reference's order of the matches inside a connected component (descending (sim, n1, n2), solve.cc:489).  Since
+    round 6 small components COUNT: grouped by component, every match takes the number of matches that precede it (k_rank_sort; the full
+    comparison, no ties left).  A giant component - or LFR_ONE_SORT_ORDER=1 - takes ONE sort by (component, similarity) and puts runs of
+    equal similarities into (n1, n2) descending order in place; a run above kMaxTieRun (LFR_MAX_TIE_RUN) sends that to the three stable
     sorts.  Quantized similarities in small components (short runs), in a giant component (runs of thousands) and the fuzz cases (three
     similarity values): labels bit-identical to the host stage whichever way the order was made."""
     from test_graph_stage import fuzz_pairs
+    if road == "one_sort":
+        monkeypatch.setenv("LFR_ONE_SORT_ORDER", "1")
     if max_run is not None:
         monkeypatch.setenv("LFR_MAX_TIE_RUN", max_run)
     small = synthetic.generate(seed=311, n_images=64, n_tracks=3000, eps_out=0.001)
     small.sim[:] = np.round(small.sim * 64.0) / 64.0                               # ~17 matches per component over a few dozen values
     _, pd = _labels_equal(small)
-    assert pd.stats()["tie_resorts"] == (1 if max_run == "2" else 0)               # default: fixed in place ("0": three sorts from the start)
+    assert pd.stats()["tie_resorts"] == (1 if max_run == "2" else 0)               # counted / fixed in place ("0": three sorts from the start)
     giant = synthetic.generate(seed=312, n_images=40, n_tracks=3000, eps_out=0.05)
     giant.sim[:] = np.round(giant.sim * 8.0) / 8.0
     ph, pd = _labels_equal(giant)
