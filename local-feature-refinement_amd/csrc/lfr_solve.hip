@@ -749,6 +749,12 @@ struct BlockShared {
 
 using f64x4 = __attribute__((ext_vector_type(4))) double;
 
+// A value every lane of the wave holds (a workgroup reduction read back from LDS, the scalars of the LM loop derived from such): moved
+// to SGPRs, bit for bit.  The compiler keeps what the VALU produced in VGPRs whether or not the lanes agree; the state of the
+// trust-region loop - two dozen doubles that live across the inlined sweeps - was what spilled to scratch around every sweep.
+__device__ __forceinline__ double uni(double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 template <int kBlockThreads>
 __device__ __forceinline__ double block_sum(double v, BlockShared &sh) {
     v = wave_sum(v);
@@ -758,7 +764,7 @@ __device__ __forceinline__ double block_sum(double v, BlockShared &sh) {
     double s = 0.0;
 #pragma unroll
     for (int w = 0; w < kBlockThreads / 64; ++w) s += sh.red[w];
-    return s;
+    return uni(s);
 }
 template <int kBlockThreads>
 __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
@@ -769,7 +775,7 @@ __device__ __forceinline__ double block_max(double v, BlockShared &sh) {
     double s = sh.red[0];
 #pragma unroll
     for (int w = 1; w < kBlockThreads / 64; ++w) s = fmax(s, sh.red[w]);
-    return s;
+    return uni(s);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1511,7 +1517,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
     };
 
     int exec_passes = 1;
-    double cost = sweep(vx, vg, true);
+    double cost = uni(sweep(vx, vg, true));          // (uni: the scalars of this loop are wave-uniform - SGPRs, not spilled VGPRs)
     PROF_MARK(0);                                     // 0: sweeps (evaluate + owner-computes assembly)
     for (int i = tid; i < n; i += kBlockThreads) vscale[i] = 1.0 / (1.0 + sqrt(vadiag[i]));
     __syncthreads();
@@ -1642,14 +1648,14 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                 if (!isfinite(st)) bad = 1.0;
                 part += -rhs0 * st + vD[i] * vD[i] * st * st;
             }
-            model_cost_change = 0.5 * block_sum<kBlockThreads>(part, sh);
+            model_cost_change = uni(0.5 * block_sum<kBlockThreads>(part, sh));
             bad = block_max<kBlockThreads>(bad, sh);
             valid = bad == 0.0 && model_cost_change > 0.0;
         }
         if (!valid) {
             if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
+            radius = uni(radius / decrease_factor);
+            decrease_factor = uni(decrease_factor * 2.0);
             continue;
         }
         n_invalid = 0;
@@ -1673,7 +1679,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                 for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], __dmul_rn(alpha, vdelta[i])));
                 __syncthreads();
                 PROF_MARK(4);
-                cost_c = sweep(vxc, vgn, true);       // also assembles J^T J at the trial point into Mat
+                cost_c = uni(sweep(vxc, vgn, true));  // also assembles J^T J at the trial point into Mat
                 PROF_MARK(2);                         // 2: line-search sweeps
                 ++exec_passes; ++n_ls_evals;
                 current.x = alpha; current.value = cost_c; current.value_valid = isfinite(cost_c);
@@ -1688,17 +1694,17 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
                 const double nstep = ls_next_step_regs(initial, previous, current, dir_max, n_iter);
                 if (nstep < 0.0) break;
                 previous = current;
-                alpha = nstep;
+                alpha = uni(nstep);
             }
         }
         if (!ls_ok) {
             for (int i = tid; i < n; i += kBlockThreads) vxc[i] = clampb(__dadd_rn(vx[i], vdelta[i]));
             __syncthreads();
-            cost_c = sweep(vxc, vgn, true);
+            cost_c = uni(sweep(vxc, vgn, true));
             ++exec_passes;
         }
         ++n_cand;
-        const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
+        const double cost_cand = uni(isfinite(cost_c) ? cost_c : DBL_MAX);
         double sn = 0.0;
         for (int i = tid; i < n; i += kBlockThreads) sn += (vx[i] - vxc[i]) * (vx[i] - vxc[i]);
         const double step_norm = sqrt(block_sum<kBlockThreads>(sn, sh));
@@ -1710,7 +1716,7 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
             double xn = 0.0;
             __syncthreads();
             for (int i = tid; i < n; i += kBlockThreads) { vx[i] = vxc[i]; xn += vxc[i] * vxc[i]; }
-            x_norm = sqrt(block_sum<kBlockThreads>(xn, sh));
+            x_norm = uni(sqrt(block_sum<kBlockThreads>(xn, sh)));
             // the accepted candidate is the last evaluated point: its cost, gradient and J^T J (in Mat,
             // the factorization was no longer needed) are already there - no extra sweep
             for (int i = tid; i < n; i += kBlockThreads) vg[i] = vgn[i];
@@ -1721,12 +1727,12 @@ __device__ __forceinline__ void solve_component(const KernelArgs &a, const int m
             step_successful = true;
             ++n_successful;
             const double t = 2.0 * rel - 1.0;
-            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            radius = uni(fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t)));
             decrease_factor = 2.0;
             reuse_diagonal = false;
         } else {
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
+            radius = uni(radius / decrease_factor);
+            decrease_factor = uni(decrease_factor * 2.0);
         }
     }
     __syncthreads();
@@ -2817,9 +2823,9 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
     // (-DLFR_PROFILE_PHASES: 0 sweeps, 1 factorization, 5 scaling, 6 back substitution, 4 everything else - the slots of the LDS kernels)
     int exec_passes = 1;
     SweepOut sw = sweep(vx, vdelta, 0.0, false, vxc, vg);
-    double cost = sw.cost;
+    double cost = uni(sw.cost);                       // (uni: the loop's scalars are replicated - SGPRs, like the LDS kernel's)
     PROF_MARK(0);
-    double gmax = sw.gm;
+    double gmax = uni(sw.gm);
     double x_norm = 0.0, radius = kInitialRadius, decrease_factor = 2.0;
     bool reuse_diagonal = false, step_successful = true, matrix_valid = true;
     int n_invalid = 0, iteration = 0, term = LFR_TERM_CONVERGENCE;
@@ -2895,7 +2901,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             }
             treduce4(partial, gd_part, zero, dm_part);
             TR(14, 0);
-            model_cost_change = 0.5 * partial; g_dot_delta = gd_part; dir_max = dm_part;
+            model_cost_change = uni(0.5 * partial); g_dot_delta = uni(gd_part); dir_max = uni(dm_part);
             valid = isfinite(dir_max) && model_cost_change > 0.0;
         }
         if (!valid) {
@@ -2903,8 +2909,8 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             // read it first - no sweep or reduction, hence no team barrier, lies on this path otherwise)
             if constexpr (TEAM) tsync();
             if (++n_invalid >= kMaxInvalid) { term = LFR_TERM_FAILURE; break; }
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
+            radius = uni(radius / decrease_factor);
+            decrease_factor = uni(decrease_factor * 2.0);
             continue;
         }
         n_invalid = 0;
@@ -2917,7 +2923,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
             for (;;) {
                 PROF_MARK(4);
                 sw = sweep(vx, vdelta, alpha, true, vxc, vgn);             // also assembles J^T J at the trial point
-                cost_c = sw.cost;
+                cost_c = uni(sw.cost);
                 matrix_valid = false;
                 PROF_MARK(0);
                 ++exec_passes; ++n_ls_evals;
@@ -2925,7 +2931,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                 current.gradient = 0.0; current.gradient_valid = false;
                 if (current.value_valid && !(cost_c > cost + kLsSufficientDecrease * g_dot_delta * alpha)) { ls_ok = true; break; }
                 if (current.value_valid) {
-                    current.gradient = sw.gd;                 // delta . g(trial point), summed by the sweep's node pass
+                    current.gradient = uni(sw.gd);                 // delta . g(trial point), summed by the sweep's node pass
                     current.gradient_valid = isfinite(current.gradient);
                 }
                 TR(15, 0);
@@ -2940,7 +2946,7 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
                         if (lane == 0) sh.bcast[0] = v;
                     }
                     __syncthreads();
-                    nstep = sh.bcast[0];
+                    nstep = uni(sh.bcast[0]);
                     ++n_iter;                                    // (= what ls_next_step_regs did to wave 0's copy)
                     __syncthreads();
                 }
@@ -2952,12 +2958,12 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         }
         if (!ls_ok) {
             sw = sweep(vx, vdelta, 1.0, true, vxc, vgn);
-            cost_c = sw.cost;
+            cost_c = uni(sw.cost);
             matrix_valid = false;
             ++exec_passes;
         }
         ++n_cand;
-        const double cost_cand = isfinite(cost_c) ? cost_c : DBL_MAX;
+        const double cost_cand = uni(isfinite(cost_c) ? cost_c : DBL_MAX);
         // step norm, and - should the candidate be accepted - its norm and projected gradient: from the sweep
         const double step_norm = sqrt(sw.sn);
         if (step_norm <= kParameterTol * (x_norm + kParameterTol)) break;
@@ -2966,19 +2972,19 @@ __device__ __forceinline__ void solve_tree_component(const KernelArgs &a, const 
         const double rel = cost_change / model_cost_change;
         if (rel > kMinRelDecrease) {
             { double *t = vx; vx = vxc; vxc = t; t = vg; vg = vgn; vgn = t; }      // the candidate becomes x, its gradient g
-            x_norm = sqrt(sw.xn);
+            x_norm = uni(sqrt(sw.xn));
             cost = cost_cand;
             matrix_valid = true;              // the accepted candidate is the last evaluated point: its J^T J is in the tiles
-            gmax = sw.gm;
+            gmax = uni(sw.gm);
             step_successful = true;
             ++n_successful;
             const double t = 2.0 * rel - 1.0;
-            radius = fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t));
+            radius = uni(fmin(kMaxRadius, radius / fmax(1.0 / 3.0, 1.0 - t * t * t)));
             decrease_factor = 2.0;
             reuse_diagonal = false;
         } else {
-            radius = radius / decrease_factor;
-            decrease_factor *= 2.0;
+            radius = uni(radius / decrease_factor);
+            decrease_factor = uni(decrease_factor * 2.0);
         }
     }
     PROF_MARK(4);
@@ -3225,8 +3231,14 @@ __device__ __forceinline__ void block_kernel_body(const KernelArgs &a, int max_r
         __syncthreads();                              // the component's last LDS reads are done
     }
 }
+// (LFR_BLOCK_WPE_256=1 with LFR_THREADS_L=256: the experiment of round 6 - the 192-row class on 256 threads with 512 registers and no
+// spill at all ran 5.92 ms per config-5 solve against 5.80 with the spills and 4.55 for 512 threads: the kernel lives on its threads, the
+// spills are not what holds it; profiles/r06_ab/block_kernel_spills.txt)
+#ifndef LFR_BLOCK_WPE_256
+#define LFR_BLOCK_WPE_256 2
+#endif
 template <int kBlockThreads>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(kBlockThreads == 256 ? LFR_BLOCK_WPE_256 : 2, kBlockThreads == 256 ? LFR_BLOCK_WPE_256 : 2))) void solve_block_kernel(const KernelArgs a, int max_rows) {
     block_kernel_body<kBlockThreads>(a, max_rows);
 }
 
