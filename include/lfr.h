@@ -281,6 +281,12 @@ int64_t lfr_batch_spin_timeouts(lfr_batch *b);
  * solve.cc:147,617-635 - here the elimination tree's columns, the sweeps and the vector passes of ONE problem are spread over several
  * CUs).  Returns how many components the latest solve of the batch handed to a team (< 0: error). */
 int64_t lfr_batch_team_runs(lfr_batch *b);
+/* The teams of one launch form from workgroups that are resident on an XCD at the same time (the reference: a pool thread per problem,
+ * solve.cc:617-635 - no such constraint).  When the CUs are not there - other kernels, another process, a smaller partition - and nobody
+ * is at work and nothing moves for LFR_TEAM_PATIENCE_MS (default 50), the launch goes on with ONE workgroup per component: nothing
+ * fails, no wait runs out (lfr_batch_spin_timeouts stays 0); the positions of such a component are those of a team of one (equal to the
+ * team's to rounding, not bit for bit).  Returns how many components of the latest solve were solved that way (< 0: error). */
+int64_t lfr_batch_team_fallbacks(lfr_batch *b);
 /* positions: 2 * n_nodes doubles of the WHOLE graph; only this shard's nodes are written.  Waits for the
  * latest lfr_batch_solve of this batch, whatever stream it was issued on. */
 int lfr_batch_download(lfr_batch *b, double *positions);
@@ -329,6 +335,11 @@ int lfr_debug_sort_pairs(int device, int64_t n, int key_bytes, const void *keys,
  * of item_bytes (4 or 8) byte unsigned integers; out[i] = in[0] + ... + in[i-1] (32-bit sums wrap, 64-bit sums must stay below 2^62).
  * Test infrastructure, not part of the solve path. */
 int lfr_debug_exclusive_sum(int device, int64_t n, int item_bytes, const void *in, void *out);
+
+/* Keeps `workgroups` CUs of the device busy for `milliseconds` (512-thread workgroups at the elimination-tree kernel's register budget, on
+ * a stream of their own; returns when they have started): the tests take CUs away from a solve with it (lfr_batch_team_fallbacks).
+ * Test infrastructure, not part of the solve path. */
+int lfr_debug_occupy(int device, int workgroups, double milliseconds);
 
 /* One-call convenience used by the `solve` launcher: upload, solve, download on one device. */
 int lfr_solve_hip(const lfr_problem *p, int device, int tukey_variant, double *positions,

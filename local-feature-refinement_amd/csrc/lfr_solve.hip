@@ -79,6 +79,7 @@ struct KernelArgs {
     double *team_red;
     uint32_t team_work[3];
     uint32_t team_epoch;        // differs between launches that share the reduction slots
+    uint32_t team_patience_us;  // teams that cannot form for this long with nobody at work: the launch goes on one workgroup per component (LFR_TEAM_PATIENCE_MS)
     unsigned long long *trace;  // -DLFR_TRACE_TREE: [0] = words used, then {s_memtime, type << 56 | wave of the team << 48 | iteration << 32 | column} pairs
 };
 
@@ -1829,15 +1830,28 @@ struct TreeShared {
 // (registration below); workgroups that cannot complete a unit of their XCD work alone.
 //
 // Control words of a launch (KernelArgs::team_ctl, zeroed per solve): [0..7] workgroups registered per XCC, [8] registered in total,
-// [9] abort (a bounded spin ran out somewhere: every wait gives up, the components involved fail), [16 + 16 u + m] mailbox of member m
-// of unit u (a one-slot channel: the leader stores when it reads 0, the member clears), [16 + 16 u + 8 + L] arrival counter of the team
-// led by rank L.  Reduction slots (KernelArgs::team_red): per unit and leader, two parities x members x 4 doubles.
+// [9] abort (a bounded spin ran out somewhere: every wait gives up, the components involved fail), [10] components solved by a team,
+// [11] SOLO mode (below), [12] components being solved right now, [13] components solved off their team size, [16 + 16 u + m] mailbox
+// of member m of unit u (a one-slot channel: the leader stores when it reads 0, the member clears), [16 + 16 u + 8 + L] arrival counter
+// of the team led by rank L, [kTeamUnitState + u] state of unit u (0 forming, 1 complete, 2 dissolved: decided ONCE by compare-and-swap,
+// so that the members of a unit agree).  Reduction slots (KernelArgs::team_red): per unit and leader, two parities x members x 4 doubles.
+//
+// Residency.  Units form from workgroups that are resident at the same time, and nothing guarantees that: another
+// kernel may hold CUs (the other classes of the same solve do, by design; so may another process or a smaller partition).  Waiting is
+// harmless while SOMEBODY works - a team at work ends, takes the next component, exits when the queue is empty, and the CUs it frees
+// bring the missing registrations.  The one state that would never end by itself: nobody at work ([12] = 0), the queue not empty, and
+// everyone resident waiting - in registration for members that cannot arrive, or at the head of the queue for a team size that does not
+// exist.  A waiter that sees [12] = 0 and neither a registration nor the queue's head move for team_patience_us (wall clock, 50 ms by
+// default) raises [11]: units still forming dissolve, and from then on ANY leader takes the head of the queue and solves it alone -
+// the launch degrades to one workgroup per component (the plain solve_tree_kernel's way; that component's bits are those of a team of
+// one, counted in [13] = lfr_batch_team_fallbacks), no wait runs out, nothing fails.
 #ifndef LFR_TEAM_MAX
 #define LFR_TEAM_MAX 8
 #endif
 constexpr int kTeamMax = LFR_TEAM_MAX;                     // workgroups per unit (a power of two <= 8)
 constexpr int kTeamUnitsPerXcc = 256 / kTeamMax;           // a launch has at most 256 workgroups
-constexpr int kTeamCtlWords = 16 + 16 * 8 * kTeamUnitsPerXcc;
+constexpr int kTeamUnitState = 16 + 16 * 8 * kTeamUnitsPerXcc;
+constexpr int kTeamCtlWords = kTeamUnitState + 8 * kTeamUnitsPerXcc;
 constexpr int kTeamRedPerUnit = (kTeamMax / 2) * 2 * kTeamMax * 16;
 constexpr unsigned kTeamMsgEnd = 0xf0000000u;
 static_assert(kTeamMax == 2 || kTeamMax == 4 || kTeamMax == 8, "team size");
@@ -3040,6 +3054,17 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
 // team splits into equal sub-teams for good (the first keeps the component, the leaders of the others go to the queue themselves).
 // A plan that is not "thin" (dense components: barrier schedule) is solved by the leader alone while its members wait.
 // Workgroups that cannot complete a unit (their XCD received no multiple of kTeamMax of them) work as teams of one.
+// One thread, every 256 polls of a wait that only somebody else can end: has the launch stalled for good?  Nobody at work and neither a
+// registration nor the queue's head moved for the launch's patience (wall clock: s_memrealtime counts at 100 MHz) => SOLO mode.
+struct TeamWatch {
+    unsigned long long t_last = 0ull, sig_last = ~0ull;
+    __device__ __forceinline__ void look(const KernelArgs &a, unsigned int *ctl) {
+        const unsigned long long sig = (unsigned long long)team_ld(ctl + 8) << 32 | team_ld(a.queue + a.cls);
+        const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+        if (sig != sig_last || team_ld(ctl + 12) != 0u) { sig_last = sig; t_last = now; return; }
+        if (now - t_last > 100ull * a.team_patience_us) team_st(ctl + 11, 1u);
+    }
+};
 __device__ __forceinline__ int tree_team_size(const KernelArgs &a, const int ci) {
     const CompDesc d = a.descs[ci];
     const uint32_t work = (uint32_t)d.n_var * (1u + ((uint32_t)d.n_nodes - d.n_var > 1u ? 1u : 0u));      // = k_wg_order_keys
@@ -3061,22 +3086,28 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the XCD's count is out before the total says "everyone has registered")
         __hip_atomic_fetch_add(ctl + 8, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const unsigned unit = slot / kTeamMax;
-        // the unit is complete when kTeamMax (unit + 1) workgroups of this XCD have registered; once the whole grid has registered
-        // and it still is not, it never will be
-        bool complete = false;
+        // A unit is complete when kTeamMax workgroups of this XCD hold its slots, and dissolved when that cannot happen (the whole grid
+        // has registered and the XCD's count is short) or the launch has gone SOLO.  Its members must agree, so the unit's state word
+        // is decided once, by compare-and-swap: "complete" by the holder of the unit's last slot (slots are handed out in order: the
+        // other kTeamMax - 1 registered before it), "dissolved" by whichever waiter finds a reason first.
+        unsigned state = 2u;
         if (unit < (unsigned)kTeamUnitsPerXcc) {
+            unsigned int *const us = ctl + kTeamUnitState + xcc * kTeamUnitsPerXcc + unit;
+            auto decide = [&](unsigned v) { unsigned expect = 0u; __hip_atomic_compare_exchange_strong(us, &expect, v, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            if (slot % kTeamMax == kTeamMax - 1) decide(1u);
+            TeamWatch watch;
             int spins = 0;
-            for (;;) {
-                if (team_ld(ctl + xcc) >= (unit + 1u) * kTeamMax) { complete = true; break; }
-                if (team_ld(ctl + 8) >= gridDim.x) { complete = team_ld(ctl + xcc) >= (unit + 1u) * kTeamMax; break; }
+            while ((state = team_ld(us)) == 0u) {
+                if (team_ld(ctl + 11) != 0u) { decide(2u); continue; }
+                if (team_ld(ctl + 8) >= gridDim.x && team_ld(ctl + xcc) < (unit + 1u) * kTeamMax) { decide(2u); continue; }
                 __builtin_amdgcn_s_sleep(4);
-                if ((++spins & 255) == 0 && (team_ld(ctl + 9) != 0u || (spins >> 25) != 0)) {
-                    if (team_ld(ctl + 9) == 0u) atomicAdd(a.queue + 15, 1u);
-                    team_st(ctl + 9, 1u);
-                    break;
+                if ((++spins & 255) == 0) {
+                    if (team_ld(ctl + 9) != 0u) { state = 2u; break; }
+                    watch.look(a, ctl);
                 }
             }
         }
+        const bool complete = state == 1u;
         bc[0] = xcc * kTeamUnitsPerXcc + (complete ? unit : 0u); bc[1] = slot % kTeamMax; bc[2] = complete ? (unsigned)kTeamMax : 1u;
     }
     __syncthreads();
@@ -3098,6 +3129,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
                 // larger team to take it (the queue hands out by key, descending: whoever has split has seen the last component of
                 // its former size leave).  Look, then pop by compare-and-swap.
                 int spins = 0;
+                TeamWatch watch;
                 for (;;) {
                     const unsigned head = team_ld(a.queue + a.cls);
                     const int k = a.desc_begin + (int)head;
@@ -3105,17 +3137,24 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
                     const int ci = (int)a.wg_order[k - a.wg_begin];
                     const bool thin = reinterpret_cast<const uint32_t *>(a.workspace + a.ws_off[ci])[28] != 0u;
                     const int want = thin ? tree_team_size(a, ci) : 1;
-                    if (want <= S) {
+                    // SOLO mode (the comment above TeamCtx: Residency): the team this component asks for cannot form - its leader alone
+                    const bool off_size = want > S && team_ld(ctl + 11) != 0u;
+                    if (want <= S || off_size) {
                         unsigned expect = head;
                         if (__hip_atomic_compare_exchange_strong(a.queue + a.cls, &expect, head + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                            // (a plan that keeps the barrier schedule: the leader alone - message 0 -, the team stays as it is)
-                            msg = (thin ? (unsigned)(32 - __builtin_clz((unsigned)want)) << 28 : 0u) | (unsigned)(ci + 1);
+                            atomicAdd(ctl + 12, 1u);               // somebody is at work (until the matching decrement below)
+                            if (off_size) atomicAdd(ctl + 13, 1u);
+                            // (a plan that keeps the barrier schedule, or an off-size component: the leader alone - message 0 -, the team stays as it is)
+                            msg = (thin && !off_size ? (unsigned)(32 - __builtin_clz((unsigned)want)) << 28 : 0u) | (unsigned)(ci + 1);
                             break;
                         }
                         continue;                                  // someone else took it: look again
                     }
                     __builtin_amdgcn_s_sleep(16);                  // too large for this team: a larger one will take it
-                    if ((++spins & 255) == 0 && (spins >> 25) != 0) { atomicAdd(a.queue + 15, 1u); team_st(ctl + 9, 1u); break; }
+                    if ((++spins & 255) == 0) {
+                        watch.look(a, ctl);
+                        if ((spins >> 25) != 0) { atomicAdd(a.queue + 15, 1u); team_st(ctl + 9, 1u); break; }
+                    }
                 }
                 if (msg == kTeamMsgEnd || (msg >> 28) != 0u) {
                     for (int m = L + 1; m < L + S; ++m) {                                  // (a member clears its mailbox when it has read it)
@@ -3164,6 +3203,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
             if (tid == 0 && tm.r == 0) atomicAdd(ctl + 10, 1u);           // (statistics: components solved by a team)
             solve_tree_component<kBlockThreads, true>(a, ci, sh, ts, tm);
         }
+        if (tid == 0 && rank == L) atomicSub(ctl + 12, 1u);              // (the workgroup that took the component from the queue)
         __syncthreads();
     }
 }
@@ -3315,6 +3355,7 @@ struct lfr_batch {
     double *d_team_red = nullptr;
     uint32_t team_work[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu};
     int team_wgs = 0;
+    uint32_t team_patience_us = 50000u;                  // LFR_TEAM_PATIENCE_MS: the comment above TeamCtx (Residency)
     std::vector<int64_t> tree_comp_stats;                // 5 per component
     int64_t tree_tiles = 0, tree_dense_tiles = 0;          // KC_GLOBAL: 16x16 tiles stored / tiles of the dense lower triangles
     uint64_t *d_ws_off = nullptr, *d_es_off = nullptr;
@@ -3636,6 +3677,7 @@ int finish_workspace(lfr_batch *b, const lfr::Problem &p) {
             wgs += t;
         }
         b->team_wgs = 0;
+        if (const char *e = getenv("LFR_TEAM_PATIENCE_MS")) b->team_patience_us = (uint32_t)(std::min(60000.0, std::max(0.01, atof(e))) * 1000.0);
         if (any && b->n_desc < (1 << 28)) {
             for (int k = 0; k < 3; ++k) b->team_work[k] = w[k];
             b->team_wgs = (int)std::min<int64_t>(256, (wgs + 31) / 32 * 32);
@@ -4060,6 +4102,7 @@ int lfr_batch_solve(lfr_batch *b, void *hip_stream, lfr_solve_stats *stats) {
 #endif
     for (int k = 0; k < 3; ++k) a.team_work[k] = b->team_work[k];
     a.team_epoch = (uint32_t)(b->n_solves + 1);
+    a.team_patience_us = b->team_patience_us;
     bool materialised = false;
     if (b->fused) {
         const lfr::DevGraph &dgr = *b->dev_hold->graph;
@@ -4351,6 +4394,55 @@ int64_t lfr_batch_team_runs(lfr_batch *b) {
     unsigned int v = 0;
     HIP_TRY(hipMemcpy(&v, b->d_team_ctl + 10, sizeof v, hipMemcpyDeviceToHost));
     return (int64_t)v;
+}
+
+// Components the latest solve's teams could not serve at their size and a single workgroup solved instead (SOLO mode: the comment above
+// TeamCtx, Residency) - 0 whenever the launch's workgroups were resident together.
+int64_t lfr_batch_team_fallbacks(lfr_batch *b) {
+    if (!b) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (b->n_solves == 0 || !b->d_team_ctl) return 0;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->last_stream));
+    unsigned int v = 0;
+    HIP_TRY(hipMemcpy(&v, b->d_team_ctl + 13, sizeof v, hipMemcpyDeviceToHost));
+    return (int64_t)v;
+}
+
+// Test infrastructure: `workgroups` 512-thread workgroups of 256 registers per lane (a whole CU each, like the elimination-tree kernel's)
+// that do nothing but stay resident for `milliseconds`, on a stream of their own; returns once they have started.
+namespace {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_occupy(unsigned long long ticks, unsigned int *started) {
+    extern __shared__ unsigned int occ_lds[];                 // (100 KB of dynamic LDS: no second large workgroup fits the CU either way)
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) { occ_lds[0] = 1u; atomicAdd(started, occ_lds[0]); }
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+}
+int lfr_debug_occupy(int device, int workgroups, double milliseconds) {
+    if (workgroups < 1 || workgroups > 4096 || !(milliseconds > 0.0) || milliseconds > 2000.0) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    lfr::DevCtx *ctx = lfr::dev_ctx(device);
+    if (!ctx) return LFR_ERR_HIP;
+    HIP_TRY(hipSetDevice(device));
+    static hipStream_t s_occ[16] = {};
+    static unsigned int *h_started[16] = {};
+    if (device < 0 || device >= 16) { lfr::set_error("bad argument"); return LFR_ERR_ARG; }
+    if (!s_occ[device]) {
+        HIP_TRY(hipStreamCreateWithFlags(&s_occ[device], hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc((void **)&h_started[device], 64, hipHostMallocMapped));
+    }
+    HIP_TRY(hipStreamSynchronize(s_occ[device]));            // (an earlier occupation has ended)
+    volatile unsigned int *seen = h_started[device];
+    *seen = 0u;
+    unsigned int *d_started = nullptr;
+    HIP_TRY(hipHostGetDevicePointer((void **)&d_started, h_started[device], 0));
+    HIP_TRY(hipFuncSetAttribute((const void *)k_occupy, hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    hipLaunchKernelGGL(k_occupy, dim3((unsigned)workgroups), dim3(512), 100 * 1024, s_occ[device], (unsigned long long)(milliseconds * 1e5), d_started);
+    HIP_TRY(hipGetLastError());
+    // the workgroups that fit are resident once the count stops growing: at most n_cu of them at a time
+    const unsigned want = (unsigned)std::min(workgroups, ctx->n_cu);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (*seen < want && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < std::min(milliseconds, 100.0)) std::this_thread::yield();
+    return LFR_OK;
 }
 
 int lfr_batch_timing(lfr_batch *b, int solves_back, double *total_ms, double *class_ms, int64_t *class_edges) {

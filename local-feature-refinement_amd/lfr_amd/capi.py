@@ -108,6 +108,8 @@ def lib():
         "lfr_batch_component_info": (i64, [vp, vp, vp, vp, vp, vp, vp]),
         "lfr_batch_spin_timeouts": (i64, [vp]),
         "lfr_batch_team_runs": (i64, [vp]),
+        "lfr_batch_team_fallbacks": (i64, [vp]),
+        "lfr_debug_occupy": (C.c_int, [C.c_int, C.c_int, C.c_double]),
         "lfr_batch_tree_stats": (i64, [vp, vp, vp, vp, vp, vp]),
         "lfr_debug_eval_edges": (C.c_int, [C.c_int, i64, vp, vp, vp, vp, vp, C.c_int, vp, vp]),
         "lfr_debug_ls_next_step": (C.c_int, [C.c_int, i64, vp, vp, C.c_int, vp]),
@@ -135,7 +137,7 @@ EXPORTS = ["lfr_version", "lfr_last_error", "lfr_graph_from_files", "lfr_graph_f
            "lfr_graph_num_images", "lfr_graph_get_nodes", "lfr_graph_image_name", "lfr_graph_image_fact",
            "lfr_write_matching_file", "lfr_problem_build", "lfr_problem_build_labels", "lfr_problem_build_hip", "lfr_problem_free", "lfr_problem_get_stats",
            "lfr_problem_get_labels", "lfr_problem_shard_components", "lfr_hip_warmup", "lfr_batch_create", "lfr_batch_free", "lfr_batch_solve",
-           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_team_runs", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_solve_graph_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
+           "lfr_batch_download", "lfr_batch_timing", "lfr_batch_spin_timeouts", "lfr_batch_team_runs", "lfr_batch_team_fallbacks", "lfr_debug_occupy", "lfr_batch_tree_stats", "lfr_batch_component_info", "lfr_solve_hip", "lfr_solve_hip_multi", "lfr_solve_graph_hip_multi", "lfr_write_solution", "lfr_apply_displacements"]
 
 
 def _check(rc):
@@ -336,6 +338,11 @@ def exclusive_sum_hip(values, device=0):
     out = np.empty_like(values)
     _check(lib().lfr_debug_exclusive_sum(device, values.size, values.dtype.itemsize, _ptr(values), _ptr(out)))
     return out
+
+
+def occupy_hip(workgroups, milliseconds, device=0):
+    """Keeps `workgroups` CUs busy for `milliseconds` on a stream of their own (lfr_debug_occupy); returns when they have started."""
+    _check(lib().lfr_debug_occupy(device, int(workgroups), float(milliseconds)))
 
 
 def bisect_graph(edges, weights):
@@ -547,6 +554,13 @@ class Batch:
     def team_runs(self):
         """Components the latest solve handed to a team of two or more workgroups (elimination-tree class)."""
         n = lib().lfr_batch_team_runs(self._h)
+        if n < 0:
+            _check(int(n))
+        return int(n)
+
+    def team_fallbacks(self):
+        """Components the latest solve's teams could not serve at their size (CUs not resident together) and one workgroup solved."""
+        n = lib().lfr_batch_team_fallbacks(self._h)
         if n < 0:
             _check(int(n))
         return int(n)

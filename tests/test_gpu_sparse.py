@@ -121,3 +121,42 @@ def test_star_and_comb_shaped_tracks(lfr_lib):
     assert (oi["termination"] == info["termination"]).all() and (oi["iterations"] == info["iterations"]).all()
     ts = b.tree_stats()
     assert (ts["columns"] > 0).all() and (ts["levels"] >= 1).all()
+
+
+@pytest.mark.parametrize("occupied", [128, 248])
+def test_teams_without_their_cus(lfr_lib, monkeypatch, occupied):
+    """the teams of a launch form from workgroups that are resident on one XCD at the same time.  Another kernel holds
+    `occupied` of the 256 CUs (lfr_debug_occupy: 512-thread workgroups at the tree kernel's register budget, dealt round-robin to the XCDs)
+    while the batch is solved.  128: sixteen CUs per XCD are left - two units each, the rest of the grid arrives when those have emptied
+    the queue: same bits as the undisturbed solve.  248: ONE CU per XCD is left, no unit can ever form: after LFR_TEAM_PATIENCE_MS with
+    nobody at work the launch goes on with one workgroup per component - nothing fails, no wait runs out, the positions are those of
+    one-workgroup solves (equal to the teams' to rounding) - instead of 2^25 polls per wait and failed components."""
+    import time
+    monkeypatch.setenv("LFR_TEAM_PATIENCE_MS", "2")
+    ma = synthetic.capsized_sparse(n_tracks=2500, seed=7)
+    p = capi.Problem(capi.Graph.from_arrays(ma))
+    b = capi.Batch(p, 0)
+    st = b.solve()
+    pos0 = b.download().copy()
+    info0 = b.component_info()
+    assert st["n_failed"] == 0 and b.team_runs() > 0 and b.team_fallbacks() == 0 and b.spin_timeouts() == 0
+    hold_ms = 300.0
+    capi.occupy_hip(occupied, hold_ms)
+    t0 = time.perf_counter()
+    st = b.solve()
+    pos1 = b.download().copy()
+    dt = time.perf_counter() - t0
+    info1 = b.component_info()
+    assert st["n_failed"] == 0 and b.spin_timeouts() == 0
+    assert dt < 3.0, dt                                                           # (a wait that ran out used to take tens of seconds)
+    if occupied == 128:
+        assert b.team_fallbacks() == 0 and (pos1 == pos0).all()
+    else:
+        assert b.team_fallbacks() > 0
+        assert np.abs(pos1 - pos0).max() <= 1e-9
+        assert (info1["termination"] == info0["termination"]).all()
+        assert (info1["iterations"] == info0["iterations"]).mean() >= 0.99
+    time.sleep(hold_ms / 1e3)                                                     # the CUs are back: teams again, the same bits as before
+    st = b.solve()
+    assert st["n_failed"] == 0 and b.team_fallbacks() == 0 and b.spin_timeouts() == 0 and b.team_runs() > 0
+    assert (b.download() == pos0).all()
