@@ -3157,10 +3157,17 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu((
                     }
                 }
                 if (msg == kTeamMsgEnd || (msg >> 28) != 0u) {
-                    for (int m = L + 1; m < L + S; ++m) {                                  // (a member clears its mailbox when it has read it)
+                    // From the highest rank DOWN, each store acknowledged before the next: when the team splits, the leader of a sub-team
+                    // (the lowest rank of its members) goes to the queue as soon as it has read this message, and whatever it then sends its
+                    // members must queue up BEHIND this message in their one-slot mailboxes.  Until round 6 the order was ascending: a
+                    // sub-leader that was through the queue before this loop reached its members could overtake, and a member that read
+                    // the two messages in the wrong order joined the wrong component (scripts/tree_sync_model.py run_team_formation found
+                    // it; a window of a few L2 round trips against a dozen on the sub-leader's side - never seen on the hardware).
+                    for (int m = L + S - 1; m > L; --m) {                                  // (a member clears its mailbox when it has read it)
                         int spins = 0;
                         while (team_ld(mbox + m) != 0u && (++spins >> 22) == 0) __builtin_amdgcn_s_sleep(1);
                         team_st(mbox + m, msg);
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     }
                 }
             } else {

@@ -12,6 +12,13 @@ synchronisation word) and a deadlock detector (some wave can always proceed):
     granule until its tag equals the reduction number, sums.  Checked: a slot is never overwritten before every member has read it (a
     member would then poll for a tag that is gone), and every member reads exactly the values of that reduction.
   * team barrier: a monotonic arrival counter; member i leaves barrier b when the counter has reached b * S.
+  * team formation and the queue (solve_tree_team_kernel): workgroups become resident as CUs allow, register with their XCD, form units of T
+    (the unit's state word decided once by compare-and-swap: complete by the holder of its last slot, dissolved by a waiter that finds the
+    grid exhausted or the launch in SOLO mode), leaders pop the queue's head when their team is large enough and split permanently when it
+    is larger, members follow their mailboxes; a waiter that sees nobody at work and nothing moving for its patience raises SOLO mode:
+    any leader then takes the head alone.  Checked under random interleavings and ANY residency (CUs taken away per XCD): every component
+    solved exactly once by a team of the size it asks for or, in SOLO mode, by one workgroup; the members of a unit agree on its state;
+    every workgroup exits.  The variant without the state word (completeness read off the registration count) is caught.
 
 The model takes the plan the kernel runs (capi.tree_plan: the same words).  usage: python scripts/tree_sync_model.py [n_tracks] [seed]"""
 import os, random, sys
@@ -175,6 +182,128 @@ def run_team_barriers(S, rounds, rng):
             left[m] = arrived[m]
 
 
+def run_team_formation(X, T, grid, capacity, wants, rng, patience=400, consensus=True, descending_sends=True, max_steps=2_000_000):
+    """Registration, unit states, queue, splitting, SOLO mode of solve_tree_team_kernel under a random interleaving.
+    X XCDs, units of T workgroups, `grid` workgroups dealt round-robin to the XCDs, capacity[x] = workgroups XCD x holds at a time
+    (None: the whole grid), wants = team size each queued component asks for (descending).  A leader fills its members' mailboxes from the
+    highest rank down: the leader of a sub-team hears of a split only after its members' mailboxes hold that message, so what it sends
+    them next queues up behind it (descending_sends=False: the round-5 order - a fast sub-leader's message could overtake, and its member
+    joined the wrong component).  Returns (components solved off-size, steps)."""
+    cap = [c if c is not None else grid for c in capacity]
+    fifo = [[i for i in range(grid) if i % X == x] for x in range(X)]           # not yet dispatched, in grid order
+    resident = [0] * X
+    count = [0] * X; total = 0; ustate = {}; solo = False; active = 0; head = 0
+    mbox = {}                                                                     # (x, unit, rank) -> message
+    solved = [0] * len(wants); off_size = 0
+    wg = {}                                                                       # id -> dict
+    team_arrivals = {}
+    live = []
+    now = 0
+
+    def sig(): return (total, head)
+
+    def members(w):
+        r = range(w["L"] + 1, w["L"] + w["S"])
+        return list(reversed(r)) if descending_sends else list(r)
+
+    def watch(w):                                                                 # TeamWatch::look
+        nonlocal solo
+        if w["sig"] != sig() or active != 0: w["sig"] = sig(); w["t"] = now; return
+        if now - w["t"] > patience: solo = True
+
+    exited = 0
+    while exited < grid:
+        assert now < max_steps, "no end in sight: %d of %d workgroups left, head %d of %d, solo %s, active %d, states %s" % (
+            grid - exited, grid, head, len(wants), solo, active, sorted((v["st"], v.get("S")) for v in wg.values() if v["st"] != "exit")[:12])
+        now += 1
+        for x in range(X):                                                         # the dispatcher: a free CU takes the next workgroup of its XCD
+            while fifo[x] and resident[x] < cap[x]:
+                i = fifo[x].pop(0); resident[x] += 1
+                wg[i] = {"x": x, "st": "register", "t": now, "sig": None}; live.append(i)
+        i = rng.choice(live)
+        w = wg[i]; x = w["x"]; st = w["st"]
+        if st == "register":
+            w["slot"] = count[x]; count[x] += 1; total += 1
+            w["unit"] = w["slot"] // T; w["rank"] = w["slot"] % T
+            if consensus and w["rank"] == T - 1: ustate.setdefault((x, w["unit"]), 1)
+            w["st"] = "forming"
+        elif st == "forming":
+            key = (x, w["unit"])
+            if consensus:
+                state = ustate.get(key, 0)
+                if state == 0:
+                    if solo or (total >= grid and count[x] < (w["unit"] + 1) * T): ustate.setdefault(key, 2)
+                    else: watch(w)
+                    continue
+            else:                                                                  # the round-5 rule + a solo flag: no agreement
+                if count[x] >= (w["unit"] + 1) * T: state = 1
+                elif solo or total >= grid: state = 2
+                else: watch(w); continue
+            w["state"] = state
+            if state == 1: w["S"] = T; w["L"] = 0
+            else: w["S"] = 1; w["L"] = w["rank"]
+            w["st"] = "leader" if w["rank"] == w["L"] else "member"
+        elif st == "leader":
+            if head >= len(wants):                                                 # queue empty: tell the members, leave
+                w["send"] = [("end", None, m) for m in members(w)]; w["st"] = "sending"; w["then"] = "exit"
+                continue
+            want = wants[head]
+            off = want > w["S"] and solo
+            if want <= w["S"] or off:
+                ci = head; head += 1; active += 1
+                if off: off_size += 1
+                if off or want == 1 and w["S"] == 1:
+                    w["job"] = (ci, 1); w["st"] = "solve_alone"
+                else:
+                    w["send"] = [("go", (ci, want), m) for m in members(w)]; w["st"] = "sending"; w["then"] = "team"; w["job"] = (ci, want)
+            else: watch(w)
+        elif st == "sending":                                                      # one mailbox per step, only into an empty one
+            if not w["send"]:
+                if w["then"] == "exit": w["st"] = "exit"
+                else:
+                    ci, want = w["job"]; w["S"] = want; w["st"] = "team_solve"; w["arrive"] = (x, w["unit"], w["L"], ci)
+                continue
+            kind, payload, m = w["send"][0]
+            if mbox.get((x, w["unit"], m)) is None:
+                tgt = [v for v in wg.values() if v["x"] == x and v.get("unit") == w["unit"] and v.get("rank") == m]
+                assert tgt and tgt[0].get("state", 1) == 1 and tgt[0]["st"] != "exit", "message for a workgroup that is not in the unit (unit %s rank %d)" % ((x, w["unit"]), m)
+                mbox[(x, w["unit"], m)] = (kind, payload); w["send"].pop(0)
+        elif st == "member":
+            msg = mbox.get((x, w["unit"], w["rank"]))
+            if msg is None: continue
+            mbox[(x, w["unit"], w["rank"])] = None
+            if msg[0] == "end": w["st"] = "exit"
+            else:
+                ci, s_new = msg[1]
+                L_new = w["L"] + ((w["rank"] - w["L"]) // s_new) * s_new
+                mine = L_new == w["L"]
+                w["S"] = s_new; w["L"] = L_new
+                if not mine: w["st"] = "leader" if w["rank"] == L_new else "member"
+                else:
+                    lead = [v for v in wg.values() if v["x"] == x and v.get("unit") == w["unit"] and v.get("rank") == L_new][0]
+                    assert lead.get("job", (None,))[0] == ci, "member %d of unit %s joins component %d, its leader %d works on %s" % (w["rank"], (x, w["unit"]), ci, L_new, lead.get("job"))
+                    w["st"] = "team_solve"; w["arrive"] = (x, w["unit"], w["L"], ci)
+        elif st == "solve_alone":
+            ci, _ = w["job"]; solved[ci] += 1; active -= 1; w["st"] = "leader"
+        elif st == "team_solve":                                                   # the team's barrier: everybody arrives, then the leader reports
+            key = w["arrive"]
+            arrived = w.setdefault("barrier", None)
+            if arrived is None:
+                team_arrivals[key] = team_arrivals.get(key, 0) + 1; w["barrier"] = True
+            elif team_arrivals[key] >= w["S"]:
+                w["barrier"] = None
+                if w["rank"] == w["L"]:
+                    ci = key[3]; solved[ci] += 1; active -= 1
+                    assert w["S"] == wants[ci], "component %d asks for %d workgroups, solved by %d" % (ci, wants[ci], w["S"])
+                    w["st"] = "leader"
+                else: w["st"] = "member"
+        if w["st"] == "exit":
+            live.remove(i); resident[x] -= 1; exited += 1
+    assert solved == [1] * len(wants), "components solved %s times" % solved
+    return off_size, now
+
+
+
 if __name__ == "__main__":
     from lfr_amd import capi, synthetic
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
@@ -194,3 +323,7 @@ if __name__ == "__main__":
         for _ in range(20):
             run_team_reductions(S, 50, rng); run_team_barriers(S, 50, rng)
     print("team reductions / barriers: 20 random interleavings each for teams of 2, 4, 8: ok")
+    wants = [8] * 3 + [4] * 6 + [2] * 10 + [1] * 12
+    for capacity in ([None] * 4, [8, 8, 8, 8], [7, 7, 7, 7], [1, 1, 1, 1], [8, 3, 1, 5]):
+        res = [run_team_formation(4, 8, 64, capacity, wants, rng) for _ in range(5)]
+        print("team formation, 64 workgroups on 4 XCDs, residency %s: components solved off-size %s" % (capacity, [r[0] for r in res]))

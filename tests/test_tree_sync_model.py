@@ -62,3 +62,39 @@ def test_team_reductions_and_barriers(members):
     with pytest.raises(AssertionError):      # one set of slots instead of two: a fast member overwrites what a slow one has not read
         for _ in range(200):
             M.run_team_reductions(members, 40, rng, parities=1)
+
+
+WANTS = [8] * 3 + [4] * 6 + [2] * 10 + [1] * 12
+
+
+@pytest.mark.parametrize("capacity", [[None] * 4, [8, 8, 8, 8], [7, 7, 7, 7], [1, 1, 1, 1], [8, 3, 1, 5], [16, 1, 2, 9]])
+def test_team_formation_under_any_residency(capacity):
+    """Registration, unit states, queue, permanent splits and SOLO mode of solve_tree_team_kernel: 64 workgroups on 4
+    XCDs, units of 8, with the CUs of each XCD limited to `capacity`.  Every component is solved exactly once - by a team of the size it
+    asks for, or alone once no such team can form -, the members of a unit agree on its state, every workgroup exits."""
+    rng = random.Random(len(capacity) + sum(c or 0 for c in capacity))
+    for _ in range(25):
+        off_size, _ = M.run_team_formation(4, 8, 64, capacity, WANTS, rng)
+        can_form = all(c is None or c >= 8 for c in capacity) or any(c is not None and c >= 8 for c in capacity)
+        assert (off_size == 0) == can_form, (capacity, off_size)
+
+
+def test_the_model_catches_units_without_an_agreed_state_and_overtaking_messages():
+    """Two deliberately broken protocols.  (1) Completeness read off the registration count (round 5) plus a solo flag: the members of a
+    unit decide differently and a leader talks to a workgroup that has left.  (2) Mailboxes filled in ascending rank order (rounds 5-6
+    until this model): the leader of a sub-team is through the queue before the old leader has reached its members, its message
+    overtakes, and a member joins a component its team is not working on."""
+    caught = 0
+    for k in range(30):
+        try:
+            M.run_team_formation(4, 8, 64, [7, 7, 7, 9], WANTS, random.Random(k), consensus=False, max_steps=200000)
+        except AssertionError:
+            caught += 1
+    assert caught >= 25
+    caught = 0
+    for k in range(30):
+        try:
+            M.run_team_formation(4, 8, 64, [None] * 4, WANTS, random.Random(k), descending_sends=False, max_steps=200000)
+        except AssertionError:
+            caught += 1
+    assert caught >= 20
