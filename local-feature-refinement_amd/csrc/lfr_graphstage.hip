@@ -559,6 +559,12 @@ __device__ __forceinline__ void rounds_barrier(uint32_t *bar, uint32_t &gen) {
     }
     __syncthreads();
 }
+#ifndef LFR_ROUNDS_TAIL_PENDING
+#define LFR_ROUNDS_TAIL_PENDING 0
+#endif
+#ifndef LFR_ROUNDS_TAIL_WGS
+#define LFR_ROUNDS_TAIL_WGS 4
+#endif
 struct RoundsArgs {
     int64_t M, first_block, serial_limit;
     const uint32_t *flags, *seg_id, *starts, *order, *n1, *n2;
@@ -1358,8 +1364,18 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         // more than the kernel boundaries they replace.
         bool xcd_tail = false;
         { const char *hx = getenv("LFR_ROUNDS_XCD"); if (hx && hx[0] == '1' && !(getenv("LFR_ROUNDS_COOPERATIVE") && getenv("LFR_ROUNDS_COOPERATIVE")[0] == '1')) xcd_tail = true; }
-        uint32_t *xbar = nullptr;
-        if (xcd_tail) { xbar = rounds_arena.take_n<uint32_t>(160); if (!xbar) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; } }
+        // Round 6: the one-XCD loop for SHORT lists only.  Below a few thousand pending matches a round is two kernel
+        // boundaries around a chain of ~10 dependent accesses (~26 us whatever the count, 40 of config 5's 76 rounds), and a batch of
+        // eight rounds is launched whole even when the list empties in its second; a handful of workgroups on one XCD then runs the
+        // rest of the block's rounds in ONE launch (L2-local barriers, no read-back in between).  LFR_ROUNDS_TAIL="pending,workgroups"
+        // (0 = off): the list length below which the block is finished that way, and how many workgroups take part.
+        static const std::pair<uint32_t, int> tail_cfg = [] {
+            unsigned t = LFR_ROUNDS_TAIL_PENDING, w = LFR_ROUNDS_TAIL_WGS;
+            if (const char *e = getenv("LFR_ROUNDS_TAIL")) { unsigned a = 0, b = 0; const int got = sscanf(e, "%u,%u", &a, &b); if (got >= 1) t = a; if (got >= 2 && b >= 1 && b <= 32) w = b; }
+            return std::make_pair((uint32_t)t, (int)w);
+        }();
+        uint32_t *xbar = rounds_arena.take_n<uint32_t>(160);
+        if (!xbar) { set_error("graph stage: rounds arena exhausted"); return LFR_ERR_NOMEM; }
         const char *hl = getenv("LFR_ROUNDS_COOPERATIVE");
         if (hl && hl[0] == '1') {
             static int blocks_per_cu = -1, n_cu = 0;
@@ -1438,6 +1454,26 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
                 bound = 0;
             }
             while (bound > 0) {
+                if (tail_cfg.first && bound <= tail_cfg.first && !xcd_tail) {
+                    // the rest of this block's rounds on one XCD: pa holds `bound` entries (rc_[0] after the shift below), launched rounds have run
+                    hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
+                    LFR_HIP_TRY(hipMemsetAsync(xbar, 0, 4 * 160, st));
+                    LFR_HIP_TRY(hipMemsetAsync(ctr + 8, 0, 4 * 8, st));
+                    LFR_HIP_TRY(hipMemcpyAsync(ctr + 8, rc_, 4, hipMemcpyDeviceToDevice, st));
+                    RoundsArgs ra{M, first_block, serial_limit, flags, segid, starts, order, n1, n2, dg->node_image, W, kMaxRounds, bits, minpos, pa, pb, par, cnt, ctr + 8, xbar, 1, (int)launched};
+                    hipLaunchKernelGGL(k_rounds_all<true>, dim3((unsigned)(8 * tail_cfg.second)), dim3(kThreads), 0, st, ra);
+                    LFR_HIP_TRY(hipGetLastError());
+                    LFR_HIP_TRY(hipMemcpyAsync(h_ctr, ctr + 8, 4 * 5, hipMemcpyDeviceToHost, st));
+                    LFR_HIP_TRY(hipMemsetAsync(rc_, 0, 4 * (kRoundBatch + 2), st));
+                    LFR_HIP_TRY(stream_wait(st));
+                    if (h_ctr[4]) return use_host("a path-shaped dependency chain");
+                    if (((int64_t)h_ctr[2] - launched) & 1) std::swap(pa, pb);              // (the kernel swapped its lists once per round)
+                    rounds += (int64_t)h_ctr[2] - launched;
+                    launched = h_ctr[2];
+                    if (trace > 2) fprintf(stderr, "lfr graph stage:   block [%lld, %lld): pending %u finished on one XCD, %lld rounds so far\n", (long long)k_lo, (long long)k_hi, bound, (long long)rounds);
+                    bound = 0;
+                    break;
+                }
                 if (launched + kRoundBatch > kMaxRounds) return use_host("round limit");   // a path-shaped dependency chain: sequential anyway
                 hipLaunchKernelGGL(k_round_counters_shift, dim3(1), dim3(64), 0, st, rc_, kRoundBatch);
                 for (int j = 0; j < kRoundBatch; ++j, ++launched) {
