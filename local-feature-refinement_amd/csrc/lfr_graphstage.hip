@@ -1369,7 +1369,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         // eight rounds is launched whole even when the list empties in its second; a handful of workgroups on one XCD then runs the
         // rest of the block's rounds in ONE launch (L2-local barriers, no read-back in between).  LFR_ROUNDS_TAIL="pending,workgroups"
         // (0 = off): the list length below which the block is finished that way, and how many workgroups take part.
-        static const std::pair<uint32_t, int> tail_cfg = [] {
+        const std::pair<uint32_t, int> tail_cfg = [] {
             unsigned t = LFR_ROUNDS_TAIL_PENDING, w = LFR_ROUNDS_TAIL_WGS;
             if (const char *e = getenv("LFR_ROUNDS_TAIL")) { unsigned a = 0, b = 0; const int got = sscanf(e, "%u,%u", &a, &b); if (got >= 1) t = a; if (got >= 2 && b >= 1 && b <= 32) w = b; }
             return std::make_pair((uint32_t)t, (int)w);

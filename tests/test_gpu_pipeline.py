@@ -200,13 +200,17 @@ def test_real_shaped_configs_stay_on_the_device_stage(lfr_lib, maker):
     assert pd.stats()["tracks_ms"] > 0 and pd.stats()["assemble_ms"] == 0    # device stage ran (the host stage fills assemble_ms only when it assembles)
 
 
-@pytest.mark.parametrize("cooperative", ["0", "1"])
+@pytest.mark.parametrize("cooperative", ["0", "1", "tail"])
 def test_round_based_union_find_fuzz(lfr_lib, monkeypatch, cooperative):
     """Every connected component through the rounds (LFR_SERIAL_SEGMENT_EDGES=0): ties, duplicated matches,
-    image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523.  Both schedules of the rounds: one
-    launch per round (default) and the single cooperative launch with grid barriers (LFR_ROUNDS_COOPERATIVE=1)."""
+    image conflicts, same-image matches - the order-dependent corner cases of solve.cc:489-523.  Three schedules of the rounds: one
+    launch per round (default), the single cooperative launch with grid barriers (LFR_ROUNDS_COOPERATIVE=1), and every block's pending
+    list finished by two workgroups on one XCD (LFR_ROUNDS_TAIL, round 6: measured, off by default)."""
     from test_graph_stage import fuzz_pairs
-    monkeypatch.setenv("LFR_ROUNDS_COOPERATIVE", cooperative)
+    if cooperative == "tail":
+        monkeypatch.setenv("LFR_ROUNDS_TAIL", "1000000,2")
+    else:
+        monkeypatch.setenv("LFR_ROUNDS_COOPERATIVE", cooperative)
     monkeypatch.setenv("LFR_SERIAL_SEGMENT_EDGES", "0")
     monkeypatch.setenv("LFR_ROUNDS_FIRST_BLOCK", "3")          # block boundaries inside every component, ties across them
     n_ok = 0
