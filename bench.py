@@ -630,6 +630,7 @@ def main():
                 "dense_factorization_flops_equivalent": float((rowss[bigs].astype(np.float64) ** 3 / 3.0 * infos["iterations"][bigs]).sum()),
                 "batch_creation_ms": t_batch * 1e3, "failed": sts["n_failed"], "no_convergence": sts["n_no_convergence"], "setup_s": t_preps,
                 "team_components": bs.team_runs(),
+                "team_fallbacks": bs.team_fallbacks(),        # components a single workgroup solved because their team could not form (CUs not resident together): 0 on a free GPU
                 "note": "round 3 (block-envelope kernel: ~160 dependent 16-column panels per factorization on one wave): 35 ms; round 4: nested "
                         "dissection + columns by level of the elimination tree, the workgroup's eight waves take independent columns side by side: 9 ms; "
                         "round 5: teams of 2 / 4 / 8 workgroups on one XCD per component (LFR_TREE_TEAM), update entries streamed as their columns finish",
