@@ -101,6 +101,7 @@ __device__ __forceinline__ uint32_t sim_key(float s) {       // order-preserving
     const uint32_t b = __float_as_uint(s);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+__device__ __forceinline__ float sim_from_key(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k); }
 
 // descending order of (sim, n1, n2) == ascending order of the complemented keys; node ids are complemented inside
 // their node_bits bits (N-1-n) so that the radix sorts run over 32 + 2 x node_bits key bits instead of 96
@@ -141,7 +142,7 @@ __device__ __forceinline__ bool rank_precedes(const uint4 &q, const uint4 &me) {
     return q.x < me.x || (q.x == me.x && (q.y > me.y || (q.y == me.y && (q.z > me.z || (q.z == me.z && q.w < me.w)))));
 }
 __global__ __launch_bounds__(kThreads) void k_rank_sort(int64_t M, const uint32_t *grouped, const uint4 *rec, const uint32_t *flags, const uint32_t *seg_id,
-                                                        const uint32_t *starts, uint32_t *order) {
+                                                        const uint32_t *starts, uint32_t *order, uint4 *sorted) {
     extern __shared__ uint4 s_rec[];                  // kThreads + 2 x (longest segment) records: the host knows the longest segment by now
     const int64_t b0 = (int64_t)blockIdx.x * kThreads;
     if (b0 >= M) return;
@@ -157,6 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_rank_sort(int64_t M, const uint32_
     uint32_t rank = 0;
     for (int64_t j = lo; j < hi; ++j) rank += rank_precedes(s_rec[j - w_lo], me) ? 1u : 0u;
     order[lo + rank] = me.w;
+    sorted[lo + rank] = me;                           // the record itself in the reference's order: k_kruskal_local reads its segment as a stream
 }
 __global__ void k_gather_u64(int64_t n, const uint32_t *idx, const uint64_t *src, uint64_t *dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -327,18 +329,9 @@ __device__ __forceinline__ ulonglong2 image_signature(int32_t im) {
 // for hop, everything the union reads from its two roots at once.  Three trips per match instead of eight: 0.42 -> 0.28 ms on config 4
 // (an LDS copy of the segment and a records pre-pass had not paid - the chain, not the gathers, was the time; guessing the root one trip
 // early does not pay either: what is left is the lockstep of 64 components of different lengths per wave).
-__global__ void k_kruskal(int64_t cap, int64_t serial_limit, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
-                          const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
-                          int32_t *count, ulonglong2 *sig) {
-    // (Round 6, measured and dropped: dealing the segments to the threads BY LENGTH.  In the order they come in, config 4's 147 k components
-    // of 6..136 matches keep a wave busy 3.3 times the mean length; dealt by length over the whole list the factor is 1.00 and the kernel
-    // ran 613 us instead of 288, dealt inside a workgroup of 256 / 512 / 1024 threads through LDS 324 / 329 / 375 us.  Neighbouring
-    // threads replaying neighbouring components - one stretch of the ordered list, nodes numbered close together - is worth more than
-    // equal lengths: the kernel is bound by memory transactions, not by its longest lane.  profiles/r06_ab/kruskal_by_length.txt)
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
-    const int64_t lo = starts[s], hi = starts[s + 1];
-    if (hi - lo > serial_limit) return;                      // large connected component: parallel rounds (k_round_*)
+__device__ __forceinline__ void kruskal_segment(const int64_t lo, const int64_t hi, const uint32_t *order, const uint32_t *n1,
+                                                const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
+                                                int32_t *count, ulonglong2 *sig) {
     uint32_t m1 = order[lo], m2 = lo + 1 < hi ? order[lo + 1] : 0u;           // matches k and k + 1
     uint32_t a1 = n1[m1], b1 = n2[m1];
     for (int64_t k = lo; k < hi; ++k) {
@@ -373,8 +366,65 @@ __global__ void k_kruskal(int64_t cap, int64_t serial_limit, const uint32_t *cou
         sig[big] = make_ulonglong2(s1.x | s2.x, s1.y | s2.y);
     }
 }
-
-// ---- the same greedy rule in parallel rounds (large connected components) ----
+__global__ void k_kruskal(int64_t cap, int64_t serial_limit, const uint32_t *counts, const uint32_t *starts, const uint32_t *order, const uint32_t *n1,
+                          const uint32_t *n2, const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail,
+                          int32_t *count, ulonglong2 *sig) {
+    // (Round 6, measured and dropped: dealing the segments to the threads BY LENGTH.  In the order they come in, config 4's 147 k components
+    // of 6..136 matches keep a wave busy 3.3 times the mean length; dealt by length over the whole list the factor is 1.00 and the kernel
+    // ran 613 us instead of 288, dealt inside a workgroup of 256 / 512 / 1024 threads through LDS 324 / 329 / 375 us.  Neighbouring
+    // threads replaying neighbouring components - one stretch of the ordered list, nodes numbered close together - is worth more than
+    // equal lengths: the kernel is bound by memory transactions, not by its longest lane.  profiles/r06_ab/kruskal_by_length.txt)
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
+    const int64_t lo = starts[s], hi = starts[s + 1];
+    if (hi - lo > serial_limit) return;                      // large connected component: parallel rounds (k_round_*)
+    kruskal_segment(lo, hi, order, n1, n2, node_image, parent, next, tail, count, sig);
+}
+// The same rule fed by the stream of sorted records (round 6, counting road: k_rank_sort writes every record to its place in the
+// reference's order, 16 bytes per match): no id from `order`, no gathered ends - two of the dozen scattered 32-byte sectors a match
+// costs the kernel above.  Config 4: 284 -> 206 us, k_rank_sort + 4 us for the records.  Measured against it and dropped: the component's
+// whole state in LDS under local node numbers (one thread per component, [slot][thread] columns, images and parents out once per
+// node): 363 us - a wave's lanes diverge in every inner loop (look-up among the known ids, root walks, the image test), so every match
+// costs the longest path of 64 components, where the scattered version hides its latency behind 32 waves per CU
+// (profiles/r06_ab/kruskal_variants.txt).
+__global__ void k_kruskal_stream(int64_t cap, int64_t serial_limit, const uint32_t *counts, const uint32_t *starts, const uint4 *sorted,
+                                 const int32_t *node_image, int32_t *parent, int32_t *next, int32_t *tail, int32_t *count, ulonglong2 *sig) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= cap || s >= (int64_t)counts[CNT_SEG]) return;
+    const int64_t lo = starts[s], hi = starts[s + 1];
+    if (hi - lo > serial_limit) return;
+    uint4 q = sorted[lo];
+    for (int64_t k = lo; k < hi; ++k) {
+        const int32_t a = (int32_t)q.y, b = (int32_t)q.z;
+        if (k + 1 < hi) q = sorted[k + 1];
+        int32_t r1 = a, r2 = b, p1 = parent[a], p2 = parent[b];
+        while (p1 >= 0 || p2 >= 0) {
+            const bool h1 = p1 >= 0, h2 = p2 >= 0;
+            if (h1) r1 = p1;
+            if (h2) r2 = p2;
+            const int32_t q1 = h1 ? parent[r1] : -1, q2 = h2 ? parent[r2] : -1;
+            p1 = q1; p2 = q2;
+        }
+        if (r1 != a) parent[a] = r1;
+        if (r2 != b) parent[b] = r2;
+        if (r1 == r2) continue;
+        const ulonglong2 s1 = sig[r1], s2 = sig[r2];
+        const int32_t c1 = count[r1], c2 = count[r2], t1 = tail[r1], t2 = tail[r2];
+        bool conflict = false;
+        if ((s1.x & s2.x) | (s1.y & s2.y)) {
+            for (int32_t i = r1; i >= 0 && !conflict; i = next[i]) {
+                const int32_t im = node_image[i];
+                for (int32_t j = r2; j >= 0; j = next[j]) if (node_image[j] == im) { conflict = true; break; }
+            }
+        }
+        if (conflict) continue;
+        const bool swap = c1 < c2;
+        const int32_t big = swap ? r2 : r1, small = swap ? r1 : r2;
+        parent[small] = big;
+        next[swap ? t2 : t1] = small; tail[big] = swap ? t1 : t2; count[big] = c1 + c2;
+        sig[big] = make_ulonglong2(s1.x | s2.x, s1.y | s2.y);
+    }
+}
 // parent[] is shared with k_kruskal (-1 = root).  Finds compress by halving; within the evaluation kernel no union
 // happens, so a stale pointer is still an ancestor.
 __device__ __forceinline__ int32_t par_load(const int32_t *parent, int32_t x) {
@@ -736,7 +786,7 @@ __global__ void k_scores(int64_t M, const uint32_t *n1, const uint32_t *n2, cons
 // contribution that finds its slot taken by another node goes to memory directly - and sends one fp64 atomic per node instead of two per
 // match (agent-scope fp64 atomics leave the XCD: 5 M of them were 0.21 ms on config 4; 0.10 ms this way).  Exact sums: the order of the additions is free.
 constexpr int kScoreSlots = 128;
-__global__ void k_scores_grouped(int64_t M, const uint32_t *order, const uint32_t *n1, const uint32_t *n2, const float *sim, const int32_t *track, double *score) {
+__global__ void k_scores_grouped(int64_t M, const uint4 *sorted, const uint32_t *order, const uint32_t *n1, const uint32_t *n2, const float *sim, const int32_t *track, double *score) {
     __shared__ uint32_t s_key[kThreads / 64][kScoreSlots];
     __shared__ double s_val[kThreads / 64][kScoreSlots];
     const int lane = (int)(threadIdx.x & 63), w = (int)(threadIdx.x >> 6);
@@ -746,10 +796,16 @@ __global__ void k_scores_grouped(int64_t M, const uint32_t *order, const uint32_
     double s = 0.0;
     bool live = false;
     if (i < M) {
-        const uint32_t m = order[i];
-        node[0] = n1[m]; node[1] = n2[m];
+        if (sorted) {                                                            // (counting road: the record is there, in order - no gathers)
+            const uint4 q = sorted[i];
+            node[0] = q.y; node[1] = q.z;
+            s = (double)sim_from_key(~q.x);                                      // (-0.0 comes back as +0.0: the same sum)
+        } else {
+            const uint32_t m = order[i];
+            node[0] = n1[m]; node[1] = n2[m];
+            s = (double)sim[m];
+        }
         live = track[node[0]] == track[node[1]];
-        s = (double)sim[m];
     }
     // (a wave's LDS operations complete in order: the zeroing above is visible to its own lanes without a barrier, other waves use other rows)
 #pragma unroll
@@ -1185,7 +1241,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     dp->track = dp->slab.take_n<int32_t>(N); dp->comp = dp->slab.take_n<int32_t>(N); dp->is_root = dp->slab.take_n<uint8_t>(N);
 
     DevArena arena;                                   // temporaries of this call
-    if (!arena.init(ctx, (size_t)96 * M + (size_t)112 * N + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
+    if (!arena.init(ctx, (size_t)112 * M + (size_t)112 * N + ((size_t)32 << 20))) return LFR_ERR_NOMEM;
     size_t pin_bytes = 0;
     uint32_t *h_counts = (uint32_t *)ctx->pinned_acquire(4 * (CNT_WORDS + 16), &pin_bytes);     // + the counters of a batch of union-find rounds
     if (!h_counts) return LFR_ERR_NOMEM;
@@ -1236,6 +1292,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     TAKE(rec, uint4, M);                              // (the 64-bit keys of the one-sort road share these 16 M bytes with the records of the counting road)
     uint64_t *const khi = reinterpret_cast<uint64_t *>(rec), *const khi2 = khi + M;
     TAKE(klo, uint32_t, M); TAKE(klo2, uint32_t, M);
+    TAKE(srec, uint4, M);                             // counting road: the records in the reference's order
     TAKE(id0, uint32_t, M); TAKE(id1, uint32_t, M);
     TAKE(ck0, uint32_t, M); TAKE(ck1, uint32_t, M); TAKE(segid, uint32_t, M + 1);
     TAKE(starts, uint32_t, std::min(N, M) + 2);
@@ -1278,7 +1335,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         lap("first read-back");
         if ((int64_t)h_counts[CNT_MAX_SEG] <= kRankSortMax) {
             const size_t window = sizeof(uint4) * ((size_t)kThreads + 2 * (size_t)h_counts[CNT_MAX_SEG]);     // (8 KB for config 4's 136: eight workgroups per CU)
-            hipLaunchKernelGGL(k_rank_sort, grid_for(M), dim3(kThreads), window, st, M, id1, rec, flags, segid, starts, id0);
+            hipLaunchKernelGGL(k_rank_sort, grid_for(M), dim3(kThreads), window, st, M, id1, rec, flags, segid, starts, id0, srec);
             order = id0;
             counts_on_host = true; order_done = true;
         }
@@ -1301,8 +1358,13 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     hipLaunchKernelGGL(k_init_nodes, grid_for(N), dim3(kThreads), 0, st, N, dg->node_image, par, next, tail, cnt, sig);
     int64_t serial_limit = kSerialSegmentEdges;
     if (const char *e = getenv("LFR_SERIAL_SEGMENT_EDGES")) serial_limit = std::max<int64_t>(0, atoll(e));
-    hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
-                       dg->node_image, par, next, tail, cnt, sig);
+    // (counting road: the matches as a stream of sorted records - k_kruskal_stream; LFR_KRUSKAL_GLOBAL=1: the gathering kernel, A/B and tests)
+    const bool streamed = counts_on_host && order_done && !getenv("LFR_KRUSKAL_GLOBAL");
+    if (streamed)
+        hipLaunchKernelGGL(k_kruskal_stream, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, srec, dg->node_image, par, next, tail, cnt, sig);
+    else
+        hipLaunchKernelGGL(k_kruskal, grid_for(seg_cap), dim3(kThreads), 0, st, seg_cap, serial_limit, counts, starts, order, n1, n2,
+                           dg->node_image, par, next, tail, cnt, sig);
     // ... large ones in parallel rounds (first read-back: is there any? - the counting road has read the counts already)
     lap("sorts / connected components / small-component union-find enqueued");
     if (!counts_on_host) {
@@ -1502,7 +1564,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     // roots
     // (small connected components only: in the ordered list of a giant one a wave's matches share no nodes - config 5: 0.40 ms grouped, 0.12 plain)
     if ((int64_t)h_counts[CNT_MAX_SEG] > serial_limit) hipLaunchKernelGGL(k_scores, grid_for(M), dim3(kThreads), 0, st, M, n1, n2, sim, dp->track, score);
-    else hipLaunchKernelGGL(k_scores_grouped, grid_for(M), dim3(kThreads), 0, st, M, order, n1, n2, sim, dp->track, score);
+    else hipLaunchKernelGGL(k_scores_grouped, grid_for(M), dim3(kThreads), 0, st, M, streamed ? srec : nullptr, order, n1, n2, sim, dp->track, score);
     hipLaunchKernelGGL(k_best_score, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best);
     hipLaunchKernelGGL(k_best_node, grid_for(N), dim3(kThreads), 0, st, N, dp->track, score, best, bnode);
     hipLaunchKernelGGL(k_mark_roots, grid_for(N), dim3(kThreads), 0, st, N, counts, bnode, dp->is_root);
