@@ -148,7 +148,8 @@ __device__ __forceinline__ int classify_dev(uint32_t rows, uint32_t n_edges, uin
 __global__ void k_comp_keys(int64_t n_comp, uint32_t *c_nodes, uint32_t *c_var, uint32_t *c_edges, const uint32_t *run_begin,
                             const uint32_t *run_end, const uint32_t *node_begin, const uint32_t *node_var_end, const uint32_t *node_end,
                             unsigned long long *key, uint32_t *ids, uint32_t *too_big, uint32_t block_max,
-                            int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks) {
+                            int64_t n_tracks, const uint32_t *t_size, const int32_t *t_comp, uint32_t *c_tracks,
+                            uint32_t e_max, uint32_t v_max, int e_bits, int v_bits) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < n_tracks && t_size[c] >= 2) atomicAdd(&c_tracks[t_comp[c]], 1u);      // (thread t doubles as track t: k_count_tracks' launch saved)
     if (c >= n_comp) return;
@@ -156,15 +157,17 @@ __global__ void k_comp_keys(int64_t n_comp, uint32_t *c_nodes, uint32_t *c_var, 
     if (run_begin) c_edges[c] = 2u * (run_end[c] - run_begin[c]);       // matches sorted before the counts (k_match_keys_comp): both directions of every match of the run
     const bool solvable = c_nodes[c] >= 2 && c_var[c] >= 1;   // solve.cc:619-622; no variable: nothing to solve
     if (solvable && c_nodes[c] > 32767) *too_big = 1u;
-    const unsigned long long kv = 0xffffu - min(c_var[c], 0xffffu);             // descending
-    const unsigned long long ke = 0xffffffffu - c_edges[c];                     // descending
+    // (the fields are as wide as the host's bounds need - e_max >= every edge count, v_max >= min(variables, 0xffff): the same order
+    // in 18 key bits on config 4 instead of 52, i.e. two radix passes instead of a block sort and eight merges)
+    const unsigned long long kv = v_max - min(min(c_var[c], 0xffffu), v_max);   // descending
+    const unsigned long long ke = e_max - min(c_edges[c], e_max);               // descending
     const unsigned long long kc = solvable ? (uint32_t)classify_dev(2 * c_var[c], c_edges[c], block_max) : kNoClass;
-    key[c] = (kc << 48) | (ke << 16) | kv;
+    key[c] = (kc << (e_bits + v_bits)) | (ke << v_bits) | kv;
     ids[c] = (uint32_t)c;
 }
-__global__ void k_class_of_key(int64_t n, const unsigned long long *key, uint32_t *cls) {
+__global__ void k_class_of_key(int64_t n, const unsigned long long *key, uint32_t *cls, int class_shift) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) cls[i] = (uint32_t)(key[i] >> 48);
+    if (i < n) cls[i] = (uint32_t)(key[i] >> class_shift);
 }
 
 
@@ -172,12 +175,12 @@ __global__ void k_class_of_key(int64_t n, const unsigned long long *key, uint32_
 // (sorted_keys != nullptr: the class comes straight from the sorted keys and is written to class_sorted here - k_class_of_key's launch saved
 // on the unsharded road)
 __global__ void k_desc_sizes(int64_t n_comp, const uint32_t *perm, uint32_t *class_sorted, const unsigned long long *sorted_keys, const uint32_t *c_nodes,
-                             const uint32_t *c_edges, uint32_t *d_nodes, uint32_t *d_edges, int32_t *di_of_comp) {
+                             const uint32_t *c_edges, uint32_t *d_nodes, uint32_t *d_edges, int32_t *di_of_comp, int class_shift) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_comp) return;
     const uint32_t c = perm[i];
     uint32_t cls;
-    if (sorted_keys) { cls = (uint32_t)(sorted_keys[i] >> 48); class_sorted[i] = cls; }
+    if (sorted_keys) { cls = (uint32_t)(sorted_keys[i] >> class_shift); class_sorted[i] = cls; }
     else cls = class_sorted[i];
     const bool solvable = cls != kNoClass;
     d_nodes[i] = solvable ? c_nodes[c] : 0u;
@@ -695,21 +698,30 @@ int assemble_on_device(const Problem &p, const DevProblem &dp, int shard_rank, i
     // ---- batch order of the components: class, then edges descending, then variables descending, then id ----
     TAKE(key64, unsigned long long, C + 1); TAKE(key64s, unsigned long long, C + 1);
     TAKE(id0, uint32_t, C + 1); TAKE(id1, uint32_t, C + 1); TAKE(k0, uint32_t, C + 1); TAKE(k1, uint32_t, C + 1);
+    // field widths of the key from what the host knows: a component's matches are matches of ONE connected component of the match graph
+    // (dp.max_cc_matches, from the graph stage; 0 = unknown: 32 bits), its variables are nodes of the component (stats.max_component_size)
+    uint32_t e_max = 0xffffffffu, v_max = 0xffffu;
+    if (dp.max_cc_matches > 0 && dp.max_cc_matches < (1u << 30)) e_max = 2u * dp.max_cc_matches;
+    if (dp.max_cc_matches > 0 && p.stats.max_component_size > 0 && p.stats.max_component_size < 0xffff) v_max = (uint32_t)p.stats.max_component_size;   // (the same stage counted both)
+    int e_bits = 1, v_bits = 1;
+    while (e_bits < 32 && (e_max >> e_bits) != 0u) ++e_bits;
+    while (v_bits < 16 && (v_max >> v_bits) != 0u) ++v_bits;
+    const int class_shift = e_bits + v_bits;
     hipLaunchKernelGGL(k_comp_keys, grid_for(std::max(C, T)), dim3(kThreads), 0, st, C, cn, cv, ce, match_sort_first ? run_begin : nullptr, run_end,
                        node_sort_first ? node_begin : nullptr, node_var_end, node_end, key64, id0, &sum->too_big, (uint32_t)block_max_rows(),
-                       T, ts, tc, ct);
-    if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, 48 + kClassBits, st)) != LFR_OK) return rc;
+                       T, ts, tc, ct, e_max, v_max, e_bits, v_bits);
+    if ((rc = sort_pairs(arena, key64, key64s, id0, id1, C, 0, class_shift + kClassBits, st)) != LFR_OK) return rc;
     uint32_t *perm = id1;                  // perm[i] = component of desc i
     uint32_t *class_sorted = k1;
     if (shard_world > 1) {                 // keep this shard's components (same relative order), the rest becomes class 7
-        hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1);
+        hipLaunchKernelGGL(k_class_of_key, grid_for(C), dim3(kThreads), 0, st, C, key64s, k1, class_shift);
         hipLaunchKernelGGL(k_shard_class, grid_for(C), dim3(kThreads), 0, st, C, class_sorted, shard_rank, shard_world, k0);
         if ((rc = sort_pairs(arena, k0, k1, id1, id0, C, 0, kClassBits, st)) != LFR_OK) return rc;
         perm = id0; class_sorted = k1;     // (k1 is rewritten by the sort after k_shard_class has read it: stream ordered)
     }
 
     TAKE(no, uint32_t, C + 1); TAKE(eo, uint32_t, C + 1); TAKE(di, int32_t, C + 1);
-    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, shard_world > 1 ? nullptr : key64s, cn, ce, dn, de, di);
+    hipLaunchKernelGGL(k_desc_sizes, grid_for(C), dim3(kThreads), 0, st, C, perm, class_sorted, shard_world > 1 ? nullptr : key64s, cn, ce, dn, de, di, class_shift);
     LFR_HIP_TRY(exclusive_sum_one_launch(dn, no, C + 1, scan_state + 0 * scan_words, st));
     LFR_HIP_TRY(exclusive_sum_one_launch(de, eo, C + 1, scan_state + 1 * scan_words, st));
     const uint32_t *total_nodes_p = no + C, *total_edges_p = eo + C;

@@ -72,6 +72,7 @@ struct DevProblem {
     DevArena slab;
     int32_t *track = nullptr, *comp = nullptr;
     uint8_t *is_root = nullptr;
+    uint32_t max_cc_matches = 0;       // most matches in one connected component of the match graph (0: unknown) - bounds a component's edge count for the batch-order keys
     ~DevProblem();
 };
 // labels computed on the host (graph cut, side-car, fallbacks) -> HBM

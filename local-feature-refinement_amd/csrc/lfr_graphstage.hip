@@ -1605,6 +1605,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
     LFR_HIP_TRY(hipEventElapsedTime(&ms, ev[2], ev[3])); p.stats.graph_cut_ms = ms;
     p.stats.n_tracks = h_counts[CNT_TRACKS]; p.stats.max_track_size = h_counts[CNT_MAX_TRACK];
     p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
+    dp->max_cc_matches = h_counts[CNT_MAX_SEG];
     {
         std::lock_guard<std::mutex> lk(p.label_mu);
         p.track.clear(); p.comp.clear(); p.is_root.clear();
@@ -1721,6 +1722,7 @@ int graph_stage_on_device(const Graph &g, int64_t max_nodes, int device, bool st
         LFR_HIP_TRY(stream_wait(st));          // (the staging vectors above die at scope end)
         lap("cut: re-labelled");
         p.stats.n_components = h_counts[CNT_COMPS]; p.stats.max_component_size = h_counts[CNT_MAX_COMP];
+    dp->max_cc_matches = h_counts[CNT_MAX_SEG];
         float cms = 0.f;
         LFR_HIP_TRY(hipEventElapsedTime(&cms, c0, c1));
         p.stats.graph_cut_ms += cms;

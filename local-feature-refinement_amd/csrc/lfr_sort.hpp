@@ -25,6 +25,7 @@ namespace lfr {
 
 using LfrRadixSortConfig = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, (size_t)256 * 1024>;
 constexpr size_t kSortMergeLimit = (size_t)256 * 1024;
+constexpr int64_t kOnesweepSmallFrom = 32 * 1024;      // short keys (<= 20 bits) take the one-sweep driver from this many items on
 
 // The driver below calls rocPRIM's detail kernels with the signatures of rocPRIM 4.2.0 (ROCm 7.2).  Another version takes the library's
 // public entry point for every sort (the results are the same; the fills come back) until the driver has been checked against it.
@@ -194,7 +195,11 @@ hipError_t onesweep_pairs(void *tmp, size_t &bytes, const K *kin, K *kout, const
 // kout / vout.
 template <class K, class V>
 hipError_t sort_pairs_raw(void *tmp, size_t &bytes, const K *kin, K *kout, const V *vin, V *vout, int64_t n, int begin_bit, int end_bit, hipStream_t st) {
-    const bool big = sortdetail::single_fill_enabled() && n > (int64_t)kSortMergeLimit && n < ((int64_t)1 << 30);
+    // (the library's road below 256 K items is a block sort and log2(n / 4096) merge launches of ~6 us whatever the key width: a short key -
+    // two digit places - over tens of thousands of items is five launches through the one-sweep driver: the 147 k batch-order keys of
+    // config 4, 18 bits, 66 -> ~25 us)
+    const bool short_key = n >= kOnesweepSmallFrom && end_bit - begin_bit <= 20;
+    const bool big = sortdetail::single_fill_enabled() && (n > (int64_t)kSortMergeLimit || short_key) && n < ((int64_t)1 << 30);
     if (!tmp) {
         size_t lib = 0, own = 0;
         hipError_t e = rocprim::radix_sort_pairs<LfrRadixSortConfig>(nullptr, lib, kin, kout, vin, vout, (size_t)n, (unsigned)begin_bit, (unsigned)end_bit, st);

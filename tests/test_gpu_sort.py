@@ -37,14 +37,29 @@ def test_sort_is_the_stable_sort(lfr_lib, dtype, begin_bit, end_bit, n):
     assert (kl == ek).all() and (vl == ev).all()
 
 
+@pytest.mark.parametrize("dtype", [np.uint32, np.uint64])
+@pytest.mark.parametrize("n,bits", [(32 * 1024, 18), (147_000, 18), (147_000, 20), (MERGE_LIMIT, 9), (32 * 1024 - 1, 18), (147_000, 21)])
+def test_short_keys_of_small_sorts(lfr_lib, dtype, n, bits):
+    """Round 6: from 32 K items on, keys of at most 20 bits go through the one-sweep driver below the merge-sort limit too (the batch-order
+    keys of the assembly: 147 k components, 18 bits - five launches instead of a block sort and eight merges); 32 K - 1 items and 21 bits
+    stay with the library.  Every key many times: stability is visible in the values."""
+    rng = np.random.default_rng(n + bits)
+    keys = rng.integers(0, 2 ** min(bits, 12), n, dtype=np.uint64).astype(dtype) << dtype(max(bits - 12, 0))
+    keys |= rng.integers(0, 2, n, dtype=np.uint64).astype(dtype)
+    vals = np.arange(n, dtype=np.uint32)
+    ek, ev = expected(keys, vals, 0, bits)
+    k, v = capi.sort_pairs_hip(keys, vals, 0, bits)
+    assert (k == ek).all() and (v == ev).all()
+
+
 @pytest.mark.parametrize("n", [1, 2, 1000, MERGE_LIMIT - 1, MERGE_LIMIT])
 def test_small_sorts_take_the_library_road(lfr_lib, n):
-    """At and below the merge-sort limit the call is rocprim::radix_sort_pairs as before; same answer."""
+    """At and below the merge-sort limit the call is rocprim::radix_sort_pairs as before (keys of more than 20 bits, or fewer than 32 K items); same answer."""
     rng = np.random.default_rng(n)
-    keys = rng.integers(0, 2 ** 20, n, dtype=np.uint64).astype(np.uint32)
+    keys = rng.integers(0, 2 ** 24, n, dtype=np.uint64).astype(np.uint32)
     vals = np.arange(n, dtype=np.uint32)
-    ek, ev = expected(keys, vals, 0, 20)
-    k, v = capi.sort_pairs_hip(keys, vals, 0, 20)
+    ek, ev = expected(keys, vals, 0, 24)
+    k, v = capi.sort_pairs_hip(keys, vals, 0, 24)
     assert (k == ek).all() and (v == ev).all()
 
 
