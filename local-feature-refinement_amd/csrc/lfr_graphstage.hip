@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kThreads) void k_rank_sort(int64_t M, const uint32_
     uint32_t rank = 0;
     for (int64_t j = lo; j < hi; ++j) rank += rank_precedes(s_rec[j - w_lo], me) ? 1u : 0u;
     order[lo + rank] = me.w;
-    sorted[lo + rank] = me;                           // the record itself in the reference's order: k_kruskal_local reads its segment as a stream
+    sorted[lo + rank] = me;                           // the record itself in the reference's order: k_kruskal_stream and k_scores_grouped read their matches as this stream
 }
 __global__ void k_gather_u64(int64_t n, const uint32_t *idx, const uint64_t *src, uint64_t *dst) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
